@@ -1,0 +1,121 @@
+"""The CPU restatement (oracle/restatement.py) against the golden vectors captured
+from the unmodified reference classes (oracle/gen_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from mgnns_amd import synth
+from oracle import golden_inputs as GI
+from oracle import restatement as R
+from tests import helpers as H
+
+
+def test_gen_A_and_gen_adj_match_reference():
+    g = H.load_golden("adjacency.npz")
+    for tag in ("object", "place"):
+        for t in (0.3, 0.4, 0.5, 0.6):
+            key = "%s_t%02d" % (tag, int(round(t * 10)))
+            A = torch.from_numpy(R.gen_A(g[tag + "_counts"], g[tag + "_nums"], t, 0.2)).float()
+            assert H.maxabs(A, g[key + "_A"]) == 0.0
+            assert H.maxabs(R.gen_adj(A), g[key + "_adj"]) == 0.0
+
+
+def test_synth_gen_A_formula_equals_reference_formula():
+    g = H.load_golden("adjacency.npz")
+    P = (g["object_counts"] / g["object_nums"][:, None] >= 0.4).astype(np.float64)
+    assert np.array_equal(synth.gen_A_from_binary(P, 0.2), g["object_t04_A"])
+
+
+def test_image_gcn_and_readout():
+    g = H.load_golden("image_gcn.npz")
+    adj = H.load_golden("adjacency.npz")
+    p = H.params_for({"gc1.weight": (300, 1024), "gc2.weight": (1024, 2048)})
+    proj = torch.from_numpy(GI.gcn_projection())
+    for tag, key in (("object", "object_t04"), ("place", "place_t03")):
+        X, pooled = (torch.from_numpy(a) for a in GI.image_gcn_case(tag))
+        G = R.image_gcn(torch.from_numpy(adj[key + "_A"]), X, p["gc1.weight"], p["gc2.weight"])
+        assert H.relerr(G @ proj, g[tag + "_Gproj"]) < 1e-5
+        assert H.relerr(pooled @ G.t(), g[tag + "_x"]) < 1e-5
+
+
+def test_label_attention():
+    g = H.load_golden("label_attention.npz")
+    lq = torch.from_numpy(g["label_query"])
+    for tag, C in (("object", 80), ("place", 365)):
+        p = H.params_for(H.label_attention_shapes(tag, C))
+        key = torch.from_numpy(GI.label_attention_key(tag))
+        y = R.label_attention(p, tag + "_attention", lq, key)
+        assert H.maxabs(y, g[tag + "_y"]) < 1e-5
+        assert H.maxabs(R.label_attention_tail(p, tag, y), g[tag + "_z"]) < 1e-5
+
+
+def test_custom_layernorm():
+    g = H.load_golden("layernorm.npz")
+    p = H.params_for({"ln.gamma": (300,), "ln.beta": (300,)})
+    y = R.layer_norm(torch.from_numpy(g["x"]), p["ln.gamma"], p["ln.beta"])
+    assert H.maxabs(y, g["y"]) == 0.0
+    # nn.LayerNorm semantics would be off by ~6e-3: make sure we are not that
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(g["x"]), (300,), p["ln.gamma"], p["ln.beta"], 1e-6)
+    assert H.maxabs(ref, g["y"]) > 1e-3
+
+
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_single_query_mha_layer(Hn, tag, L, masked):
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    p = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    q, bank, mask = (None if a is None else torch.from_numpy(a) for a in GI.mha_case(Hn, tag, L, masked))
+    out, attn = R.sq_mha_layer(p, name, q, bank, mask, Hn, 128)
+    assert H.maxabs(out, g[name + "_out"]) < 2e-5
+    assert H.maxabs(attn, g[name + "_attn"]) < 1e-5
+    assert attn.shape == (Hn * GI.MHA_B, 1, L)
+    if masked:   # padded positions carry exactly zero probability
+        m = torch.from_numpy(np.tile(GI.mha_case(Hn, tag, L, masked)[2], (Hn, 1)))
+        assert float((attn[:, 0, :] * (1 - m)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ngram", [1, 4])
+def test_text_gcn(ngram):
+    g = H.load_golden("text_gcn.npz")
+    V, count = int(g["V"]), int(g["count"])
+    pmi, c2 = synth.synth_pmi(V, per_row=8, seed=int(g["pmi_seed"]))
+    assert c2 == count
+    p = H.params_for({"text_features.node_hidden.weight": (V, 300),
+                      "text_features.seq_edge_w.weight": (count, 1)})
+    y = R.text_gcn(g["ng%d_tok" % ngram], p["text_features.node_hidden.weight"],
+                   p["text_features.seq_edge_w.weight"], pmi, ngram)
+    assert H.relerr(y, g["ng%d_out" % ngram]) < 1e-5      # summation order only
+    assert float(y.min()) >= 0.0
+
+
+def test_text_memory_bank():
+    g = H.load_golden("text_bank.npz")
+    V = int(g["V"])
+    shapes = {k: s for k, s in H.surface().items() if k.startswith("lstm.")}
+    shapes["embedding.weight"] = (V, 300)
+    p = H.params_for(shapes)
+    bank = R.text_memory_bank(p, torch.from_numpy(g["tok"]), torch.from_numpy(g["lens"]))
+    assert H.maxabs(bank, g["bank"]) < 1e-6
+    for b, n in enumerate(g["lens"]):
+        assert float(bank[b, int(n):].abs().max()) == 0.0 if n < bank.shape[1] else True
+
+
+@pytest.mark.parametrize("cfg_name", ["mvsa_single_b8", "tumemo_b64", "mvsa_multiple_b256"])
+def test_full_forward_logits(cfg_name):
+    g = H.load_golden("full_%s.npz" % cfg_name)
+    adj = H.load_golden("adjacency.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    B = int(g["B"])
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    p = H.full_params(cfg, count, adj["object_t04_A"], adj["place_t03_A"])
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(cfg, B=B, pmi=pmi).items()}
+    assert np.array_equal(inp["text"].numpy(), g["text"])
+    logits, parts = R.forward(p, inp, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                              label_query=torch.from_numpy(g["label_query"]), return_parts=True)
+    assert logits.shape == (B, cfg.NL)
+    assert H.relerr(parts["text_feature"], g["text_feature"]) < 1e-5
+    assert H.relerr(parts["object_x"], g["object_x"]) < 1e-5
+    assert H.relerr(parts["place_x"], g["place_x"]) < 1e-5
+    assert H.maxabs(parts["tio"], g["tio"]) < 2e-5
+    assert H.maxabs(parts["iot"], g["iot"]) < 2e-5
+    assert H.maxabs(logits, g["logits"]) < 2e-5
