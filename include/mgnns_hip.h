@@ -1,0 +1,137 @@
+/*
+ * mgnns_hip.h -- C ABI of libmgnns_hip.so: the MI355X (gfx950) forward hot path of MGNNS.
+ *
+ * The reference has no native code and no FFI: its operators are Python nn.Modules that
+ * dispatch to cuDNN/cuBLAS/DGL kernels.  Each entry point below replaces the device work
+ * behind one reference call site (cited as file:line into the reference tree) and is what
+ * a ctypes binding of that call site would bind.  See INTEGRATION.md for the Python stubs.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (row-major, contiguous);
+ *     the library never allocates, frees or synchronises; workspaces are passed in;
+ *   - `stream` is a hipStream_t (as void*); all work is enqueued on it, no hidden syncs;
+ *   - return value 0 = enqueued, negative = rejected (mgnns_last_error() has the text);
+ *   - fp32 everywhere unless an argument says otherwise; int64 token ids as PyTorch makes them.
+ */
+#ifndef MGNNS_HIP_H
+#define MGNNS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mgnns_stream_t;
+
+/* activation codes for mgnns_linear_fwd / mgnns_matmul_fwd */
+#define MGNNS_ACT_NONE   0
+#define MGNNS_ACT_RELU   1   /* F.relu, submodules.py:135 */
+#define MGNNS_ACT_LRELU2 2   /* nn.LeakyReLU(0.2), Multi_GCN_Multihead_att.py:306 */
+
+#define MGNNS_ERR_ARG     (-1)
+#define MGNNS_ERR_LAUNCH  (-2)
+#define MGNNS_ERR_UNSUPP  (-3)
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* mgnns_last_error(void);
+/* ABI version (bumped on any signature change). */
+int mgnns_abi_version(void);
+
+/* ---- a1: text-level GCN channel -------------------------------------------------------
+ * Replaces Text_GCN.Model.forward (models/Text_GCN.py:213-275) including the host graph
+ * construction seq_to_graph / add_seq_edges (Text_GCN.py:142-211):
+ *   per document b: t = non-zero ids of tok[b, :min(T,max_length)];
+ *   edge t_i -> t_j for |i-j| <= ngram (and the self loop), weight edge_w[pmi(t_i,t_j)];
+ *   h'_v = max_e w_e * node_hidden[src_e];  out[b] = relu(sum over distinct v of h'_v).
+ * tok [B,T] int64 (0 = PAD); node_hidden [V,D] (D <= 320); edge_w [n_edge_w] (seq_edge_w
+ * [count,1] flattened); PMI map as CSR over V rows with sorted int32 columns and edge ids
+ * (id 0 / absent = "no PMI entry", utils/pmi.py:86-97); out [B,D].
+ */
+int mgnns_textgcn_fwd(const int64_t* tok, int B, int T,
+                      const float* node_hidden, int V, int D,
+                      const float* edge_w, int n_edge_w,
+                      const int32_t* pmi_row_ptr, const int32_t* pmi_col, const int32_t* pmi_eid,
+                      int ngram, int max_length, float* out, mgnns_stream_t stream);
+
+/* ---- a2: embedding gather ---------------------------------------------------------------
+ * nn.Embedding lookups (Multi_GCN_Multihead_att.py:371; Text_GCN.py:184,206):
+ * out[i,:] = table[idx[i],:], idx [n] int64 in [0,V), table [V,D], out [n,D].
+ */
+int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V, int D,
+                        float* out, mgnns_stream_t stream);
+
+/* ---- a3: adjacency normalisation ----------------------------------------------------------
+ * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].
+ * A, adj [C,C].  Also emits adj as CSR (row_ptr [C+1] int32, col/val [C*C] capacity,
+ * ascending columns) for mgnns_spmm_csr_fwd; csr pointers may be NULL to skip.
+ */
+int mgnns_gen_adj(const float* A, int C, float* adj, float* work /* [C] floats */,
+                  int32_t* csr_row_ptr, int32_t* csr_col, float* csr_val, mgnns_stream_t stream);
+
+/* ---- a4: GraphConvolution = dense X*W then sparse adj*support --------------------------------
+ * mgnns_matmul_fwd:   Y[M,N] = act(X[M,K] * W[K,N])      (GraphConvolution.weight layout
+ *                     [in,out], Multi_GCN_Multihead_att.py:53)
+ * mgnns_spmm_csr_fwd: Y[i,:] = act(sum_p val[p] * X[col[p],:]), p in row i   (MODEL:54 with
+ *                     the adjacency in CSR; F % 4 == 0)
+ */
+int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float* Y, int act,
+                     mgnns_stream_t stream);
+int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
+                       const float* X, int F, float* Y, int act, mgnns_stream_t stream);
+
+/* ---- nn.Linear -------------------------------------------------------------------------------
+ * Y[M,N] = act(X[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N]);  bias/residual may be NULL.
+ * Serves every nn.Linear / Conv1d(k=1) on the path (MODEL:78-82,320-335; submodules.py:24-26,
+ * 34,126-127) and the read-out pooled*G^T (MODEL:474,500) with W = G [C,2048].
+ */
+int mgnns_linear_fwd(const float* X, int M, int K, const float* W, const float* bias, int N,
+                     const float* residual, float* Y, int act, mgnns_stream_t stream);
+
+/* ---- a5+a6: image memory bank + global max-pool, one pass over the feature map ------------------
+ * get_img_{object,place}_memory_bank (MODEL:400-428) fused with MaxPool2d(14,14) (MODEL:454-455):
+ *   bank[b,p,:] = W * feat[b,:,p] + bias    feat [B,K,P] (NCHW map viewed [B,2048,196])
+ *   pooled[b,k] = max_p feat[b,k,p]
+ * Wt is the Linear weight TRANSPOSED and padded: [K, ldw] with ldw >= N, ldw % 16 == 0, columns
+ * N..ldw-1 zero (build it once per weight version with mgnns_transpose_pad).  N <= 304, P <= 208,
+ * K % 16 == 0.  bank [B,P,N]; pooled [B,K] (NULL to skip).
+ */
+int mgnns_imgbank_pool_fwd(const float* feat, int B, int K, int P,
+                           const float* Wt, int ldw, const float* bias, int N,
+                           float* bank, float* pooled, mgnns_stream_t stream);
+/* out[c, r] = in[r, c] for r < rows, c < cols; out is [cols, ld] with zero padding. */
+int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld, mgnns_stream_t stream);
+
+/* ---- a7: label-query attention core -----------------------------------------------------------------
+ * The element-wise "attention" of Attention.forward (MODEL:101-131) between the projections:
+ *   x[b,l,h*dh+d] = softmax_d(Q[l,h,d]*K[b,h,d]/sqrt(dh)) * V[b,h,d]
+ * Q [NLQ,hid], K,V [B,hid] (already through w_q/w_k/w_v), x [B,NLQ,hid]; hid = n_heads*dh, dh <= 64.
+ * Replaces the B-iteration torch.cat loop (MODEL:114-115).
+ */
+int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
+                              int n_heads, int dh, float* x, mgnns_stream_t stream);
+
+/* ---- a8: single-query multi-head attention, K/V projection fused ---------------------------------------
+ * MultiHeadAttention.forward + ScaledDotProductAttention.forward (submodules.py:55-119) for len_q == 1,
+ * up to (not including) fc:  per (b,h)
+ *   s[l] = qh[b,h,:] . (Wk_h bank[b,l,:] + bk_h) / sqrt(dk);  s[l] = -inf where mask[b,l] == 0
+ *   p = softmax_l(s);  o[b,h,:] = sum_l p[l] (Wv_h bank[b,l,:] + bv_h)
+ * K and V are never written to memory.  qh [B,H*dk] (already through w_qs); bank [B,L,D];
+ * mask [B,L] float or NULL; Wk,Wv [H*dk, D]; o [B,H*dk]; attn [H*B, L] (row h*B+b, submodules.py:72-78)
+ * or NULL.  dk == 128, D <= 320, L <= 208.
+ */
+int mgnns_sq_mha_core_fwd(const float* qh, const float* bank, const float* mask,
+                          int B, int L, int D, int H, int dk,
+                          const float* Wk, const float* bk, const float* Wv, const float* bv,
+                          float* o, float* attn, mgnns_stream_t stream);
+
+/* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
+ * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.
+ */
+int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
+                        float eps, float* y, mgnns_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGNNS_HIP_H */

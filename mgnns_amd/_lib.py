@@ -1,0 +1,67 @@
+"""ctypes binding of libmgnns_hip.so (include/mgnns_hip.h).
+
+The library is required: there is no CPU or PyTorch fallback for any operator.  `lib()`
+raises if the shared object has not been built (python -m mgnns_amd.build).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
+ABI_VERSION = 1
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+
+# name -> argtypes, in the order of include/mgnns_hip.h
+SIGNATURES = {
+    "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
+    "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
+    "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P],
+    "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
+    "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
+    "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
+    "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
+    "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mgnns_sq_mha_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
+}
+
+_lib = None
+
+
+class MgnnsLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MgnnsLibraryError(
+            "%s is missing: the HIP extension is mandatory (no CPU/PyTorch fallback exists). "
+            "Build it with `python -m mgnns_amd.build`." % LIB_PATH)
+    import torch  # noqa: F401  -- loads libamdhip64 first so the kernels share PyTorch's HIP runtime
+    L = ctypes.CDLL(LIB_PATH)
+    L.mgnns_last_error.restype = ctypes.c_char_p
+    L.mgnns_last_error.argtypes = []
+    L.mgnns_abi_version.restype = _I
+    L.mgnns_abi_version.argtypes = []
+    if L.mgnns_abi_version() != ABI_VERSION:
+        raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    for name, args in SIGNATURES.items():
+        fn = getattr(L, name)      # AttributeError if the symbol is missing
+        fn.restype = _I
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib().mgnns_last_error().decode()))

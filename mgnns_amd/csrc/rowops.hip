@@ -1,0 +1,156 @@
+// Row-wise / gather kernels: embedding gather, custom LayerNorm, label-attention core,
+// transpose-with-padding (weight layout prep).
+#include "common.hpp"
+
+namespace {
+
+// ---- embedding gather: one wave per row, 16-B lanes when D % 4 == 0 -------------------------
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ idx, int64_t n,
+                                                        const float* __restrict__ table, int V, int D,
+                                                        float* __restrict__ out, int vec) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t r = row0; r < n; r += stride) {
+        int64_t id = idx[r];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // clamped; the wrapper validates ranges
+        const float* src = table + id * D;
+        float* dst = out + r * D;
+        if (vec) {
+            for (int c = lane; c < D / 4; c += 64)
+                reinterpret_cast<f32x4*>(dst)[c] = reinterpret_cast<const f32x4*>(src)[c];
+        } else {
+            for (int c = lane; c < D; c += 64) dst[c] = src[c];
+        }
+    }
+}
+
+// ---- custom LayerNorm: one wave per row (submodules.py:153-156) ------------------------------
+// mean over D, UNBIASED std (divide by D-1), eps added to std.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int D,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * D;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float var = wave_sum(q) / (float)(D - 1);
+    const float inv = 1.0f / (sqrtf(var) + eps);
+    float* yr = y + (size_t)r * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < D) yr[c] = gamma[c] * (v[i] - mean) * inv + beta[c];
+    }
+}
+
+// ---- label attention core (MODEL:101-131): one wave per (b, l, h), lanes over dh <= 64 ---------
+__global__ __launch_bounds__(256) void label_attn_core_kernel(const float* __restrict__ Q,
+                                                              const float* __restrict__ K,
+                                                              const float* __restrict__ V, int B, int NLQ,
+                                                              int n_heads, int dh, float inv_scale,
+                                                              float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)B * NLQ * n_heads;
+    if (item >= total) return;
+    const int h = (int)(item % n_heads);
+    const int l = (int)((item / n_heads) % NLQ);
+    const int b = (int)(item / ((int64_t)n_heads * NLQ));
+    const int hid = n_heads * dh;
+    const bool on = lane < dh;
+    const float e = on ? Q[(size_t)l * hid + h * dh + lane] * K[(size_t)b * hid + h * dh + lane] * inv_scale
+                       : -INFINITY;
+    const float m = wave_max(e);
+    const float p = on ? expf(e - m) : 0.f;
+    const float z = wave_sum(p);
+    if (on) x[((size_t)b * NLQ + l) * hid + h * dh + lane] = (p / z) * V[(size_t)b * hid + h * dh + lane];
+}
+
+// ---- out[c*ld + r] = in[r*cols + c], zero padded to ld ------------------------------------------
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, int rows, int cols,
+                                                            float* __restrict__ out, int ld) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;   // out row = c, out col = r
+        if (c < cols && r < ld) out[(size_t)c * ld + r] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V, int D,
+                                   float* out, mgnns_stream_t stream) {
+    MG_REQUIRE(idx && table && out, "mgnns_embedding_fwd: null pointer");
+    MG_REQUIRE(n >= 0 && V > 0 && D > 0, "mgnns_embedding_fwd: bad dims n=%lld V=%d D=%d", (long long)n, V, D);
+    if (n == 0) return 0;
+    const int vec = (D % 4 == 0) && mg_aligned16(table) && mg_aligned16(out);
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, n, table,
+                       V, D, out, vec);
+    MG_CHECK_LAUNCH("mgnns_embedding_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
+                                   float eps, float* y, mgnns_stream_t stream) {
+    MG_REQUIRE(x && gamma && beta && y, "mgnns_layernorm_fwd: null pointer");
+    MG_REQUIRE(rows >= 0 && D > 1 && D <= 1024, "mgnns_layernorm_fwd: D=%d out of range (2..1024)", D);
+    if (rows == 0) return 0;
+    dim3 grid((rows + 3) / 4);
+    if (D <= 320)
+        hipLaunchKernelGGL(layernorm_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, D, gamma, beta, eps, y);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, D, gamma, beta, eps, y);
+    MG_CHECK_LAUNCH("mgnns_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
+                                         int n_heads, int dh, float* x, mgnns_stream_t stream) {
+    MG_REQUIRE(Q && K && V && x, "mgnns_label_attn_core_fwd: null pointer");
+    MG_REQUIRE(B >= 0 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64,
+               "mgnns_label_attn_core_fwd: bad dims B=%d NLQ=%d heads=%d dh=%d (dh<=64)", B, NLQ, n_heads, dh);
+    if (B == 0) return 0;
+    const int64_t total = (int64_t)B * NLQ * n_heads;
+    hipLaunchKernelGGL(label_attn_core_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       Q, K, V, B, NLQ, n_heads, dh, 1.0f / sqrtf((float)dh), x);
+    MG_CHECK_LAUNCH("mgnns_label_attn_core_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld,
+                                   mgnns_stream_t stream) {
+    MG_REQUIRE(in && out, "mgnns_transpose_pad: null pointer");
+    MG_REQUIRE(rows > 0 && cols > 0 && ld >= rows, "mgnns_transpose_pad: bad dims rows=%d cols=%d ld=%d", rows, cols, ld);
+    dim3 grid((cols + 31) / 32, (ld + 31) / 32);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows, cols, out, ld);
+    MG_CHECK_LAUNCH("mgnns_transpose_pad");
+    return 0;
+}

@@ -1,0 +1,214 @@
+"""Operator wrappers: torch CUDA tensors in, torch CUDA tensors out, all arithmetic in
+libmgnns_hip.so on the caller's current stream.  Shape / dtype / device / contiguity are
+validated here (the reference's convention is Python exceptions); nothing in this file
+computes.
+"""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU2 = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float32, ndim=None):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: mgnns_amd operators run on the GPU only (no CPU path)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must be %d-d, got shape %s" % (name, ndim, tuple(t.shape)))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---- nn.Linear / matmul ---------------------------------------------------------------
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None):
+    """act(x @ weight.T + bias) (+ residual); x [..., K], weight [N, K]."""
+    K = x.shape[-1]
+    x2 = _chk(x.reshape(-1, K), "x")
+    _chk(weight, "weight", ndim=2)
+    if weight.shape[1] != K:
+        raise ValueError("weight %s does not match x[..., %d]" % (tuple(weight.shape), K))
+    N = weight.shape[0]
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+    y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual.reshape(-1, N), "residual")
+        if residual.shape[0] != x2.shape[0]:
+            raise ValueError("residual rows mismatch")
+    L = _lib.lib()
+    _lib.check(L.mgnns_linear_fwd(_p(x2), x2.shape[0], K, _p(weight), _p(bias), N, _p(residual), _p(y), act,
+                                  _stream()), "mgnns_linear_fwd")
+    return y.view(*x.shape[:-1], N)
+
+
+def matmul(x, w, act=ACT_NONE):
+    """act(x @ w); x [M, K], w [K, N] (GraphConvolution weight layout)."""
+    _chk(x, "x", ndim=2)
+    _chk(w, "w", ndim=2)
+    if x.shape[1] != w.shape[0]:
+        raise ValueError("matmul shapes %s x %s" % (tuple(x.shape), tuple(w.shape)))
+    y = torch.empty(x.shape[0], w.shape[1], device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_matmul_fwd(_p(x), x.shape[0], x.shape[1], _p(w), w.shape[1], _p(y), act, _stream()),
+               "mgnns_matmul_fwd")
+    return y
+
+
+# ---- adjacency ----------------------------------------------------------------------------
+def gen_adj(A, want_csr=False):
+    """D^-1/2 A^T D^-1/2 (utils/util.py:421-426).  Returns adj, or (adj, (row_ptr, col, val))."""
+    _chk(A, "A", ndim=2)
+    C = A.shape[0]
+    if A.shape[1] != C:
+        raise ValueError("A must be square")
+    adj = torch.empty_like(A)
+    work = torch.empty(C, device=A.device, dtype=torch.float32)
+    rp = col = val = None
+    if want_csr:
+        rp = torch.empty(C + 1, device=A.device, dtype=torch.int32)
+        col = torch.empty(C * C, device=A.device, dtype=torch.int32)
+        val = torch.empty(C * C, device=A.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_gen_adj(_p(A), C, _p(adj), _p(work), _p(rp), _p(col), _p(val), _stream()), "mgnns_gen_adj")
+    return (adj, (rp, col, val)) if want_csr else adj
+
+
+def spmm_csr(csr, x, act=ACT_NONE):
+    """act(adj @ x) with adj in CSR (row_ptr, col, val); x [C, F]."""
+    rp, col, val = csr
+    _chk(rp, "row_ptr", torch.int32, 1)
+    _chk(col, "col", torch.int32, 1)
+    _chk(val, "val", torch.float32, 1)
+    _chk(x, "x", ndim=2)
+    n = rp.shape[0] - 1
+    y = torch.empty(n, x.shape[1], device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_spmm_csr_fwd(_p(rp), _p(col), _p(val), n, _p(x), x.shape[1], _p(y), act, _stream()),
+               "mgnns_spmm_csr_fwd")
+    return y
+
+
+# ---- gathers -------------------------------------------------------------------------------
+def embedding(idx, table):
+    _chk(idx, "idx", torch.int64)
+    _chk(table, "table", ndim=2)
+    out = torch.empty(*idx.shape, table.shape[1], device=table.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_embedding_fwd(_p(idx), idx.numel(), _p(table), table.shape[0], table.shape[1], _p(out),
+                                     _stream()), "mgnns_embedding_fwd")
+    return out
+
+
+# ---- text GCN --------------------------------------------------------------------------------
+def textgcn(tok, node_hidden, edge_w, pmi_dev, ngram, max_length=100):
+    """Text_GCN.Model.forward (Text_GCN.py:213-275): tok [B,T] int64 -> [B,D]."""
+    _chk(tok, "doc_ids", torch.int64, 2)
+    _chk(node_hidden, "node_hidden.weight", ndim=2)
+    ew = _chk(edge_w.reshape(-1), "seq_edge_w.weight")
+    rp, col, eid = pmi_dev
+    _chk(rp, "pmi row_ptr", torch.int32, 1)
+    _chk(col, "pmi col", torch.int32, 1)
+    _chk(eid, "pmi eid", torch.int32, 1)
+    B, T = tok.shape
+    V, D = node_hidden.shape
+    if rp.shape[0] != V + 1:
+        raise ValueError("PMI map has %d rows, vocabulary has %d" % (rp.shape[0] - 1, V))
+    out = torch.empty(B, D, device=tok.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_textgcn_fwd(_p(tok), B, T, _p(node_hidden), V, D, _p(ew), ew.shape[0], _p(rp), _p(col),
+                                   _p(eid), int(ngram), int(max_length), _p(out), _stream()), "mgnns_textgcn_fwd")
+    return out
+
+
+# ---- image bank + pool ---------------------------------------------------------------------------
+IMGBANK_LDW = 304
+
+
+def transpose_pad(w, ld):
+    """[rows, cols] -> [cols, ld] transposed, zero padded."""
+    _chk(w, "w", ndim=2)
+    out = torch.empty(w.shape[1], ld, device=w.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_transpose_pad(_p(w), w.shape[0], w.shape[1], _p(out), ld, _stream()), "mgnns_transpose_pad")
+    return out
+
+
+def imgbank_pool(feat, wt, bias, n_out, want_pool=True):
+    """feat [B,K,P]; wt = transpose_pad(liner_img.weight, 304) [K,304] -> bank [B,P,N], pooled [B,K]."""
+    _chk(feat, "feature map", ndim=3)
+    _chk(wt, "wt", ndim=2)
+    B, K, P = feat.shape
+    if wt.shape[0] != K:
+        raise ValueError("wt rows %d != K %d" % (wt.shape[0], K))
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+    bank = torch.empty(B, P, n_out, device=feat.device, dtype=torch.float32)
+    pooled = torch.empty(B, K, device=feat.device, dtype=torch.float32) if want_pool else None
+    L = _lib.lib()
+    _lib.check(L.mgnns_imgbank_pool_fwd(_p(feat), B, K, P, _p(wt), wt.shape[1], _p(bias), n_out, _p(bank),
+                                        _p(pooled), _stream()), "mgnns_imgbank_pool_fwd")
+    return bank, pooled
+
+
+# ---- label attention core ---------------------------------------------------------------------------
+def label_attn_core(Q, K, V, n_heads):
+    _chk(Q, "Q", ndim=2)
+    _chk(K, "K", ndim=2)
+    _chk(V, "V", ndim=2)
+    NLQ, hid = Q.shape
+    B = K.shape[0]
+    if K.shape[1] != hid or V.shape != K.shape or hid % n_heads:
+        raise ValueError("label attention shapes Q%s K%s V%s" % (tuple(Q.shape), tuple(K.shape), tuple(V.shape)))
+    x = torch.empty(B, NLQ, hid, device=K.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_label_attn_core_fwd(_p(Q), _p(K), _p(V), B, NLQ, n_heads, hid // n_heads, _p(x), _stream()),
+               "mgnns_label_attn_core_fwd")
+    return x
+
+
+# ---- single-query MHA core -------------------------------------------------------------------------------
+def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
+    _chk(qh, "qh", ndim=2)
+    _chk(bank, "memory bank", ndim=3)
+    B, L_, D = bank.shape
+    if qh.shape != (B, n_head * d_kv):
+        raise ValueError("qh shape %s, expected %s" % (tuple(qh.shape), (B, n_head * d_kv)))
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    for n, t in (("w_ks.weight", wk), ("w_vs.weight", wv)):
+        _chk(t, n, ndim=2)
+        if t.shape != (n_head * d_kv, D):
+            raise ValueError("%s shape %s" % (n, tuple(t.shape)))
+    o = torch.empty(B, n_head * d_kv, device=bank.device, dtype=torch.float32)
+    attn = torch.empty(n_head * B, 1, L_, device=bank.device, dtype=torch.float32) if want_attn else None
+    L = _lib.lib()
+    _lib.check(L.mgnns_sq_mha_core_fwd(_p(qh), _p(bank), _p(mask), B, L_, D, n_head, d_kv, _p(wk), _p(bk), _p(wv),
+                                       _p(bv), _p(o), _p(attn), _stream()), "mgnns_sq_mha_core_fwd")
+    return o, attn
+
+
+def layernorm(x, gamma, beta, eps=1e-6):
+    D = x.shape[-1]
+    x2 = _chk(x.reshape(-1, D), "x")
+    _chk(gamma, "gamma", ndim=1)
+    _chk(beta, "beta", ndim=1)
+    y = torch.empty_like(x2)
+    L = _lib.lib()
+    _lib.check(L.mgnns_layernorm_fwd(_p(x2), x2.shape[0], D, _p(gamma), _p(beta), float(eps), _p(y), _stream()),
+               "mgnns_layernorm_fwd")
+    return y.view(x.shape)

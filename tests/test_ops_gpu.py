@@ -1,0 +1,192 @@
+"""Per-operator parity: HIP kernels (through the C ABI) vs the CPU oracle and the committed
+golden vectors.  fp32 tolerance: 1e-5 relative per op unless stated (summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+from mgnns_amd import ops, synth
+from oracle import golden_inputs as GI
+from oracle import restatement as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.as_tensor(x).to(DEV).contiguous()
+
+
+def dparams(p):
+    return {k: v.to(DEV).contiguous() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 300, 7), (7, 300, 300), (256, 1024, 300), (80, 300, 1024), (365, 1024, 2048),
+                                   (5, 365, 300), (33, 37, 65), (256, 2048, 365)])
+def test_linear_and_matmul(M, K, N):
+    rs = np.random.RandomState(M * 7 + K + N)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    w = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    ref = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    y = ops.linear(dev(x), dev(w), dev(b)).cpu()
+    assert H.relerr(y, ref) < 2e-6
+    y = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_RELU, residual=dev(res)).cpu()
+    assert H.relerr(y, torch.relu(ref) + torch.from_numpy(res).double()) < 2e-6
+    y = ops.linear(dev(x), dev(w), None, act=ops.ACT_LRELU2).cpu()
+    assert H.relerr(y, torch.nn.functional.leaky_relu(ref - torch.from_numpy(b).double(), 0.2)) < 2e-6
+    wt = np.ascontiguousarray(w.T)                              # [K,N] layout, asymmetric on purpose
+    y = ops.matmul(dev(x), dev(wt)).cpu()
+    assert H.relerr(y, ref - torch.from_numpy(b).double()) < 2e-6
+
+
+def test_embedding_gather():
+    rs = np.random.RandomState(1)
+    table = rs.standard_normal((1000, 300)).astype(np.float32)
+    idx = rs.randint(0, 1000, size=(7, 53)).astype(np.int64)
+    out = ops.embedding(dev(idx), dev(table)).cpu().numpy()
+    assert np.array_equal(out, table[idx])                      # a gather is bit-exact
+    t2 = rs.standard_normal((50, 7)).astype(np.float32)         # D % 4 != 0 path
+    i2 = rs.randint(0, 50, size=(11,)).astype(np.int64)
+    assert np.array_equal(ops.embedding(dev(i2), dev(t2)).cpu().numpy(), t2[i2])
+
+
+def test_gen_adj_and_csr_against_reference_goldens():
+    g = H.load_golden("adjacency.npz")
+    for tag in ("object", "place"):
+        for t in (3, 4, 5, 6):
+            key = "%s_t%02d" % (tag, t)
+            A = g[key + "_A"]
+            adj, (rp, col, val) = ops.gen_adj(dev(A), want_csr=True)
+            adj = adj.cpu()
+            assert H.relerr(adj, g[key + "_adj"]) < 1e-6
+            # same sparsity pattern as the reference result
+            assert np.array_equal(adj.numpy() != 0, g[key + "_adj"] != 0)
+            rp, col, val = rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+            C = A.shape[0]
+            dense = np.zeros((C, C), np.float32)
+            for i in range(C):
+                cs = col[rp[i]:rp[i + 1]]
+                assert np.all(np.diff(cs) > 0)
+                dense[i, cs] = val[rp[i]:rp[i + 1]]
+            assert np.array_equal(dense, adj.numpy())
+
+
+def test_image_gcn_chain_against_goldens():
+    g = H.load_golden("image_gcn.npz")
+    adjg = H.load_golden("adjacency.npz")
+    p = dparams(H.params_for({"gc1.weight": (300, 1024), "gc2.weight": (1024, 2048)}))
+    proj = torch.from_numpy(GI.gcn_projection())
+    for tag, key in (("object", "object_t04"), ("place", "place_t03")):
+        X, pooled = GI.image_gcn_case(tag)
+        _, csr = ops.gen_adj(dev(adjg[key + "_A"]), want_csr=True)
+        s1 = ops.matmul(dev(X), p["gc1.weight"])
+        h1 = ops.spmm_csr(csr, s1, act=ops.ACT_LRELU2)
+        s2 = ops.matmul(h1, p["gc2.weight"])
+        G = ops.spmm_csr(csr, s2)
+        x = ops.linear(dev(pooled), G)                           # pooled @ G^T
+        assert H.relerr(G.cpu() @ proj, g[tag + "_Gproj"]) < 1e-5
+        assert H.relerr(x.cpu(), g[tag + "_x"]) < 1e-5
+
+
+def test_label_attention_against_goldens():
+    g = H.load_golden("label_attention.npz")
+    lq = dev(g["label_query"])
+    for tag, C in (("object", 80), ("place", 365)):
+        p = dparams(H.params_for(H.label_attention_shapes(tag, C)))
+        key = dev(GI.label_attention_key(tag))
+        a = tag + "_attention."
+        Q = ops.linear(lq, p[a + "w_q.weight"], p[a + "w_q.bias"])
+        K = ops.linear(key, p[a + "w_k.weight"], p[a + "w_k.bias"])
+        V = ops.linear(key, p[a + "w_v.weight"], p[a + "w_v.bias"])
+        x = ops.label_attn_core(Q, K, V, 5)
+        y = ops.linear(x, p[a + "fc.weight"], p[a + "fc.bias"])
+        assert H.maxabs(y.cpu(), g[tag + "_y"]) < 1e-5
+        z = ops.linear(y, p[tag + "_linear_5.weight"], p[tag + "_linear_5.bias"]).reshape(y.shape[0], -1)
+        z = ops.linear(z, p[tag + "_x_linear.weight"], p[tag + "_x_linear.bias"])
+        assert H.maxabs(z.cpu(), g[tag + "_z"]) < 1e-5
+
+
+def test_layernorm_against_golden():
+    g = H.load_golden("layernorm.npz")
+    p = dparams(H.params_for({"ln.gamma": (300,), "ln.beta": (300,)}))
+    y = ops.layernorm(dev(g["x"]), p["ln.gamma"], p["ln.beta"]).cpu()
+    rows = [r for r in range(g["x"].shape[0]) if r != 3]
+    assert H.maxabs(y[rows], g["y"][rows]) < 2e-6
+    # row 3 is constant: (x-mean)/(std+eps) is 0/0-like there and amplifies the rounding of the mean by
+    # 1/eps = 1e6 in the reference itself, so only boundedness is comparable (|y-beta| <= |gamma|*sqrt(D))
+    assert torch.isfinite(y[3]).all()
+    assert float((y[3] - p["ln.beta"].cpu()).abs().max()) <= float(p["ln.gamma"].abs().max()) * 300 ** 0.5
+
+
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_sq_mha_core_against_goldens(Hn, tag, L, masked):
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+    a = name + ".slf_attn."
+    qh = ops.linear(dev(q), p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    o, attn = ops.sq_mha_core(qh, dev(bank), None if mask is None else dev(mask), Hn, 128,
+                              p[a + "w_ks.weight"], p[a + "w_ks.bias"], p[a + "w_vs.weight"], p[a + "w_vs.bias"])
+    assert H.maxabs(attn.cpu(), g[name + "_attn"]) < 1e-5
+    # finish the layer with the remaining ops and compare with the reference layer output
+    y = ops.linear(o, p[a + "fc.weight"], p[a + "fc.bias"], residual=dev(q))
+    y = ops.layernorm(y, p[a + "layer_norm.gamma"], p[a + "layer_norm.beta"])
+    f = name + ".pos_ffn."
+    h1 = ops.linear(y, p[f + "w_1.weight"].squeeze(-1).contiguous(), p[f + "w_1.bias"], act=ops.ACT_RELU)
+    z = ops.linear(h1, p[f + "w_2.weight"].squeeze(-1).contiguous(), p[f + "w_2.bias"], residual=y)
+    out = ops.layernorm(z, p[f + "layer_norm.gamma"], p[f + "layer_norm.beta"])
+    assert H.maxabs(out.cpu(), g[name + "_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("ngram", [1, 4])
+def test_textgcn_against_goldens(ngram):
+    g = H.load_golden("text_gcn.npz")
+    V, count = int(g["V"]), int(g["count"])
+    pmi, _ = synth.synth_pmi(V, per_row=8, seed=int(g["pmi_seed"]))
+    p = dparams(H.params_for({"text_features.node_hidden.weight": (V, 300),
+                              "text_features.seq_edge_w.weight": (count, 1)}))
+    y = ops.textgcn(dev(g["ng%d_tok" % ngram]), p["text_features.node_hidden.weight"],
+                    p["text_features.seq_edge_w.weight"], pmi.device_arrays(DEV), ngram)
+    assert H.relerr(y.cpu(), g["ng%d_out" % ngram]) < 1e-5
+
+
+def test_textgcn_vs_oracle_full_length_and_edge_cases():
+    V, T, B = 5000, 100, 33
+    pmi, count = synth.synth_pmi(V, seed=5)
+    tok, lens, _ = synth.synth_tokens(B, T, V, pmi, seed=11)
+    tok[3] = 0
+    tok[3, 50] = 9                                              # lone token after leading PADs
+    tok[4, ::2] = 0                                             # interleaved PADs
+    tok[5, :] = tok[5, 0]                                       # one distinct token repeated
+    p = H.params_for({"text_features.node_hidden.weight": (V, 300), "text_features.seq_edge_w.weight": (count, 1)})
+    for ngram in (0, 2, 5):
+        ref = R.text_gcn(tok, p["text_features.node_hidden.weight"], p["text_features.seq_edge_w.weight"], pmi, ngram)
+        y = ops.textgcn(dev(tok), dev(p["text_features.node_hidden.weight"]),
+                        dev(p["text_features.seq_edge_w.weight"]), pmi.device_arrays(DEV), ngram)
+        assert H.relerr(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_imgbank_pool_vs_oracle(B):
+    rs = np.random.RandomState(3 + B)
+    feat = np.maximum(rs.standard_normal((B, 2048, 196)), 0).astype(np.float32)
+    w = (0.05 * rs.standard_normal((300, 2048))).astype(np.float32)
+    bias = (0.05 * rs.standard_normal(300)).astype(np.float32)
+    wt = ops.transpose_pad(dev(w), ops.IMGBANK_LDW)
+    assert np.array_equal(wt.cpu().numpy()[:, :300], w.T) and float(wt[:, 300:].abs().max()) == 0.0
+    bank, pooled = ops.imgbank_pool(dev(feat), wt, dev(bias), 300)
+    ref = R.img_memory_bank(torch.from_numpy(feat), torch.from_numpy(w), torch.from_numpy(bias))
+    assert H.relerr(bank.cpu(), ref) < 1e-5
+    assert np.array_equal(pooled.cpu().numpy(), feat.max(axis=2))   # max is exact
+
+
+def test_errors_are_loud():
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    with pytest.raises(RuntimeError, match="d_kv"):
+        ops.sq_mha_core(torch.zeros(1, 64, device=DEV), torch.zeros(1, 4, 300, device=DEV), None, 1, 64,
+                        torch.zeros(64, 300, device=DEV), None, torch.zeros(64, 300, device=DEV), None)
