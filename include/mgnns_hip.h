@@ -69,6 +69,11 @@ int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V
 int mgnns_gen_adj(const float* A, int C, float* adj, float* work /* [C] floats */,
                   int32_t* csr_row_ptr, int32_t* csr_col, float* csr_val, mgnns_stream_t stream);
 
+/* Dense [C,C] -> CSR (ascending columns; col/val capacity C*C): for GraphConvolution.forward(input, adj)
+ * callers that hand over a dense adjacency (MODEL:52). */
+int mgnns_dense_to_csr(const float* M, int C, int32_t* csr_row_ptr, int32_t* csr_col, float* csr_val,
+                       mgnns_stream_t stream);
+
 /* ---- a4: GraphConvolution = dense X*W then sparse adj*support --------------------------------
  * mgnns_matmul_fwd:   Y[M,N] = act(X[M,K] * W[K,N])      (GraphConvolution.weight layout
  *                     [in,out], Multi_GCN_Multihead_att.py:53)

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
     "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P],
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
     "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P],

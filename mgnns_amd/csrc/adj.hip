@@ -155,6 +155,19 @@ extern "C" int mgnns_gen_adj(const float* A, int C, float* adj, float* work, int
     return 0;
 }
 
+extern "C" int mgnns_dense_to_csr(const float* M, int C, int32_t* csr_row_ptr, int32_t* csr_col, float* csr_val,
+                                  mgnns_stream_t stream) {
+    MG_REQUIRE(M && csr_row_ptr && csr_col && csr_val, "mgnns_dense_to_csr: null pointer");
+    MG_REQUIRE(C > 0, "mgnns_dense_to_csr: C=%d", C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_nnz_kernel, dim3((C + 3) / 4), dim3(256), 0, s, M, C, csr_row_ptr);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, csr_row_ptr, C);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((C + 3) / 4), dim3(256), 0, s, M, C, (const int32_t*)csr_row_ptr, csr_col,
+                       csr_val);
+    MG_CHECK_LAUNCH("mgnns_dense_to_csr");
+    return 0;
+}
+
 extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
                                   const float* X, int F, float* Y, int act, mgnns_stream_t stream) {
     MG_REQUIRE(row_ptr && col && val && X && Y, "mgnns_spmm_csr_fwd: null pointer");

@@ -1,0 +1,140 @@
+"""Single-query multi-head fusion blocks with the reference's module surface.
+
+Mirrors models/submodules.py (LayerNorm :142-156, MultiHeadAttention :15-94,
+PositionwiseFeedForward :122-139) and models/moudles.py (MyMultiHeadAttention :198-230,
+MyAnotherMultiHeadAttention :298-324): same class names, constructor arguments, parameter
+names and shapes (so reference checkpoints load with strict=True), same return values.
+The arithmetic is in libmgnns_hip.so; these classes only hold parameters and sequence kernels.
+
+Eval/forward only: the kernels implement no dropout and no backward, so forward() refuses to
+run in training mode instead of silently diverging from the reference.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _require_eval(mod):
+    if mod.training:
+        raise RuntimeError("%s: mgnns_amd implements the eval-mode forward only (dropout/backward are "
+                           "not part of the HIP path); call .eval()" % type(mod).__name__)
+
+
+class LayerNorm(nn.Module):
+    """gamma * (x - mean) / (std_unbiased + eps) + beta  (submodules.py:153-156)."""
+
+    def __init__(self, features, eps=1e-6):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(features))
+        self.beta = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.layernorm(x.contiguous(), self.gamma.detach(), self.beta.detach(), self.eps)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, is_regu=False):
+        super().__init__()
+        if d_k != d_v:
+            raise ValueError("d_k must equal d_v (the reference always passes d_kv for both)")
+        self.n_head, self.d_k, self.d_v, self.is_regu = n_head, d_k, d_v, is_regu
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        nn.init.normal_(self.w_qs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_ks.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_vs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_v)))
+        self.layer_norm = LayerNorm(d_model)
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        nn.init.xavier_normal_(self.fc.weight)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, q, k, v, mask=None):
+        """q [B,1,d]; k = v = memory bank [B,L,d]; mask [B,1,L] or None -> (out [B,1,d], attn [H*B,1,L])."""
+        _require_eval(self)
+        if self.is_regu:
+            raise NotImplementedError("is_regu=True (head-difference regulariser, training only) is not on the HIP path")
+        if q.dim() != 3 or q.shape[1] != 1:
+            raise ValueError("the fusion attention is single-query: q must be [B,1,d], got %s" % (tuple(q.shape),))
+        if k.data_ptr() != v.data_ptr() or k.shape != v.shape:
+            raise ValueError("key and value must be the same memory bank (as at every reference call site)")
+        B = q.shape[0]
+        q2 = q.reshape(B, -1).contiguous()
+        m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
+        qh = ops.linear(q2, self.w_qs.weight.detach(), self.w_qs.bias.detach())
+        o, attn = ops.sq_mha_core(qh, k.contiguous(), m2, self.n_head, self.d_k,
+                                  self.w_ks.weight.detach(), self.w_ks.bias.detach(),
+                                  self.w_vs.weight.detach(), self.w_vs.bias.detach())
+        y = ops.linear(o, self.fc.weight.detach(), self.fc.bias.detach(), residual=q2)
+        y = self.layer_norm(y)
+        return y.view(B, 1, -1), attn
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_in, d_hid, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Conv1d(d_in, d_hid, 1)
+        self.w_2 = nn.Conv1d(d_hid, d_in, 1)
+        self.layer_norm = LayerNorm(d_in)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        _require_eval(self)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        w1 = self.w_1.weight.detach().view(self.w_1.out_channels, self.w_1.in_channels)
+        w2 = self.w_2.weight.detach().view(self.w_2.out_channels, self.w_2.in_channels)
+        h = ops.linear(x2, w1, self.w_1.bias.detach(), act=ops.ACT_RELU)
+        z = ops.linear(h, w2, self.w_2.bias.detach(), residual=x2)
+        return self.layer_norm(z).view(shp)
+
+
+class MyMultiHeadAttention(nn.Module):
+    def __init__(self, n_head, d_model, d_kv, dropout=0.1, need_mask=False, is_regu=False, interaction_type=None):
+        super().__init__()
+        self.need_mask = need_mask
+        self.is_regu = is_regu
+        self.interaction_type = interaction_type
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_kv, d_kv, dropout=dropout, is_regu=is_regu)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_model, dropout=dropout)
+
+    def forward(self, q, k, v, mask=None):
+        """q [B,d] or [B,1,d]; k,v [B,L,d]; mask [B,L] -> (out [B,d], attn [H*B,1,L])  (moudles.py:207-230)."""
+        if q.dim() == 2:
+            q = q.unsqueeze(1)
+        if mask is not None:
+            mask = mask.unsqueeze(1)
+        if self.need_mask:
+            assert mask is not None, 'Please pass the attention mask to the multi-head'
+        enc_output, enc_slf_attn = self.slf_attn(q, k, v, mask)
+        enc_output = self.pos_ffn(enc_output)
+        return enc_output.squeeze(1), enc_slf_attn
+
+
+class _AnotherMultiHeadAttention(nn.Module):
+    """Parameter holder of moudles.py:232-296 (constructed by the reference, never called)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
+        super().__init__()
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        self.layer_norm = LayerNorm(d_model)
+        self.fc = nn.Linear(n_head * d_v, d_model)
+
+
+class MyAnotherMultiHeadAttention(nn.Module):
+    """Dead branch of the reference (Multi_GCN_Multihead_att.py:517-519,530-532 are commented out);
+    kept only so that state_dict keys/shapes match for strict checkpoint loading."""
+
+    def __init__(self, n_head, d_model, d_kv, dropout=0.1, need_mask=False, interaction_type=None):
+        super().__init__()
+        self.need_mask = need_mask
+        self.slf_attn = _AnotherMultiHeadAttention(n_head, d_model, d_kv, d_kv, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_model, dropout=dropout)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("MyAnotherMultiHeadAttention is never called by the reference forward")

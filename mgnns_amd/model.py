@@ -1,0 +1,355 @@
+"""Multi_GCN_Multihead_Att with the reference's nn.Module surface
+(models/Multi_GCN_Multihead_att.py): same class names, constructor / forward signatures,
+parameter names and shapes, so the reference's training script and
+engine can construct it, load its checkpoints with strict=True and call
+``model(text, text_lens, text_mask, object_img, place_img, object_inp, place_inp)``
+(engine/Multi_GCN_Multihead_Att_engine.py:825) unchanged.
+
+All forward arithmetic of the hot path runs in libmgnns_hip.so.  Eval / forward only.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from . import ops
+from .adjacency import gen_A, gen_adj_csr
+from .fusion import MyAnotherMultiHeadAttention, MyMultiHeadAttention
+from .text_gcn import Model as Text_GCN_Model
+
+LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
+
+
+class GraphConvolution(nn.Module):
+    """support = X W (dense, MFMA) then adj @ support (MODEL:30-63).  `adj` may be the dense
+    normalised adjacency (it is turned into CSR on the fly) or a (row_ptr, col, val) CSR triple."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = Parameter(torch.Tensor(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.Tensor(1, 1, out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / np.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, adj, act=ops.ACT_NONE):
+        if self.bias is not None:
+            raise NotImplementedError("GraphConvolution(bias=True) is never built by the reference model")
+        support = ops.matmul(input.float().contiguous(), self.weight.detach())
+        if torch.is_tensor(adj):
+            adj = ops.dense_to_csr(adj.contiguous())
+        return ops.spmm_csr(adj, support, act=act)
+
+    def __repr__(self):
+        return '%s (%d -> %d)' % (self.__class__.__name__, self.in_features, self.out_features)
+
+
+class Attention(nn.Module):
+    """Label-GloVe query x image-GCN scores "attention" (MODEL:65-133)."""
+
+    def __init__(self, hid_dim, image_dim, n_heads, dropout):
+        super().__init__()
+        self.hid_dim = hid_dim
+        self.n_heads = n_heads
+        assert hid_dim % n_heads == 0
+        self.w_q = nn.Linear(hid_dim, hid_dim)
+        self.w_k = nn.Linear(image_dim, hid_dim)
+        self.w_v = nn.Linear(image_dim, hid_dim)
+        self.fc = nn.Linear(hid_dim, hid_dim)
+        self.do = nn.Dropout(dropout)
+
+    def forward(self, query, key, value, mask=None):
+        """query [NLQ,hid] (label GloVe, any float dtype), key = value [B,image_dim] -> [B,NLQ,hid]."""
+        if self.training:
+            raise RuntimeError("Attention: eval-mode forward only on the HIP path; call .eval()")
+        if mask is not None:
+            raise NotImplementedError("Attention(mask=...) is never used by the reference forward")
+        if key.data_ptr() != value.data_ptr():
+            raise ValueError("key and value must be the same tensor (as at MODEL:476,503)")
+        Q = ops.linear(query.float().contiguous(), self.w_q.weight.detach(), self.w_q.bias.detach())
+        K = ops.linear(key.contiguous(), self.w_k.weight.detach(), self.w_k.bias.detach())
+        V = ops.linear(key.contiguous(), self.w_v.weight.detach(), self.w_v.bias.detach())
+        x = ops.label_attn_core(Q, K, V, self.n_heads)
+        return ops.linear(x, self.fc.weight.detach(), self.fc.bias.detach())
+
+
+class _NoTrunk(nn.Module):
+    """Placeholder when no CNN trunk is supplied: the model then only accepts precomputed
+    [B,2048,h,w] feature maps (the benchmark entry)."""
+
+    def forward(self, x):
+        raise RuntimeError("no CNN trunk was given to Multi_GCN_Multihead_Att; pass [B,2048,14,14] feature maps")
+
+
+def _trunk(m):
+    if m is None:
+        return _NoTrunk()
+    return nn.Sequential(m.conv1, m.bn1, m.relu, m.maxpool, m.layer1, m.layer2, m.layer3, m.layer4)
+
+
+class Multi_GCN_Multihead_Att(nn.Module):
+    def __init__(self, opt, num_labels, text_model, object_model, place_model,
+                 object_num_classes, place_num_classes, object_t=0, place_t=0, in_channel=300,
+                 object_adj_file=None, place_adj_file=None, label_glove=None):
+        super().__init__()
+        self.emb_path = opt['emb_path']
+        self.bidirectional = opt['bidirectional']
+        self.num_directions = 2 if self.bidirectional else 1
+        self.hidden_size = opt['hidden_size']
+        self.bi_hidden_size = self.num_directions * opt['hidden_size']
+        opt['bi_hidden_size'] = self.bi_hidden_size
+        self.d_model = self.bi_hidden_size
+        self.pad_idx = 0
+        self.stack_num = opt['stack_num']
+        self.n_head = opt['n_head']
+        self.d_kv = opt['d_kv']
+        self.is_regu = opt['is_regu']
+
+        self.embedding = nn.Embedding(opt['vocab_size'], opt['emb_size'], padding_idx=self.pad_idx)
+        self.init_weights(opt['emb_type'], self.pad_idx)
+        rnn_kw = dict(input_size=opt['emb_size'], hidden_size=opt['hidden_size'], num_layers=opt['num_layers'],
+                      bidirectional=opt['bidirectional'], batch_first=True, dropout=opt['dropout'])
+        self.rnn = nn.GRU(**rnn_kw)          # constructed, never used (MODEL:172-177,377)
+        self.lstm = nn.LSTM(**rnn_kw)
+        self.object_gate = nn.Linear(self.bi_hidden_size * 2, self.bi_hidden_size)   # dead (MODEL:548-556)
+        self.place_gate = nn.Linear(self.bi_hidden_size * 2, self.bi_hidden_size)
+
+        def stack(need_mask, kind):
+            return nn.ModuleList([MyMultiHeadAttention(self.n_head, self.d_model, self.d_kv, dropout=opt['dropout'],
+                                                       need_mask=need_mask, is_regu=self.is_regu, interaction_type=kind)
+                                  for _ in range(self.stack_num)])
+
+        self.img_object_text_multi_head_att = stack(True, 'img_object_text')
+        self.text_object_text_multi_head_att = MyAnotherMultiHeadAttention(
+            self.n_head, self.d_model, self.d_kv, dropout=opt['dropout'], need_mask=False,
+            interaction_type='text_object_text')
+        self.img_place_text_multi_head_att = stack(True, 'img_place_text')
+        self.text_place_text_multi_head_att = MyAnotherMultiHeadAttention(
+            self.n_head, self.d_model, self.d_kv, dropout=opt['dropout'], need_mask=False,
+            interaction_type='text_place_text')
+        self.text_img_object_multi_head_att = stack(False, 'text_img_object')
+        self.text_img_place_multi_head_att = stack(False, 'text_img_place')
+
+        self.liner_img_object = nn.Linear(2048, self.bi_hidden_size)
+        self.liner_img_place = nn.Linear(2048, self.bi_hidden_size)
+
+        self.text_features = text_model
+        self.object_features = _trunk(object_model)
+        self.place_features = _trunk(place_model)
+
+        self.num_labels = num_labels
+        self.object_num_classes = object_num_classes
+        self.place_num_classes = place_num_classes
+        self.object_t = object_t
+        self.place_t = place_t
+
+        self.pooling = nn.MaxPool2d(14, 14)   # kept for the surface; the pool is fused into the bank kernel
+        self.gc1 = GraphConvolution(in_channel, 1024)
+        self.gc2 = GraphConvolution(1024, 2048)
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        self.tanh = nn.Tanh()
+        self.relu = nn.ReLU()
+        self.object_attention = Attention(hid_dim=300, image_dim=self.object_num_classes, n_heads=5, dropout=0.5)
+        self.place_attention = Attention(hid_dim=300, image_dim=self.place_num_classes, n_heads=5, dropout=0.5)
+
+        self.object_linear_1 = nn.Linear(2048, 1024)    # dead
+        self.object_linear_2 = nn.Linear(1024, 512)     # dead
+        self.object_linear_3 = nn.Linear(512, 256)      # dead
+        self.object_linear_5 = nn.Linear(300, 100)
+        self.object_x_linear = nn.Linear(700, 300)
+        self.place_linear_1 = nn.Linear(2048, 1024)     # dead
+        self.place_linear_2 = nn.Linear(1024, 512)      # dead
+        self.place_linear_3 = nn.Linear(512, 256)       # dead
+        self.place_linear_5 = nn.Linear(300, 100)
+        self.place_x_linear = nn.Linear(700, 300)
+        self.dropout = nn.Dropout(0.5)
+        self.multi_linear_1 = nn.Linear(1200, self.bi_hidden_size)
+        self.multi_linear_2 = nn.Linear(self.bi_hidden_size, num_labels)
+
+        self.object_A = Parameter(self._init_A(object_num_classes, object_t, object_adj_file))
+        self.place_A = Parameter(self._init_A(place_num_classes, place_t, place_adj_file))
+
+        self.image_normalization_mean = [0.485, 0.456, 0.406]
+        self.image_normalization_std = [0.229, 0.224, 0.225]
+
+        # label-GloVe query: a module-level pickle load in the reference (MODEL:19-27)
+        self.register_buffer('label_query', None, persistent=False)
+        self._load_label_query(label_glove if label_glove is not None else opt.get('label_glove'))
+        self._wt_cache = {}
+
+    # ---- construction helpers -------------------------------------------------------------------
+    @staticmethod
+    def _init_A(num_classes, t, adj_file):
+        if adj_file is None:          # weights arrive through load_state_dict
+            return torch.eye(num_classes)
+        adj, _ = gen_A(num_classes, t, adj_file)
+        return torch.from_numpy(adj).float()
+
+    def _load_label_query(self, src):
+        if torch.is_tensor(src) or isinstance(src, np.ndarray):
+            self.label_query = torch.as_tensor(src).float()
+            return
+        paths = [src] if src else list(LABEL_GLOVE_CANDIDATES)
+        for p in paths:
+            if p and os.path.exists(p):
+                with open(p, 'rb') as f:
+                    self.label_query = torch.from_numpy(np.array(pickle.load(f))).float()
+                return
+
+    def set_label_query(self, q):
+        self.label_query = torch.as_tensor(q).float().to(self.embedding.weight.device)
+
+    def init_weights(self, emb_type, pad_idx):
+        if emb_type == 'random':
+            self.embedding.weight.data.uniform_(-0.1, 0.1)
+        else:
+            with open(self.emb_path, 'rb') as f:
+                weights = pickle.load(f)
+            self.embedding.weight.data = torch.Tensor(weights)
+        self.embedding.weight.data[pad_idx] = 0
+
+    # ---- forward pieces ----------------------------------------------------------------------------
+    def get_text_memory_bank(self, text, text_lens, return_last_state=True):
+        """Embedding gather (HIP) + packed 2-layer BiLSTM (MODEL:366-398)."""
+        batch_size, max_text_len = list(text.size())
+        text_embed = ops.embedding(text.long().contiguous(), self.embedding.weight.detach())
+        packed = nn.utils.rnn.pack_padded_sequence(text_embed, text_lens.cpu(), batch_first=True, enforce_sorted=False)
+        memory_bank, (enc_final_state, c_n) = self.lstm(packed)
+        memory_bank, _ = nn.utils.rnn.pad_packed_sequence(memory_bank, batch_first=True, total_length=max_text_len)
+        memory_bank = memory_bank.contiguous()
+        assert memory_bank.size() == torch.Size([batch_size, max_text_len, self.bi_hidden_size])
+        if self.bidirectional:
+            last = torch.cat((enc_final_state[-1, :, :], enc_final_state[-2, :, :]), 1)
+        else:
+            last = enc_final_state[-1, :, :]
+        if return_last_state:
+            return memory_bank, last
+        return memory_bank
+
+    def _wt(self, lin):
+        """Linear(2048, 300).weight transposed + padded for the bank kernel, cached per weight version."""
+        w = lin.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._wt_cache.get(id(lin))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.transpose_pad(w.detach().contiguous(), ops.IMGBANK_LDW))
+            self._wt_cache[id(lin)] = hit
+        return hit[1]
+
+    def _img_bank_and_pool(self, feats, lin):
+        B = feats.shape[0]
+        f3 = feats.float().contiguous().view(B, feats.shape[1], -1)
+        return ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
+
+    def get_img_object_memory_bank(self, img_object_feats):
+        return self._img_bank_and_pool(img_object_feats, self.liner_img_object)[0]
+
+    def get_img_place_memory_bank(self, img_place_feats):
+        return self._img_bank_and_pool(img_place_feats, self.liner_img_place)[0]
+
+    def _channel(self, feats, lin, A, inp, attention, linear_5, x_linear):
+        """One image channel (MODEL:450-479 / 482-506): bank, pooled read-out through the label GCN,
+        label attention, 300->100->700->300 tail."""
+        bank, pooled = self._img_bank_and_pool(feats, lin)
+        _, csr = gen_adj_csr(A)
+        x = self.gc1(inp[0].float().contiguous(), csr, act=ops.ACT_LRELU2)
+        G = self.gc2(x, csr)                                     # [C, 2048]
+        x = ops.linear(pooled, G)                                # pooled @ G^T -> [B, C]
+        att = attention(query=self.label_query, key=x, value=x)  # [B, NLQ, 300]
+        att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(feats.shape[0], -1)
+        att = ops.linear(att, x_linear.weight.detach(), x_linear.bias.detach())
+        return bank, att
+
+    def _features(self, trunk, x):
+        if x.dim() == 4 and x.shape[1] == 2048:
+            return x              # precomputed trunk output
+        return trunk(x)
+
+    def forward(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp,
+                return_last_state=True):
+        if self.training:
+            raise RuntimeError("Multi_GCN_Multihead_Att: eval-mode forward only on the HIP path; call .eval()")
+        if self.label_query is None:
+            raise RuntimeError("label query missing: pass label_glove=... / opt['label_glove'], call "
+                               "set_label_query(), or run from a directory holding %s" % (LABEL_GLOVE_CANDIDATES,))
+        if self.label_query.device != text.device:
+            self.label_query = self.label_query.to(text.device)
+        with torch.no_grad():
+            text_feature = self.text_features(text)
+            text_memory_bank, _ = self.get_text_memory_bank(text, text_lens, return_last_state)
+            self.object_feature = self._features(self.object_features, object_feature)
+            img_object_memory_bank, object_x_attention = self._channel(
+                self.object_feature, self.liner_img_object, self.object_A, object_inp,
+                self.object_attention, self.object_linear_5, self.object_x_linear)
+            self.place_feature = self._features(self.place_features, place_feature)
+            img_place_memory_bank, place_x_attention = self._channel(
+                self.place_feature, self.liner_img_place, self.place_A, place_inp,
+                self.place_attention, self.place_linear_5, self.place_x_linear)
+
+            text_mask = text_mask.float().contiguous()
+            iot = object_x_attention
+            for layer in self.img_object_text_multi_head_att:
+                iot, _ = layer(q=iot, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
+            ipt = place_x_attention
+            for layer in self.img_place_text_multi_head_att:
+                ipt, _ = layer(q=ipt, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
+            tio = text_feature
+            for layer in self.text_img_object_multi_head_att:
+                tio, _ = layer(q=tio, k=img_object_memory_bank, v=img_object_memory_bank)
+            tip = text_feature
+            for layer in self.text_img_place_multi_head_att:
+                tip, _ = layer(q=tip, k=img_place_memory_bank, v=img_place_memory_bank)
+
+            multi_feature = torch.cat([tio, tip, iot, ipt], dim=1)
+            multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
+                                       self.multi_linear_1.bias.detach())
+            return ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
+
+    def get_config_optim(self, lr, lrp):
+        return [
+            {'params': self.text_features.parameters(), 'lr': lr * 10},
+            {'params': self.object_features.parameters(), 'lr': lr * lrp},
+            {'params': self.place_features.parameters(), 'lr': lr * lrp},
+            {'params': self.gc1.parameters(), 'lr': lr},
+            {'params': self.gc2.parameters(), 'lr': lr},
+            {'params': self.object_attention.parameters(), 'lr': lr},
+            {'params': self.place_attention.parameters(), 'lr': lr},
+            {'params': self.lstm.parameters(), 'lr': lr * 10},
+            {'params': self.img_object_text_multi_head_att.parameters(), 'lr': lr},
+            {'params': self.img_place_text_multi_head_att.parameters(), 'lr': lr},
+            {'params': self.text_img_object_multi_head_att.parameters(), 'lr': lr},
+            {'params': self.text_img_place_multi_head_att.parameters(), 'lr': lr},
+        ]
+
+
+def Text_model(vocab, edges_mappings, count, num_labels, ngram, text_dropout, edges_weights=None):
+    """Text channel factory.  The reference's Text_model (MODEL:598-615) builds the vocabulary and
+    the dense PMI matrices from the training split (utils/pmi.py, out of scope); this one takes the
+    resulting vocabulary, edge map (dense, scipy sparse or PmiCsr) and edge count directly."""
+    return Text_GCN_Model(num_labels, hidden_size_node=300, vocab=vocab, n_gram=ngram, drop_out=text_dropout,
+                          edges_matrix=edges_mappings, edges_num=count, pmi=edges_weights, cuda=True,
+                          trainable_edges=True)
+
+
+def multi_gcn_multihead_att_model(opt, num_labels, object_num_classes, place_num_classes, object_t, place_t,
+                                  text_model, object_model=None, place_model=None,
+                                  object_adj_file=None, place_adj_file=None, in_channel=300, label_glove=None):
+    """Factory mirroring MODEL:619-642 with the text model and the (optional) CNN trunks injected
+    instead of being built from files that only exist on the authors' machine."""
+    return Multi_GCN_Multihead_Att(opt, num_labels, text_model=text_model, object_model=object_model,
+                                   place_model=place_model, object_num_classes=object_num_classes,
+                                   place_num_classes=place_num_classes, in_channel=in_channel,
+                                   object_t=object_t, place_t=place_t, object_adj_file=object_adj_file,
+                                   place_adj_file=place_adj_file, label_glove=label_glove)

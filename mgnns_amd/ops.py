@@ -86,6 +86,19 @@ def gen_adj(A, want_csr=False):
     return (adj, (rp, col, val)) if want_csr else adj
 
 
+def dense_to_csr(m):
+    _chk(m, "adj", ndim=2)
+    C = m.shape[0]
+    if m.shape[1] != C:
+        raise ValueError("adj must be square")
+    rp = torch.empty(C + 1, device=m.device, dtype=torch.int32)
+    col = torch.empty(C * C, device=m.device, dtype=torch.int32)
+    val = torch.empty(C * C, device=m.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_dense_to_csr(_p(m), C, _p(rp), _p(col), _p(val), _stream()), "mgnns_dense_to_csr")
+    return rp, col, val
+
+
 def spmm_csr(csr, x, act=ACT_NONE):
     """act(adj @ x) with adj in CSR (row_ptr, col, val); x [C, F]."""
     rp, col, val = csr

@@ -1,0 +1,62 @@
+"""Whole-forward parity on the GPU: the product nn.Module (HIP kernels) vs the golden logits captured
+from the unmodified reference, and vs the CPU oracle at larger batches.  Gate: 1e-4 abs on logits
+(north-star tolerance, fp32 path)."""
+import numpy as np
+import pytest
+import torch
+
+from mgnns_amd import synth
+from oracle import restatement as R
+from tests import helpers as H
+from tests.model_util import build_model, call_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("cfg_name", ["mvsa_single_b8", "tumemo_b64", "mvsa_multiple_b256"])
+def test_forward_matches_reference_golden_logits(cfg_name):
+    g = H.load_golden("full_%s.npz" % cfg_name)
+    adj = H.load_golden("adjacency.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    B = int(g["B"])
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], g["label_query"], DEV)
+    inp = synth.make_inputs(cfg, B=B, pmi=pmi)
+    logits = model(*call_args(inp, DEV))
+    assert logits.shape == (B, cfg.NL) and logits.dtype == torch.float32
+    assert H.maxabs(logits.cpu(), g["logits"]) < TOL
+
+
+def test_forward_matches_oracle_batch32_ragged():
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    B = 32
+    inp = synth.make_inputs(cfg, B=B, seed=777, pmi=pmi)
+    model = build_model(cfg, pmi, count, adj["object_t06_A"], adj["place_t05_A"], lq, DEV)
+    logits = model(*call_args(inp, DEV)).cpu()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ti = {k: torch.from_numpy(v) for k, v in inp.items()}
+    ref = R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=torch.from_numpy(lq))
+    assert H.maxabs(logits, ref) < TOL
+    # batch independence: a sample's logits do not depend on its batch mates (what sharding relies on)
+    half = {k: v[:B // 2] for k, v in inp.items() if k != "label_query"}
+    half["label_query"] = inp["label_query"]
+    l2 = model(*call_args(half, DEV)).cpu()
+    assert H.maxabs(l2, logits[:B // 2]) < 1e-6
+
+
+def test_module_surface_on_gpu():
+    cfg = synth.CONFIGS["mvsa_single_b8"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    groups = model.get_config_optim(1e-3, 0.1)
+    assert len(groups) == 12 and groups[0]["lr"] == pytest.approx(1e-2)
+    model.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        model(*call_args(synth.make_inputs(cfg, B=2, pmi=pmi), DEV))

@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the C ABI exports what include/mgnns_hip.h declares,
+the nn.Module exposes the reference's state_dict surface, and nothing computes without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mgnns_amd import _lib, ops, synth
+from mgnns_amd.pmi import PmiCsr
+from tests import helpers as H
+from tests.model_util import build_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mgnns_hip.h")).read()
+    declared = set(re.findall(r"\b(mgnns_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("mgnns_stream_t")
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libmgnns_hip.so does not export %s" % name
+    assert set(_lib.SIGNATURES) | {"mgnns_last_error", "mgnns_abi_version"} == declared
+    assert L.mgnns_abi_version() == _lib.ABI_VERSION
+
+
+def test_state_dict_surface_equals_reference():
+    cfg = synth.CONFIGS["tumemo_b64"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    adj = H.load_golden("adjacency.npz")
+    m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], np.zeros((7, 300), np.float32))
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == H.surface()           # keys AND shapes, dead parameters included (strict loading)
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.layernorm(torch.zeros(2, 4), torch.ones(4), torch.zeros(4))
+    cfg = synth.CONFIGS["mvsa_single_b8"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    adj = H.load_golden("adjacency.npz")
+    m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], np.zeros((7, 300), np.float32))
+    inp = synth.make_inputs(cfg, B=2, pmi=pmi)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(t["text"], t["text_lens"], t["text_mask"], t["object_feature"], t["place_feature"], t["object_inp"],
+          t["place_inp"])
+
+
+def test_pmi_csr_matches_dense_lookup():
+    rs = np.random.RandomState(0)
+    V = 60
+    dense = np.zeros((V, V), dtype=np.int64)
+    k = 1
+    for i in range(V):
+        for j in range(V):
+            if rs.uniform() < 0.1:
+                dense[i, j] = k
+                k += 1
+    m = PmiCsr.from_dense(dense)
+    for i in range(V):
+        for j in range(V):
+            assert m[i, j] == dense[i, j]
+    assert m.nnz == k - 1 and m.max_eid() == k - 1
+    import scipy.sparse as sp
+    m2 = PmiCsr.coerce(sp.csr_matrix(dense))
+    assert np.array_equal(m2.col, m.col) and np.array_equal(m2.eid, m.eid)
