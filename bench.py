@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- forward samples/s of the MGNNS hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--dtype f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of the whole model (text GCN + BiLSTM text bank + object/scene GCN channels +
+label attention + 4 stacks of single-query multi-head fusion + classifier) over one synthetic
+MVSA-Multiple-shaped batch (configs[2]: B=256 per GPU, T=100, V=20154, 8 heads, 2 layers), entered at
+the [B,2048,14,14] feature maps, inputs resident in HBM.  N>1: one process per GPU, batch-sharded
+(weak scaling: 256 samples per GPU), logits all-gathered over RCCL inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mgnns_amd import harness, ops, synth          # noqa: E402
+from mgnns_amd.sharded import ShardedForward       # noqa: E402
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def mha_core_flops(B, L, D, H, dk):
+    """Algorithmic FLOPs of one fused single-query MHA launch:
+    K and V projections 2 * (2*L*D*H*dk) + QK^T and PV 2 * (2*H*dk*L) per sample."""
+    return B * (4.0 * L * D * H * dk + 4.0 * H * dk * L)
+
+
+def cpu_baseline(cfg, model, inp, pmi, budget_s=20.0):
+    """The CPU oracle (oracle/restatement.py, the pinned restatement of the reference forward) timed on
+    this box's host cores on the SAME synthetic batch.  Checker/baseline only -- never the product."""
+    from oracle import restatement as R
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ti = {k: torch.as_tensor(v) for k, v in inp.items()}
+    lq = model.label_query.detach().cpu()
+    cores = torch.get_num_threads()
+
+    def run():
+        return R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=lq)
+
+    t0 = time.time()
+    ref = run()                                   # warm-up (also the parity reference)
+    first = time.time() - t0
+    times = []
+    while sum(times) + first < budget_s and len(times) < 8:
+        t0 = time.time()
+        run()
+        times.append(time.time() - t0)
+    if not times:
+        times = [first]
+    B = ti["text"].shape[0]
+    best = float(np.median(times))
+    return ref, {"value": round(B / best, 2), "unit": "samples/s", "cores": int(cores), "kind": "port",
+                 "sample": "%d timed forwards of the same B=%d synthetic batch through oracle/restatement.py "
+                           "(torch-CPU fp32, %d threads; median %.3f s)" % (len(times), B, cores, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--config", default="mvsa_multiple_b256")
+    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synth.CONFIGS[args.config]
+    B = args.batch
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    A_obj, A_place = harness.synthetic_adjacencies(cfg)
+    inp = synth.make_inputs(cfg, B=B, seed=cfg.seed + 1000 * rank, pmi=pmi)     # this rank's shard
+    model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
+    call = harness.call_args(inp, dev)
+    fwd = ShardedForward(lambda *a: model(*a))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = fwd(*call)
+        timer = ops.KernelTimer(["mgnns_sq_mha_core_fwd"])
+        ops.set_timer(timer)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = fwd(*call)
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.set_timer(None)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: the image-bank fused MHA launches (L = 196, unmasked) ----
+    P = inp["object_feature"].shape[2] * inp["object_feature"].shape[3]
+    durs = timer.durations_ms().get(("mgnns_sq_mha_core_fwd", P, False), [])
+    roofline = None
+    if durs:
+        avg_ms = float(np.mean(durs))
+        fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "sq_mha_core_kernel (L=%d, H=%d)" % (P, cfg.n_head),
+                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),
+                    "flops_per_launch": fl}
+
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline:
+        ref, cpu = cpu_baseline(cfg, model, inp, pmi)
+        parity = float((out[:B].float().cpu() - ref).abs().max())
+
+    ms = dt / args.steps * 1e3
+    line = {
+        "metric": "forward samples/sec at batch 256 (3-channel GCN + fusion)",
+        "value": round(world * B / (dt / args.steps), 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "%s: B=%d per GPU, T=%d, V=%d, n_head=%d, stack_num=%d, C=(%d,%d), "
+                               "feature maps [B,2048,14,14] fp32 resident in HBM, logits all-gathered"
+                               % (cfg.name, B, cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
+                   "global_batch": world * B, "parallelism": "batch-shard x%d" % world},
+        "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,45 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Opt-in per-launch HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream
+    the kernels are launched on (PyTorch's current stream), around the C-ABI call only."""
+
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)
+        self.events = {}
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def durations_ms(self):
+        """{key: [ms, ...]} -- call after torch.cuda.synchronize()."""
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _launch(name, key, fn, *args):
+    """Call one C-ABI entry point, optionally bracketed by events; raise on a non-zero return."""
+    t = _TIMER
+    if t is not None and t.wants(name):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        t.events.setdefault(key, []).append((a, b))
+    else:
+        rc = fn(*args)
+    _lib.check(rc, name)
+
+
 def _chk(t, name, dtype=torch.float32, ndim=None):
     if not torch.is_tensor(t):
         raise TypeError("%s must be a torch tensor" % name)
@@ -141,8 +180,8 @@ def textgcn(tok, node_hidden, edge_w, pmi_dev, ngram, max_length=100):
         raise ValueError("PMI map has %d rows, vocabulary has %d" % (rp.shape[0] - 1, V))
     out = torch.empty(B, D, device=tok.device, dtype=torch.float32)
     L = _lib.lib()
-    _lib.check(L.mgnns_textgcn_fwd(_p(tok), B, T, _p(node_hidden), V, D, _p(ew), ew.shape[0], _p(rp), _p(col),
-                                   _p(eid), int(ngram), int(max_length), _p(out), _stream()), "mgnns_textgcn_fwd")
+    _launch("mgnns_textgcn_fwd", ("mgnns_textgcn_fwd",), L.mgnns_textgcn_fwd, _p(tok), B, T, _p(node_hidden), V, D,
+            _p(ew), ew.shape[0], _p(rp), _p(col), _p(eid), int(ngram), int(max_length), _p(out), _stream())
     return out
 
 
@@ -171,8 +210,8 @@ def imgbank_pool(feat, wt, bias, n_out, want_pool=True):
     bank = torch.empty(B, P, n_out, device=feat.device, dtype=torch.float32)
     pooled = torch.empty(B, K, device=feat.device, dtype=torch.float32) if want_pool else None
     L = _lib.lib()
-    _lib.check(L.mgnns_imgbank_pool_fwd(_p(feat), B, K, P, _p(wt), wt.shape[1], _p(bias), n_out, _p(bank),
-                                        _p(pooled), _stream()), "mgnns_imgbank_pool_fwd")
+    _launch("mgnns_imgbank_pool_fwd", ("mgnns_imgbank_pool_fwd",), L.mgnns_imgbank_pool_fwd, _p(feat), B, K, P,
+            _p(wt), wt.shape[1], _p(bias), n_out, _p(bank), _p(pooled), _stream())
     return bank, pooled
 
 
@@ -210,8 +249,9 @@ def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
     o = torch.empty(B, n_head * d_kv, device=bank.device, dtype=torch.float32)
     attn = torch.empty(n_head * B, 1, L_, device=bank.device, dtype=torch.float32) if want_attn else None
     L = _lib.lib()
-    _lib.check(L.mgnns_sq_mha_core_fwd(_p(qh), _p(bank), _p(mask), B, L_, D, n_head, d_kv, _p(wk), _p(bk), _p(wv),
-                                       _p(bv), _p(o), _p(attn), _stream()), "mgnns_sq_mha_core_fwd")
+    _launch("mgnns_sq_mha_core_fwd", ("mgnns_sq_mha_core_fwd", L_, mask is not None), L.mgnns_sq_mha_core_fwd,
+            _p(qh), _p(bank), _p(mask), B, L_, D, n_head, d_kv, _p(wk), _p(bk), _p(wv), _p(bv), _p(o), _p(attn),
+            _stream())
     return o, attn
 
 

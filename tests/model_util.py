@@ -1,35 +1,2 @@
-"""Build the product module with by-name seeded parameters (shared by GPU tests, smoke, bench)."""
-import torch
-
-from mgnns_amd import synth
-from mgnns_amd.model import Multi_GCN_Multihead_Att, Text_model
-
-
-def make_vocab(V):
-    return ["PAD", "UNK"] + ["w%d" % i for i in range(2, V)]
-
-
-def build_model(cfg, pmi, count, A_obj, A_place, label_query, device=None):
-    tm = Text_model(make_vocab(cfg.V), pmi, count, cfg.NL, cfg.ngram, 0.5)
-    m = Multi_GCN_Multihead_Att(cfg.opt(), cfg.NL, tm, None, None, cfg.C_obj, cfg.C_place,
-                                label_glove=torch.as_tensor(label_query))
-    sd = {}
-    for k, v in m.state_dict().items():
-        if k == "object_A":
-            sd[k] = torch.as_tensor(A_obj).float()
-        elif k == "place_A":
-            sd[k] = torch.as_tensor(A_place).float()
-        else:
-            sd[k] = torch.from_numpy(synth.param_value(k, tuple(v.shape)))
-    m.load_state_dict(sd, strict=True)
-    m.eval()
-    if device is not None:
-        m = m.to(device)
-    return m
-
-
-def call_args(inp, device):
-    """The 7 positional arguments of engine/Multi_GCN_Multihead_Att_engine.py:825."""
-    t = {k: torch.as_tensor(v).to(device) for k, v in inp.items()}
-    return (t["text"], t["text_lens"], t["text_mask"], t["object_feature"], t["place_feature"],
-            t["object_inp"], t["place_inp"])
+"""Re-export of the product's synthetic harness for the tests."""
+from mgnns_amd.harness import build_model, call_args, make_vocab, synthetic_adjacencies  # noqa: F401
