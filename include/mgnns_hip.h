@@ -16,6 +16,7 @@
 #ifndef MGNNS_HIP_H
 #define MGNNS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -60,6 +61,23 @@ int mgnns_textgcn_fwd(const int64_t* tok, int B, int T,
  */
 int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V, int D,
                         float* out, mgnns_stream_t stream);
+
+/* ---- a2 + a10: text memory bank = embedding gather + packed multi-layer bidirectional LSTM -----------
+ * get_text_memory_bank (Multi_GCN_Multihead_att.py:366-398): embedding(text) -> pack_padded_sequence ->
+ * nn.LSTM(hidden 150, bidirectional, batch_first) -> pad_packed_sequence(total_length=T).
+ * tok [B,T] int64; lens [B] int64 ON THE DEVICE (valid tokens per sample, clamped to [0,T]);
+ * emb_table [V,emb_dim]; per (layer l, direction d) at index 2*l+d (d=1 is PyTorch's "_reverse"):
+ * w_ih [4*hidden, in_l], w_hh [4*hidden, hidden], b_ih, b_hh [4*hidden] (gate order i,f,g,o), passed as
+ * host arrays of device pointers; out [B,T,2*hidden] (zeros at t >= lens[b]).
+ * workspace: >= mgnns_bilstm_workspace_bytes(B,T,hidden,num_layers) bytes of device memory.
+ * hidden == 150, num_layers <= 2.
+ */
+size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers);
+int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
+                     const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
+                     const float* const* w_ih, const float* const* w_hh,
+                     const float* const* b_ih, const float* const* b_hh,
+                     void* workspace, size_t workspace_bytes, float* out, mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].

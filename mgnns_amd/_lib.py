@@ -15,10 +15,13 @@ _P = _c.c_void_p
 _I = _c.c_int
 _L = _c.c_int64
 _F = _c.c_float
+_SZ = _c.c_size_t
+_PP = _c.POINTER(_c.c_void_p)
 
 # name -> argtypes, in the order of include/mgnns_hip.h
 SIGNATURES = {
     "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
+    "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
@@ -55,6 +58,8 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    L.mgnns_bilstm_workspace_bytes.restype = _SZ
+    L.mgnns_bilstm_workspace_bytes.argtypes = [_I, _I, _I, _I]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)      # AttributeError if the symbol is missing
         fn.restype = _I

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ W, int N,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ residual,
-                                                       float* __restrict__ Y, int act, int vecX, int vecW) {
+                                                       float* __restrict__ Y, int ldy, int act, int vecX, int vecW,
+                                                       const int32_t* __restrict__ gather_idx,
+                                                       const int32_t* __restrict__ m_dev) {
     __shared__ __attribute__((aligned(16))) float As[BM * SA];
     __shared__ __attribute__((aligned(16))) float Bs[W_IS_KN ? BK * SBN : BN * SA];
 
@@ -39,6 +41,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m_dev) {                      // device-side row count (packed ragged rows): M is only the upper bound
+        M = min(M, *m_dev);
+        if (m0 >= M) return;
+    }
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -48,12 +54,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
     // staging map: 64 rows x 4 float4 per BK-slice = 256 float4, one per thread
     const int s_row = tid >> 2, s_k4 = (tid & 3) * 4;
+    // optional row gather on the A side: logical row r reads X[gather_idx[r], :]
+    const size_t a_row = (m0 + s_row < M) ? (gather_idx ? (size_t)gather_idx[m0 + s_row] : (size_t)(m0 + s_row)) : 0;
 
     for (int k0 = 0; k0 < K; k0 += BK) {
         {   // A tile
             const int gm = m0 + s_row, gk = k0 + s_k4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < M) v = load4(X + (size_t)gm * K + gk, K - gk, vecX);
+            if (gm < M) v = load4(X + a_row * K + gk, K - gk, vecX);
             float* d = &As[s_row * SA + s_k4];
             *reinterpret_cast<float2*>(d) = float2{v[0], v[1]};
             *reinterpret_cast<float2*>(d + 2) = float2{v[2], v[3]};
@@ -107,12 +115,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 if (gm >= M) continue;
                 float v = mg_act(acc[i][j][r] + bv, act);
                 if (residual) v += residual[(size_t)gm * N + gn];
-                Y[(size_t)gm * N + gn] = v;
+                Y[(size_t)gm * ldy + gn] = v;
             }
         }
 }
 
 }  // namespace
+
+// internal launcher shared with lstm.hip: Y[r, 0:N] (row stride ldy) = X[gather_idx[r], :] W^T + bias, r < min(M, *m_dev)
+int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
+                     const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream) {
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    const int vecX = (K % 4 == 0) && mg_aligned16(X);
+    const int vecW = (K % 4 == 0) && mg_aligned16(W);
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, X, M, K, W, N, bias,
+                       (const float*)nullptr, Y, ldy, MGNNS_ACT_NONE, vecX, vecW, gather_idx, m_dev);
+    return 0;
+}
 
 extern "C" int mgnns_linear_fwd(const float* X, int M, int K, const float* W, const float* bias, int N,
                                 const float* residual, float* Y, int act, mgnns_stream_t stream) {
@@ -124,7 +143,7 @@ extern "C" int mgnns_linear_fwd(const float* X, int M, int K, const float* W, co
     const int vecX = (K % 4 == 0) && mg_aligned16(X);
     const int vecW = (K % 4 == 0) && mg_aligned16(W);
     hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, W, N, bias,
-                       residual, Y, act, vecX, vecW);
+                       residual, Y, N, act, vecX, vecW, (const int32_t*)nullptr, (const int32_t*)nullptr);
     MG_CHECK_LAUNCH("mgnns_linear_fwd");
     return 0;
 }
@@ -139,7 +158,8 @@ extern "C" int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, in
     const int vecX = (K % 4 == 0) && mg_aligned16(X);
     const int vecW = (N % 4 == 0) && mg_aligned16(W);
     hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, W, N,
-                       (const float*)nullptr, (const float*)nullptr, Y, act, vecX, vecW);
+                       (const float*)nullptr, (const float*)nullptr, Y, N, act, vecX, vecW, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr);
     MG_CHECK_LAUNCH("mgnns_matmul_fwd");
     return 0;
 }

@@ -1,0 +1,197 @@
+// Text memory bank: embedding gather + packed 2-layer bidirectional LSTM (hidden 150), replacing
+// get_text_memory_bank (Multi_GCN_Multihead_att.py:366-398: nn.Embedding, pack_padded_sequence,
+// nn.LSTM, pad_packed_sequence).  PyTorch/MIOpen run this as ~1000 tiny launches per forward
+// (one small GEMM + one pointwise kernel per time step per direction per layer).
+//
+// Here, per layer:
+//   1. input projection for every VALID token of the batch at once (ragged rows packed sample-major,
+//      row count on the device): Gx[r, dir*4H + n] = W_ih[dir][n,:] . x_r + b_ih[dir][n]  -- the fp32
+//      MFMA GEMM with a row gather on the A side (layer 0 gathers straight from the embedding table,
+//      so the embedded text never exists in HBM);
+//   2. the recurrence: ONE persistent workgroup per (sample, direction) walks that sample's own
+//      length.  Thread n owns gate row n of W_hh (all 150 weights in registers, loaded once), h_{t-1}
+//      is broadcast from LDS, the four gates of a unit meet in LDS for the cell update.  Samples are
+//      independent, so 2*B workgroups run concurrently and each stops at its own length (packed-sequence
+//      semantics: the reverse direction starts at the sample's last valid token); positions >= len are
+//      zero-filled by the same workgroup (pad_packed_sequence(total_length=T)).
+// Gate order i, f, g, o (PyTorch).  All arithmetic fp32; the k-loop is a sequential fmaf chain.
+#include "common.hpp"
+
+int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
+                     const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream);
+
+namespace {
+
+constexpr int HID = 150;
+constexpr int G4 = 4 * HID;          // 600 gate rows
+constexpr int HPAD = 152;            // h padded to a multiple of 4 for 16-B LDS broadcasts
+constexpr int REC_THREADS = 640;     // 10 waves; threads >= 600 idle in the GEMV part
+
+// offs[b] = sum_{i<b} len_i (exclusive), offs[B] = total (single workgroup)
+__global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restrict__ lens, int B, int T,
+                                                         int32_t* __restrict__ offs) {
+    __shared__ int32_t s_off[1025];
+    const int tid = threadIdx.x;
+    // single workgroup: serial-chunk scan of the (<= a few thousand) lengths
+    const int per = (B + 1023) / 1024;
+    const int lo = tid * per, hi = min(B, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; ++b) {
+        long long l = lens[b];
+        s += (int)(l < 0 ? 0 : (l > T ? T : l));
+    }
+    s_off[tid + 1] = s;
+    if (tid == 0) s_off[0] = 0;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid + 1 > o ? s_off[tid + 1 - o] : 0;
+        __syncthreads();
+        s_off[tid + 1] += v;
+        __syncthreads();
+    }
+    int run = s_off[tid];
+    for (int b = lo; b < hi; ++b) {
+        offs[b] = run;
+        long long l = lens[b];
+        run += (int)(l < 0 ? 0 : (l > T ? T : l));
+    }
+    if (tid == 1023) offs[B] = s_off[1024];
+}
+
+// pack_tok[r] = token id, pack_pos[r] = b*T + t for the rows r = offs[b] + t of sample b (grid = B)
+__global__ __launch_bounds__(128) void lstm_fill_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ lens,
+                                                        int T, int V, const int32_t* __restrict__ offs,
+                                                        int32_t* __restrict__ pack_tok, int32_t* __restrict__ pack_pos) {
+    const int b = blockIdx.x;
+    long long l = lens[b];
+    const int len = (int)(l < 0 ? 0 : (l > T ? T : l));
+    const int off = offs[b];
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+        long long id = tok[(size_t)b * T + t];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        pack_tok[off + t] = (int32_t)id;
+        pack_pos[off + t] = b * T + t;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __restrict__ Gx, const int32_t* __restrict__ offs,
+                                                               const int64_t* __restrict__ lens, int T,
+                                                               const float* __restrict__ Whh_f, const float* __restrict__ Whh_b,
+                                                               const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
+                                                               float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_h[2][HPAD];
+    __shared__ float s_g[G4];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int n = threadIdx.x;
+    const bool row_on = n < G4;
+    long long l = lens[b];
+    const int len = (int)(l < 0 ? 0 : (l > T ? T : l));
+    const int off = offs[b];
+    const float* Whh = dir ? Whh_b : Whh_f;
+    const float* bhh = dir ? bhh_b : bhh_f;
+
+    float w[HID];
+#pragma unroll
+    for (int k = 0; k < HID; ++k) w[k] = row_on ? Whh[(size_t)n * HID + k] : 0.f;
+    const float bias = row_on ? bhh[n] : 0.f;
+
+    if (n < HPAD) { s_h[0][n] = 0.f; s_h[1][n] = 0.f; }
+    float c = 0.f;
+    __syncthreads();
+
+    const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + n;
+    int cur = 0;
+    float gx = 0.f;
+    if (row_on && len > 0) gx = gx_base[(size_t)(dir ? len - 1 : 0) * (2 * G4)];
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? len - 1 - s : s;
+        float acc = 0.f;
+        const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h[cur]);
+#pragma unroll
+        for (int k4 = 0; k4 < HID / 4; ++k4) {
+            const f32x4 hv = h4[k4];
+            acc = fmaf(w[4 * k4 + 0], hv[0], acc);
+            acc = fmaf(w[4 * k4 + 1], hv[1], acc);
+            acc = fmaf(w[4 * k4 + 2], hv[2], acc);
+            acc = fmaf(w[4 * k4 + 3], hv[3], acc);
+        }
+        {   // tail: HID = 4*37 + 2
+            const f32x4 hv = h4[HID / 4];
+#pragma unroll
+            for (int k = 4 * (HID / 4); k < HID; ++k) acc = fmaf(w[k], hv[k - 4 * (HID / 4)], acc);
+        }
+        if (row_on) s_g[n] = (gx + bias) + acc;
+        // prefetch the next step's input projection while the cell update runs
+        if (row_on && s + 1 < len) gx = gx_base[(size_t)(dir ? len - 2 - s : s + 1) * (2 * G4)];
+        __syncthreads();
+        if (n < HID) {
+            const float ig = sigmoidf_(s_g[n]);
+            const float fg = sigmoidf_(s_g[HID + n]);
+            const float gg = tanhf(s_g[2 * HID + n]);
+            const float og = sigmoidf_(s_g[3 * HID + n]);
+            c = fg * c + ig * gg;
+            const float hh = og * tanhf(c);
+            s_h[cur ^ 1][n] = hh;
+            out[((size_t)b * T + t) * (2 * HID) + dir * HID + n] = hh;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // pad_packed_sequence(total_length=T): zeros behind the sample's length
+    for (int i = n; i < (T - len) * HID; i += REC_THREADS) {
+        const int t = len + i / HID, j = i % HID;
+        out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers) {
+    (void)num_layers;
+    const size_t rows = (size_t)B * T;
+    size_t bytes = rows * 8 * (size_t)hidden * sizeof(float);   // Gx [rows, 2*4*hidden]
+    bytes += rows * 2 * (size_t)hidden * sizeof(float);          // layer-0 output [rows, 2*hidden]
+    bytes += (2 * rows + (size_t)B + 1 + 8) * sizeof(int32_t);   // pack_tok, pack_pos, offs
+    return (bytes + 255) & ~(size_t)255;
+}
+
+extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+                                int emb_dim, int hidden, int num_layers, const float* const* w_ih,
+                                const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                                void* workspace, size_t workspace_bytes, float* out, mgnns_stream_t stream) {
+    MG_REQUIRE(tok && lens && emb_table && w_ih && w_hh && b_ih && b_hh && workspace && out,
+               "mgnns_bilstm_fwd: null pointer");
+    MG_REQUIRE(hidden == HID, "mgnns_bilstm_fwd: hidden_size=%d unsupported (150 only)", hidden);
+    MG_REQUIRE(num_layers >= 1 && num_layers <= 2, "mgnns_bilstm_fwd: num_layers=%d unsupported (1..2)", num_layers);
+    MG_REQUIRE(B > 0 && T > 0 && V > 0 && emb_dim > 0, "mgnns_bilstm_fwd: bad dims B=%d T=%d V=%d E=%d", B, T, V, emb_dim);
+    MG_REQUIRE(workspace_bytes >= mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers),
+               "mgnns_bilstm_fwd: workspace too small (%zu < %zu)", workspace_bytes,
+               mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers));
+    for (int i = 0; i < 2 * num_layers; ++i)
+        MG_REQUIRE(w_ih[i] && w_hh[i] && b_ih[i] && b_hh[i], "mgnns_bilstm_fwd: null weight pointer %d", i);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)B * T;
+    float* Gx = reinterpret_cast<float*>(workspace);
+    float* mid = Gx + rows * 2 * G4;
+    int32_t* pack_tok = reinterpret_cast<int32_t*>(mid + rows * 2 * HID);
+    int32_t* pack_pos = pack_tok + rows;
+    int32_t* offs = pack_pos + rows;
+
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs);
+    hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
+    for (int layer = 0; layer < num_layers; ++layer) {
+        const float* X = layer == 0 ? emb_table : mid;
+        const int K = layer == 0 ? emb_dim : 2 * HID;
+        const int32_t* gidx = layer == 0 ? pack_tok : pack_pos;
+        float* dst = (layer == num_layers - 1) ? out : mid;
+        for (int dir = 0; dir < 2; ++dir)
+            mg_launch_linear(X, (int)rows, K, w_ih[2 * layer + dir], b_ih[2 * layer + dir], G4, Gx + dir * G4, 2 * G4, gidx,
+                             offs + B, s);
+        hipLaunchKernelGGL(lstm_rec_kernel, dim3(B, 2), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
+                           T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1], dst);
+    }
+    MG_CHECK_LAUNCH("mgnns_bilstm_fwd");
+    return 0;
+}

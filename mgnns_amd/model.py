@@ -221,22 +221,33 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.embedding.weight.data[pad_idx] = 0
 
     # ---- forward pieces ----------------------------------------------------------------------------
+    def _lstm_weights(self):
+        ws = []
+        for layer in range(self.lstm.num_layers):
+            for suffix in ("", "_reverse"):
+                ws.append(tuple(getattr(self.lstm, "%s_l%d%s" % (n, layer, suffix)).detach()
+                                for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")))
+        return ws
+
     def get_text_memory_bank(self, text, text_lens, return_last_state=True):
-        """Embedding gather (HIP) + packed 2-layer BiLSTM (MODEL:366-398)."""
+        """Embedding gather + packed 2-layer BiLSTM + re-padding to T (MODEL:366-398) as HIP kernels.
+        Returns (memory_bank [B,T,2*hidden], final state of the last layer [B,2*hidden]) like the reference;
+        the final state is read back out of the bank (forward: position len-1, reverse: position 0)."""
+        if not self.bidirectional:
+            raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
         batch_size, max_text_len = list(text.size())
-        text_embed = ops.embedding(text.long().contiguous(), self.embedding.weight.detach())
-        packed = nn.utils.rnn.pack_padded_sequence(text_embed, text_lens.cpu(), batch_first=True, enforce_sorted=False)
-        memory_bank, (enc_final_state, c_n) = self.lstm(packed)
-        memory_bank, _ = nn.utils.rnn.pad_packed_sequence(memory_bank, batch_first=True, total_length=max_text_len)
-        memory_bank = memory_bank.contiguous()
+        lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
+        memory_bank = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
+                                 self._lstm_weights(), self.hidden_size, self.lstm.num_layers)
         assert memory_bank.size() == torch.Size([batch_size, max_text_len, self.bi_hidden_size])
-        if self.bidirectional:
-            last = torch.cat((enc_final_state[-1, :, :], enc_final_state[-2, :, :]), 1)
-        else:
-            last = enc_final_state[-1, :, :]
-        if return_last_state:
-            return memory_bank, last
-        return memory_bank
+        if not return_last_state:
+            return memory_bank
+        H = self.hidden_size
+        idx = (lens - 1).clamp(min=0)
+        fwd_last = memory_bank[torch.arange(batch_size, device=text.device), idx, :H]
+        bwd_last = memory_bank[:, 0, H:]
+        # reference order: cat(enc_final_state[-1] (reverse), enc_final_state[-2] (forward)) (MODEL:392)
+        return memory_bank, torch.cat((bwd_last, fwd_last), 1)
 
     def _wt(self, lin):
         """Linear(2048, 300).weight transposed + padded for the bank kernel, cached per weight version."""
@@ -288,7 +299,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             self.label_query = self.label_query.to(text.device)
         with torch.no_grad():
             text_feature = self.text_features(text)
-            text_memory_bank, _ = self.get_text_memory_bank(text, text_lens, return_last_state)
+            text_memory_bank = self.get_text_memory_bank(text, text_lens, return_last_state=False)
             self.object_feature = self._features(self.object_features, object_feature)
             img_object_memory_bank, object_x_attention = self._channel(
                 self.object_feature, self.liner_img_object, self.object_A, object_inp,

@@ -164,6 +164,52 @@ def embedding(idx, table):
     return out
 
 
+# ---- text memory bank: embedding + packed BiLSTM -----------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers):
+    """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
+    (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length."""
+    import ctypes
+    _chk(tok, "text", torch.int64, 2)
+    _chk(lens, "text_lens", torch.int64, 1)
+    _chk(emb_table, "embedding.weight", ndim=2)
+    B, T = tok.shape
+    if lens.shape[0] != B:
+        raise ValueError("text_lens has %d entries for batch %d" % (lens.shape[0], B))
+    if len(weights) != 2 * num_layers:
+        raise ValueError("need %d (layer, direction) weight tuples" % (2 * num_layers))
+    arrs = [[], [], [], []]
+    for li, tup in enumerate(weights):
+        in_dim = emb_table.shape[1] if li < 2 else 2 * hidden
+        shapes = ((4 * hidden, in_dim), (4 * hidden, hidden), (4 * hidden,), (4 * hidden,))
+        for a, t, shp in zip(arrs, tup, shapes):
+            _chk(t, "lstm weight")
+            if tuple(t.shape) != shp:
+                raise ValueError("lstm weight shape %s, expected %s" % (tuple(t.shape), shp))
+            a.append(t.data_ptr())
+    n = 2 * num_layers
+    cptr = [(ctypes.c_void_p * n)(*a) for a in arrs]
+    L = _lib.lib()
+    nbytes = L.mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers)
+    ws = _workspace(nbytes, tok.device)
+    out = torch.empty(B, T, 2 * hidden, device=tok.device, dtype=torch.float32)
+    _launch("mgnns_bilstm_fwd", ("mgnns_bilstm_fwd",), L.mgnns_bilstm_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
+            emb_table.shape[0], emb_table.shape[1], hidden, num_layers, cptr[0], cptr[1], cptr[2], cptr[3],
+            _p(ws), ws.numel(), _p(out), _stream())
+    return out
+
+
 # ---- text GCN --------------------------------------------------------------------------------
 def textgcn(tok, node_hidden, edge_w, pmi_dev, ngram, max_length=100):
     """Text_GCN.Model.forward (Text_GCN.py:213-275): tok [B,T] int64 -> [B,D]."""

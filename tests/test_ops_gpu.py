@@ -190,3 +190,34 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError, match="d_kv"):
         ops.sq_mha_core(torch.zeros(1, 64, device=DEV), torch.zeros(1, 4, 300, device=DEV), None, 1, 64,
                         torch.zeros(64, 300, device=DEV), None, torch.zeros(64, 300, device=DEV), None)
+
+
+def test_bilstm_text_bank_against_golden_and_oracle():
+    """HIP embedding+packed-BiLSTM vs the reference's get_text_memory_bank golden, then a bigger ragged batch
+    (lengths 1..T, one at T) vs the oracle (torch CPU nn.LSTM)."""
+    g = H.load_golden("text_bank.npz")
+    V = int(g["V"])
+    shapes = {k: s for k, s in H.surface().items() if k.startswith("lstm.")}
+    shapes["embedding.weight"] = (V, 300)
+    pc = H.params_for(shapes)
+    p = dparams(pc)
+
+    def weights():
+        return [tuple(p["lstm.%s_l%d%s" % (n, l, sfx)] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                for l in range(2) for sfx in ("", "_reverse")]
+
+    bank = ops.bilstm(dev(g["tok"]), dev(g["lens"]), p["embedding.weight"], weights(), 150, 2)
+    assert H.maxabs(bank.cpu(), g["bank"]) < 2e-6
+    rs = np.random.RandomState(4)
+    B, T = 37, 100
+    lens = rs.randint(1, T + 1, size=B).astype(np.int64)
+    lens[0], lens[1] = T, 1
+    tok = np.zeros((B, T), np.int64)
+    for b in range(B):
+        tok[b, :lens[b]] = rs.randint(1, V, size=lens[b])
+    ref = R.text_memory_bank(pc, torch.from_numpy(tok), torch.from_numpy(lens))
+    bank = ops.bilstm(dev(tok), dev(lens), p["embedding.weight"], weights(), 150, 2).cpu()
+    assert H.maxabs(bank, ref) < 5e-6
+    for b in range(B):
+        if lens[b] < T:
+            assert float(bank[b, lens[b]:].abs().max()) == 0.0
