@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--config", default="mvsa_multiple_b256")
-    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,6 +95,8 @@ def main():
     A_obj, A_place = harness.synthetic_adjacencies(cfg)
     inp = synth.make_inputs(cfg, B=B, seed=cfg.seed + 1000 * rank, pmi=pmi)     # this rank's shard
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
+    model.set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    core = "mgnns_sq_mha_core_bf16_fwd" if args.dtype == "bf16" else "mgnns_sq_mha_core_fwd"
     call = harness.call_args(inp, dev)
     fwd = ShardedForward(lambda *a: model(*a))
 
@@ -106,7 +108,7 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             out = fwd(*call)
-        timer = ops.KernelTimer(["mgnns_sq_mha_core_fwd"])
+        timer = ops.KernelTimer([core])
         ops.set_timer(timer)
         barrier()
         t0 = time.perf_counter()
@@ -128,13 +130,14 @@ def main():
 
     # ---- roofline of the dominant kernel: the image-bank fused MHA launches (L = 196, unmasked) ----
     P = inp["object_feature"].shape[2] * inp["object_feature"].shape[3]
-    durs = timer.durations_ms().get(("mgnns_sq_mha_core_fwd", P, False), [])
+    durs = timer.durations_ms().get((core, P, False), [])
     roofline = None
     if durs:
         avg_ms = float(np.mean(durs))
         fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
         ach = fl / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "sq_mha_core_kernel (L=%d, H=%d)" % (P, cfg.n_head),
+        roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % ("sq_mha_core_bf16_kernel" if args.dtype == "bf16" else
+                                                          "sq_mha_core_kernel", P, cfg.n_head),
                     "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),

@@ -148,6 +148,22 @@ int mgnns_sq_mha_core_fwd(const float* qh, const float* bank, const float* mask,
                           const float* Wk, const float* bk, const float* Wv, const float* bv,
                           float* o, float* attn, mgnns_stream_t stream);
 
+/* ---- a8, bf16-operand variant (BASELINE config 3: "bf16 MFMA") ------------------------------------------
+ * Same contract as mgnns_sq_mha_core_fwd, but the projections run on v_mfma_f32_16x16x32_bf16 (bf16 operands,
+ * fp32 accumulation; scores/softmax/weighted sum fp32).  The memory bank is bf16 [B, L, ld] with ld == 320
+ * (model dim 300 zero padded; build with mgnns_cast_pad_bf16 or let mgnns_imgbank_pool_bf16_fwd emit it);
+ * the K/V weights are pre-packed once per weight version by mgnns_sq_mha_pack_weights_bf16 into
+ * mgnns_sq_mha_packed_weight_bytes(H) bytes (MFMA-fragment-major, 1 KiB per fragment).
+ */
+size_t mgnns_sq_mha_packed_weight_bytes(int H);
+int mgnns_sq_mha_pack_weights_bf16(const float* Wk, const float* Wv, int H, int dk, int D, void* Wp,
+                                   mgnns_stream_t stream);
+int mgnns_cast_pad_bf16(const float* x, int64_t rows, int D, int ld, void* y, mgnns_stream_t stream);
+int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const float* mask,
+                               int B, int L, int ld, int H, int dk,
+                               const void* Wp, const float* bk, const float* bv,
+                               float* o, float* attn, mgnns_stream_t stream);
+
 /* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
  * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.
  */

@@ -1,0 +1,350 @@
+// bf16-operand variant of the fused single-query multi-head attention (submodules.py:55-119, len_q == 1):
+// K/V projections on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; scores, mask, softmax and the
+// probability-weighted sum stay fp32.  K and V never leave the accumulators.
+//
+// Geometry (MI355X): one 512-thread workgroup per sample walks the heads in PAIRS.  The sample's memory
+// bank X [L<=208, 320] (bf16, 640-B rows) is staged ONCE into LDS with a 672-B row stride (42 x 16 B:
+// conflict-free for the ds_read_b128 A-fragment pattern row = lane&15, chunk = lane>>4) and reused by
+// every head.  Waves 0-3 own head h0, waves 4-7 head h1; each wave owns 32 head dims (2 column tiles) x
+// up to 13 row tiles -> 26 accumulator tiles.  The B operand (W_k,h / W_v,h) is read straight from global
+// memory in a pre-packed fragment-major layout (1 KiB contiguous per fragment, L2 resident), so LDS only
+// carries X.  Per head pair: phase 0 = K tiles -> scores -> softmax, phase 1 = V tiles -> weighted sum.
+// Row tiles behind the last unmasked position are skipped (their probability is exactly 0).
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int MT = 13;                  // row tiles of 16 (L <= 208)
+constexpr int LMAX = MT * 16;
+constexpr int KP = 320;                 // model dim padded to 10 k-steps of 32
+constexpr int KSTEPS = KP / 32;
+constexpr int CH = KP / 8;              // 40 16-byte chunks per row
+constexpr int LSTR = 42;                // LDS row stride in chunks (672 B)
+constexpr int DK = 128;
+constexpr int NTHR = 512;
+
+__device__ __forceinline__ unsigned short f2bf(float x) {      // round-to-nearest-even
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// Wp[h][kv][nt][ks][lane][8] = W_kv[h*128 + nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j]  (0 beyond D)
+__global__ __launch_bounds__(256) void pack_kv_weights_kernel(const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                              int H, int D, unsigned short* __restrict__ Wp) {
+    const size_t total = (size_t)H * 2 * 8 * KSTEPS * 64;       // fragments-lanes
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        size_t r = i >> 6;
+        const int ks = (int)(r % KSTEPS); r /= KSTEPS;
+        const int nt = (int)(r & 7); r >>= 3;
+        const int kv = (int)(r & 1);
+        const int h = (int)(r >> 1);
+        const float* W = kv ? Wv : Wk;
+        const int row = h * DK + nt * 16 + (lane & 15);
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < D) ? f2bf(W[(size_t)row * D + k0 + j]) : (unsigned short)0;
+        uint4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16);
+        o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16);
+        o.w = v[6] | ((unsigned)v[7] << 16);
+        reinterpret_cast<uint4*>(Wp)[i] = o;
+    }
+}
+
+// y[r, 0:ld] = bf16(x[r, 0:D]) zero padded to ld
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ x, size_t rows, int D, int ld,
+                                                            unsigned short* __restrict__ y) {
+    const size_t total = rows * (size_t)(ld / 8);
+    const int c8n = ld / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / c8n;
+        const int c0 = (int)(i - r * c8n) * 8;
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < D) ? f2bf(x[r * D + c0 + j]) : (unsigned short)0;
+        uint4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16);
+        o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16);
+        o.w = v[6] | ((unsigned)v[7] << 16);
+        reinterpret_cast<uint4*>(y)[i] = o;
+    }
+}
+
+// sum over the 16 lanes of a DPP row (the 16 head dims a C-tile column group holds), result in every lane;
+// pure VALU (v_add_f32 with DPP modifiers) -- no LDS crossbar traffic, unlike __shfl_xor (ds_bpermute).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// acc[i][j] += X[tile i] * W^T[tile j] over the padded model dim, for a COMPILE-TIME number of live row tiles.
+// Fully unrolled, software pipelined in two half-groups of row tiles: while the MFMAs of one half run, the A
+// fragments (ds_read_b128 from the staged bank) of the OTHER half / next k-step are in flight, so an LDS read is
+// issued >= 12 MFMAs (~200 cycles) ahead of its use; B fragments (global, fragment-major, L2 resident) run BD
+// k-steps ahead.  sched_barrier(0) fences keep the compiler from sinking the prefetches back to their uses.
+template <int NMT>
+__device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], const uint4* __restrict__ a_base,
+                                        const uint4* __restrict__ wb) {
+    constexpr int HA = (NMT + 1) / 2, HB = NMT - HA;      // tiles [0,HA) and [HA,NMT)
+    constexpr int BD = NMT <= 4 ? 4 : 2;                  // B-fragment lookahead (k-steps)
+    uint4 ga[HA], gb[HB > 0 ? HB : 1];
+    uint4 bq[BD][2];
+#pragma unroll
+    for (int d = 0; d < BD; ++d) {
+        bq[d][0] = wb[(size_t)d * 64];
+        bq[d][1] = wb[(size_t)(KSTEPS + d) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < HA; ++i) ga[i] = a_base[i * 16 * LSTR];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) gb[i] = a_base[(HA + i) * 16 * LSTR];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[ks % BD][0]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[ks % BD][1]);
+        // ---- half A: MFMAs on ga (k-step ks), then refill ga for k-step ks+1 --------------------------
+#pragma unroll
+        for (int i = 0; i < HA; ++i) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, ga[i]);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[i][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+            for (int i = 0; i < HA; ++i) ga[i] = a_base[i * 16 * LSTR + (ks + 1) * 4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half B ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, gb[i]);
+            acc[HA + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[HA + i][0], 0, 0, 0);
+            acc[HA + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[HA + i][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) gb[i] = a_base[(HA + i) * 16 * LSTR + (ks + 1) * 4];
+        }
+        if (ks + BD < KSTEPS) {
+            bq[ks % BD][0] = wb[(size_t)(ks + BD) * 64];
+            bq[ks % BD][1] = wb[(size_t)(KSTEPS + ks + BD) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __restrict__ qh,
+                                                                const unsigned short* __restrict__ bank,   // [B,L,KP] bf16
+                                                                const float* __restrict__ mask, int B, int L, int H,
+                                                                const unsigned short* __restrict__ Wp,
+                                                                const float* __restrict__ bk, const float* __restrict__ bv,
+                                                                float temp, float* __restrict__ o, float* __restrict__ attn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* Xs = reinterpret_cast<uint4*>(smem);                                   // [LMAX][LSTR] chunks
+    float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
+    float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
+    float* s_red = s_p + 2 * LMAX;                                                // [16]
+    int* s_lvalid = reinterpret_cast<int*>(s_red + 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int hp_wave = wave >> 2;                      // which head of the pair this wave serves
+    const int wq = wave & 3;                            // 32-dim slice of that head
+    const uint4* xb = reinterpret_cast<const uint4*>(bank) + (size_t)b * L * CH;
+
+    // ---- live rows -------------------------------------------------------------------------------------
+    if (tid == 0) *s_lvalid = mask ? 0 : L;
+    __syncthreads();
+    if (mask) {
+        int last = 0;
+        for (int t = tid; t < L; t += NTHR)
+            if (mask[(size_t)b * L + t] != 0.0f) last = t + 1;
+        if (last) atomicMax(s_lvalid, last);
+        __syncthreads();
+    }
+    const int lvalid = *s_lvalid;
+    const int n_mt = (lvalid + 15) >> 4;
+    // tile-count class the branch-free GEMM body is instantiated for
+    const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : MT;
+    const int rows_live = n_sel * 16;
+
+    // ---- stage X (bf16) once: rows >= L are zero --------------------------------------------------------
+    for (int q = tid; q < rows_live * CH; q += NTHR) {
+        const int row = q / CH, c = q - row * CH;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < L) v = xb[(size_t)row * CH + c];
+        Xs[row * LSTR + c] = v;
+    }
+    __syncthreads();
+
+    const uint4* a_base = Xs + (lane & 15) * LSTR + (lane >> 4);     // + i*16*LSTR + ks*4
+
+    for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
+        const int h = hp * 2 + hp_wave;
+        const bool head_on = h < H;                                    // odd H: the second half idles
+        const float* qv = qh + (size_t)b * H * DK + (size_t)(head_on ? h : 0) * DK;
+        float r_o[2] = {0.f, 0.f};
+
+        for (int phase = 0; phase < 2; ++phase) {
+            f32x4 acc[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (head_on) {
+                // fragment stream of this wave: [h][phase][nt = wq*2 + j][ks][lane]
+                const uint4* wb = reinterpret_cast<const uint4*>(Wp) +
+                                  ((((size_t)h * 2 + phase) * 8 + wq * 2) * KSTEPS) * 64 + lane;
+                switch (n_sel) {
+                    case 1: kv_gemm<1>(acc, a_base, wb); break;
+                    case 2: kv_gemm<2>(acc, a_base, wb); break;
+                    case 4: kv_gemm<4>(acc, a_base, wb); break;
+                    case 7: kv_gemm<7>(acc, a_base, wb); break;
+                    default: kv_gemm<MT>(acc, a_base, wb); break;
+                }
+            }
+
+            const int c0 = wq * 32 + (lane & 15);
+            if (phase == 0) {
+                // ---- partial scores of this wave's 32 head dims ------------------------------------------
+                if (head_on) {
+                    const float q0 = qv[c0], q1 = qv[c0 + 16];
+                    const float k0b = bk ? bk[h * DK + c0] : 0.f, k1b = bk ? bk[h * DK + c0 + 16] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        if (i < n_mt) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = row16_sum(q0 * (acc[i][0][r] + k0b) + q1 * (acc[i][1][r] + k1b));
+                                if ((lane & 15) == 0) s_part[wave * LMAX + i * 16 + (lane >> 4) * 4 + r] = v;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- masked softmax, one head per 256-thread half ----------------------------------------------
+                const int pos = tid & 255, hh = tid >> 8;
+                const int hs = hp * 2 + hh;
+                float s = -INFINITY;
+                if (pos < lvalid && hs < H) {
+                    const float* sp = s_part + (hh * 4) * LMAX + pos;
+                    s = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) / temp;
+                    if (mask && mask[(size_t)b * L + pos] == 0.0f) s = -INFINITY;
+                }
+                float m = wave_max(s);
+                if (lane == 0) s_red[wave] = m;
+                __syncthreads();
+                m = fmaxf(fmaxf(s_red[hh * 4], s_red[hh * 4 + 1]), fmaxf(s_red[hh * 4 + 2], s_red[hh * 4 + 3]));
+                const float e = (s != -INFINITY) ? expf(s - m) : 0.f;
+                float z = wave_sum(e);
+                if (lane == 0) s_red[8 + wave] = z;
+                __syncthreads();
+                z = (s_red[8 + hh * 4] + s_red[8 + hh * 4 + 1]) + (s_red[8 + hh * 4 + 2] + s_red[8 + hh * 4 + 3]);
+                const float p = (hs < H) ? e / z : 0.f;
+                if (pos < LMAX) s_p[hh * LMAX + pos] = p;
+                if (attn && hs < H && pos < L) attn[((size_t)hs * B + b) * L + pos] = p;
+                __syncthreads();
+            } else {
+                // ---- o[c] = sum_l p[l] * (V[l,c] + bv[c]) ---------------------------------------------------------
+                if (head_on) {
+                    const float v0b = bv ? bv[h * DK + c0] : 0.f, v1b = bv ? bv[h * DK + c0 + 16] : 0.f;
+                    const float* pp = s_p + hp_wave * LMAX + (lane >> 4) * 4;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        if (i < n_mt) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float p = pp[i * 16 + r];
+                                r_o[0] = fmaf(p, acc[i][0][r] + v0b, r_o[0]);
+                                r_o[1] = fmaf(p, acc[i][1][r] + v1b, r_o[1]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        r_o[j] += __shfl_xor(r_o[j], 16, 64);
+                        r_o[j] += __shfl_xor(r_o[j], 32, 64);
+                    }
+                    if (lane < 16) {
+                        float* ob = o + (size_t)b * H * DK + h * DK + wq * 32 + lane;
+                        ob[0] = r_o[0];
+                        ob[16] = r_o[1];
+                    }
+                }
+                __syncthreads();      // s_p / s_part are rewritten by the next head pair
+            }
+        }
+    }
+}
+
+constexpr size_t SMEM_BYTES = (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float) + 16;
+
+}  // namespace
+
+extern "C" size_t mgnns_sq_mha_packed_weight_bytes(int H) { return (size_t)H * 2 * 8 * KSTEPS * 64 * 16; }
+
+extern "C" int mgnns_sq_mha_pack_weights_bf16(const float* Wk, const float* Wv, int H, int dk, int D, void* Wp,
+                                              mgnns_stream_t stream) {
+    MG_REQUIRE(Wk && Wv && Wp, "mgnns_sq_mha_pack_weights_bf16: null pointer");
+    MG_REQUIRE(dk == DK && H > 0 && D > 0 && D <= KP, "mgnns_sq_mha_pack_weights_bf16: unsupported dk=%d D=%d", dk, D);
+    const size_t total = (size_t)H * 2 * 8 * KSTEPS * 64;
+    hipLaunchKernelGGL(pack_kv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wk,
+                       Wv, H, D, reinterpret_cast<unsigned short*>(Wp));
+    MG_CHECK_LAUNCH("mgnns_sq_mha_pack_weights_bf16");
+    return 0;
+}
+
+extern "C" int mgnns_cast_pad_bf16(const float* x, int64_t rows, int D, int ld, void* y, mgnns_stream_t stream) {
+    MG_REQUIRE(x && y, "mgnns_cast_pad_bf16: null pointer");
+    MG_REQUIRE(rows >= 0 && D > 0 && ld >= D && ld % 8 == 0, "mgnns_cast_pad_bf16: bad dims D=%d ld=%d", D, ld);
+    if (rows == 0) return 0;
+    const size_t total = (size_t)rows * (ld / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)rows, D, ld,
+                       reinterpret_cast<unsigned short*>(y));
+    MG_CHECK_LAUNCH("mgnns_cast_pad_bf16");
+    return 0;
+}
+
+extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const float* mask, int B, int L, int ld,
+                                          int H, int dk, const void* Wp, const float* bk, const float* bv, float* o,
+                                          float* attn, mgnns_stream_t stream) {
+    MG_REQUIRE(qh && bank_bf16 && Wp && o, "mgnns_sq_mha_core_bf16_fwd: null pointer");
+    MG_REQUIRE(dk == DK, "mgnns_sq_mha_core_bf16_fwd: d_kv=%d unsupported (128 only)", dk);
+    MG_REQUIRE(ld == KP, "mgnns_sq_mha_core_bf16_fwd: bank row length %d must be %d (bf16, zero padded)", ld, KP);
+    MG_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= LMAX, "mgnns_sq_mha_core_bf16_fwd: L=%d unsupported (1..%d)", L, LMAX);
+    MG_REQUIRE(mg_aligned16(bank_bf16) && mg_aligned16(Wp), "mgnns_sq_mha_core_bf16_fwd: bank/Wp must be 16-byte aligned");
+    if (B == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sq_mha_core_bf16_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+        attr_set = true;
+    }
+    // one workgroup per sample owns all head pairs when the batch fills the chip; small batches split the pairs
+    const int pairs = (H + 1) / 2;
+    int gy = 1;
+    while (gy < pairs && B * gy < 256) gy *= 2;
+    if (gy > pairs) gy = pairs;
+    const float temp = (float)sqrt((double)dk);
+    hipLaunchKernelGGL(sq_mha_core_bf16_kernel, dim3(B, gy), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, qh,
+                       reinterpret_cast<const unsigned short*>(bank_bf16), mask, B, L, H,
+                       reinterpret_cast<const unsigned short*>(Wp), bk, bv, temp, o, attn);
+    MG_CHECK_LAUNCH("mgnns_sq_mha_core_bf16_fwd");
+    return 0;
+}

@@ -22,6 +22,29 @@ def _require_eval(mod):
                            "not part of the HIP path); call .eval()" % type(mod).__name__)
 
 
+class MemoryBank:
+    """A key/value memory bank in the forms the kernels consume: fp32 [B,L,D] and/or bf16 [B,L,320]
+    (zero padded).  MyMultiHeadAttention accepts it wherever the reference passes the bank tensor, so a
+    bank that feeds several layers is converted once."""
+
+    def __init__(self, f32=None, bf16=None):
+        if f32 is None and bf16 is None:
+            raise ValueError("empty MemoryBank")
+        self.f32 = f32
+        self._bf16 = bf16
+
+    @property
+    def bf16(self):
+        if self._bf16 is None:
+            self._bf16 = ops.cast_pad_bf16(self.f32.contiguous())
+        return self._bf16
+
+    @property
+    def shape(self):
+        t = self.f32 if self.f32 is not None else self._bf16
+        return t.shape
+
+
 class LayerNorm(nn.Module):
     """gamma * (x - mean) / (std_unbiased + eps) + beta  (submodules.py:153-156)."""
 
@@ -41,6 +64,8 @@ class MultiHeadAttention(nn.Module):
         if d_k != d_v:
             raise ValueError("d_k must equal d_v (the reference always passes d_kv for both)")
         self.n_head, self.d_k, self.d_v, self.is_regu = n_head, d_k, d_v, is_regu
+        self.precision = 'fp32'      # 'fp32' (exact-f32 MFMA) | 'bf16' (bf16 operands, fp32 accumulate)
+        self._wp = None
         self.w_qs = nn.Linear(d_model, n_head * d_k)
         self.w_ks = nn.Linear(d_model, n_head * d_k)
         self.w_vs = nn.Linear(d_model, n_head * d_v)
@@ -59,18 +84,35 @@ class MultiHeadAttention(nn.Module):
             raise NotImplementedError("is_regu=True (head-difference regulariser, training only) is not on the HIP path")
         if q.dim() != 3 or q.shape[1] != 1:
             raise ValueError("the fusion attention is single-query: q must be [B,1,d], got %s" % (tuple(q.shape),))
-        if k.data_ptr() != v.data_ptr() or k.shape != v.shape:
+        if k is not v and (isinstance(k, MemoryBank) or isinstance(v, MemoryBank) or
+                           k.data_ptr() != v.data_ptr() or k.shape != v.shape):
             raise ValueError("key and value must be the same memory bank (as at every reference call site)")
+        bank = k if isinstance(k, MemoryBank) else MemoryBank(f32=k.contiguous())
         B = q.shape[0]
         q2 = q.reshape(B, -1).contiguous()
         m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
         qh = ops.linear(q2, self.w_qs.weight.detach(), self.w_qs.bias.detach())
-        o, attn = ops.sq_mha_core(qh, k.contiguous(), m2, self.n_head, self.d_k,
-                                  self.w_ks.weight.detach(), self.w_ks.bias.detach(),
-                                  self.w_vs.weight.detach(), self.w_vs.bias.detach())
+        if self.precision == 'bf16':
+            o, attn = ops.sq_mha_core_bf16(qh, bank.bf16, m2, self.n_head, self.d_k, self._packed_kv(),
+                                           self.w_ks.bias.detach(), self.w_vs.bias.detach())
+        else:
+            if bank.f32 is None:
+                raise ValueError("fp32 attention needs the fp32 memory bank")
+            o, attn = ops.sq_mha_core(qh, bank.f32, m2, self.n_head, self.d_k,
+                                      self.w_ks.weight.detach(), self.w_ks.bias.detach(),
+                                      self.w_vs.weight.detach(), self.w_vs.bias.detach())
         y = ops.linear(o, self.fc.weight.detach(), self.fc.bias.detach(), residual=q2)
         y = self.layer_norm(y)
         return y.view(B, 1, -1), attn
+
+
+    def _packed_kv(self):
+        """w_ks / w_vs in the MFMA-fragment-major bf16 layout, rebuilt when either weight changes."""
+        wk, wv = self.w_ks.weight, self.w_vs.weight
+        key = (wk.data_ptr(), wk._version, wv.data_ptr(), wv._version, str(wk.device))
+        if self._wp is None or self._wp[0] != key:
+            self._wp = (key, ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k))
+        return self._wp[1]
 
 
 class PositionwiseFeedForward(nn.Module):

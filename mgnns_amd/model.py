@@ -17,7 +17,7 @@ from torch.nn import Parameter
 
 from . import ops
 from .adjacency import gen_A, gen_adj_csr
-from .fusion import MyAnotherMultiHeadAttention, MyMultiHeadAttention
+from .fusion import MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention
 from .text_gcn import Model as Text_GCN_Model
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
@@ -188,6 +188,20 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.register_buffer('label_query', None, persistent=False)
         self._load_label_query(label_glove if label_glove is not None else opt.get('label_glove'))
         self._wt_cache = {}
+        self.precision = 'fp32'
+        self.set_precision(opt.get('precision', 'fp32'))
+
+    def set_precision(self, precision):
+        """'fp32': every contraction on the exact-f32 MFMA (the parity path, <=1e-4 on logits).
+        'bf16': the fusion-attention K/V projections use bf16 operands with fp32 accumulation
+        (BASELINE config 3); everything else stays fp32."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        for m in self.modules():
+            if isinstance(m, MultiHeadAttention):
+                m.precision = precision
+        return self
 
     # ---- construction helpers -------------------------------------------------------------------
     @staticmethod
@@ -310,6 +324,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
                 self.place_attention, self.place_linear_5, self.place_x_linear)
 
             text_mask = text_mask.float().contiguous()
+            # banks feed 2-4 layers each: wrap once so a bf16 copy (if used) is made once
+            text_memory_bank = MemoryBank(f32=text_memory_bank)
+            img_object_memory_bank = MemoryBank(f32=img_object_memory_bank)
+            img_place_memory_bank = MemoryBank(f32=img_place_memory_bank)
             iot = object_x_attention
             for layer in self.img_object_text_multi_head_att:
                 iot, _ = layer(q=iot, k=text_memory_bank, v=text_memory_bank, mask=text_mask)

@@ -301,6 +301,50 @@ def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
     return o, attn
 
 
+BANK_LD = 320      # bf16 memory banks are [B, L, 320]: model dim 300 zero padded to 10 MFMA k-steps of 32
+
+
+def pack_kv_weights_bf16(wk, wv, n_head, d_kv):
+    """w_ks / w_vs [H*dk, D] fp32 -> MFMA-fragment-major bf16 buffer for sq_mha_core_bf16."""
+    _chk(wk, "w_ks.weight", ndim=2)
+    _chk(wv, "w_vs.weight", ndim=2)
+    L = _lib.lib()
+    buf = torch.empty(L.mgnns_sq_mha_packed_weight_bytes(n_head), dtype=torch.uint8, device=wk.device)
+    _lib.check(L.mgnns_sq_mha_pack_weights_bf16(_p(wk), _p(wv), n_head, d_kv, wk.shape[1], _p(buf), _stream()),
+               "mgnns_sq_mha_pack_weights_bf16")
+    return buf
+
+
+def cast_pad_bf16(x, ld=BANK_LD):
+    """[..., D] fp32 -> [..., ld] bf16 (round to nearest even), zero padded."""
+    D = x.shape[-1]
+    x2 = _chk(x.reshape(-1, D), "x")
+    y = torch.empty(x2.shape[0], ld, dtype=torch.bfloat16, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.mgnns_cast_pad_bf16(_p(x2), x2.shape[0], D, ld, _p(y), _stream()), "mgnns_cast_pad_bf16")
+    return y.view(*x.shape[:-1], ld)
+
+
+def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=True):
+    _chk(qh, "qh", ndim=2)
+    _chk(bank_bf16, "memory bank (bf16)", torch.bfloat16, 3)
+    _chk(wp, "packed K/V weights", torch.uint8, 1)
+    B, L_, ld = bank_bf16.shape
+    if qh.shape != (B, n_head * d_kv):
+        raise ValueError("qh shape %s, expected %s" % (tuple(qh.shape), (B, n_head * d_kv)))
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
+    attn = torch.empty(n_head * B, 1, L_, device=qh.device, dtype=torch.float32) if want_attn else None
+    L = _lib.lib()
+    _launch("mgnns_sq_mha_core_bf16_fwd", ("mgnns_sq_mha_core_bf16_fwd", L_, mask is not None),
+            L.mgnns_sq_mha_core_bf16_fwd, _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk),
+            _p(bv), _p(o), _p(attn), _stream())
+    return o, attn
+
+
 def layernorm(x, gamma, beta, eps=1e-6):
     D = x.shape[-1]
     x2 = _chk(x.reshape(-1, D), "x")

@@ -60,3 +60,21 @@ def test_module_surface_on_gpu():
     model.train()
     with pytest.raises(RuntimeError, match="eval"):
         model(*call_args(synth.make_inputs(cfg, B=2, pmi=pmi), DEV))
+
+
+def test_bf16_precision_mode_is_close_and_reports_error():
+    """bf16-operand fusion attention (BASELINE config 3): logits stay within bf16-class error of the fp32
+    reference golden and the predicted class does not change."""
+    cfg_name = "mvsa_multiple_b256"
+    g = H.load_golden("full_%s.npz" % cfg_name)
+    adj = H.load_golden("adjacency.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    B = int(g["B"])
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], g["label_query"], DEV)
+    model.set_precision("bf16")
+    logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV)).cpu()
+    err = H.maxabs(logits, g["logits"])
+    print("bf16 mode max|logit diff| vs fp32 reference: %.3e" % err)
+    assert err < 5e-2
+    assert torch.equal(logits.argmax(1), torch.from_numpy(g["logits"]).argmax(1))

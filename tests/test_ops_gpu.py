@@ -221,3 +221,48 @@ def test_bilstm_text_bank_against_golden_and_oracle():
     for b in range(B):
         if lens[b] < T:
             assert float(bank[b, lens[b]:].abs().max()) == 0.0
+
+
+def _bf16_round(x):
+    return torch.as_tensor(x).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_sq_mha_core_bf16(Hn, tag, L, masked):
+    """bf16-operand kernel: (i) exact-logic check against the oracle fed the SAME bf16-rounded bank and
+    K/V weights (only fp32 summation order differs -> tight), (ii) error vs the fp32 reference golden is
+    reported and bounded loosely (bf16 operands: ~3 significant digits)."""
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+    a = name + ".slf_attn."
+    qh = ops.linear(dev(q), p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    bank_bf = ops.cast_pad_bf16(dev(bank))
+    assert bank_bf.shape == (bank.shape[0], L, ops.BANK_LD)
+    assert torch.equal(bank_bf[..., :300].float().cpu(), _bf16_round(bank))      # RNE like torch
+    assert float(bank_bf[..., 300:].float().abs().max()) == 0.0
+    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128)
+    o, attn = ops.sq_mha_core_bf16(qh, bank_bf, None if mask is None else dev(mask), Hn, 128, wp,
+                                   p[a + "w_ks.bias"], p[a + "w_vs.bias"])
+    # (i) oracle on bf16-rounded operands
+    pr = dict(pc)
+    pr[a + "w_ks.weight"] = _bf16_round(pc[a + "w_ks.weight"])
+    pr[a + "w_vs.weight"] = _bf16_round(pc[a + "w_vs.weight"])
+    tb = _bf16_round(bank)
+    tm = None if mask is None else torch.from_numpy(mask)
+    B = q.shape[0]
+    qh_c = qh.cpu().view(B, Hn, 128)
+    kh = torch.nn.functional.linear(tb, pr[a + "w_ks.weight"], pr[a + "w_ks.bias"]).view(B, L, Hn, 128)
+    vh = torch.nn.functional.linear(tb, pr[a + "w_vs.weight"], pr[a + "w_vs.bias"]).view(B, L, Hn, 128)
+    s = torch.einsum("bhd,blhd->bhl", qh_c, kh) / float(np.power(128, 0.5))
+    if tm is not None:
+        s = s.masked_fill(tm[:, None, :] == 0.0, float("-inf"))
+    pa = torch.softmax(s, dim=2)
+    o_ref = torch.einsum("bhl,blhd->bhd", pa, vh).reshape(B, Hn * 128)
+    assert H.maxabs(attn.cpu(), pa.permute(1, 0, 2).reshape(Hn * B, 1, L)) < 2e-5
+    assert H.relerr(o.cpu(), o_ref) < 2e-5
+    # (ii) against the fp32 reference
+    err = H.maxabs(attn.cpu(), g[name + "_attn"])
+    assert err < 5e-2, err
