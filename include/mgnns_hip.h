@@ -122,6 +122,16 @@ int mgnns_linear_fwd(const float* X, int M, int K, const float* W, const float* 
 int mgnns_imgbank_pool_fwd(const float* feat, int B, int K, int P,
                            const float* Wt, int ldw, const float* bias, int N,
                            float* bank, float* pooled, mgnns_stream_t stream);
+/* bf16-operand variant (BASELINE config 3): same reads (the fp32 map crosses HBM once, max-pool exact fp32),
+ * W pre-packed by mgnns_imgbank_pack_weights_bf16 into mgnns_imgbank_packed_weight_bytes(K) bytes, the bank is
+ * emitted as bf16 [B, P, ld] with ld == 320 (zero padded) -- the layout mgnns_sq_mha_core_bf16_fwd consumes.
+ * pooled_work: [B, 2, K] floats of scratch.  104 < P <= 200, P % 4 == 0, N <= 304, K % 64 == 0.
+ */
+size_t mgnns_imgbank_packed_weight_bytes(int K);
+int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnns_stream_t stream);
+int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,
+                                void* bank_bf16, int ld, float* pooled, float* pooled_work, mgnns_stream_t stream);
+
 /* out[c, r] = in[r, c] for r < rows, c < cols; out is [cols, ld] with zero padding. */
 int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld, mgnns_stream_t stream);
 

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
     "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
     "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
+    "mgnns_imgbank_pack_weights_bf16": [_P, _I, _I, _P, _P],
+    "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mgnns_sq_mha_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -61,6 +63,8 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    L.mgnns_imgbank_packed_weight_bytes.restype = _SZ
+    L.mgnns_imgbank_packed_weight_bytes.argtypes = [_I]
     L.mgnns_sq_mha_packed_weight_bytes.restype = _SZ
     L.mgnns_sq_mha_packed_weight_bytes.argtypes = [_I]
     L.mgnns_bilstm_workspace_bytes.restype = _SZ

@@ -1,0 +1,244 @@
+// bf16-operand image memory bank + global max-pool, one pass over the fp32 [B,2048,196] feature map
+// (get_img_*_memory_bank, MODEL:400-428, fused with MaxPool2d(14,14), MODEL:454-455):
+//   bank[b,p,:] = bf16( W * feat[b,:,p] + bias )   -> [B, P, 320] bf16 (model dim zero padded: the layout the
+//                                                     bf16 fusion-attention kernel stages straight into LDS)
+//   pooled[b,k] = max_p feat[b,k,p]                 (exact fp32)
+// The kernel is HBM bound on the fp32 map (1.6 MB per sample-channel, read exactly once).
+//
+// Two 512-thread workgroups per sample, one per half of the 196 regions (7 | 6 row tiles of 16), each streams
+// its half of every feature row (448-B segments) in BK = 64 slices: global -> registers (fp32; the max-pool is
+// taken here) -> bf16 -> LDS transposed to [p][k] (XOR-swizzled 16-B chunks: conflict-free for both the
+// ds_write_b128 of the transpose and the ds_read_b128 MFMA A fragments).  8 waves split the 19 column tiles
+// (300 outputs) 3,3,3,2,2,2,2,2; the B operand (W) comes straight from L2 in a pre-packed fragment-major layout.
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation; epilogue transposes through LDS so bank rows leave as 16-B lanes.
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BK = 64;                  // k-slice (2 MFMA k-steps)
+constexpr int MTH = 7;                  // row tiles per half (112 rows)
+constexpr int ROWS = MTH * 16;
+constexpr int FSTR = 10;                // LDS row stride of the staged slice in 16-B chunks (8 data + 2 pad)
+constexpr int NTW = 3;                  // column tiles per wave (max)
+constexpr int NT = 19;                  // 304 / 16
+constexpr int OUT_LD = 320;             // bank row length (bf16)
+constexpr int OCH = OUT_LD / 8;         // 40 chunks per output row
+constexpr int NTHR = 512;
+constexpr int P_SPLIT = 104;            // half 0: regions [0,104) (tiles 0..6), half 1: [104,196) (tiles 0..5)
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf(a) | ((unsigned int)f2bf(b) << 16); }
+
+// Wp[nt][ks][lane][8] = W[nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j]   (0 for rows >= N)
+__global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W, int N, int K, unsigned short* __restrict__ Wp) {
+    const int KS = K / 32;
+    const size_t total = (size_t)NT * KS * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        size_t r = i >> 6;
+        const int ks = (int)(r % KS);
+        const int nt = (int)(r / KS);
+        const int row = nt * 16 + (lane & 15);
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (row < N) {
+            const float* w = W + (size_t)row * K + k0;
+            o.x = pack2(w[0], w[1]);
+            o.y = pack2(w[2], w[3]);
+            o.z = pack2(w[4], w[5]);
+            o.w = pack2(w[6], w[7]);
+        }
+        reinterpret_cast<uint4*>(Wp)[i] = o;
+    }
+}
+
+// NTN = column tiles of this wave (3 for waves 0-2, 2 for waves 3-7): compile-time so the MFMA stream is branch-free.
+// Every wave runs the same number of barriers; the two instantiations only differ in the tile count.
+template <int NTN>
+__device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* __restrict__ feat, int K, int P,
+                                             const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
+                                             unsigned short* __restrict__ bank, float* __restrict__ pooled_part) {
+    uint4* Fs = reinterpret_cast<uint4*>(smem);                            // [2][ROWS][FSTR] chunks
+    uint4* Os = Fs + 2 * ROWS * FSTR;                                      // [ROWS][OCH] chunks (epilogue)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x >> 1, mh = blockIdx.x & 1;
+    const int p0 = mh ? P_SPLIT : 0;
+    const int p_store_end = mh ? P : P_SPLIT;                              // rows [p0, p_store_end) are ours
+    const int nt0 = wave < 3 ? 3 * wave : 9 + 2 * (wave - 3);
+    const int KS = K / 32;
+
+    // staging role: wave = 8-row group kc of the slice, lane = region quad pq
+    const int pq = lane;
+    const int npq = mh ? (P - P_SPLIT + 3) / 4 : ROWS / 4;                 // 23 | 28 quads carry data
+    const bool st_on = pq < ROWS / 4;                                      // lanes that own LDS rows (28)
+    const bool ld_on = st_on && pq < npq && (p0 + 4 * pq + 3 < P);
+    const float* fsrc = feat + ((size_t)b * K + 8 * wave) * P + p0 + 4 * pq;
+
+    f32x4 acc[MTH][NTN];
+#pragma unroll
+    for (int i = 0; i < MTH; ++i)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 st[8];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ld_on) st[i] = *reinterpret_cast<const f32x4*>(fsrc + ((size_t)c * BK + i) * P);
+        }
+    };
+    auto lstore = [&](int c, int buf) {
+        // max-pool of the 8 feature rows this wave just loaded (exact fp32), then transpose-write as bf16
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float m = ld_on ? fmaxf(fmaxf(st[i][0], st[i][1]), fmaxf(st[i][2], st[i][3])) : -INFINITY;
+            m = wave_max(m);
+            if (lane == 0) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 8 * wave + i] = m;
+        }
+        if (st_on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint4 o;
+                o.x = pack2(st[0][j], st[1][j]);
+                o.y = pack2(st[2][j], st[3][j]);
+                o.z = pack2(st[4][j], st[5][j]);
+                o.w = pack2(st[6][j], st[7][j]);
+                const int row = 4 * pq + j;
+                Fs[(buf * ROWS + row) * FSTR + (wave ^ (pq & 7))] = o;
+            }
+        }
+    };
+
+    const uint4* wb = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64 + lane;
+    const int nchunk = K / BK;
+    gload(0);
+    lstore(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        const uint4* fb = Fs + (size_t)buf * ROWS * FSTR;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 bq[NTN];
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) bq[j] = wb[((size_t)j * KS + (c * 2 + kk)) * 64];
+            uint4 a[MTH];
+#pragma unroll
+            for (int i = 0; i < MTH; ++i) {
+                const int row = i * 16 + (lane & 15);
+                a[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MTH; ++i) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
+#pragma unroll
+                for (int j = 0; j < NTN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bq[j]), acc[i][j],
+                                                                       0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) lstore(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, bf16, transpose through LDS, 16-B row stores; columns N..319 are zero ------------
+    unsigned short* os = reinterpret_cast<unsigned short*>(Os);
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+        const int n = (nt0 + j) * 16 + (lane & 15);
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MTH; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + (lane >> 4) * 4 + r;
+                os[row * OUT_LD + n] = (n < N) ? f2bf(acc[i][j][r] + bv) : (unsigned short)0;
+            }
+        }
+    }
+    // zero the pad columns 304..319 (two chunks per row)
+    for (int q = tid; q < ROWS * 2; q += NTHR) Os[(q >> 1) * OCH + (NT * 2) + (q & 1)] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)b * P * OCH;
+    const int nrows = p_store_end - p0;
+    for (int q = tid; q < nrows * OCH; q += NTHR) {
+        const int row = q / OCH, ch = q - row * OCH;
+        ob[(size_t)(p0 + row) * OCH + ch] = Os[row * OCH + ch];
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __restrict__ feat, int K, int P,
+                                                                 const unsigned short* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, int N,
+                                                                 unsigned short* __restrict__ bank,
+                                                                 float* __restrict__ pooled_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 3 * 64)
+        imgbank_body<3>(smem, feat, K, P, Wp, bias, N, bank, pooled_part);
+    else
+        imgbank_body<2>(smem, feat, K, P, Wp, bias, N, bank, pooled_part);
+}
+
+// pooled[b,k] = max(part[b,0,k], part[b,1,k])
+__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ part, int B, int K, float* __restrict__ pooled) {
+    const size_t total = (size_t)B * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / K, k = i - b * K;
+        pooled[i] = fmaxf(part[(b * 2) * K + k], part[(b * 2 + 1) * K + k]);
+    }
+}
+
+constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR + ROWS * OCH) * 16;
+
+}  // namespace
+
+extern "C" size_t mgnns_imgbank_packed_weight_bytes(int K) { return (size_t)NT * (K / 32) * 64 * 16; }
+
+extern "C" int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnns_stream_t stream) {
+    MG_REQUIRE(W && Wp, "mgnns_imgbank_pack_weights_bf16: null pointer");
+    MG_REQUIRE(N > 0 && N <= NT * 16 && K > 0 && K % BK == 0, "mgnns_imgbank_pack_weights_bf16: unsupported N=%d K=%d", N, K);
+    const size_t total = (size_t)NT * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, N, K,
+                       reinterpret_cast<unsigned short*>(Wp));
+    MG_CHECK_LAUNCH("mgnns_imgbank_pack_weights_bf16");
+    return 0;
+}
+
+extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,
+                                           void* bank_bf16, int ld, float* pooled, float* pooled_work,
+                                           mgnns_stream_t stream) {
+    MG_REQUIRE(feat && Wp && bank_bf16 && pooled && pooled_work, "mgnns_imgbank_pool_bf16_fwd: null pointer");
+    MG_REQUIRE(B >= 0 && K > 0 && K % BK == 0, "mgnns_imgbank_pool_bf16_fwd: K=%d must be a positive multiple of %d", K, BK);
+    MG_REQUIRE(P % 4 == 0 && P > P_SPLIT && P <= P_SPLIT + (MTH - 1) * 16,
+               "mgnns_imgbank_pool_bf16_fwd: P=%d unsupported (multiple of 4 in (%d, %d])", P, P_SPLIT, P_SPLIT + (MTH - 1) * 16);
+    MG_REQUIRE(N > 0 && N <= NT * 16, "mgnns_imgbank_pool_bf16_fwd: N=%d unsupported (<= %d)", N, NT * 16);
+    MG_REQUIRE(ld == OUT_LD, "mgnns_imgbank_pool_bf16_fwd: bank row length must be %d", OUT_LD);
+    MG_REQUIRE(mg_aligned16(feat) && mg_aligned16(Wp) && mg_aligned16(bank_bf16),
+               "mgnns_imgbank_pool_bf16_fwd: feat/Wp/bank must be 16-byte aligned");
+    if (B == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imgbank_pool_bf16_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+        attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(2 * B), dim3(NTHR), SMEM_BYTES, s, feat, K, P,
+                       reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
+                       pooled_work);
+    const size_t total = (size_t)B * K;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pool_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)pooled_work, B, K, pooled);
+    MG_CHECK_LAUNCH("mgnns_imgbank_pool_bf16_fwd");
+    return 0;
+}

@@ -273,16 +273,36 @@ class Multi_GCN_Multihead_Att(nn.Module):
             self._wt_cache[id(lin)] = hit
         return hit[1]
 
+    def _wp(self, lin):
+        """The same weight in the MFMA-fragment-major bf16 layout of the bf16 bank kernel."""
+        w = lin.weight
+        key = (w.data_ptr(), w._version, str(w.device), 'bf16')
+        hit = self._wt_cache.get((id(lin), 'bf16'))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_imgbank_weights_bf16(w.detach().contiguous()))
+            self._wt_cache[(id(lin), 'bf16')] = hit
+        return hit[1]
+
     def _img_bank_and_pool(self, feats, lin):
+        """-> (MemoryBank, pooled [B,2048]); one pass over the feature map."""
         B = feats.shape[0]
         f3 = feats.float().contiguous().view(B, feats.shape[1], -1)
-        return ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
+        if self.precision == 'bf16' and 104 < f3.shape[2] <= 200 and f3.shape[2] % 4 == 0:
+            bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features)
+            return MemoryBank(bf16=bank), pooled
+        bank, pooled = ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
+        return MemoryBank(f32=bank), pooled
 
     def get_img_object_memory_bank(self, img_object_feats):
-        return self._img_bank_and_pool(img_object_feats, self.liner_img_object)[0]
+        """[B,2048,14,14] -> [B,196,300] fp32 (MODEL:400-416)."""
+        f3 = img_object_feats.float().contiguous().view(img_object_feats.shape[0], img_object_feats.shape[1], -1)
+        return ops.imgbank_pool(f3, self._wt(self.liner_img_object), self.liner_img_object.bias.detach(),
+                                self.liner_img_object.out_features, want_pool=False)[0]
 
     def get_img_place_memory_bank(self, img_place_feats):
-        return self._img_bank_and_pool(img_place_feats, self.liner_img_place)[0]
+        f3 = img_place_feats.float().contiguous().view(img_place_feats.shape[0], img_place_feats.shape[1], -1)
+        return ops.imgbank_pool(f3, self._wt(self.liner_img_place), self.liner_img_place.bias.detach(),
+                                self.liner_img_place.out_features, want_pool=False)[0]
 
     def _channel(self, feats, lin, A, inp, attention, linear_5, x_linear):
         """One image channel (MODEL:450-479 / 482-506): bank, pooled read-out through the label GCN,
@@ -326,8 +346,6 @@ class Multi_GCN_Multihead_Att(nn.Module):
             text_mask = text_mask.float().contiguous()
             # banks feed 2-4 layers each: wrap once so a bf16 copy (if used) is made once
             text_memory_bank = MemoryBank(f32=text_memory_bank)
-            img_object_memory_bank = MemoryBank(f32=img_object_memory_bank)
-            img_place_memory_bank = MemoryBank(f32=img_place_memory_bank)
             iot = object_x_attention
             for layer in self.img_object_text_multi_head_att:
                 iot, _ = layer(q=iot, k=text_memory_bank, v=text_memory_bank, mask=text_mask)

@@ -261,6 +261,32 @@ def imgbank_pool(feat, wt, bias, n_out, want_pool=True):
     return bank, pooled
 
 
+def pack_imgbank_weights_bf16(w):
+    """liner_img_*.weight [N, K] fp32 -> MFMA-fragment-major bf16 buffer for imgbank_pool_bf16."""
+    _chk(w, "weight", ndim=2)
+    L = _lib.lib()
+    buf = torch.empty(L.mgnns_imgbank_packed_weight_bytes(w.shape[1]), dtype=torch.uint8, device=w.device)
+    _lib.check(L.mgnns_imgbank_pack_weights_bf16(_p(w), w.shape[0], w.shape[1], _p(buf), _stream()),
+               "mgnns_imgbank_pack_weights_bf16")
+    return buf
+
+
+def imgbank_pool_bf16(feat, wp, bias, n_out):
+    """feat [B,K,P] fp32 -> (bank bf16 [B,P,320], pooled fp32 [B,K])."""
+    _chk(feat, "feature map", ndim=3)
+    _chk(wp, "packed weight", torch.uint8, 1)
+    B, K, P = feat.shape
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+    bank = torch.empty(B, P, BANK_LD, device=feat.device, dtype=torch.bfloat16)
+    pooled = torch.empty(B, K, device=feat.device, dtype=torch.float32)
+    work = torch.empty(B, 2, K, device=feat.device, dtype=torch.float32)
+    L = _lib.lib()
+    _launch("mgnns_imgbank_pool_bf16_fwd", ("mgnns_imgbank_pool_bf16_fwd",), L.mgnns_imgbank_pool_bf16_fwd, _p(feat),
+            B, K, P, _p(wp), _p(bias), n_out, _p(bank), BANK_LD, _p(pooled), _p(work), _stream())
+    return bank, pooled
+
+
 # ---- label attention core ---------------------------------------------------------------------------
 def label_attn_core(Q, K, V, n_heads):
     _chk(Q, "Q", ndim=2)

@@ -266,3 +266,27 @@ def test_sq_mha_core_bf16(Hn, tag, L, masked):
     # (ii) against the fp32 reference
     err = H.maxabs(attn.cpu(), g[name + "_attn"])
     assert err < 5e-2, err
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_imgbank_pool_bf16(B):
+    """bf16-operand bank kernel vs fp64 math on the SAME bf16-rounded operands (tight), exact fp32 max-pool,
+    zero padding of the 320-wide bank rows, and the error vs the fp32 result (loose, reported)."""
+    rs = np.random.RandomState(30 + B)
+    feat = np.maximum(rs.standard_normal((B, 2048, 196)), 0).astype(np.float32)
+    feat[0, 5, :] = -rs.uniform(0.1, 1.0, 196).astype(np.float32)        # an all-negative feature row (max < 0)
+    w = (0.05 * rs.standard_normal((300, 2048))).astype(np.float32)
+    bias = (0.05 * rs.standard_normal(300)).astype(np.float32)
+    wp = ops.pack_imgbank_weights_bf16(dev(w))
+    bank, pooled = ops.imgbank_pool_bf16(dev(feat), wp, dev(bias), 300)
+    assert bank.shape == (B, 196, ops.BANK_LD) and bank.dtype == torch.bfloat16
+    assert np.array_equal(pooled.cpu().numpy(), feat.max(axis=2))
+    assert float(bank[..., 300:].float().abs().max()) == 0.0
+    fr = _bf16_round(feat).double()
+    wr = _bf16_round(w).double()
+    ref = torch.einsum("bkp,nk->bpn", fr, wr) + torch.from_numpy(bias).double()
+    got = bank[..., :300].float().cpu().double()
+    # the result itself is rounded to bf16 on store: half an ulp = 2^-9 relative
+    assert float(((got - ref).abs() / (ref.abs() + 1e-2)).max()) < 6e-3
+    ref32 = R.img_memory_bank(torch.from_numpy(feat), torch.from_numpy(w), torch.from_numpy(bias))
+    print("bf16 bank max abs err vs fp32: %.3e (|bank| max %.2f)" % (H.maxabs(got, ref32), float(ref32.abs().max())))
