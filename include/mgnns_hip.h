@@ -99,7 +99,7 @@ int mgnns_dense_to_csr(const float* M, int C, int32_t* csr_row_ptr, int32_t* csr
  *                     the adjacency in CSR; F % 4 == 0)
  */
 int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float* Y, int act,
-                     mgnns_stream_t stream);
+                     void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
 int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
                        const float* X, int F, float* Y, int act, mgnns_stream_t stream);
 
@@ -109,7 +109,12 @@ int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* 
  * 34,126-127) and the read-out pooled*G^T (MODEL:474,500) with W = G [C,2048].
  */
 int mgnns_linear_fwd(const float* X, int M, int K, const float* W, const float* bias, int N,
-                     const float* residual, float* Y, int act, mgnns_stream_t stream);
+                     const float* residual, float* Y, int act,
+                     void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
+/* Both GEMM entry points split the K dimension over extra workgroups when the 64x64 tiling alone would leave
+ * most of the 256 CUs idle (M = batch = 256 layers); `workspace` (device, >= mgnns_gemm_workspace_bytes(), one
+ * per stream in flight) receives the partial sums, reduced in a fixed order.  NULL workspace = no K split. */
+size_t mgnns_gemm_workspace_bytes(void);
 
 /* ---- a5+a6: image memory bank + global max-pool, one pass over the feature map ------------------
  * get_img_{object,place}_memory_bank (MODEL:400-428) fused with MaxPool2d(14,14) (MODEL:454-455):

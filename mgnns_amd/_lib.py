@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
 _P = _c.c_void_p
@@ -25,9 +25,9 @@ SIGNATURES = {
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
-    "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P],
+    "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P, _SZ, _P],
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
-    "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
+    "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _SZ, _P],
     "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_imgbank_pack_weights_bf16": [_P, _I, _I, _P, _P],
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
@@ -63,6 +63,8 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    L.mgnns_gemm_workspace_bytes.restype = _SZ
+    L.mgnns_gemm_workspace_bytes.argtypes = []
     L.mgnns_imgbank_packed_weight_bytes.restype = _SZ
     L.mgnns_imgbank_packed_weight_bytes.argtypes = [_I]
     L.mgnns_sq_mha_packed_weight_bytes.restype = _SZ

@@ -1,17 +1,20 @@
-// Generic fp32 GEMM on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the small dense layers of
-// the path (nn.Linear / Conv1d(k=1) / GraphConvolution X*W / read-out).  64x64 block tile,
-// 4 waves as 2x2, each wave 2x2 MFMA tiles of 16x16, BK = 16, LDS-staged operands.
+// Generic fp32 GEMM on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the small dense layers of the path
+// (nn.Linear / Conv1d(k=1) / GraphConvolution X*W / read-out / LSTM input projection).
 //   NT: Y = act(X[M,K] * W[N,K]^T + bias) + residual      (nn.Linear weight layout)
 //   NN: Y = act(X[M,K] * W[K,N])                          (GraphConvolution weight layout)
+// 64x64 block tile, 4 waves as 2x2, each wave 2x2 MFMA tiles of 16x16, BK = 32, LDS-staged operands with a
+// register prefetch of the next K-slice (one barrier pair per slice, global latency under the MFMAs).
+// These layers are tiny (M = batch = 256): a 64x64 tiling alone yields 8-80 workgroups on a 256-CU chip and a
+// serial K loop, so the K dimension is split across gridDim.z workgroups (partials in a workspace) and a second
+// small kernel reduces the slices in a fixed order and applies bias / activation / residual.
 #include "common.hpp"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int SA = BK + 2;    // [row][k] stride: 18 floats -> conflict-free ds_read_b32 fragments
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int SA = BK + 2;    // [row][k] stride 34 floats: rows 0..15 x k{0,1} -> 32 distinct banks (ds_read_b32)
 constexpr int SBN = BN + 16;  // [k][n] stride for the NN form: 80 floats
 
-// load 4 consecutive floats p[0..3] with element-wise bound `n_valid` (<=4), vector path if aligned
 __device__ __forceinline__ f32x4 load4(const float* p, int n_valid, bool vec_ok) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (n_valid >= 4 && vec_ok) {
@@ -25,6 +28,8 @@ __device__ __forceinline__ f32x4 load4(const float* p, int n_valid, bool vec_ok)
     return v;
 }
 
+// grid (ceil(N/64), ceil(M/64), S).  S == 1: full epilogue here.  S > 1: raw partial sums of K-slice z go to
+// part[z][M][N] and gemm_reduce_kernel finishes.
 template <bool W_IS_KN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ X, int M, int K,
                                                        const float* __restrict__ W, int N,
@@ -32,7 +37,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ residual,
                                                        float* __restrict__ Y, int ldy, int act, int vecX, int vecW,
                                                        const int32_t* __restrict__ gather_idx,
-                                                       const int32_t* __restrict__ m_dev) {
+                                                       const int32_t* __restrict__ m_dev, int kslice,
+                                                       float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[BM * SA];
     __shared__ __attribute__((aligned(16))) float Bs[W_IS_KN ? BK * SBN : BN * SA];
 
@@ -45,6 +51,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         M = min(M, *m_dev);
         if (m0 >= M) return;
     }
+    const int kbeg = blockIdx.z * kslice;
+    const int kend = min(K, kbeg + kslice);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -52,35 +60,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging map: 64 rows x 4 float4 per BK-slice = 256 float4, one per thread
-    const int s_row = tid >> 2, s_k4 = (tid & 3) * 4;
-    // optional row gather on the A side: logical row r reads X[gather_idx[r], :]
-    const size_t a_row = (m0 + s_row < M) ? (gather_idx ? (size_t)gather_idx[m0 + s_row] : (size_t)(m0 + s_row)) : 0;
+    // staging map (A, and B in NT form): 64 rows x 8 float4 per slice = 512 float4, two per thread
+    const int s_row = tid >> 3, s_k4 = (tid & 7) * 4;                    // rows s_row and s_row + 32
+    size_t a_row[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int gm = m0 + s_row + 32 * u;
+        a_row[u] = gm < M ? (gather_idx ? (size_t)gather_idx[gm] : (size_t)gm) : 0;
+    }
+    // NN form: 32 k-rows x 16 float4 = 512 float4, two per thread
+    const int b_kr = tid >> 4, b_n4 = (tid & 15) * 4;                    // k-rows b_kr and b_kr + 16
 
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        {   // A tile
-            const int gm = m0 + s_row, gk = k0 + s_k4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < M) v = load4(X + a_row * K + gk, K - gk, vecX);
-            float* d = &As[s_row * SA + s_k4];
-            *reinterpret_cast<float2*>(d) = float2{v[0], v[1]};
-            *reinterpret_cast<float2*>(d + 2) = float2{v[2], v[3]};
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int gm = m0 + s_row + 32 * u, gk = k0 + s_k4;
+            ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gm < M) ra[u] = load4(X + a_row[u] * K + gk, kend - gk, vecX);
+            if (!W_IS_KN) {
+                const int gn = n0 + s_row + 32 * u;
+                rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gn < N) rb[u] = load4(W + (size_t)gn * K + gk, kend - gk, vecW);
+            } else {
+                const int gkk = k0 + b_kr + 16 * u, gn = n0 + b_n4;
+                rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gkk < kend) rb[u] = load4(W + (size_t)gkk * N + gn, N - gn, vecW);
+            }
         }
-        if (!W_IS_KN) {  // W [N,K]
-            const int gn = n0 + s_row, gk = k0 + s_k4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gn < N) v = load4(W + (size_t)gn * K + gk, K - gk, vecW);
-            float* d = &Bs[s_row * SA + s_k4];
-            *reinterpret_cast<float2*>(d) = float2{v[0], v[1]};
-            *reinterpret_cast<float2*>(d + 2) = float2{v[2], v[3]};
-        } else {         // W [K,N]: 16 k-rows x 16 float4
-            const int kr = tid >> 4, n4 = (tid & 15) * 4;
-            const int gk = k0 + kr, gn = n0 + n4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gk < K) v = load4(W + (size_t)gk * N + gn, N - gn, vecW);
-            *reinterpret_cast<f32x4*>(&Bs[kr * SBN + n4]) = v;
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float* d = &As[(s_row + 32 * u) * SA + s_k4];
+            *reinterpret_cast<float2*>(d) = float2{ra[u][0], ra[u][1]};
+            *reinterpret_cast<float2*>(d + 2) = float2{ra[u][2], ra[u][3]};
+            if (!W_IS_KN) {
+                float* e = &Bs[(s_row + 32 * u) * SA + s_k4];
+                *reinterpret_cast<float2*>(e) = float2{rb[u][0], rb[u][1]};
+                *reinterpret_cast<float2*>(e + 2) = float2{rb[u][2], rb[u][3]};
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[(b_kr + 16 * u) * SBN + b_n4]) = rb[u];
+            }
         }
+    };
+
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        lstore();
         __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK);          // next slice in flight under this slice's MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[2], b[2];
@@ -102,22 +131,81 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 
     // epilogue: C layout col = lane&15, row = (lane>>4)*4 + r
+    const bool partial = gridDim.z > 1;
+    float* pz = partial ? part + (size_t)blockIdx.z * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wc * 32 + j * 16 + (lane & 15);
             if (gn >= N) continue;
-            const float bv = bias ? bias[gn] : 0.0f;
+            const float bv = (!partial && bias) ? bias[gn] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
                 if (gm >= M) continue;
-                float v = mg_act(acc[i][j][r] + bv, act);
-                if (residual) v += residual[(size_t)gm * N + gn];
-                Y[(size_t)gm * ldy + gn] = v;
+                if (partial) {
+                    pz[(size_t)gm * N + gn] = acc[i][j][r];
+                } else {
+                    float v = mg_act(acc[i][j][r] + bv, act);
+                    if (residual) v += residual[(size_t)gm * N + gn];
+                    Y[(size_t)gm * ldy + gn] = v;
+                }
             }
         }
+}
+
+// Y = act(sum_z part[z] + bias) + residual, slices summed in ascending z (deterministic)
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ residual, float* __restrict__ Y,
+                                                          int ldy, int act) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / N;
+        const int n = (int)(i - m * N);
+        float s = part[i];
+        for (int z = 1; z < S; ++z) s += part[(size_t)z * total + i];
+        float v = mg_act(s + (bias ? bias[n] : 0.f), act);
+        if (residual) v += residual[i];
+        Y[m * ldy + n] = v;
+    }
+}
+
+// K-split factor: enough workgroups to cover the chip, slices of at least 2 x BK, bounded by the workspace
+int choose_split(int M, int N, int K, size_t ws_floats) {
+    const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+    if (tiles >= 192 || K < 4 * BK) return 1;
+    int s = (384 + tiles - 1) / tiles;
+    const int smax = K / (2 * BK);
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    while (s > 1 && (size_t)s * M * N > ws_floats) --s;
+    return s < 1 ? 1 : s;
+}
+
+template <bool W_IS_KN>
+int launch_gemm(const float* X, int M, int K, const float* W, int N, const float* bias, const float* residual, float* Y,
+                int ldy, int act, const int32_t* gather_idx, const int32_t* m_dev, float* ws, size_t ws_floats,
+                hipStream_t stream) {
+    const int vecX = (K % 4 == 0) && mg_aligned16(X);
+    const int vecW = W_IS_KN ? ((N % 4 == 0) && mg_aligned16(W)) : ((K % 4 == 0) && mg_aligned16(W));
+    int S = (ws && !m_dev) ? choose_split(M, N, K, ws_floats) : 1;
+    int kslice = K;
+    if (S > 1) {
+        kslice = (((K + S - 1) / S) + BK - 1) / BK * BK;
+        S = (K + kslice - 1) / kslice;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, S);
+    hipLaunchKernelGGL(gemm_f32_kernel<W_IS_KN>, grid, dim3(256), 0, stream, X, M, K, W, N, bias, residual, Y, ldy, act,
+                       vecX, vecW, gather_idx, m_dev, kslice, ws);
+    if (S > 1) {
+        size_t blocks = ((size_t)M * N + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)ws, S, M, N, bias,
+                           residual, Y, ldy, act);
+    }
+    return 0;
 }
 
 }  // namespace
@@ -125,41 +213,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // internal launcher shared with lstm.hip: Y[r, 0:N] (row stride ldy) = X[gather_idx[r], :] W^T + bias, r < min(M, *m_dev)
 int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                      const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream) {
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    const int vecX = (K % 4 == 0) && mg_aligned16(X);
-    const int vecW = (K % 4 == 0) && mg_aligned16(W);
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, X, M, K, W, N, bias,
-                       (const float*)nullptr, Y, ldy, MGNNS_ACT_NONE, vecX, vecW, gather_idx, m_dev);
-    return 0;
+    return launch_gemm<false>(X, M, K, W, N, bias, nullptr, Y, ldy, MGNNS_ACT_NONE, gather_idx, m_dev, nullptr, 0, stream);
 }
 
+extern "C" size_t mgnns_gemm_workspace_bytes(void) { return (size_t)16 << 20; }   // 16 MiB of K-split partials
+
 extern "C" int mgnns_linear_fwd(const float* X, int M, int K, const float* W, const float* bias, int N,
-                                const float* residual, float* Y, int act, mgnns_stream_t stream) {
+                                const float* residual, float* Y, int act, void* workspace, size_t workspace_bytes,
+                                mgnns_stream_t stream) {
     MG_REQUIRE(X && W && Y, "mgnns_linear_fwd: null pointer");
     MG_REQUIRE(M >= 0 && K > 0 && N > 0, "mgnns_linear_fwd: bad dims M=%d K=%d N=%d", M, K, N);
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_linear_fwd: unknown activation %d", act);
     if (M == 0) return 0;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    const int vecX = (K % 4 == 0) && mg_aligned16(X);
-    const int vecW = (K % 4 == 0) && mg_aligned16(W);
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, W, N, bias,
-                       residual, Y, N, act, vecX, vecW, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    launch_gemm<false>(X, M, K, W, N, bias, residual, Y, N, act, nullptr, nullptr, reinterpret_cast<float*>(workspace),
+                       workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream);
     MG_CHECK_LAUNCH("mgnns_linear_fwd");
     return 0;
 }
 
-extern "C" int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float* Y, int act,
-                                mgnns_stream_t stream) {
+extern "C" int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float* Y, int act, void* workspace,
+                                size_t workspace_bytes, mgnns_stream_t stream) {
     MG_REQUIRE(X && W && Y, "mgnns_matmul_fwd: null pointer");
     MG_REQUIRE(M >= 0 && K > 0 && N > 0, "mgnns_matmul_fwd: bad dims M=%d K=%d N=%d", M, K, N);
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_matmul_fwd: unknown activation %d", act);
     if (M == 0) return 0;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    const int vecX = (K % 4 == 0) && mg_aligned16(X);
-    const int vecW = (N % 4 == 0) && mg_aligned16(W);
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, W, N,
-                       (const float*)nullptr, (const float*)nullptr, Y, N, act, vecX, vecW, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr);
+    launch_gemm<true>(X, M, K, W, N, nullptr, nullptr, Y, N, act, nullptr, nullptr, reinterpret_cast<float*>(workspace),
+                      workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream);
     MG_CHECK_LAUNCH("mgnns_matmul_fwd");
     return 0;
 }

@@ -71,6 +71,19 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_gemm_ws = {}
+
+
+def _gemm_workspace(device):
+    """K-split scratch of the GEMM kernels: one buffer per (device, stream) so concurrent streams never share."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _gemm_ws.get(key)
+    if buf is None:
+        buf = torch.empty(_lib.lib().mgnns_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+        _gemm_ws[key] = buf
+    return buf
+
+
 # ---- nn.Linear / matmul ---------------------------------------------------------------
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None):
     """act(x @ weight.T + bias) (+ residual); x [..., K], weight [N, K]."""
@@ -88,8 +101,9 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None):
         if residual.shape[0] != x2.shape[0]:
             raise ValueError("residual rows mismatch")
     L = _lib.lib()
+    ws = _gemm_workspace(x.device)
     _lib.check(L.mgnns_linear_fwd(_p(x2), x2.shape[0], K, _p(weight), _p(bias), N, _p(residual), _p(y), act,
-                                  _stream()), "mgnns_linear_fwd")
+                                  _p(ws), ws.numel(), _stream()), "mgnns_linear_fwd")
     return y.view(*x.shape[:-1], N)
 
 
@@ -101,8 +115,9 @@ def matmul(x, w, act=ACT_NONE):
         raise ValueError("matmul shapes %s x %s" % (tuple(x.shape), tuple(w.shape)))
     y = torch.empty(x.shape[0], w.shape[1], device=x.device, dtype=torch.float32)
     L = _lib.lib()
-    _lib.check(L.mgnns_matmul_fwd(_p(x), x.shape[0], x.shape[1], _p(w), w.shape[1], _p(y), act, _stream()),
-               "mgnns_matmul_fwd")
+    ws = _gemm_workspace(x.device)
+    _lib.check(L.mgnns_matmul_fwd(_p(x), x.shape[0], x.shape[1], _p(w), w.shape[1], _p(y), act, _p(ws), ws.numel(),
+                                  _stream()), "mgnns_matmul_fwd")
     return y
 
 
