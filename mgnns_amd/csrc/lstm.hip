@@ -26,10 +26,12 @@ constexpr int HID = 150;
 constexpr int G4 = 4 * HID;          // 600 gate rows
 constexpr int HPAD = 152;            // h padded to a multiple of 4 for 16-B LDS broadcasts
 constexpr int REC_THREADS = 640;     // 10 waves; threads >= 600 idle in the GEMV part
+constexpr int WREG = 136;            // weights of a gate row kept in registers (10 waves -> 168-VGPR budget) ...
+constexpr int WLDS = HID - WREG;     // ... the last 14 live in LDS ([k][row], conflict-free row-consecutive reads)
 
 // offs[b] = sum_{i<b} len_i (exclusive), offs[B] = total (single workgroup)
 __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restrict__ lens, int B, int T,
-                                                         int32_t* __restrict__ offs) {
+                                                         int32_t* __restrict__ offs, int32_t* __restrict__ order) {
     __shared__ int32_t s_off[1025];
     const int tid = threadIdx.x;
     // single workgroup: serial-chunk scan of the (<= a few thousand) lengths
@@ -56,6 +58,19 @@ __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restri
         run += (int)(l < 0 ? 0 : (l > T ? T : l));
     }
     if (tid == 1023) offs[B] = s_off[1024];
+    // order[r] = sample with the r-th longest text (ties by index): the recurrence launches 2*B workgroups on
+    // 256 CUs, one per CU at a time, so the long chains must start first (rank by counting, O(B^2/1024) per thread)
+    for (int b = tid; b < B; b += 1024) {
+        long long lb = lens[b];
+        lb = lb < 0 ? 0 : (lb > T ? T : lb);
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            long long lj = lens[j];
+            lj = lj < 0 ? 0 : (lj > T ? T : lj);
+            rank += (lj > lb) || (lj == lb && j < b);
+        }
+        order[rank] = b;
+    }
 }
 
 // pack_tok[r] = token id, pack_pos[r] = b*T + t for the rows r = offs[b] + t of sample b (grid = B)
@@ -75,15 +90,19 @@ __global__ __launch_bounds__(128) void lstm_fill_kernel(const int64_t* __restric
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh(x) = 2*sigmoid(2x) - 1: one exp instead of libm's tanhf polynomial/branch mix (abs err < 2e-7)
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + expf(-2.0f * x)) - 1.0f; }
 
 __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __restrict__ Gx, const int32_t* __restrict__ offs,
                                                                const int64_t* __restrict__ lens, int T,
                                                                const float* __restrict__ Whh_f, const float* __restrict__ Whh_b,
                                                                const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
-                                                               float* __restrict__ out) {
+                                                               const int32_t* __restrict__ order, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float s_h[2][HPAD];
     __shared__ float s_g[G4];
-    const int b = blockIdx.x, dir = blockIdx.y;
+    __shared__ float s_w[WLDS][REC_THREADS];
+    // workgroup id -> (rank, direction): both directions of the longest sample first
+    const int b = order[blockIdx.x >> 1], dir = blockIdx.x & 1;
     const int n = threadIdx.x;
     const bool row_on = n < G4;
     long long l = lens[b];
@@ -92,9 +111,11 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     const float* Whh = dir ? Whh_b : Whh_f;
     const float* bhh = dir ? bhh_b : bhh_f;
 
-    float w[HID];
+    float w[WREG];
 #pragma unroll
-    for (int k = 0; k < HID; ++k) w[k] = row_on ? Whh[(size_t)n * HID + k] : 0.f;
+    for (int k = 0; k < WREG; ++k) w[k] = row_on ? Whh[(size_t)n * HID + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < WLDS; ++k) s_w[k][n] = row_on ? Whh[(size_t)n * HID + WREG + k] : 0.f;
     const float bias = row_on ? bhh[n] : 0.f;
 
     if (n < HPAD) { s_h[0][n] = 0.f; s_h[1][n] = 0.f; }
@@ -107,21 +128,33 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     if (row_on && len > 0) gx = gx_base[(size_t)(dir ? len - 1 : 0) * (2 * G4)];
     for (int s = 0; s < len; ++s) {
         const int t = dir ? len - 1 - s : s;
-        float acc = 0.f;
+        // four interleaved partial sums (k mod 4): 38-deep dependent chains instead of 150
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h[cur]);
 #pragma unroll
-        for (int k4 = 0; k4 < HID / 4; ++k4) {
+        for (int k4 = 0; k4 < WREG / 4; ++k4) {
             const f32x4 hv = h4[k4];
-            acc = fmaf(w[4 * k4 + 0], hv[0], acc);
-            acc = fmaf(w[4 * k4 + 1], hv[1], acc);
-            acc = fmaf(w[4 * k4 + 2], hv[2], acc);
-            acc = fmaf(w[4 * k4 + 3], hv[3], acc);
+            a0 = fmaf(w[4 * k4 + 0], hv[0], a0);
+            a1 = fmaf(w[4 * k4 + 1], hv[1], a1);
+            a2 = fmaf(w[4 * k4 + 2], hv[2], a2);
+            a3 = fmaf(w[4 * k4 + 3], hv[3], a3);
         }
-        {   // tail: HID = 4*37 + 2
-            const f32x4 hv = h4[HID / 4];
 #pragma unroll
-            for (int k = 4 * (HID / 4); k < HID; ++k) acc = fmaf(w[k], hv[k - 4 * (HID / 4)], acc);
+        for (int k4 = WREG / 4; k4 < HPAD / 4; ++k4) {      // k = 136..151 (h is zero padded beyond 149)
+            const f32x4 hv = h4[k4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * k4 + j;
+                if (k < HID) {
+                    const float wk = s_w[k - WREG][n];
+                    if (j == 0) a0 = fmaf(wk, hv[0], a0);
+                    if (j == 1) a1 = fmaf(wk, hv[1], a1);
+                    if (j == 2) a2 = fmaf(wk, hv[2], a2);
+                    if (j == 3) a3 = fmaf(wk, hv[3], a3);
+                }
+            }
         }
+        const float acc = (a0 + a1) + (a2 + a3);
         if (row_on) s_g[n] = (gx + bias) + acc;
         // prefetch the next step's input projection while the cell update runs
         if (row_on && s + 1 < len) gx = gx_base[(size_t)(dir ? len - 2 - s : s + 1) * (2 * G4)];
@@ -129,10 +162,10 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
         if (n < HID) {
             const float ig = sigmoidf_(s_g[n]);
             const float fg = sigmoidf_(s_g[HID + n]);
-            const float gg = tanhf(s_g[2 * HID + n]);
+            const float gg = tanhf_(s_g[2 * HID + n]);
             const float og = sigmoidf_(s_g[3 * HID + n]);
             c = fg * c + ig * gg;
-            const float hh = og * tanhf(c);
+            const float hh = og * tanhf_(c);
             s_h[cur ^ 1][n] = hh;
             out[((size_t)b * T + t) * (2 * HID) + dir * HID + n] = hh;
         }
@@ -153,7 +186,7 @@ extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num
     const size_t rows = (size_t)B * T;
     size_t bytes = rows * 8 * (size_t)hidden * sizeof(float);   // Gx [rows, 2*4*hidden]
     bytes += rows * 2 * (size_t)hidden * sizeof(float);          // layer-0 output [rows, 2*hidden]
-    bytes += (2 * rows + (size_t)B + 1 + 8) * sizeof(int32_t);   // pack_tok, pack_pos, offs
+    bytes += (2 * rows + 2 * (size_t)B + 1 + 8) * sizeof(int32_t);   // pack_tok, pack_pos, offs, order
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -178,8 +211,9 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
     int32_t* pack_tok = reinterpret_cast<int32_t*>(mid + rows * 2 * HID);
     int32_t* pack_pos = pack_tok + rows;
     int32_t* offs = pack_pos + rows;
+    int32_t* order = offs + B + 1;
 
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs);
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
     hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
     for (int layer = 0; layer < num_layers; ++layer) {
         const float* X = layer == 0 ? emb_table : mid;
@@ -189,8 +223,9 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
         for (int dir = 0; dir < 2; ++dir)
             mg_launch_linear(X, (int)rows, K, w_ih[2 * layer + dir], b_ih[2 * layer + dir], G4, Gx + dir * G4, 2 * G4, gidx,
                              offs + B, s);
-        hipLaunchKernelGGL(lstm_rec_kernel, dim3(B, 2), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
-                           T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1], dst);
+        hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
+                           T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1],
+                           (const int32_t*)order, dst);
     }
     MG_CHECK_LAUNCH("mgnns_bilstm_fwd");
     return 0;
