@@ -25,9 +25,7 @@ namespace {
 constexpr int HID = 150;
 constexpr int G4 = 4 * HID;          // 600 gate rows
 constexpr int HPAD = 152;            // h padded to a multiple of 4 for 16-B LDS broadcasts
-constexpr int REC_THREADS = 640;     // 10 waves; threads >= 600 idle in the GEMV part
-constexpr int WREG = 136;            // weights of a gate row kept in registers (10 waves -> 168-VGPR budget) ...
-constexpr int WLDS = HID - WREG;     // ... the last 14 live in LDS ([k][row], conflict-free row-consecutive reads)
+constexpr int REC_THREADS = 768;     // 12 waves
 
 // offs[b] = sum_{i<b} len_i (exclusive), offs[B] = total (single workgroup)
 __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restrict__ lens, int B, int T,
@@ -60,13 +58,12 @@ __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restri
     if (tid == 1023) offs[B] = s_off[1024];
     // order[r] = sample with the r-th longest text (ties by index): the recurrence launches 2*B workgroups on
     // 256 CUs, one per CU at a time, so the long chains must start first (rank by counting, O(B^2/1024) per thread)
-    for (int b = tid; b < B; b += 1024) {
-        long long lb = lens[b];
-        lb = lb < 0 ? 0 : (lb > T ? T : lb);
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {                      // clamped length of sample b = offs[b+1] - offs[b]
+        const int lb = offs[b + 1] - offs[b];
         int rank = 0;
         for (int j = 0; j < B; ++j) {
-            long long lj = lens[j];
-            lj = lj < 0 ? 0 : (lj > T ? T : lj);
+            const int lj = offs[j + 1] - offs[j];
             rank += (lj > lb) || (lj == lb && j < b);
         }
         order[rank] = b;
@@ -93,87 +90,103 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // tanh(x) = 2*sigmoid(2x) - 1: one exp instead of libm's tanhf polynomial/branch mix (abs err < 2e-7)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + expf(-2.0f * x)) - 1.0f; }
 
+// One workgroup (12 waves) per (sample, direction).  The recurrent GEMV gates[600] += W_hh[600,150] h[150] is split
+// along K across the waves: wave w owns the 13 hidden units k in [13w, 13w+13) for ALL 600 gate rows (lane l holds
+// rows l, l+64, ..: 10 x 13 = 130 weights in registers, loaded once).  Per step a wave therefore needs only ITS 13
+// values of h (four 16-B LDS broadcasts instead of 38 for a row-per-thread split, which made the LDS the
+// bottleneck), and leaves 600 partial sums in LDS; after one barrier the 150 cell threads add the 10 partials of
+// their four gate rows in a fixed order (12 partials each), apply the cell update and publish h (LDS + the output row).
+constexpr int KW = 13;               // hidden units per wave (12 x 13 = 156 >= 150, the tail is zero)
+constexpr int NWAVE = 12;
+constexpr int RPL = 10;              // gate rows per lane (ceil(600 / 64))
+constexpr int PSTR = 640;            // row stride of the partial-sum array
+
 __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __restrict__ Gx, const int32_t* __restrict__ offs,
                                                                const int64_t* __restrict__ lens, int T,
                                                                const float* __restrict__ Whh_f, const float* __restrict__ Whh_b,
                                                                const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                                const int32_t* __restrict__ order, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float s_h[2][HPAD];
-    __shared__ float s_g[G4];
-    __shared__ float s_w[WLDS][REC_THREADS];
+    __shared__ __attribute__((aligned(16))) float s_h[2][NWAVE][16];     // h, chunked per owning wave (15 + 1 pad)
+    __shared__ float s_part[NWAVE][PSTR];
+    __shared__ float s_act[G4];
     // workgroup id -> (rank, direction): both directions of the longest sample first
     const int b = order[blockIdx.x >> 1], dir = blockIdx.x & 1;
-    const int n = threadIdx.x;
-    const bool row_on = n < G4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     long long l = lens[b];
     const int len = (int)(l < 0 ? 0 : (l > T ? T : l));
     const int off = offs[b];
     const float* Whh = dir ? Whh_b : Whh_f;
     const float* bhh = dir ? bhh_b : bhh_f;
 
-    float w[WREG];
+    float w[RPL][KW];
 #pragma unroll
-    for (int k = 0; k < WREG; ++k) w[k] = row_on ? Whh[(size_t)n * HID + k] : 0.f;
+    for (int i = 0; i < RPL; ++i) {
+        const int row = lane + 64 * i;
 #pragma unroll
-    for (int k = 0; k < WLDS; ++k) s_w[k][n] = row_on ? Whh[(size_t)n * HID + WREG + k] : 0.f;
-    const float bias = row_on ? bhh[n] : 0.f;
-
-    if (n < HPAD) { s_h[0][n] = 0.f; s_h[1][n] = 0.f; }
+        for (int kk = 0; kk < KW; ++kk)
+            w[i][kk] = (row < G4 && wave * KW + kk < HID) ? Whh[(size_t)row * HID + wave * KW + kk] : 0.f;
+    }
+    // gate threads: thread n (< 600) finishes gate row n (sum of the 12 partials + input projection + bias, then the
+    // row's activation: rows [300,450) are the tanh gate g, the rest sigmoid); cell threads: unit j = tid (< 150)
+    const bool gate_on = tid < G4;
+    const bool cell = tid < HID;
+    const bool is_tanh = tid >= 2 * HID && tid < 3 * HID;
+    const float bias = gate_on ? bhh[tid] : 0.f;
+    if (tid < 2 * NWAVE * 16) (&s_h[0][0][0])[tid] = 0.f;
     float c = 0.f;
     __syncthreads();
 
-    const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + n;
-    int cur = 0;
+    const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + tid;
     float gx = 0.f;
-    if (row_on && len > 0) gx = gx_base[(size_t)(dir ? len - 1 : 0) * (2 * G4)];
+    if (gate_on && len > 0) gx = gx_base[(size_t)(dir ? len - 1 : 0) * (2 * G4)];
+    int cur = 0;
+    // LDS indices kept opaque inside the loop so every access is base + IMMEDIATE offset (the compiler otherwise
+    // hoists dozens of loop-invariant "base + const" addresses into registers and spills the weights)
+    float* const sp = &s_part[0][0];
+    int wr_idx = wave * PSTR + lane, rd_idx = tid;
     for (int s = 0; s < len; ++s) {
         const int t = dir ? len - 1 - s : s;
-        // four interleaved partial sums (k mod 4): 38-deep dependent chains instead of 150
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h[cur]);
+        asm volatile("" : "+v"(wr_idx), "+v"(rd_idx));
+        // ---- 1. partial GEMV over this wave's 13 hidden units ---------------------------------------------------
+        const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h[cur][wave]);
+        const f32x4 h0 = h4[0], h1 = h4[1], h2 = h4[2], h3 = h4[3];
+        const float hv[16] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3],
+                              h2[0], h2[1], h2[2], h2[3], h3[0], h3[1], h3[2], h3[3]};
 #pragma unroll
-        for (int k4 = 0; k4 < WREG / 4; ++k4) {
-            const f32x4 hv = h4[k4];
-            a0 = fmaf(w[4 * k4 + 0], hv[0], a0);
-            a1 = fmaf(w[4 * k4 + 1], hv[1], a1);
-            a2 = fmaf(w[4 * k4 + 2], hv[2], a2);
-            a3 = fmaf(w[4 * k4 + 3], hv[3], a3);
-        }
+        for (int i = 0; i < RPL; ++i) {
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int k4 = WREG / 4; k4 < HPAD / 4; ++k4) {      // k = 136..151 (h is zero padded beyond 149)
-            const f32x4 hv = h4[k4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * k4 + j;
-                if (k < HID) {
-                    const float wk = s_w[k - WREG][n];
-                    if (j == 0) a0 = fmaf(wk, hv[0], a0);
-                    if (j == 1) a1 = fmaf(wk, hv[1], a1);
-                    if (j == 2) a2 = fmaf(wk, hv[2], a2);
-                    if (j == 3) a3 = fmaf(wk, hv[3], a3);
-                }
+            for (int kk = 0; kk + 1 < KW; kk += 2) {
+                a0 = fmaf(w[i][kk], hv[kk], a0);
+                a1 = fmaf(w[i][kk + 1], hv[kk + 1], a1);
             }
+            a0 = fmaf(w[i][KW - 1], hv[KW - 1], a0);
+            sp[wr_idx + 64 * i] = a0 + a1;
         }
-        const float acc = (a0 + a1) + (a2 + a3);
-        if (row_on) s_g[n] = (gx + bias) + acc;
-        // prefetch the next step's input projection while the cell update runs
-        if (row_on && s + 1 < len) gx = gx_base[(size_t)(dir ? len - 2 - s : s + 1) * (2 * G4)];
         __syncthreads();
-        if (n < HID) {
-            const float ig = sigmoidf_(s_g[n]);
-            const float fg = sigmoidf_(s_g[HID + n]);
-            const float gg = tanhf_(s_g[2 * HID + n]);
-            const float og = sigmoidf_(s_g[3 * HID + n]);
+        // ---- 2. every gate row: ordered sum of the 12 partials, + W_ih x + b_ih (Gx) + b_hh, activation ----------
+        if (gate_on) {
+            float sum = sp[rd_idx];
+#pragma unroll
+            for (int ww = 1; ww < NWAVE; ++ww) sum += sp[rd_idx + ww * PSTR];
+            const float pre = (gx + bias) + sum;
+            if (s + 1 < len) gx = gx_base[(size_t)(dir ? len - 2 - s : s + 1) * (2 * G4)];   // next step, in flight
+            s_act[tid] = is_tanh ? tanhf_(pre) : sigmoidf_(pre);
+        }
+        __syncthreads();
+        // ---- 3. cell update by the 150 unit threads -------------------------------------------------------------------
+        if (cell) {
+            const float ig = s_act[tid], fg = s_act[HID + tid], gg = s_act[2 * HID + tid], og = s_act[3 * HID + tid];
             c = fg * c + ig * gg;
             const float hh = og * tanhf_(c);
-            s_h[cur ^ 1][n] = hh;
-            out[((size_t)b * T + t) * (2 * HID) + dir * HID + n] = hh;
+            s_h[cur ^ 1][tid / KW][tid % KW] = hh;
+            out[((size_t)b * T + t) * (2 * HID) + dir * HID + tid] = hh;
         }
         __syncthreads();
         cur ^= 1;
     }
     // pad_packed_sequence(total_length=T): zeros behind the sample's length
-    for (int i = n; i < (T - len) * HID; i += REC_THREADS) {
+    for (int i = tid; i < (T - len) * HID; i += REC_THREADS) {
         const int t = len + i / HID, j = i % HID;
         out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = 0.f;
     }

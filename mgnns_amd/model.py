@@ -188,6 +188,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.register_buffer('label_query', None, persistent=False)
         self._load_label_query(label_glove if label_glove is not None else opt.get('label_glove'))
         self._wt_cache = {}
+        self._streams = None
+        self.use_streams = bool(opt.get('use_streams', True))
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
 
@@ -329,40 +331,75 @@ class Multi_GCN_Multihead_Att(nn.Module):
         if self.label_query is None:
             raise RuntimeError("label query missing: pass label_glove=... / opt['label_glove'], call "
                                "set_label_query(), or run from a directory holding %s" % (LABEL_GLOVE_CANDIDATES,))
+        for name, t in (("text", text), ("object_feature", object_feature), ("place_feature", place_feature)):
+            if not t.is_cuda:
+                raise RuntimeError("%s is on %s: mgnns_amd operators run on the GPU only (no CPU path)" % (name, t.device))
         if self.label_query.device != text.device:
             self.label_query = self.label_query.to(text.device)
         with torch.no_grad():
-            text_feature = self.text_features(text)
-            text_memory_bank = self.get_text_memory_bank(text, text_lens, return_last_state=False)
-            self.object_feature = self._features(self.object_features, object_feature)
-            img_object_memory_bank, object_x_attention = self._channel(
-                self.object_feature, self.liner_img_object, self.object_A, object_inp,
-                self.object_attention, self.object_linear_5, self.object_x_linear)
-            self.place_feature = self._features(self.place_features, place_feature)
-            img_place_memory_bank, place_x_attention = self._channel(
-                self.place_feature, self.liner_img_place, self.place_A, place_inp,
-                self.place_attention, self.place_linear_5, self.place_x_linear)
+            return self._forward_streams(text, text_lens, text_mask, object_feature, place_feature,
+                                         object_inp, place_inp)
 
-            text_mask = text_mask.float().contiguous()
-            # banks feed 2-4 layers each: wrap once so a bf16 copy (if used) is made once
-            text_memory_bank = MemoryBank(f32=text_memory_bank)
-            iot = object_x_attention
+    def _side_streams(self, device):
+        key = str(device)
+        if self._streams is None or self._streams[0] != key:
+            self._streams = (key, [torch.cuda.Stream(device=device) for _ in range(3)])
+        return self._streams[1]
+
+    def _forward_streams(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp):
+        """The three channels and then the four fusion stacks are independent of each other (MODEL:444-546), so
+        they are enqueued on separate HIP streams (fork/join with events: no host sync, capturable into one
+        hipGraph) and overlap on the GPU instead of running as one serial chain of small launches."""
+        main = torch.cuda.current_stream()
+        s_obj, s_place, s_aux = self._side_streams(text.device) if self.use_streams else (main, main, main)
+        for st in (s_obj, s_place):
+            st.wait_stream(main)
+
+        # -- text channel (main stream): text-level GCN, then the BiLSTM memory bank ---------------------------
+        text_feature = self.text_features(text)
+        text_memory_bank = MemoryBank(f32=self.get_text_memory_bank(text, text_lens, return_last_state=False))
+        if self.precision == 'bf16':
+            text_memory_bank.bf16            # one conversion, shared by the four text-bank layers
+        text_mask = text_mask.float().contiguous()
+
+        # -- object / place channels ------------------------------------------------------------------------------
+        with torch.cuda.stream(s_obj):
+            self.object_feature = self._features(self.object_features, object_feature)
+            bank_obj, att_obj = self._channel(self.object_feature, self.liner_img_object, self.object_A, object_inp,
+                                              self.object_attention, self.object_linear_5, self.object_x_linear)
+        with torch.cuda.stream(s_place):
+            self.place_feature = self._features(self.place_features, place_feature)
+            bank_place, att_place = self._channel(self.place_feature, self.liner_img_place, self.place_A, place_inp,
+                                                  self.place_attention, self.place_linear_5, self.place_x_linear)
+
+        # -- four fusion stacks: image->text on the channel streams, text->image on main / aux --------------------
+        s_obj.wait_stream(main)                  # needs the text bank
+        with torch.cuda.stream(s_obj):
+            iot = att_obj
             for layer in self.img_object_text_multi_head_att:
                 iot, _ = layer(q=iot, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
-            ipt = place_x_attention
+        s_place.wait_stream(main)
+        with torch.cuda.stream(s_place):
+            ipt = att_place
             for layer in self.img_place_text_multi_head_att:
                 ipt, _ = layer(q=ipt, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
-            tio = text_feature
-            for layer in self.text_img_object_multi_head_att:
-                tio, _ = layer(q=tio, k=img_object_memory_bank, v=img_object_memory_bank)
+        s_aux.wait_stream(main)
+        s_aux.wait_stream(s_place)               # place bank (its stream also carries ipt; ordering is harmless)
+        with torch.cuda.stream(s_aux):
             tip = text_feature
             for layer in self.text_img_place_multi_head_att:
-                tip, _ = layer(q=tip, k=img_place_memory_bank, v=img_place_memory_bank)
+                tip, _ = layer(q=tip, k=bank_place, v=bank_place)
+        main.wait_stream(s_obj)
+        tio = text_feature
+        for layer in self.text_img_object_multi_head_att:
+            tio, _ = layer(q=tio, k=bank_obj, v=bank_obj)
 
-            multi_feature = torch.cat([tio, tip, iot, ipt], dim=1)
-            multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
-                                       self.multi_linear_1.bias.detach())
-            return ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
+        main.wait_stream(s_place)
+        main.wait_stream(s_aux)
+        multi_feature = torch.cat([tio, tip, iot, ipt], dim=1)
+        multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
+                                   self.multi_linear_1.bias.detach())
+        return ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
 
     def get_config_optim(self, lr, lrp):
         return [
