@@ -36,6 +36,41 @@ __device__ __forceinline__ float mg_act(float v, int act) {
     return v;
 }
 
+// ---- DPP (pure VALU, no LDS crossbar) reductions -----------------------------------------------------------
+// 16-lane row reductions: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -> all 16 lanes
+#define MG_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += MG_DPP(v, 0xB1);
+    v += MG_DPP(v, 0x4E);
+    v += MG_DPP(v, 0x141);
+    v += MG_DPP(v, 0x140);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, MG_DPP(v, 0xB1));
+    v = fmaxf(v, MG_DPP(v, 0x4E));
+    v = fmaxf(v, MG_DPP(v, 0x141));
+    v = fmaxf(v, MG_DPP(v, 0x140));
+    return v;
+}
+// full-wave max, result wave-uniform: DPP inside the four rows, then the four row results via v_readlane
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = row16_max(v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = row16_sum(v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
+}
+
 // 64-lane butterfly reductions (wave = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -33,7 +33,12 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf(a) | ((unsigned int)f2bf(b) << 16); }
+// two fp32 -> packed bf16x2 (round to nearest even) in ONE instruction; there is no builtin for it on gfx950
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Wp[nt][ks][lane][8] = W[nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j]   (0 for rows >= N)
 __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W, int N, int K, unsigned short* __restrict__ Wp) {
@@ -61,14 +66,19 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
 // NTN = column tiles of this wave (3 for waves 0-2, 2 for waves 3-7): compile-time so the MFMA stream is branch-free.
 // Every wave runs the same number of barriers; the two instantiations only differ in the tile count.
 template <int NTN>
-__device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* __restrict__ feat, int K, int P,
+__device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* __restrict__ feat, int Bn, int K, int P,
                                              const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
                                              unsigned short* __restrict__ bank, float* __restrict__ pooled_part) {
     uint4* Fs = reinterpret_cast<uint4*>(smem);                            // [2][ROWS][FSTR] chunks
     uint4* Os = Fs + 2 * ROWS * FSTR;                                      // [ROWS][OCH] chunks (epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x >> 1, mh = blockIdx.x & 1;
+    // the two halves of a sample share the 128-B lines at their seam and the same W stream: keep the pair on ONE
+    // XCD (workgroup id % 8 is the XCD in practice) so those lines are served by one L2; any mapping is correct
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int b_raw = (jq >> 1) * 8 + xcd, mh = jq & 1;
+    if (b_raw >= Bn) return;                   // tail when B % 8 != 0 (whole workgroup exits together)
+    const int b = b_raw;
     const int p0 = mh ? P_SPLIT : 0;
     const int p_store_end = mh ? P : P_SPLIT;                              // rows [p0, p_store_end) are ours
     const int nt0 = wave < 3 ? 3 * wave : 9 + 2 * (wave - 3);
@@ -92,17 +102,24 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ld_on) st[i] = *reinterpret_cast<const f32x4*>(fsrc + ((size_t)c * BK + i) * P);
+            // streamed once: non-temporal, so the map does not evict the W fragments every workgroup re-reads from L2
+            if (ld_on) st[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(fsrc + ((size_t)c * BK + i) * P));
         }
     };
     auto lstore = [&](int c, int buf) {
         // max-pool of the 8 feature rows this wave just loaded (exact fp32), then transpose-write as bf16
+        // (only lanes 0..27 carry data: two DPP rows -> lanes 0 and 16 hold the row maxima; lane i keeps row i's
+        // result so the 8 maxima leave as ONE 32-byte store per wave)
+        float mine = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float m = ld_on ? fmaxf(fmaxf(st[i][0], st[i][1]), fmaxf(st[i][2], st[i][3])) : -INFINITY;
-            m = wave_max(m);
-            if (lane == 0) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 8 * wave + i] = m;
+            m = row16_max(m);
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+            if (lane == i) mine = fmaxf(r0, r1);
         }
+        if (lane < 8) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 8 * wave + lane] = mine;
         if (st_on) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -119,6 +136,10 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
 
     const uint4* wb = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64 + lane;
     const int nchunk = K / BK;
+    // B fragments (L2) run one k-step ahead of the MFMAs that consume them
+    uint4 bq[2][NTN];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) bq[0][j] = wb[((size_t)j * KS) * 64];
     gload(0);
     lstore(0, 0);
     __syncthreads();
@@ -128,9 +149,11 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
         const uint4* fb = Fs + (size_t)buf * ROWS * FSTR;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 bq[NTN];
+            const int ks_next = c * 2 + kk + 1;
+            if (ks_next < KS) {
 #pragma unroll
-            for (int j = 0; j < NTN; ++j) bq[j] = wb[((size_t)j * KS + (c * 2 + kk)) * 64];
+                for (int j = 0; j < NTN; ++j) bq[(kk + 1) & 1][j] = wb[((size_t)j * KS + ks_next) * 64];
+            }
             uint4 a[MTH];
 #pragma unroll
             for (int i = 0; i < MTH; ++i) {
@@ -142,8 +165,8 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
                 const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
 #pragma unroll
                 for (int j = 0; j < NTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bq[j]), acc[i][j],
-                                                                       0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bq[kk & 1][j]),
+                                                                       acc[i][j], 0, 0, 0);
             }
         }
         if (c + 1 < nchunk) lstore(c + 1, buf ^ 1);
@@ -176,16 +199,16 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
     }
 }
 
-__global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __restrict__ feat, int K, int P,
+__global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __restrict__ feat, int Bn, int K, int P,
                                                                  const unsigned short* __restrict__ Wp,
                                                                  const float* __restrict__ bias, int N,
                                                                  unsigned short* __restrict__ bank,
                                                                  float* __restrict__ pooled_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 3 * 64)
-        imgbank_body<3>(smem, feat, K, P, Wp, bias, N, bank, pooled_part);
+        imgbank_body<3>(smem, feat, Bn, K, P, Wp, bias, N, bank, pooled_part);
     else
-        imgbank_body<2>(smem, feat, K, P, Wp, bias, N, bank, pooled_part);
+        imgbank_body<2>(smem, feat, Bn, K, P, Wp, bias, N, bank, pooled_part);
 }
 
 // pooled[b,k] = max(part[b,0,k], part[b,1,k])
@@ -232,7 +255,8 @@ extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int 
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(2 * B), dim3(NTHR), SMEM_BYTES, s, feat, K, P,
+    const int nblk = ((B + 7) / 8) * 16;      // pairs laid out XCD-major, padded to a multiple of 8 samples
+    hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(nblk), dim3(NTHR), SMEM_BYTES, s, feat, B, K, P,
                        reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
                        pooled_work);
     const size_t total = (size_t)B * K;

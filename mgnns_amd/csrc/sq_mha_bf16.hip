@@ -77,16 +77,6 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
     }
 }
 
-// sum over the 16 lanes of a DPP row (the 16 head dims a C-tile column group holds), result in every lane;
-// pure VALU (v_add_f32 with DPP modifiers) -- no LDS crossbar traffic, unlike __shfl_xor (ds_bpermute).
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    return v;
-}
-
 // acc[i][j] += X[tile i] * W^T[tile j] over the padded model dim, for a COMPILE-TIME number of live row tiles.
 // Fully unrolled, software pipelined in two half-groups of row tiles: while the MFMAs of one half run, the A
 // fragments (ds_read_b128 from the staged bank) of the OTHER half / next k-step are in flight, so an LDS read is
