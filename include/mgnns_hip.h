@@ -179,6 +179,24 @@ int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const flo
                                const void* Wp, const float* bk, const float* bv,
                                float* o, float* attn, mgnns_stream_t stream);
 
+/* ---- a8, rest of the layer: fc + residual + LayerNorm + position-wise FFN + residual + LayerNorm in ONE launch ----
+ * MultiHeadAttention.forward after the attention (submodules.py:88-94) and PositionwiseFeedForward.forward
+ * (submodules.py:132-139), optionally followed by the NEXT layer's query projection w_qs (submodules.py:68):
+ *   y = LN1(fc(o) + q);  out = LN2(w_2 relu(w_1 y + b_1) + b_2 + y);  qh_next = w_qs'(out) + b'
+ * o [B, HK] (HK = n_head*d_v), q [B, 300] (the layer's query = the residual), out [B, 300], qh_next [B, HK_next].
+ * Every weight is passed PRE-PACKED by mgnns_pack_weight_f32 (MFMA-fragment-major fp32, one 16-B load = four
+ * k-steps): fc [300, HK], w_1 / w_2 [300, 300] (Conv1d k=1 weight viewed 2-D), w_qs' [HK_next, 300].
+ * wq_next_wp == NULL skips the last step.  Exact fp32.  d_model == 300.
+ */
+size_t mgnns_packed_f32_weight_bytes(int N, int K);
+int mgnns_pack_weight_f32(const float* W, int N, int K, float* Wp, mgnns_stream_t stream);
+int mgnns_mha_tail_fwd(const float* o, int HK, const float* q, int B, int d_model,
+                       const float* fc_wp, const float* fc_b, const float* ln1_gamma, const float* ln1_beta,
+                       const float* w1_wp, const float* b1, const float* w2_wp, const float* b2,
+                       const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                       const float* wq_next_wp, const float* bq_next, int HK_next, float* qh_next,
+                       mgnns_stream_t stream);
+
 /* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
  * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.
  */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "mgnns_sq_mha_pack_weights_bf16": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_cast_pad_bf16": [_P, _L, _I, _I, _P, _P],
     "mgnns_sq_mha_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_pack_weight_f32": [_P, _I, _I, _P, _P],
+    "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
 }
 
@@ -63,6 +65,8 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    L.mgnns_packed_f32_weight_bytes.restype = _SZ
+    L.mgnns_packed_f32_weight_bytes.argtypes = [_I, _I]
     L.mgnns_gemm_workspace_bytes.restype = _SZ
     L.mgnns_gemm_workspace_bytes.argtypes = []
     L.mgnns_imgbank_packed_weight_bytes.restype = _SZ

@@ -156,6 +156,72 @@ class MyMultiHeadAttention(nn.Module):
         return enc_output.squeeze(1), enc_slf_attn
 
 
+def _versions(*params):
+    return tuple((p.data_ptr(), p._version) for p in params) + (str(params[0].device),)
+
+
+def _tail_pack(layer):
+    """Pre-packed weights of one layer's fused tail, rebuilt when any of them changes."""
+    a, f = layer.slf_attn, layer.pos_ffn
+    ps = (a.fc.weight, a.fc.bias, a.layer_norm.gamma, a.layer_norm.beta, f.w_1.weight, f.w_1.bias, f.w_2.weight,
+          f.w_2.bias, f.layer_norm.gamma, f.layer_norm.beta)
+    key = _versions(*ps)
+    hit = getattr(layer, "_tail_cache", None)
+    if hit is None or hit[0] != key:
+        d = {"fc_wp": ops.pack_weight_f32(a.fc.weight.detach()), "fc_b": a.fc.bias.detach(),
+             "g1": a.layer_norm.gamma.detach(), "be1": a.layer_norm.beta.detach(),
+             "w1_wp": ops.pack_weight_f32(f.w_1.weight.detach().view(f.w_1.out_channels, f.w_1.in_channels)),
+             "b1": f.w_1.bias.detach(),
+             "w2_wp": ops.pack_weight_f32(f.w_2.weight.detach().view(f.w_2.out_channels, f.w_2.in_channels)),
+             "b2": f.w_2.bias.detach(), "g2": f.layer_norm.gamma.detach(), "be2": f.layer_norm.beta.detach()}
+        hit = (key, d)
+        layer._tail_cache = hit
+    return hit[1]
+
+
+def _wq_pack(layer):
+    a = layer.slf_attn
+    key = _versions(a.w_qs.weight, a.w_qs.bias)
+    hit = getattr(layer, "_wq_cache", None)
+    if hit is None or hit[0] != key:
+        hit = (key, (ops.pack_weight_f32(a.w_qs.weight.detach()), a.w_qs.bias.detach(), a.w_qs.out_features))
+        layer._wq_cache = hit
+    return hit[1]
+
+
+def run_stack(layers, q, bank, mask=None):
+    """A stack of MyMultiHeadAttention layers sharing one memory bank (MODEL:509-546): per layer TWO launches --
+    the fused attention core and the fused tail (which also emits the next layer's projected query) -- instead
+    of the reference's ~12 small kernels.  Numerically the same chain as calling the layers one by one."""
+    layers = list(layers)
+    if not layers:
+        return q
+    for m in layers:
+        _require_eval(m)
+        if m.need_mask:
+            assert mask is not None, 'Please pass the attention mask to the multi-head'
+        if m.is_regu:
+            raise NotImplementedError("is_regu=True (training-only regulariser) is not on the HIP path")
+    if not isinstance(bank, MemoryBank):
+        bank = MemoryBank(f32=bank.contiguous())
+    B = q.shape[0]
+    q = q.reshape(B, -1).contiguous()
+    m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
+    a0 = layers[0].slf_attn
+    qh = ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
+    for i, layer in enumerate(layers):
+        a = layer.slf_attn
+        if a.precision == 'bf16':
+            o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
+                                        a.w_vs.bias.detach(), want_attn=False)
+        else:
+            o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
+                                   a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)
+        nxt = _wq_pack(layers[i + 1]) if i + 1 < len(layers) else None
+        q, qh = ops.mha_tail(o, q, _tail_pack(layer), a.layer_norm.eps, nxt)
+    return q
+
+
 class _AnotherMultiHeadAttention(nn.Module):
     """Parameter holder of moudles.py:232-296 (constructed by the reference, never called)."""
 

@@ -17,7 +17,7 @@ from torch.nn import Parameter
 
 from . import ops
 from .adjacency import gen_A, gen_adj_csr
-from .fusion import MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention
+from .fusion import MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, run_stack
 from .text_gcn import Model as Text_GCN_Model
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
@@ -375,24 +375,16 @@ class Multi_GCN_Multihead_Att(nn.Module):
         # -- four fusion stacks: image->text on the channel streams, text->image on main / aux --------------------
         s_obj.wait_stream(main)                  # needs the text bank
         with torch.cuda.stream(s_obj):
-            iot = att_obj
-            for layer in self.img_object_text_multi_head_att:
-                iot, _ = layer(q=iot, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
+            iot = run_stack(self.img_object_text_multi_head_att, att_obj, text_memory_bank, text_mask)
         s_place.wait_stream(main)
         with torch.cuda.stream(s_place):
-            ipt = att_place
-            for layer in self.img_place_text_multi_head_att:
-                ipt, _ = layer(q=ipt, k=text_memory_bank, v=text_memory_bank, mask=text_mask)
+            ipt = run_stack(self.img_place_text_multi_head_att, att_place, text_memory_bank, text_mask)
         s_aux.wait_stream(main)
         s_aux.wait_stream(s_place)               # place bank (its stream also carries ipt; ordering is harmless)
         with torch.cuda.stream(s_aux):
-            tip = text_feature
-            for layer in self.text_img_place_multi_head_att:
-                tip, _ = layer(q=tip, k=bank_place, v=bank_place)
+            tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
         main.wait_stream(s_obj)
-        tio = text_feature
-        for layer in self.text_img_object_multi_head_att:
-            tio, _ = layer(q=tio, k=bank_obj, v=bank_obj)
+        tio = run_stack(self.text_img_object_multi_head_att, text_feature, bank_obj)
 
         main.wait_stream(s_place)
         main.wait_stream(s_aux)

@@ -386,6 +386,38 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     return o, attn
 
 
+def pack_weight_f32(w):
+    """[N, K] fp32 (nn.Linear layout) -> MFMA-fragment-major fp32 buffer for mha_tail."""
+    _chk(w, "weight", ndim=2)
+    L = _lib.lib()
+    buf = torch.empty(L.mgnns_packed_f32_weight_bytes(w.shape[0], w.shape[1]) // 4, dtype=torch.float32, device=w.device)
+    _lib.check(L.mgnns_pack_weight_f32(_p(w), w.shape[0], w.shape[1], _p(buf), _stream()), "mgnns_pack_weight_f32")
+    return buf
+
+
+def mha_tail(o, q, packed, eps, next_packed=None):
+    """Fused fc + residual + LN + FFN + residual + LN (+ next layer's w_qs).  `packed` = dict with fc_wp, fc_b,
+    g1, be1, w1_wp, b1, w2_wp, b2, g2, be2; next_packed = (wq_wp, bq, HK_next) or None.
+    Returns (out [B,300], qh_next [B,HK_next] or None)."""
+    _chk(o, "o", ndim=2)
+    _chk(q, "q", ndim=2)
+    B, HK = o.shape
+    if q.shape != (B, 300):
+        raise ValueError("q shape %s, expected (%d, 300)" % (tuple(q.shape), B))
+    out = torch.empty(B, 300, device=o.device, dtype=torch.float32)
+    wq = bq = qh = None
+    hkn = 0
+    if next_packed is not None:
+        wq, bq, hkn = next_packed
+        qh = torch.empty(B, hkn, device=o.device, dtype=torch.float32)
+    L = _lib.lib()
+    _launch("mgnns_mha_tail_fwd", ("mgnns_mha_tail_fwd",), L.mgnns_mha_tail_fwd, _p(o), HK, _p(q), B, 300,
+            _p(packed["fc_wp"]), _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["w1_wp"]),
+            _p(packed["b1"]), _p(packed["w2_wp"]), _p(packed["b2"]), _p(packed["g2"]), _p(packed["be2"]), float(eps),
+            _p(out), _p(wq), _p(bq), hkn, _p(qh), _stream())
+    return out, qh
+
+
 def layernorm(x, gamma, beta, eps=1e-6):
     D = x.shape[-1]
     x2 = _chk(x.reshape(-1, D), "x")

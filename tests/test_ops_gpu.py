@@ -290,3 +290,30 @@ def test_imgbank_pool_bf16(B):
     assert float(((got - ref).abs() / (ref.abs() + 1e-2)).max()) < 6e-3
     ref32 = R.img_memory_bank(torch.from_numpy(feat), torch.from_numpy(w), torch.from_numpy(bias))
     print("bf16 bank max abs err vs fp32: %.3e (|bank| max %.2f)" % (H.maxabs(got, ref32), float(ref32.abs().max())))
+
+
+@pytest.mark.parametrize("Hn", [1, 4, 8])
+def test_run_stack_fused_tail_matches_layer_by_layer_and_golden(Hn):
+    """fusion.run_stack (fused core + fused tail + chained query projection) == the per-layer module path ==
+    the reference layer golden (single layer), for a 2-layer stack vs the oracle."""
+    from mgnns_amd.fusion import MyMultiHeadAttention, run_stack
+    g = H.load_golden("mha.npz")
+    for tag, L, masked in (("text", 100, True), ("img", 196, False)):
+        name = "h%d_%s" % (Hn, tag)
+        pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+        layer = MyMultiHeadAttention(Hn, 300, 128, dropout=0.5, need_mask=masked).eval()
+        layer.load_state_dict({k[len(name) + 1:]: v for k, v in pc.items()})
+        layer = layer.to(DEV)
+        q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+        dm = None if mask is None else dev(mask)
+        out1 = run_stack([layer], dev(q), dev(bank), dm)
+        assert H.maxabs(out1.cpu(), g[name + "_out"]) < 2e-5
+        dbank = dev(bank)
+        out_mod, _ = layer(q=dev(q), k=dbank, v=dbank, mask=dm)
+        assert H.maxabs(out1.cpu(), out_mod.cpu()) < 2e-5
+        # two layers chained (same weights twice): oracle mha_stack semantics
+        ref = R.mha_stack({("s.%d." % i) + k[len(name) + 1:]: v for i in range(2) for k, v in pc.items()}, "s",
+                          torch.from_numpy(q), torch.from_numpy(bank), None if mask is None else torch.from_numpy(mask),
+                          Hn, 128, 2)
+        out2 = run_stack([layer, layer], dev(q), dev(bank), dm)
+        assert H.maxabs(out2.cpu(), ref) < 3e-5
