@@ -66,18 +66,22 @@ int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V
  * get_text_memory_bank (Multi_GCN_Multihead_att.py:366-398): embedding(text) -> pack_padded_sequence ->
  * nn.LSTM(hidden 150, bidirectional, batch_first) -> pad_packed_sequence(total_length=T).
  * tok [B,T] int64; lens [B] int64 ON THE DEVICE (valid tokens per sample, clamped to [0,T]);
- * emb_table [V,emb_dim]; per (layer l, direction d) at index 2*l+d (d=1 is PyTorch's "_reverse"):
- * w_ih [4*hidden, in_l], w_hh [4*hidden, hidden], b_ih, b_hh [4*hidden] (gate order i,f,g,o), passed as
- * host arrays of device pointers; out [B,T,2*hidden] (zeros at t >= lens[b]).
+ * emb_table [V,emb_dim]; per layer l: w_ih_cat[l] = [weight_ih_l{l} ; weight_ih_l{l}_reverse] stacked to
+ * [2*4*hidden, in_l] and b_ih_cat[l] [2*4*hidden] (both directions' input projections run as one GEMM);
+ * per (layer l, direction d) at index 2*l+d (d=1 is "_reverse"): w_hh [4*hidden, hidden], b_hh [4*hidden]
+ * (gate order i,f,g,o); all passed as host arrays of device pointers; out [B,T,2*hidden] (zeros at t >= lens[b]);
+ * out_bf16 (optional, may be NULL): the same bank as bf16 [B,T,ld_bf16], zero padded -- what
+ * mgnns_sq_mha_core_bf16_fwd consumes.
  * workspace: >= mgnns_bilstm_workspace_bytes(B,T,hidden,num_layers) bytes of device memory.
  * hidden == 150, num_layers <= 2.
  */
 size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers);
 int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
                      const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
-                     const float* const* w_ih, const float* const* w_hh,
-                     const float* const* b_ih, const float* const* b_hh,
-                     void* workspace, size_t workspace_bytes, float* out, mgnns_stream_t stream);
+                     const float* const* w_ih_cat, const float* const* b_ih_cat,
+                     const float* const* w_hh, const float* const* b_hh,
+                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                     mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].
@@ -196,6 +200,20 @@ int mgnns_mha_tail_fwd(const float* o, int HK, const float* q, int B, int d_mode
                        const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
                        const float* wq_next_wp, const float* bq_next, int HK_next, float* qh_next,
                        mgnns_stream_t stream);
+
+/* bf16-MFMA variant of the fused tail (bf16 precision mode).  terms = 1: bf16 operands; terms = 3: split-bf16
+ * (x = hi + lo, a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate: ~2^-16 relative per product).  Weights
+ * pre-packed by mgnns_pack_weight_bf16_split into TWO buffers (hi, lo) of mgnns_packed_bf16_weight_bytes(N,K)
+ * bytes each; `packed` = host array of 8 device pointers {fc_hi, fc_lo, w1_hi, w1_lo, w2_hi, w2_lo, wq'_hi, wq'_lo}
+ * (the last two NULL to skip the next-layer projection).  Biases, residuals and LayerNorms are fp32.
+ */
+size_t mgnns_packed_bf16_weight_bytes(int N, int K);
+int mgnns_pack_weight_bf16_split(const float* W, int N, int K, void* Whi, void* Wlo, mgnns_stream_t stream);
+int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d_model, int terms,
+                            const void* const* packed,
+                            const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
+                            const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                            const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
 
 /* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
  * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c = ctypes
 _P = _c.c_void_p
@@ -21,7 +21,7 @@ _PP = _c.POINTER(_c.c_void_p)
 # name -> argtypes, in the order of include/mgnns_hip.h
 SIGNATURES = {
     "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
-    "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P],
+    "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
@@ -39,6 +39,8 @@ SIGNATURES = {
     "mgnns_sq_mha_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_pack_weight_f32": [_P, _I, _I, _P, _P],
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
+    "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
+    "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
 }
 
@@ -65,6 +67,8 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
+    L.mgnns_packed_bf16_weight_bytes.restype = _SZ
+    L.mgnns_packed_bf16_weight_bytes.argtypes = [_I, _I]
     L.mgnns_packed_f32_weight_bytes.restype = _SZ
     L.mgnns_packed_f32_weight_bytes.argtypes = [_I, _I]
     L.mgnns_gemm_workspace_bytes.restype = _SZ

@@ -11,4 +11,4 @@ void mgnns_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 2; }
+extern "C" int mgnns_abi_version(void) { return 3; }

@@ -86,6 +86,11 @@ __global__ __launch_bounds__(128) void lstm_fill_kernel(const int64_t* __restric
     }
 }
 
+__device__ __forceinline__ unsigned short f2bf_rne(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // tanh(x) = 2*sigmoid(2x) - 1: one exp instead of libm's tanhf polynomial/branch mix (abs err < 2e-7)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + expf(-2.0f * x)) - 1.0f; }
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
                                                                const int64_t* __restrict__ lens, int T,
                                                                const float* __restrict__ Whh_f, const float* __restrict__ Whh_b,
                                                                const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
-                                                               const int32_t* __restrict__ order, float* __restrict__ out) {
+                                                               const int32_t* __restrict__ order, float* __restrict__ out,
+                                                               unsigned short* __restrict__ out_bf16, int ld_bf16) {
     __shared__ __attribute__((aligned(16))) float s_h[2][NWAVE][16];     // h, chunked per owning wave (15 + 1 pad)
     __shared__ float s_part[NWAVE][PSTR];
     __shared__ float s_act[G4];
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
             const float hh = og * tanhf_(c);
             s_h[cur ^ 1][tid / KW][tid % KW] = hh;
             out[((size_t)b * T + t) * (2 * HID) + dir * HID + tid] = hh;
+            if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + tid] = f2bf_rne(hh);
         }
         __syncthreads();
         cur ^= 1;
@@ -189,6 +196,13 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     for (int i = tid; i < (T - len) * HID; i += REC_THREADS) {
         const int t = len + i / HID, j = i % HID;
         out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = 0.f;
+        if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + j] = 0;
+    }
+    // bf16 copy: the zero padding of the model dim (columns 2*HID .. ld-1) of every row, by the forward workgroup
+    if (out_bf16 && dir == 0) {
+        const int padw = ld_bf16 - 2 * HID;
+        for (int i = tid; i < T * padw; i += REC_THREADS)
+            out_bf16[((size_t)b * T + i / padw) * ld_bf16 + 2 * HID + i % padw] = 0;
     }
 }
 
@@ -204,19 +218,21 @@ extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num
 }
 
 extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
-                                int emb_dim, int hidden, int num_layers, const float* const* w_ih,
-                                const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
-                                void* workspace, size_t workspace_bytes, float* out, mgnns_stream_t stream) {
-    MG_REQUIRE(tok && lens && emb_table && w_ih && w_hh && b_ih && b_hh && workspace && out,
+                                int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
+                                const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
+                                void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                                mgnns_stream_t stream) {
+    MG_REQUIRE(tok && lens && emb_table && w_ih_cat && w_hh && b_ih_cat && b_hh && workspace && out,
                "mgnns_bilstm_fwd: null pointer");
+    MG_REQUIRE(!out_bf16 || (ld_bf16 >= 2 * hidden && ld_bf16 % 8 == 0), "mgnns_bilstm_fwd: bad bf16 row length %d", ld_bf16);
     MG_REQUIRE(hidden == HID, "mgnns_bilstm_fwd: hidden_size=%d unsupported (150 only)", hidden);
     MG_REQUIRE(num_layers >= 1 && num_layers <= 2, "mgnns_bilstm_fwd: num_layers=%d unsupported (1..2)", num_layers);
     MG_REQUIRE(B > 0 && T > 0 && V > 0 && emb_dim > 0, "mgnns_bilstm_fwd: bad dims B=%d T=%d V=%d E=%d", B, T, V, emb_dim);
     MG_REQUIRE(workspace_bytes >= mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers),
                "mgnns_bilstm_fwd: workspace too small (%zu < %zu)", workspace_bytes,
                mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers));
-    for (int i = 0; i < 2 * num_layers; ++i)
-        MG_REQUIRE(w_ih[i] && w_hh[i] && b_ih[i] && b_hh[i], "mgnns_bilstm_fwd: null weight pointer %d", i);
+    for (int i = 0; i < 2 * num_layers; ++i) MG_REQUIRE(w_hh[i] && b_hh[i], "mgnns_bilstm_fwd: null weight pointer %d", i);
+    for (int i = 0; i < num_layers; ++i) MG_REQUIRE(w_ih_cat[i] && b_ih_cat[i], "mgnns_bilstm_fwd: null weight pointer %d", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)B * T;
     float* Gx = reinterpret_cast<float*>(workspace);
@@ -233,12 +249,13 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
         const int K = layer == 0 ? emb_dim : 2 * HID;
         const int32_t* gidx = layer == 0 ? pack_tok : pack_pos;
         float* dst = (layer == num_layers - 1) ? out : mid;
-        for (int dir = 0; dir < 2; ++dir)
-            mg_launch_linear(X, (int)rows, K, w_ih[2 * layer + dir], b_ih[2 * layer + dir], G4, Gx + dir * G4, 2 * G4, gidx,
-                             offs + B, s);
+        // both directions' input projections in one GEMM: W_ih = [forward ; reverse] stacked to [2*4H, in]
+        mg_launch_linear(X, (int)rows, K, w_ih_cat[layer], b_ih_cat[layer], 2 * G4, Gx, 2 * G4, gidx, offs + B, s);
         hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
                            T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1],
-                           (const int32_t*)order, dst);
+                           (const int32_t*)order, dst,
+                           (layer == num_layers - 1) ? reinterpret_cast<unsigned short*>(out_bf16) : (unsigned short*)nullptr,
+                           ld_bf16);
     }
     MG_CHECK_LAUNCH("mgnns_bilstm_fwd");
     return 0;

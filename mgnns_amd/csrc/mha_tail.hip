@@ -259,3 +259,281 @@ extern "C" int mgnns_mha_tail_fwd(const float* o, int HK, const float* q, int B,
     MG_CHECK_LAUNCH("mgnns_mha_tail_fwd");
     return 0;
 }
+
+// =====================================================================================================================
+// bf16-MFMA variant of the same fused tail (used with the bf16 precision mode).  TERMS = 1: plain bf16 operands.
+// TERMS = 3: split-bf16 -- every fp32 operand x is carried as hi = bf16(x), lo = bf16(x - hi) and a product is
+// formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): ~2^-16 relative
+// error per product instead of 2^-8, at 3/16 of the exact-f32 MFMA cost.  Residuals, biases and both LayerNorms
+// stay fp32.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int SCD = 42;                      // LDS stride (16-B chunks) of 300(->320)-wide bf16 activations
+
+__device__ __forceinline__ unsigned short f2bf_t(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f_t(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ void split_store(unsigned short* hi, unsigned short* lo, int idx, float x) {
+    const unsigned short h = f2bf_t(x);
+    hi[idx] = h;
+    lo[idx] = f2bf_t(x - bf2f_t(h));
+}
+
+// Wp{hi,lo}[nt][ks][lane][8] = split(W[nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j])   (0 outside [N,K])
+__global__ __launch_bounds__(256) void pack_w_split_kernel(const float* __restrict__ W, int N, int K,
+                                                           unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo) {
+    const int KS = (K + 31) / 32, NTt = (N + 15) / 16;
+    const size_t total = (size_t)NTt * KS * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        size_t r = i >> 6;
+        const int ks = (int)(r % KS);
+        const int nt = (int)(r / KS);
+        const int n = nt * 16 + (lane & 15);
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (n < N && k0 + j < K) ? W[(size_t)n * K + k0 + j] : 0.f;
+            split_store(Whi, Wlo, (int)(i * 8 + j), x);
+        }
+    }
+}
+
+template <int TPW, int TERMS>
+__device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* __restrict__ Ahi, const uint4* __restrict__ Alo,
+                                               int sa, int KS, const unsigned short* __restrict__ Whi,
+                                               const unsigned short* __restrict__ Wlo, int NTt, int wave, int lane, int t0) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int aoff = (lane & 15) * sa + (lane >> 4);
+    size_t woff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int nt = wave + 8 * (t0 + t);
+        woff[t] = ((size_t)(nt < NTt ? nt : 0) * KS) * 64 + lane;
+    }
+    const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
+    const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
+    constexpr int PF = 2;
+    uint4 rh[PF][TPW], rl[PF][TPW];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            rh[d][t] = d < KS ? Wh[woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
+            if (TERMS == 3) rl[d][t] = d < KS ? Wl[woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    for (int ks0 = 0; ks0 < KS; ks0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int ks = ks0 + d;
+            if (ks < KS) {
+                uint4 ch[TPW], cl[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    ch[t] = rh[d][t];
+                    if (TERMS == 3) cl[t] = rl[d][t];
+                }
+                if (ks + PF < KS) {
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        rh[d][t] = Wh[woff[t] + (size_t)(ks + PF) * 64];
+                        if (TERMS == 3) rl[d][t] = Wl[woff[t] + (size_t)(ks + PF) * 64];
+                    }
+                }
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi[aoff + ks * 4]);
+                bf16x8 al = ah;
+                if (TERMS == 3) al = __builtin_bit_cast(bf16x8, Alo[aoff + ks * 4]);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, ch[t]), acc[t], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, cl[t]), acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, ch[t]), acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct TailW {            // packed hi/lo pairs + fp32 vectors of one layer
+    const unsigned short *fc_h, *fc_l, *w1_h, *w1_l, *w2_h, *w2_l, *wq_h, *wq_l;
+    const float *fc_b, *g1, *be1, *b1, *b2, *g2, *be2, *bq;
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __restrict__ o, int HK, const float* __restrict__ q, int B,
+                                                             TailW w, float eps, float* __restrict__ out, int HKn,
+                                                             float* __restrict__ qh_next) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int so = (HK >> 3) + 2;                                   // chunk stride of the o tile: == 2 (mod 4)
+    uint4* s_oh = reinterpret_cast<uint4*>(smem_b);                 // [16][so]
+    uint4* s_ol = s_oh + ROWS * so;
+    uint4* s_ah = s_ol + ROWS * so;                                 // [16][SCD] activation hi (y, h, out in turn)
+    uint4* s_al = s_ah + ROWS * SCD;
+    float* s_y = reinterpret_cast<float*>(s_al + ROWS * SCD);       // [16][SD] fp32 y (residual of the FFN)
+    float* s_t = s_y + ROWS * SD;                                   // [16][SD] fp32 pre-LayerNorm scratch / out
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * ROWS;
+    const int KSo = (HK + 31) / 32, KSd = (D + 31) / 32;
+
+    // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
+    for (int i = tid; i < ROWS * so; i += NTHR) {
+        const int r = i / so, c = i - r * so;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = c * 8 + j;
+            const float x = (r0 + r < B && col < HK) ? o[(size_t)(r0 + r) * HK + col] : 0.f;
+            h[j] = f2bf_t(x);
+            l[j] = f2bf_t(x - bf2f_t(h[j]));
+        }
+        s_oh[i] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
+        s_ol[i] = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
+    }
+    for (int i = tid; i < 2 * ROWS * SCD; i += NTHR) s_ah[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    unsigned short* ah16 = reinterpret_cast<unsigned short*>(s_ah);
+    unsigned short* al16 = reinterpret_cast<unsigned short*>(s_al);
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    f32x4 acc[3];
+    // ---- 1. y = LN1(fc(o) + q) ----------------------------------------------------------------------------------------
+    tile_gemm_bf16<3, TERMS>(acc, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol;
+        if (wave + 8 * t < DT && n < D) {
+            const float bv = w.fc_b[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = r0 + crow + r;
+                s_y[(crow + r) * SD + n] = acc[t][r] + bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    ln_rows(s_y, w.g1, w.be1, eps, wave, lane);
+    __syncthreads();
+    for (int i = tid; i < ROWS * D; i += NTHR) {
+        const int r = i / D, c = i - r * D;
+        split_store(ah16, al16, r * SCD * 8 + c, s_y[r * SD + c]);
+    }
+    __syncthreads();
+    // ---- 2. h = relu(w_1 y + b_1) ----------------------------------------------------------------------------------------
+    tile_gemm_bf16<3, TERMS>(acc, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);
+    __syncthreads();                                   // all A reads of y done before h overwrites the buffer
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol;
+        if (wave + 8 * t < DT && n < D) {
+            const float bv = w.b1[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split_store(ah16, al16, (crow + r) * SCD * 8 + n, fmaxf(acc[t][r] + bv, 0.f));
+        }
+    }
+    __syncthreads();
+    // ---- 3. out = LN2(w_2 h + b_2 + y) --------------------------------------------------------------------------------------
+    tile_gemm_bf16<3, TERMS>(acc, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol;
+        if (wave + 8 * t < DT && n < D) {
+            const float bv = w.b2[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_t[(crow + r) * SD + n] = acc[t][r] + bv + s_y[(crow + r) * SD + n];
+        }
+    }
+    __syncthreads();
+    ln_rows(s_t, w.g2, w.be2, eps, wave, lane);
+    __syncthreads();
+    for (int i = tid; i < ROWS * D; i += NTHR) {
+        const int r = i / D, c = i - r * D;
+        const float v = s_t[r * SD + c];
+        if (r0 + r < B) out[(size_t)(r0 + r) * D + c] = v;
+        if (w.wq_h) split_store(ah16, al16, r * SCD * 8 + c, v);
+    }
+    // ---- 4. next layer's query projection -------------------------------------------------------------------------------------
+    if (w.wq_h) {
+        __syncthreads();
+        const int NTq = (HKn + 15) / 16;
+        for (int t0 = 0; t0 * 8 < NTq; t0 += 4) {
+            f32x4 a4[4];
+            tile_gemm_bf16<4, TERMS>(a4, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int nt = wave + 8 * (t0 + t);
+                const int n = nt * 16 + ccol;
+                if (nt < NTq && n < HKn) {
+                    const float bv = w.bq ? w.bq[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = r0 + crow + r;
+                        if (gr < B) qh_next[(size_t)gr * HKn + n] = a4[t][r] + bv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mgnns_packed_bf16_weight_bytes(int N, int K) {      // ONE of the two (hi / lo) buffers
+    return (size_t)((N + 15) / 16) * ((K + 31) / 32) * 64 * 16;
+}
+
+extern "C" int mgnns_pack_weight_bf16_split(const float* W, int N, int K, void* Whi, void* Wlo, mgnns_stream_t stream) {
+    MG_REQUIRE(W && Whi && Wlo && N > 0 && K > 0, "mgnns_pack_weight_bf16_split: bad arguments");
+    const size_t total = (size_t)((N + 15) / 16) * ((K + 31) / 32) * 64;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_w_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, N, K,
+                       reinterpret_cast<unsigned short*>(Whi), reinterpret_cast<unsigned short*>(Wlo));
+    MG_CHECK_LAUNCH("mgnns_pack_weight_bf16_split");
+    return 0;
+}
+
+extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d_model, int terms,
+                                       const void* const* packed /* fc_h,fc_l,w1_h,w1_l,w2_h,w2_l,wq_h,wq_l */,
+                                       const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
+                                       const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                                       const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream) {
+    MG_REQUIRE(o && q && packed && fc_b && ln1_gamma && ln1_beta && b1 && b2 && ln2_gamma && ln2_beta && out,
+               "mgnns_mha_tail_bf16_fwd: null pointer");
+    MG_REQUIRE(d_model == D, "mgnns_mha_tail_bf16_fwd: d_model=%d unsupported (300 only)", d_model);
+    MG_REQUIRE(terms == 1 || terms == 3, "mgnns_mha_tail_bf16_fwd: terms must be 1 (bf16) or 3 (split-bf16)");
+    MG_REQUIRE(HK > 0 && HK % 32 == 0 && HK <= 2048, "mgnns_mha_tail_bf16_fwd: n_head*d_v=%d unsupported (multiple of 32, <= 2048)", HK);
+    for (int i = 0; i < 6; ++i) MG_REQUIRE(packed[i], "mgnns_mha_tail_bf16_fwd: packed weight %d missing", i);
+    MG_REQUIRE(!packed[6] || (packed[7] && qh_next && HK_next > 0), "mgnns_mha_tail_bf16_fwd: next-layer projection incomplete");
+    if (B <= 0) return 0;
+    TailW w;
+    w.fc_h = (const unsigned short*)packed[0]; w.fc_l = (const unsigned short*)packed[1];
+    w.w1_h = (const unsigned short*)packed[2]; w.w1_l = (const unsigned short*)packed[3];
+    w.w2_h = (const unsigned short*)packed[4]; w.w2_l = (const unsigned short*)packed[5];
+    w.wq_h = (const unsigned short*)packed[6]; w.wq_l = (const unsigned short*)packed[7];
+    w.fc_b = fc_b; w.g1 = ln1_gamma; w.be1 = ln1_beta; w.b1 = b1; w.b2 = b2; w.g2 = ln2_gamma; w.be2 = ln2_beta; w.bq = bq_next;
+    const int so = (HK >> 3) + 2;
+    const size_t lds = (size_t)(2 * ROWS * so + 2 * ROWS * SCD) * 16 + 2 * (size_t)ROWS * SD * sizeof(float);
+    MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_bf16_fwd: needs %zu B of LDS", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_tail_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_tail_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((B + ROWS - 1) / ROWS);
+    if (terms == 3)
+        hipLaunchKernelGGL(mha_tail_bf16_kernel<3>, grid, dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w, eps, out, HK_next, qh_next);
+    else
+        hipLaunchKernelGGL(mha_tail_bf16_kernel<1>, grid, dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w, eps, out, HK_next, qh_next);
+    MG_CHECK_LAUNCH("mgnns_mha_tail_bf16_fwd");
+    return 0;
+}

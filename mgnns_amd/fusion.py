@@ -16,6 +16,9 @@ import torch.nn as nn
 from . import ops
 
 
+TAIL_TERMS = 3      # bf16-mode tail: 3 = split-bf16 (hi/lo operands), 1 = plain bf16 operands
+
+
 def _require_eval(mod):
     if mod.training:
         raise RuntimeError("%s: mgnns_amd implements the eval-mode forward only (dropout/backward are "
@@ -179,6 +182,34 @@ def _tail_pack(layer):
     return hit[1]
 
 
+def _tail_pack_bf16(layer):
+    a, f = layer.slf_attn, layer.pos_ffn
+    ps = (a.fc.weight, a.fc.bias, a.layer_norm.gamma, a.layer_norm.beta, f.w_1.weight, f.w_1.bias, f.w_2.weight,
+          f.w_2.bias, f.layer_norm.gamma, f.layer_norm.beta)
+    key = _versions(*ps)
+    hit = getattr(layer, "_tail_cache_bf16", None)
+    if hit is None or hit[0] != key:
+        d = {"fc": ops.pack_weight_bf16_split(a.fc.weight.detach()), "fc_b": a.fc.bias.detach(),
+             "g1": a.layer_norm.gamma.detach(), "be1": a.layer_norm.beta.detach(),
+             "w1": ops.pack_weight_bf16_split(f.w_1.weight.detach().view(f.w_1.out_channels, f.w_1.in_channels)),
+             "b1": f.w_1.bias.detach(),
+             "w2": ops.pack_weight_bf16_split(f.w_2.weight.detach().view(f.w_2.out_channels, f.w_2.in_channels)),
+             "b2": f.w_2.bias.detach(), "g2": f.layer_norm.gamma.detach(), "be2": f.layer_norm.beta.detach()}
+        hit = (key, d)
+        layer._tail_cache_bf16 = hit
+    return hit[1]
+
+
+def _wq_pack_bf16(layer):
+    a = layer.slf_attn
+    key = _versions(a.w_qs.weight, a.w_qs.bias)
+    hit = getattr(layer, "_wq_cache_bf16", None)
+    if hit is None or hit[0] != key:
+        hit = (key, (ops.pack_weight_bf16_split(a.w_qs.weight.detach()), a.w_qs.bias.detach(), a.w_qs.out_features))
+        layer._wq_cache_bf16 = hit
+    return hit[1]
+
+
 def _wq_pack(layer):
     a = layer.slf_attn
     key = _versions(a.w_qs.weight, a.w_qs.bias)
@@ -217,8 +248,13 @@ def run_stack(layers, q, bank, mask=None):
         else:
             o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
                                    a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)
-        nxt = _wq_pack(layers[i + 1]) if i + 1 < len(layers) else None
-        q, qh = ops.mha_tail(o, q, _tail_pack(layer), a.layer_norm.eps, nxt)
+        if a.precision == 'bf16' and a.n_head * a.d_v % 32 == 0:
+            # split-bf16 MFMA tail: fp32-class accuracy (hi+lo operands) at a fraction of the exact-f32 MFMA cost
+            nxt = _wq_pack_bf16(layers[i + 1]) if i + 1 < len(layers) else None
+            q, qh = ops.mha_tail_bf16(o, q, _tail_pack_bf16(layer), a.layer_norm.eps, nxt, terms=TAIL_TERMS)
+        else:
+            nxt = _wq_pack(layers[i + 1]) if i + 1 < len(layers) else None
+            q, qh = ops.mha_tail(o, q, _tail_pack(layer), a.layer_norm.eps, nxt)
     return q
 
 

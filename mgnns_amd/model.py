@@ -245,6 +245,16 @@ class Multi_GCN_Multihead_Att(nn.Module):
                                 for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")))
         return ws
 
+    def _text_bank(self, text, text_lens):
+        """MemoryBank of the text (fp32 + bf16 copy in bf16 mode, both written by the LSTM kernel)."""
+        lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
+        if self.precision == 'bf16':
+            f32, bf = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
+                                 self.hidden_size, self.lstm.num_layers, want_bf16=True)
+            return MemoryBank(f32=f32, bf16=bf)
+        return MemoryBank(f32=ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
+                                         self._lstm_weights(), self.hidden_size, self.lstm.num_layers))
+
     def get_text_memory_bank(self, text, text_lens, return_last_state=True):
         """Embedding gather + packed 2-layer BiLSTM + re-padding to T (MODEL:366-398) as HIP kernels.
         Returns (memory_bank [B,T,2*hidden], final state of the last layer [B,2*hidden]) like the reference;
@@ -309,10 +319,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
     def _channel(self, feats, lin, A, inp, attention, linear_5, x_linear):
         """One image channel (MODEL:450-479 / 482-506): bank, pooled read-out through the label GCN,
         label attention, 300->100->700->300 tail."""
-        bank, pooled = self._img_bank_and_pool(feats, lin)
+        # the label GCN does not depend on the image: enqueue it first so it overlaps the other streams' head
         _, csr = gen_adj_csr(A)
         x = self.gc1(inp[0].float().contiguous(), csr, act=ops.ACT_LRELU2)
         G = self.gc2(x, csr)                                     # [C, 2048]
+        bank, pooled = self._img_bank_and_pool(feats, lin)
         x = ops.linear(pooled, G)                                # pooled @ G^T -> [B, C]
         att = attention(query=self.label_query, key=x, value=x)  # [B, NLQ, 300]
         att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(feats.shape[0], -1)
@@ -355,11 +366,16 @@ class Multi_GCN_Multihead_Att(nn.Module):
         for st in (s_obj, s_place):
             st.wait_stream(main)
 
-        # -- text channel (main stream): text-level GCN, then the BiLSTM memory bank ---------------------------
-        text_feature = self.text_features(text)
-        text_memory_bank = MemoryBank(f32=self.get_text_memory_bank(text, text_lens, return_last_state=False))
-        if self.precision == 'bf16':
-            text_memory_bank.bf16            # one conversion, shared by the four text-bank layers
+        for st in (s_aux,):
+            st.wait_stream(main)
+        # -- text channel: the text-level GCN (aux stream) and the BiLSTM memory bank (main stream) ---------------
+        with torch.cuda.stream(s_aux):
+            text_feature = self.text_features(text)
+            ev_text_feature = torch.cuda.Event()
+            ev_text_feature.record(s_aux)
+        if not self.bidirectional:
+            raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
+        text_memory_bank = self._text_bank(text, text_lens)
         text_mask = text_mask.float().contiguous()
 
         # -- object / place channels ------------------------------------------------------------------------------
@@ -379,11 +395,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
         s_place.wait_stream(main)
         with torch.cuda.stream(s_place):
             ipt = run_stack(self.img_place_text_multi_head_att, att_place, text_memory_bank, text_mask)
-        s_aux.wait_stream(main)
         s_aux.wait_stream(s_place)               # place bank (its stream also carries ipt; ordering is harmless)
         with torch.cuda.stream(s_aux):
             tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
         main.wait_stream(s_obj)
+        main.wait_event(ev_text_feature)         # text_feature was produced on the aux stream
         tio = run_stack(self.text_img_object_multi_head_att, text_feature, bank_obj)
 
         main.wait_stream(s_place)

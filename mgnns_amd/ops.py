@@ -8,6 +8,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU2 = 0, 1, 2
+BANK_LD = 320      # bf16 memory banks are [B, L, 320]: model dim 300 zero padded to 10 MFMA k-steps of 32
 
 
 def _stream():
@@ -192,9 +193,26 @@ def _workspace(nbytes, device):
     return buf
 
 
-def bilstm(tok, lens, emb_table, weights, hidden, num_layers):
+_lstm_cat_cache = {}
+
+
+def _lstm_cat(weights, num_layers):
+    """Per layer [W_ih ; W_ih_reverse] and [b_ih ; b_ih_reverse], rebuilt when a weight changes (one input-projection
+    GEMM per layer instead of two)."""
+    key = tuple((t.data_ptr(), t._version) for tup in weights for t in (tup[0], tup[2]))
+    hit = _lstm_cat_cache.get(key)
+    if hit is None:
+        _lstm_cat_cache.clear()
+        hit = [(torch.cat([weights[2 * l][0], weights[2 * l + 1][0]], 0).contiguous(),
+                torch.cat([weights[2 * l][2], weights[2 * l + 1][2]], 0).contiguous()) for l in range(num_layers)]
+        _lstm_cat_cache[key] = hit
+    return hit
+
+
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False):
     """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
-    (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length."""
+    (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length
+    (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16)."""
     import ctypes
     _chk(tok, "text", torch.int64, 2)
     _chk(lens, "text_lens", torch.int64, 1)
@@ -204,25 +222,28 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers):
         raise ValueError("text_lens has %d entries for batch %d" % (lens.shape[0], B))
     if len(weights) != 2 * num_layers:
         raise ValueError("need %d (layer, direction) weight tuples" % (2 * num_layers))
-    arrs = [[], [], [], []]
     for li, tup in enumerate(weights):
         in_dim = emb_table.shape[1] if li < 2 else 2 * hidden
         shapes = ((4 * hidden, in_dim), (4 * hidden, hidden), (4 * hidden,), (4 * hidden,))
-        for a, t, shp in zip(arrs, tup, shapes):
+        for t, shp in zip(tup, shapes):
             _chk(t, "lstm weight")
             if tuple(t.shape) != shp:
                 raise ValueError("lstm weight shape %s, expected %s" % (tuple(t.shape), shp))
-            a.append(t.data_ptr())
-    n = 2 * num_layers
-    cptr = [(ctypes.c_void_p * n)(*a) for a in arrs]
+    cat = _lstm_cat(weights, num_layers)
+    arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
+    c_wih = arr([c[0].data_ptr() for c in cat])
+    c_bih = arr([c[1].data_ptr() for c in cat])
+    c_whh = arr([w[1].data_ptr() for w in weights])
+    c_bhh = arr([w[3].data_ptr() for w in weights])
     L = _lib.lib()
     nbytes = L.mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers)
     ws = _workspace(nbytes, tok.device)
     out = torch.empty(B, T, 2 * hidden, device=tok.device, dtype=torch.float32)
+    out_bf = torch.empty(B, T, BANK_LD, device=tok.device, dtype=torch.bfloat16) if want_bf16 else None
     _launch("mgnns_bilstm_fwd", ("mgnns_bilstm_fwd",), L.mgnns_bilstm_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
-            emb_table.shape[0], emb_table.shape[1], hidden, num_layers, cptr[0], cptr[1], cptr[2], cptr[3],
-            _p(ws), ws.numel(), _p(out), _stream())
-    return out
+            emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
+            _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _stream())
+    return (out, out_bf) if want_bf16 else out
 
 
 # ---- text GCN --------------------------------------------------------------------------------
@@ -342,9 +363,6 @@ def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
     return o, attn
 
 
-BANK_LD = 320      # bf16 memory banks are [B, L, 320]: model dim 300 zero padded to 10 MFMA k-steps of 32
-
-
 def pack_kv_weights_bf16(wk, wv, n_head, d_kv):
     """w_ks / w_vs [H*dk, D] fp32 -> MFMA-fragment-major bf16 buffer for sq_mha_core_bf16."""
     _chk(wk, "w_ks.weight", ndim=2)
@@ -415,6 +433,44 @@ def mha_tail(o, q, packed, eps, next_packed=None):
             _p(packed["fc_wp"]), _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["w1_wp"]),
             _p(packed["b1"]), _p(packed["w2_wp"]), _p(packed["b2"]), _p(packed["g2"]), _p(packed["be2"]), float(eps),
             _p(out), _p(wq), _p(bq), hkn, _p(qh), _stream())
+    return out, qh
+
+
+def pack_weight_bf16_split(w):
+    """[N, K] fp32 -> (hi, lo) MFMA-fragment-major bf16 buffers (w ~ hi + lo) for mha_tail_bf16."""
+    _chk(w, "weight", ndim=2)
+    L = _lib.lib()
+    n = L.mgnns_packed_bf16_weight_bytes(w.shape[0], w.shape[1])
+    hi = torch.empty(n, dtype=torch.uint8, device=w.device)
+    lo = torch.empty(n, dtype=torch.uint8, device=w.device)
+    _lib.check(L.mgnns_pack_weight_bf16_split(_p(w), w.shape[0], w.shape[1], _p(hi), _p(lo), _stream()),
+               "mgnns_pack_weight_bf16_split")
+    return hi, lo
+
+
+def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3):
+    """bf16-MFMA fused tail.  packed: dict with fc, w1, w2 = (hi, lo) buffers and fc_b, g1, be1, b1, b2, g2, be2;
+    next_packed = ((hi, lo), bq, HK_next) or None."""
+    import ctypes
+    _chk(o, "o", ndim=2)
+    _chk(q, "q", ndim=2)
+    B, HK = o.shape
+    if q.shape != (B, 300):
+        raise ValueError("q shape %s, expected (%d, 300)" % (tuple(q.shape), B))
+    out = torch.empty(B, 300, device=o.device, dtype=torch.float32)
+    ptrs = [packed["fc"][0].data_ptr(), packed["fc"][1].data_ptr(), packed["w1"][0].data_ptr(),
+            packed["w1"][1].data_ptr(), packed["w2"][0].data_ptr(), packed["w2"][1].data_ptr(), None, None]
+    bq = qh = None
+    hkn = 0
+    if next_packed is not None:
+        (wh, wl), bq, hkn = next_packed
+        ptrs[6], ptrs[7] = wh.data_ptr(), wl.data_ptr()
+        qh = torch.empty(B, hkn, device=o.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * 8)(*ptrs)
+    L = _lib.lib()
+    _launch("mgnns_mha_tail_bf16_fwd", ("mgnns_mha_tail_bf16_fwd",), L.mgnns_mha_tail_bf16_fwd, _p(o), HK, _p(q), B, 300,
+            int(terms), arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
+            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qh), _stream())
     return out, qh
 
 

@@ -317,3 +317,35 @@ def test_run_stack_fused_tail_matches_layer_by_layer_and_golden(Hn):
                           Hn, 128, 2)
         out2 = run_stack([layer, layer], dev(q), dev(bank), dm)
         assert H.maxabs(out2.cpu(), ref) < 3e-5
+
+
+@pytest.mark.parametrize("Hn", [4, 8])
+def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
+    """split-bf16 fused tail (3 MFMA terms) vs the exact-fp32 fused tail on the same inputs: fp32-class agreement;
+    the 1-term (plain bf16) tail only bf16-class."""
+    name = "h%d_img" % Hn
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    rs = np.random.RandomState(5 + Hn)
+    B = 37
+    o = dev(rs.standard_normal((B, Hn * 128)).astype(np.float32))
+    q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+    a, f = name + ".slf_attn.", name + ".pos_ffn."
+    w1 = p[f + "w_1.weight"].squeeze(-1).contiguous()
+    w2 = p[f + "w_2.weight"].squeeze(-1).contiguous()
+    common = {"fc_b": p[a + "fc.bias"], "g1": p[a + "layer_norm.gamma"], "be1": p[a + "layer_norm.beta"],
+              "b1": p[f + "w_1.bias"], "b2": p[f + "w_2.bias"], "g2": p[f + "layer_norm.gamma"],
+              "be2": p[f + "layer_norm.beta"]}
+    pk32 = dict(common, fc_wp=ops.pack_weight_f32(p[a + "fc.weight"]), w1_wp=ops.pack_weight_f32(w1),
+                w2_wp=ops.pack_weight_f32(w2))
+    nx32 = (ops.pack_weight_f32(p[a + "w_qs.weight"]), p[a + "w_qs.bias"], Hn * 128)
+    out32, qh32 = ops.mha_tail(o, q, pk32, 1e-6, nx32)
+    pkbf = dict(common, fc=ops.pack_weight_bf16_split(p[a + "fc.weight"]), w1=ops.pack_weight_bf16_split(w1),
+                w2=ops.pack_weight_bf16_split(w2))
+    nxbf = (ops.pack_weight_bf16_split(p[a + "w_qs.weight"]), p[a + "w_qs.bias"], Hn * 128)
+    out3, qh3 = ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=3)
+    assert H.maxabs(out3.cpu(), out32.cpu()) < 5e-5
+    assert H.relerr(qh3.cpu(), qh32.cpu()) < 5e-5
+    out1, qh1 = ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=1)
+    e1 = H.maxabs(out1.cpu(), out32.cpu())
+    assert 1e-4 < e1 < 5e-2
