@@ -16,7 +16,9 @@ import torch.nn as nn
 from . import ops
 
 
-TAIL_TERMS = 3      # bf16-mode tail: 3 = split-bf16 (hi/lo operands), 1 = plain bf16 operands
+import os as _os
+
+TAIL_TERMS = int(_os.environ.get('MGNNS_TAIL_TERMS', '1'))   # bf16-mode tail: 3 = split-bf16 (hi/lo), 1 = plain bf16
 
 
 def _require_eval(mod):
