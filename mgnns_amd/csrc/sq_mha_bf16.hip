@@ -77,63 +77,213 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
     }
 }
 
+// Fragments that are in flight ACROSS a phase boundary: the first k-step's A fragments (the staged bank is the
+// same for every head and phase) and the first BD k-steps' B fragments of the NEXT weight stream are requested at
+// the tail of the current GEMM, so the score / softmax / weighted-sum epilogue and its barriers run with the next
+// phase's operands already on their way instead of exposing an L2 + LDS round trip at every phase start.
+template <int NMT>
+struct Frags {
+    static constexpr int HA = (NMT + 1) / 2, HB = NMT - HA;
+    static constexpr int BD = NMT <= 4 ? 5 : 2;      // must divide KSTEPS (ring slots carry over phases)
+    // the 13-tile class has no registers to spare (104 accumulators): only its B fragments cross the phase
+    // boundary, the A fragments of k-step 0 are re-requested right after the epilogue
+    static constexpr bool CROSS_A = NMT <= 7;
+    uint4 ga[HA], gb[HB > 0 ? HB : 1];
+    uint4 bq[BD][2];
+};
+
+template <int NMT>
+__device__ __forceinline__ void frags_prime(Frags<NMT>& f, const uint4* __restrict__ a_base, const uint4* __restrict__ wb) {
+#pragma unroll
+    for (int d = 0; d < Frags<NMT>::BD; ++d) {
+        f.bq[d][0] = wb[(size_t)d * 64];
+        f.bq[d][1] = wb[(size_t)(KSTEPS + d) * 64];
+    }
+    if (Frags<NMT>::CROSS_A) {
+#pragma unroll
+        for (int i = 0; i < Frags<NMT>::HA; ++i) f.ga[i] = a_base[i * 16 * LSTR];
+#pragma unroll
+        for (int i = 0; i < Frags<NMT>::HB; ++i) f.gb[i] = a_base[(Frags<NMT>::HA + i) * 16 * LSTR];
+    }
+}
+
 // acc[i][j] += X[tile i] * W^T[tile j] over the padded model dim, for a COMPILE-TIME number of live row tiles.
 // Fully unrolled, software pipelined in two half-groups of row tiles: while the MFMAs of one half run, the A
 // fragments (ds_read_b128 from the staged bank) of the OTHER half / next k-step are in flight, so an LDS read is
 // issued >= 12 MFMAs (~200 cycles) ahead of its use; B fragments (global, fragment-major, L2 resident) run BD
-// k-steps ahead.  sched_barrier(0) fences keep the compiler from sinking the prefetches back to their uses.
+// k-steps ahead.  The last k-steps prefetch the NEXT phase's first fragments from `wb_next` (see Frags).
+// sched_barrier(0) fences keep the compiler from sinking the prefetches back to their uses.
 template <int NMT>
-__device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], const uint4* __restrict__ a_base,
-                                        const uint4* __restrict__ wb) {
-    constexpr int HA = (NMT + 1) / 2, HB = NMT - HA;      // tiles [0,HA) and [HA,NMT)
-    constexpr int BD = NMT <= 4 ? 4 : 2;                  // B-fragment lookahead (k-steps)
-    uint4 ga[HA], gb[HB > 0 ? HB : 1];
-    uint4 bq[BD][2];
+__device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, const uint4* __restrict__ a_base,
+                                        const uint4* __restrict__ wb, const uint4* __restrict__ wb_next) {
+    constexpr int HA = Frags<NMT>::HA, HB = Frags<NMT>::HB, BD = Frags<NMT>::BD;
+    if (!Frags<NMT>::CROSS_A) {
 #pragma unroll
-    for (int d = 0; d < BD; ++d) {
-        bq[d][0] = wb[(size_t)d * 64];
-        bq[d][1] = wb[(size_t)(KSTEPS + d) * 64];
+        for (int i = 0; i < HA; ++i) f.ga[i] = a_base[i * 16 * LSTR];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) f.gb[i] = a_base[(HA + i) * 16 * LSTR];
     }
-#pragma unroll
-    for (int i = 0; i < HA; ++i) ga[i] = a_base[i * 16 * LSTR];
-#pragma unroll
-    for (int i = 0; i < HB; ++i) gb[i] = a_base[(HA + i) * 16 * LSTR];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[ks % BD][0]);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bq[ks % BD][1]);
-        // ---- half A: MFMAs on ga (k-step ks), then refill ga for k-step ks+1 --------------------------
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][0]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][1]);
+        const int ksn = (ks + 1) % KSTEPS;          // k-step whose A fragments are requested next (wraps to the next phase)
+        // ---- half A: MFMAs on ga (k-step ks), then refill ga ---------------------------------------------------
 #pragma unroll
         for (int i = 0; i < HA; ++i) {
-            const bf16x8 av = __builtin_bit_cast(bf16x8, ga[i]);
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[i][1], 0, 0, 0);
+            const bf16x8 av = __builtin_bit_cast(bf16x8, f.ga[i]);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[i][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < KSTEPS) {
+        if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) {
 #pragma unroll
-            for (int i = 0; i < HA; ++i) ga[i] = a_base[i * 16 * LSTR + (ks + 1) * 4];
+            for (int i = 0; i < HA; ++i) f.ga[i] = a_base[i * 16 * LSTR + ksn * 4];
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- half B ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
-            const bf16x8 av = __builtin_bit_cast(bf16x8, gb[i]);
-            acc[HA + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[HA + i][0], 0, 0, 0);
-            acc[HA + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[HA + i][1], 0, 0, 0);
+            const bf16x8 av = __builtin_bit_cast(bf16x8, f.gb[i]);
+            acc[HA + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[HA + i][0], 0, 0, 0);
+            acc[HA + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[HA + i][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < KSTEPS) {
+        if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) {
 #pragma unroll
-            for (int i = 0; i < HB; ++i) gb[i] = a_base[(HA + i) * 16 * LSTR + (ks + 1) * 4];
+            for (int i = 0; i < HB; ++i) f.gb[i] = a_base[(HA + i) * 16 * LSTR + ksn * 4];
         }
         if (ks + BD < KSTEPS) {
-            bq[ks % BD][0] = wb[(size_t)(ks + BD) * 64];
-            bq[ks % BD][1] = wb[(size_t)(KSTEPS + ks + BD) * 64];
+            f.bq[ks % BD][0] = wb[(size_t)(ks + BD) * 64];
+            f.bq[ks % BD][1] = wb[(size_t)(KSTEPS + ks + BD) * 64];
+        } else {                                     // next phase's k-steps 0..BD-1
+            f.bq[ks % BD][0] = wb_next[(size_t)(ks + BD - KSTEPS) * 64];
+            f.bq[ks % BD][1] = wb_next[(size_t)(KSTEPS + ks + BD - KSTEPS) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// everything after the bank is staged: all head pairs of this workgroup, for a compile-time tile-count class
+template <int NMT>
+__device__ __forceinline__ void mha_body(unsigned char* smem, const float* __restrict__ qh, const float* __restrict__ mask,
+                                         int B, int L, int H, const unsigned short* __restrict__ Wp,
+                                         const float* __restrict__ bk, const float* __restrict__ bv, float temp,
+                                         float* __restrict__ o, float* __restrict__ attn, int lvalid, int n_mt) {
+    uint4* Xs = reinterpret_cast<uint4*>(smem);
+    float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
+    float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
+    float* s_red = s_p + 2 * LMAX;                                                // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int hp_wave = wave >> 2, wq = wave & 3;
+    const uint4* a_base = Xs + (lane & 15) * LSTR + (lane >> 4);     // + i*16*LSTR + ks*4
+    const int pos = tid & 255, hh = tid >> 8;
+    const bool pos_masked = mask && pos < L && mask[(size_t)b * L + pos] == 0.0f;
+    // weight stream of (head, phase) for this wave; heads beyond H (odd H) read head 0's stream and are discarded
+    auto wstream = [&](int hp, int phase) {
+        int h = hp * 2 + hp_wave;
+        if (h >= H) h = 0;
+        return reinterpret_cast<const uint4*>(Wp) + ((((size_t)h * 2 + phase) * 8 + wq * 2) * KSTEPS) * 64 + lane;
+    };
+
+    Frags<NMT> f;
+    frags_prime<NMT>(f, a_base, wstream(blockIdx.y, 0));
+
+    for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
+        const int h = hp * 2 + hp_wave;
+        const bool head_on = h < H;
+        const float* qv = qh + (size_t)b * H * DK + (size_t)(head_on ? h : 0) * DK;
+        // the tiles are computed TRANSPOSED (rows = head dims, columns = bank rows): this lane's accumulator element
+        // [i][j][r] is head dim d(j,r) = wq*32 + 16j + 4*(lane>>4) + r of bank row 16i + (lane&15)
+        const int hb = head_on ? h : 0;
+        const int dbase = wq * 32 + (lane >> 4) * 4;
+        const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv + dbase), qd1 = *reinterpret_cast<const f32x4*>(qv + dbase + 16);
+        f32x4 kb0 = {0.f, 0.f, 0.f, 0.f}, kb1 = kb0, vb0 = kb0, vb1 = kb0;
+        if (bk) { kb0 = *reinterpret_cast<const f32x4*>(bk + hb * DK + dbase); kb1 = *reinterpret_cast<const f32x4*>(bk + hb * DK + dbase + 16); }
+        if (bv) { vb0 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase); vb1 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase + 16); }
+        const int hp_next = (hp + gridDim.y) * 2 < H ? hp + gridDim.y : hp;     // last pair: harmless re-read
+
+        for (int phase = 0; phase < 2; ++phase) {
+            f32x4 acc[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            kv_gemm<NMT>(acc, f, a_base, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0));
+
+            if (phase == 0) {
+                // ---- partial scores of this wave's 32 head dims: in-register over the 8 dims of the lane, then
+                //      across the four 16-lane groups (2 exchanges per row tile instead of 4 DPP steps per element)
+                if (head_on) {
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v = fmaf(qd0[r], acc[i][0][r] + kb0[r], v);
+                            v = fmaf(qd1[r], acc[i][1][r] + kb1[r], v);
+                        }
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        if (lane < 16) s_part[wave * LMAX + i * 16 + lane] = v;
+                    }
+                }
+                __syncthreads();
+                // ---- masked softmax, one head per 256-thread half ----------------------------------------------
+                const int hs = hp * 2 + hh;
+                float s = -INFINITY;
+                if (pos < lvalid && hs < H) {
+                    const float* sp = s_part + (hh * 4) * LMAX + pos;
+                    s = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) / temp;
+                    if (pos_masked) s = -INFINITY;
+                }
+                float m = wave_max_dpp(s);
+                if (lane == 0) s_red[wave] = m;
+                __syncthreads();
+                m = fmaxf(fmaxf(s_red[hh * 4], s_red[hh * 4 + 1]), fmaxf(s_red[hh * 4 + 2], s_red[hh * 4 + 3]));
+                const float e = (s != -INFINITY) ? expf(s - m) : 0.f;
+                float z = wave_sum_dpp(e);
+                if (lane == 0) s_red[8 + wave] = z;
+                __syncthreads();
+                z = (s_red[8 + hh * 4] + s_red[8 + hh * 4 + 1]) + (s_red[8 + hh * 4 + 2] + s_red[8 + hh * 4 + 3]);
+                const float p = (hs < H) ? e / z : 0.f;
+                if (pos < LMAX) s_p[hh * LMAX + pos] = p;
+                if (attn && hs < H && pos < L) attn[((size_t)hs * B + b) * L + pos] = p;
+                __syncthreads();
+            } else {
+                // ---- o[d] = sum_l p[l] * (V[l,d] + bv[d]): p is per column here, 8 dims per lane accumulate in
+                //      registers over the row tiles, one 16-lane DPP sum per dim at the end ---------------------------
+                if (head_on) {
+                    const float* pp = s_p + hp_wave * LMAX + (lane & 15);
+                    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) {
+                        const float p = pp[i * 16];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            t0[r] = fmaf(p, acc[i][0][r] + vb0[r], t0[r]);
+                            t1[r] = fmaf(p, acc[i][1][r] + vb1[r], t1[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        t0[r] = row16_sum(t0[r]);
+                        t1[r] = row16_sum(t1[r]);
+                    }
+                    if ((lane & 15) == 0) {
+                        float* ob = o + (size_t)b * H * DK + h * DK + dbase;
+                        *reinterpret_cast<f32x4*>(ob) = t0;
+                        *reinterpret_cast<f32x4*>(ob + 16) = t1;
+                    }
+                }
+                __syncthreads();      // s_p / s_part are rewritten by the next head pair
+            }
+        }
+    }
+    (void)n_mt;
 }
 
 __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __restrict__ qh,
@@ -144,15 +294,9 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
                                                                 float temp, float* __restrict__ o, float* __restrict__ attn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* Xs = reinterpret_cast<uint4*>(smem);                                   // [LMAX][LSTR] chunks
-    float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
-    float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
-    float* s_red = s_p + 2 * LMAX;                                                // [16]
-    int* s_lvalid = reinterpret_cast<int*>(s_red + 16);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* s_lvalid = reinterpret_cast<int*>(smem + (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float));
+    const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int hp_wave = wave >> 2;                      // which head of the pair this wave serves
-    const int wq = wave & 3;                            // 32-dim slice of that head
     const uint4* xb = reinterpret_cast<const uint4*>(bank) + (size_t)b * L * CH;
 
     // ---- live rows -------------------------------------------------------------------------------------
@@ -167,7 +311,8 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     }
     const int lvalid = *s_lvalid;
     const int n_mt = (lvalid + 15) >> 4;
-    // tile-count class the branch-free GEMM body is instantiated for
+    // tile-count class the branch-free GEMM body is instantiated for (dead rows inside the class are computed on
+    // zero / masked data and get probability 0)
     const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : MT;
     const int rows_live = n_sel * 16;
 
@@ -180,104 +325,12 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     }
     __syncthreads();
 
-    const uint4* a_base = Xs + (lane & 15) * LSTR + (lane >> 4);     // + i*16*LSTR + ks*4
-
-    for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
-        const int h = hp * 2 + hp_wave;
-        const bool head_on = h < H;                                    // odd H: the second half idles
-        const float* qv = qh + (size_t)b * H * DK + (size_t)(head_on ? h : 0) * DK;
-        float r_o[2] = {0.f, 0.f};
-
-        for (int phase = 0; phase < 2; ++phase) {
-            f32x4 acc[MT][2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (head_on) {
-                // fragment stream of this wave: [h][phase][nt = wq*2 + j][ks][lane]
-                const uint4* wb = reinterpret_cast<const uint4*>(Wp) +
-                                  ((((size_t)h * 2 + phase) * 8 + wq * 2) * KSTEPS) * 64 + lane;
-                switch (n_sel) {
-                    case 1: kv_gemm<1>(acc, a_base, wb); break;
-                    case 2: kv_gemm<2>(acc, a_base, wb); break;
-                    case 4: kv_gemm<4>(acc, a_base, wb); break;
-                    case 7: kv_gemm<7>(acc, a_base, wb); break;
-                    default: kv_gemm<MT>(acc, a_base, wb); break;
-                }
-            }
-
-            const int c0 = wq * 32 + (lane & 15);
-            if (phase == 0) {
-                // ---- partial scores of this wave's 32 head dims ------------------------------------------
-                if (head_on) {
-                    const float q0 = qv[c0], q1 = qv[c0 + 16];
-                    const float k0b = bk ? bk[h * DK + c0] : 0.f, k1b = bk ? bk[h * DK + c0 + 16] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        if (i < n_mt) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = row16_sum(q0 * (acc[i][0][r] + k0b) + q1 * (acc[i][1][r] + k1b));
-                                if ((lane & 15) == 0) s_part[wave * LMAX + i * 16 + (lane >> 4) * 4 + r] = v;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                // ---- masked softmax, one head per 256-thread half ----------------------------------------------
-                const int pos = tid & 255, hh = tid >> 8;
-                const int hs = hp * 2 + hh;
-                float s = -INFINITY;
-                if (pos < lvalid && hs < H) {
-                    const float* sp = s_part + (hh * 4) * LMAX + pos;
-                    s = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) / temp;
-                    if (mask && mask[(size_t)b * L + pos] == 0.0f) s = -INFINITY;
-                }
-                float m = wave_max(s);
-                if (lane == 0) s_red[wave] = m;
-                __syncthreads();
-                m = fmaxf(fmaxf(s_red[hh * 4], s_red[hh * 4 + 1]), fmaxf(s_red[hh * 4 + 2], s_red[hh * 4 + 3]));
-                const float e = (s != -INFINITY) ? expf(s - m) : 0.f;
-                float z = wave_sum(e);
-                if (lane == 0) s_red[8 + wave] = z;
-                __syncthreads();
-                z = (s_red[8 + hh * 4] + s_red[8 + hh * 4 + 1]) + (s_red[8 + hh * 4 + 2] + s_red[8 + hh * 4 + 3]);
-                const float p = (hs < H) ? e / z : 0.f;
-                if (pos < LMAX) s_p[hh * LMAX + pos] = p;
-                if (attn && hs < H && pos < L) attn[((size_t)hs * B + b) * L + pos] = p;
-                __syncthreads();
-            } else {
-                // ---- o[c] = sum_l p[l] * (V[l,c] + bv[c]) ---------------------------------------------------------
-                if (head_on) {
-                    const float v0b = bv ? bv[h * DK + c0] : 0.f, v1b = bv ? bv[h * DK + c0 + 16] : 0.f;
-                    const float* pp = s_p + hp_wave * LMAX + (lane >> 4) * 4;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        if (i < n_mt) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float p = pp[i * 16 + r];
-                                r_o[0] = fmaf(p, acc[i][0][r] + v0b, r_o[0]);
-                                r_o[1] = fmaf(p, acc[i][1][r] + v1b, r_o[1]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        r_o[j] += __shfl_xor(r_o[j], 16, 64);
-                        r_o[j] += __shfl_xor(r_o[j], 32, 64);
-                    }
-                    if (lane < 16) {
-                        float* ob = o + (size_t)b * H * DK + h * DK + wq * 32 + lane;
-                        ob[0] = r_o[0];
-                        ob[16] = r_o[1];
-                    }
-                }
-                __syncthreads();      // s_p / s_part are rewritten by the next head pair
-            }
-        }
+    switch (n_sel) {
+        case 1: mha_body<1>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 2: mha_body<2>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 4: mha_body<4>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 7: mha_body<7>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        default: mha_body<MT>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
     }
 }
 
