@@ -16,6 +16,27 @@ constexpr int BK = 20;                   // K-slice of the model dim (300 = 15 x
 constexpr int SX = BK + 2;               // LDS row stride 22: rows 0..15 x k{0,1} hit 32 distinct banks
 constexpr int DK = 128;
 
+// one BK-slice of MFMAs for a COMPILE-TIME number of row tiles: all A fragments of a k-step are requested before
+// the MFMAs that consume them (no per-tile branch, no LDS round trip in front of every MFMA pair)
+template <int NMT>
+__device__ __forceinline__ void slice_mma(f32x4 (&acc)[MT][2], const float* __restrict__ xs, const float* __restrict__ ws,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+        const float* ap = xs + (lane & 15) * SX + kk + (lane >> 4);
+        const float* bp = ws + (wave * 32 + (lane & 15)) * SX + kk + (lane >> 4);
+        const float b0 = bp[0], b1 = bp[16 * SX];
+        float a[NMT];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) a[i] = ap[i * 16 * SX];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1, acc[i][1], 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sq_mha_core_kernel(const float* __restrict__ qh, const float* __restrict__ bank,
                                                           const float* __restrict__ mask, int B, int L, int D, int H,
                                                           const float* __restrict__ Wk, const float* __restrict__ bk,
@@ -46,7 +67,10 @@ __global__ __launch_bounds__(256) void sq_mha_core_kernel(const float* __restric
     }
     const int lvalid = s_lvalid;
     const int n_mt = (lvalid + 15) >> 4;
-    const int rows_live = n_mt * 16;
+    // tile-count class of the branch-free MFMA body; rows between n_mt*16 and n_sel*16 hold real (masked) or zero
+    // data and end up with probability 0
+    const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : n_mt <= 10 ? 10 : MT;
+    const int rows_live = n_sel * 16;
     const int nchunk = (D + BK - 1) / BK;
 
     f32x4 acc[MT][2];
@@ -109,19 +133,13 @@ __global__ __launch_bounds__(256) void sq_mha_core_kernel(const float* __restric
         for (int c = 0; c < nchunk; ++c) {
             const int buf = c & 1;
             if (c + 1 < nchunk) gload((c + 1) * BK);
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 4) {
-                const float* ap = &Xs[buf][(lane & 15) * SX + kk + (lane >> 4)];
-                const float* bp = &Ws[buf][(wave * 32 + (lane & 15)) * SX + kk + (lane >> 4)];
-                const float b0 = bp[0], b1 = bp[16 * SX];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    if (i < n_mt) {
-                        const float a = ap[i * 16 * SX];
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[i][1], 0, 0, 0);
-                    }
-                }
+            switch (n_sel) {
+                case 1: slice_mma<1>(acc, Xs[buf], Ws[buf], wave, lane); break;
+                case 2: slice_mma<2>(acc, Xs[buf], Ws[buf], wave, lane); break;
+                case 4: slice_mma<4>(acc, Xs[buf], Ws[buf], wave, lane); break;
+                case 7: slice_mma<7>(acc, Xs[buf], Ws[buf], wave, lane); break;
+                case 10: slice_mma<10>(acc, Xs[buf], Ws[buf], wave, lane); break;
+                default: slice_mma<MT>(acc, Xs[buf], Ws[buf], wave, lane); break;
             }
             if (c + 1 < nchunk) lstore(buf ^ 1);
             __syncthreads();
