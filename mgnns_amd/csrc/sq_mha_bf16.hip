@@ -200,9 +200,10 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
         const int hb = head_on ? h : 0;
         const int dbase = wq * 32 + (lane >> 4) * 4;
         const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv + dbase), qd1 = *reinterpret_cast<const f32x4*>(qv + dbase + 16);
-        f32x4 kb0 = {0.f, 0.f, 0.f, 0.f}, kb1 = kb0, vb0 = kb0, vb1 = kb0;
-        if (bk) { kb0 = *reinterpret_cast<const f32x4*>(bk + hb * DK + dbase); kb1 = *reinterpret_cast<const f32x4*>(bk + hb * DK + dbase + 16); }
-        if (bv) { vb0 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase); vb1 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase + 16); }
+        // Biases: q.(K_l + b_k) = q.K_l + q.b_k shifts every score of the head by the same constant, which the
+        // softmax cancels exactly, so b_k never enters; sum_l p_l (V_l + b_v) = sum_l p_l V_l + b_v because the
+        // probabilities sum to 1, so b_v is added once to the 8 outputs of the lane (keeps 16 VGPRs and ~200 VALU
+        // adds per head out of the loop; differences to the literal form are at fp32 rounding level)
         const int hp_next = (hp + gridDim.y) * 2 < H ? hp + gridDim.y : hp;     // last pair: harmless re-read
 
         for (int phase = 0; phase < 2; ++phase) {
@@ -223,8 +224,8 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                         float v = 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v = fmaf(qd0[r], acc[i][0][r] + kb0[r], v);
-                            v = fmaf(qd1[r], acc[i][1][r] + kb1[r], v);
+                            v = fmaf(qd0[r], acc[i][0][r], v);
+                            v = fmaf(qd1[r], acc[i][1][r], v);
                         }
                         v += __shfl_xor(v, 16, 64);
                         v += __shfl_xor(v, 32, 64);
@@ -264,8 +265,8 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                         const float p = pp[i * 16];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            t0[r] = fmaf(p, acc[i][0][r] + vb0[r], t0[r]);
-                            t1[r] = fmaf(p, acc[i][1][r] + vb1[r], t1[r]);
+                            t0[r] = fmaf(p, acc[i][0][r], t0[r]);
+                            t1[r] = fmaf(p, acc[i][1][r], t1[r]);
                         }
                     }
 #pragma unroll
@@ -274,6 +275,12 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                         t1[r] = row16_sum(t1[r]);
                     }
                     if ((lane & 15) == 0) {
+                        if (bv) {
+                            const f32x4 vb0 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase);
+                            const f32x4 vb1 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase + 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { t0[r] += vb0[r]; t1[r] += vb1[r]; }
+                        }
                         float* ob = o + (size_t)b * H * DK + h * DK + dbase;
                         *reinterpret_cast<f32x4*>(ob) = t0;
                         *reinterpret_cast<f32x4*>(ob + 16) = t1;

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""configs[4]-style stress of the label-graph GCN step on ONE GPU: N = 10 000-node graph, X [N,300],
+W1 [300,1024], W2 [1024,2048], adjacency in CSR at PMI-like (4e-4) and dense-ish (1e-2) density, read-out
+[512,2048] x [2048,N].  Reports per-kernel time and the algorithmic HBM rate of the sparse step
+(nnz*8 + 2*N*F*4 bytes per SpMM).  The dense-bf16 [N,N] GEMM variant is not built yet.
+
+    python tools/bench_stress.py [N] [batch]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mgnns_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def csr(N, density, seed):
+    rs = np.random.RandomState(seed)
+    per = rs.poisson(density * N, size=N).clip(1, N)
+    rp = np.zeros(N + 1, np.int64)
+    rp[1:] = np.cumsum(per)
+    col = np.concatenate([np.sort(rs.choice(N, size=k, replace=False)) for k in per]).astype(np.int32)
+    val = rs.uniform(0.0, 1.0, size=col.size).astype(np.float32)
+    return (torch.from_numpy(rp.astype(np.int32)).to(DEV), torch.from_numpy(col).to(DEV), torch.from_numpy(val).to(DEV)), col.size
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    g = torch.Generator(device=DEV).manual_seed(0)
+    X = torch.randn(N, 300, device=DEV, generator=g) * 0.45
+    W1 = torch.randn(300, 1024, device=DEV, generator=g) * 0.05
+    W2 = torch.randn(1024, 2048, device=DEV, generator=g) * 0.05
+    pooled = torch.relu(torch.randn(B, 2048, device=DEV, generator=g))
+    out = {"N": N, "batch": B}
+    ms = timeit(lambda: ops.matmul(X, W1))
+    out["xw1_ms"] = round(ms, 4); out["xw1_tflops"] = round(2.0 * N * 300 * 1024 / ms / 1e9, 1)
+    S1 = ops.matmul(X, W1)
+    for dens in (4e-4, 1e-2):
+        c, nnz = csr(N, dens, 1)
+        for F, S in ((1024, S1), (2048, None)):
+            if S is None:
+                S = torch.randn(N, F, device=DEV, generator=g)
+            ms = timeit(lambda: ops.spmm_csr(c, S, act=ops.ACT_LRELU2))
+            by = nnz * 8.0 + 2.0 * N * F * 4
+            gathered = nnz * (8.0 + F * 4.0) + N * F * 4.0
+            out["spmm_d%g_F%d" % (dens, F)] = {"nnz": nnz, "ms": round(ms, 4), "algorithmic_GBps": round(by / ms / 1e6, 1),
+                                                 "gathered_GBps": round(gathered / ms / 1e6, 1)}
+    H1 = torch.randn(N, 1024, device=DEV, generator=g)
+    ms = timeit(lambda: ops.matmul(H1, W2))
+    out["hw2_ms"] = round(ms, 4); out["hw2_tflops"] = round(2.0 * N * 1024 * 2048 / ms / 1e9, 1)
+    G = torch.randn(N, 2048, device=DEV, generator=g)
+    ms = timeit(lambda: ops.linear(pooled, G))
+    out["readout_ms"] = round(ms, 4); out["readout_tflops"] = round(2.0 * B * 2048 * N / ms / 1e9, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
