@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--config", default="mvsa_multiple_b256")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
     args = ap.parse_args()
@@ -156,6 +157,17 @@ def main():
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),
                     "flops_per_launch": fl}
+
+    if roofline is not None:
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (cannot be collected live)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                t = json.load(f).get("%s@L%d" % (roofline["kernel"].split(" ")[0], P))
+            if t:
+                roofline["traffic"] = t["hbm_bytes"]
+                roofline["traffic_source"] = t["source"]
+        except (OSError, ValueError):
+            pass
 
     cpu = None
     parity = None

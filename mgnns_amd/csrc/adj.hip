@@ -96,41 +96,50 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const float* __restrict__
     }
 }
 
-// Y[i, f4] = act(sum_p val[p] * X[col[p], f4]); grid (rows, ceil(F/1024)); the row's (col,val)
-// list is staged through LDS in chunks, X rows are read as coalesced 16-B lanes.
+// Y[i, :] = act(sum_p val[p] * X[col[p], :]) over the CSR row i.  Work unit = (row, 256-feature chunk) = one
+// wave (64 lanes x 16 B); waves walk the units grid-stride so a CU always has many independent 1-KiB row-segment
+// loads in flight (the rows of a PMI-like graph have ~4 non-zeros: a block per row is launch/latency bound).
+// The non-zeros of a row are consumed four at a time (four gathers in flight per wave), in ascending order.
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ row_ptr,
                                                        const int32_t* __restrict__ col,
                                                        const float* __restrict__ val,
-                                                       const float* __restrict__ X, int F,
+                                                       const float* __restrict__ X, int n_rows, int F,
                                                        float* __restrict__ Y, int act) {
-    __shared__ int32_t s_col[256];
-    __shared__ float s_val[256];
-    const int i = blockIdx.x;
-    const int f = (blockIdx.y * 256 + threadIdx.x) * 4;
-    const int lo = row_ptr[i], hi = row_ptr[i + 1];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int p0 = lo; p0 < hi; p0 += 256) {
-        const int n = min(256, hi - p0);
-        __syncthreads();
-        if ((int)threadIdx.x < n) {
-            s_col[threadIdx.x] = col[p0 + threadIdx.x];
-            s_val[threadIdx.x] = val[p0 + threadIdx.x];
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int chunks = (F + 255) >> 8;
+    const long long units = (long long)n_rows * chunks;
+    const long long wstride = (long long)gridDim.x * 4;
+    for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += wstride) {
+        const int i = (int)(u / chunks);
+        const int f = ((int)(u - (long long)i * chunks) << 8) + lane * 4;
+        const int lo = row_ptr[i], hi = row_ptr[i + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (f < F) {
-            for (int q = 0; q < n; ++q) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(X + (size_t)s_col[q] * F + f);
-                const float w = s_val[q];
-                acc[0] = fmaf(w, x[0], acc[0]);
-                acc[1] = fmaf(w, x[1], acc[1]);
-                acc[2] = fmaf(w, x[2], acc[2]);
-                acc[3] = fmaf(w, x[3], acc[3]);
+            int p = lo;
+            for (; p + 4 <= hi; p += 4) {
+                const int c0 = col[p], c1 = col[p + 1], c2 = col[p + 2], c3 = col[p + 3];
+                const float w0 = val[p], w1 = val[p + 1], w2 = val[p + 2], w3 = val[p + 3];
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (size_t)c0 * F + f);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (size_t)c1 * F + f);
+                const f32x4 x2 = *reinterpret_cast<const f32x4*>(X + (size_t)c2 * F + f);
+                const f32x4 x3 = *reinterpret_cast<const f32x4*>(X + (size_t)c3 * F + f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = fmaf(w0, x0[j], acc[j]);
+                    acc[j] = fmaf(w1, x1[j], acc[j]);
+                    acc[j] = fmaf(w2, x2[j], acc[j]);
+                    acc[j] = fmaf(w3, x3[j], acc[j]);
+                }
             }
+            for (; p < hi; ++p) {
+                const float w = val[p];
+                const f32x4 x = *reinterpret_cast<const f32x4*>(X + (size_t)col[p] * F + f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, x[j], acc[j]);
+            }
+            f32x4 o = {mg_act(acc[0], act), mg_act(acc[1], act), mg_act(acc[2], act), mg_act(acc[3], act)};
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)i * F + f));
         }
-    }
-    if (f < F) {
-        f32x4 o = {mg_act(acc[0], act), mg_act(acc[1], act), mg_act(acc[2], act), mg_act(acc[3], act)};
-        *reinterpret_cast<f32x4*>(Y + (size_t)i * F + f) = o;
     }
 }
 
@@ -175,8 +184,11 @@ extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, co
     MG_REQUIRE(mg_aligned16(X) && mg_aligned16(Y), "mgnns_spmm_csr_fwd: X/Y must be 16-byte aligned");
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_spmm_csr_fwd: unknown activation %d", act);
     if (n_rows == 0) return 0;
-    dim3 grid(n_rows, (F + 1023) / 1024);
-    hipLaunchKernelGGL(spmm_csr_kernel, grid, dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X, F, Y, act);
+    const long long units = (long long)n_rows * ((F + 255) / 256);
+    long long blocks = (units + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;          // 16 workgroups (64 waves) per CU, grid-stride beyond
+    hipLaunchKernelGGL(spmm_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X,
+                       n_rows, F, Y, act);
     MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
     return 0;
 }

@@ -78,3 +78,26 @@ def test_bf16_precision_mode_is_close_and_reports_error():
     print("bf16 mode max|logit diff| vs fp32 reference: %.3e" % err)
     assert err < 5e-2
     assert torch.equal(logits.argmax(1), torch.from_numpy(g["logits"]).argmax(1))
+
+
+def test_graph_replay_and_streams_equal_eager_single_stream():
+    """One captured hipGraph replay (4 streams) == eager multi-stream == eager single-stream forward, bit for bit
+    (same kernels, same order of arithmetic), for fresh inputs copied into the graph's static buffers."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    a1 = call_args(synth.make_inputs(cfg, B=16, seed=1, pmi=pmi), DEV)
+    a2 = call_args(synth.make_inputs(cfg, B=16, seed=2, pmi=pmi), DEV)
+    for prec in ("fp32", "bf16"):
+        model.set_precision(prec)
+        model.use_streams = False
+        ref1, ref2 = model(*a1).clone(), model(*a2).clone()
+        model.use_streams = True
+        assert torch.equal(model(*a1), ref1)
+        gf = GraphedForward(model, a1)
+        assert torch.equal(gf.replay(), ref1)
+        assert torch.equal(gf(*a2), ref2)          # copy-in + replay on new inputs
+        assert torch.equal(gf(*a1), ref1)
