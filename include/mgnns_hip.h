@@ -134,7 +134,7 @@ int mgnns_imgbank_pool_fwd(const float* feat, int B, int K, int P,
 /* bf16-operand variant (BASELINE config 3): same reads (the fp32 map crosses HBM once, max-pool exact fp32),
  * W pre-packed by mgnns_imgbank_pack_weights_bf16 into mgnns_imgbank_packed_weight_bytes(K) bytes, the bank is
  * emitted as bf16 [B, P, ld] with ld == 320 (zero padded) -- the layout mgnns_sq_mha_core_bf16_fwd consumes.
- * pooled_work: [B, 2, K] floats of scratch.  104 < P <= 200, P % 4 == 0, N <= 304, K % 64 == 0.
+ * pooled_work: [B, 2, K] floats of scratch.  104 < P <= 200, P % 4 == 0, N <= 304, K % 128 == 0.
  */
 size_t mgnns_imgbank_packed_weight_bytes(int K);
 int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnns_stream_t stream);

@@ -6,7 +6,7 @@
 // The kernel is HBM bound on the fp32 map (1.6 MB per sample-channel, read exactly once).
 //
 // Two 512-thread workgroups per sample, one per half of the 196 regions (7 | 6 row tiles of 16), each streams
-// its half of every feature row (448-B segments) in BK = 64 slices: global -> registers (fp32; the max-pool is
+// its half of every feature row (448-B segments) in BK = 128 slices: global -> registers (fp32; the max-pool is
 // taken here) -> bf16 -> LDS transposed to [p][k] (XOR-swizzled 16-B chunks: conflict-free for both the
 // ds_write_b128 of the transpose and the ds_read_b128 MFMA A fragments).  8 waves split the 19 column tiles
 // (300 outputs) 3,3,3,2,2,2,2,2; the B operand (W) comes straight from L2 in a pre-packed fragment-major layout.
@@ -17,10 +17,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int BK = 64;                  // k-slice (2 MFMA k-steps)
+constexpr int BK = 128;                 // k-slice (4 MFMA k-steps): every lane of a wave streams 8 feature rows
 constexpr int MTH = 7;                  // row tiles per half (112 rows)
 constexpr int ROWS = MTH * 16;
-constexpr int FSTR = 10;                // LDS row stride of the staged slice in 16-B chunks (8 data + 2 pad)
+constexpr int FSTR = 18;                // LDS row stride of the staged slice in 16-B chunks (16 data + 2 pad)
 constexpr int NTW = 3;                  // column tiles per wave (max)
 constexpr int NT = 19;                  // 304 / 16
 constexpr int OUT_LD = 320;             // bank row length (bf16)
@@ -84,12 +84,12 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
     const int nt0 = wave < 3 ? 3 * wave : 9 + 2 * (wave - 3);
     const int KS = K / 32;
 
-    // staging role: wave = 8-row group kc of the slice, lane = region quad pq
-    const int pq = lane;
+    // staging role: half-wave = 8-row group kc (0..15) of the 128-row slice, lane&31 = region quad pq
+    const int pq = lane & 31, kc = 2 * wave + (lane >> 5);
     const int npq = mh ? (P - P_SPLIT + 3) / 4 : ROWS / 4;                 // 23 | 28 quads carry data
-    const bool st_on = pq < ROWS / 4;                                      // lanes that own LDS rows (28)
+    const bool st_on = pq < ROWS / 4;                                      // lanes that own LDS rows (28 per half-wave)
     const bool ld_on = st_on && pq < npq && (p0 + 4 * pq + 3 < P);
-    const float* fsrc = feat + ((size_t)b * K + 8 * wave) * P + p0 + 4 * pq;
+    const float* fsrc = feat + ((size_t)b * K + 8 * kc) * P + p0 + 4 * pq;
 
     f32x4 acc[MTH][NTN];
 #pragma unroll
@@ -108,18 +108,21 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
     };
     auto lstore = [&](int c, int buf) {
         // max-pool of the 8 feature rows this wave just loaded (exact fp32), then transpose-write as bf16
-        // (only lanes 0..27 carry data: two DPP rows -> lanes 0 and 16 hold the row maxima; lane i keeps row i's
-        // result so the 8 maxima leave as ONE 32-byte store per wave)
+        // (each half-wave = two DPP rows holds one 8-row group: lanes 0/16 and 32/48 carry the row maxima; lane i
+        // keeps the result of feature row i of the wave's 16, so they leave as ONE 64-byte store per wave)
         float mine = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float m = ld_on ? fmaxf(fmaxf(st[i][0], st[i][1]), fmaxf(st[i][2], st[i][3])) : -INFINITY;
             m = row16_max(m);
-            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
-            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
-            if (lane == i) mine = fmaxf(r0, r1);
+            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
+            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
+            if (lane == i) mine = fmaxf(a0, a1);
+            if (lane == 8 + i) mine = fmaxf(b0, b1);
         }
-        if (lane < 8) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 8 * wave + lane] = mine;
+        if (lane < 16) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 16 * wave + lane] = mine;
         if (st_on) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -129,7 +132,7 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
                 o.z = pack2(st[4][j], st[5][j]);
                 o.w = pack2(st[6][j], st[7][j]);
                 const int row = 4 * pq + j;
-                Fs[(buf * ROWS + row) * FSTR + (wave ^ (pq & 7))] = o;
+                Fs[(buf * ROWS + row) * FSTR + (kc ^ (pq & 7))] = o;
             }
         }
     };
@@ -148,8 +151,8 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
         if (c + 1 < nchunk) gload(c + 1);
         const uint4* fb = Fs + (size_t)buf * ROWS * FSTR;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ks_next = c * 2 + kk + 1;
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            const int ks_next = c * (BK / 32) + kk + 1;
             if (ks_next < KS) {
 #pragma unroll
                 for (int j = 0; j < NTN; ++j) bq[(kk + 1) & 1][j] = wb[((size_t)j * KS + ks_next) * 64];
