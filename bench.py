@@ -86,9 +86,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MGNNS_FORCE_DIST") == "1":   # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synth.CONFIGS[args.config]
@@ -116,6 +117,12 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             out = fwd(*call)
+        if dist is not None:            # RCCL prints its banner at communicator init (first collective, above): get it
+            try:                        # out of every rank's C stdio buffer now, long before rank 0 prints the JSON line
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -189,10 +196,18 @@ def main():
                    "launch": "eager" if args.no_graph else "hipGraph replay"},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
-    print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line must be the last thing on stdout: push out whatever native libraries (RCCL banner) still hold in
+    # the C stdio buffer first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

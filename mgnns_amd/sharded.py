@@ -26,7 +26,7 @@ class ShardedForward:
 
     def __call__(self, *local_args):
         logits = self.forward_fn(*local_args)
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return logits
         shape = (self.world * logits.shape[0],) + tuple(logits.shape[1:])
         if self._out is None or self._out.shape != shape or self._out.device != logits.device:
