@@ -93,12 +93,15 @@ struct Frags {
 };
 
 template <int NMT>
-__device__ __forceinline__ void frags_prime(Frags<NMT>& f, const uint4* __restrict__ a_base, const uint4* __restrict__ wb) {
+__device__ __forceinline__ void frags_prime_b(Frags<NMT>& f, const uint4* __restrict__ wb) {
 #pragma unroll
     for (int d = 0; d < Frags<NMT>::BD; ++d) {
         f.bq[d][0] = wb[(size_t)d * 64];
         f.bq[d][1] = wb[(size_t)(KSTEPS + d) * 64];
     }
+}
+template <int NMT>
+__device__ __forceinline__ void frags_prime_a(Frags<NMT>& f, const uint4* __restrict__ a_base) {
     if (Frags<NMT>::CROSS_A) {
 #pragma unroll
         for (int i = 0; i < Frags<NMT>::HA; ++i) f.ga[i] = a_base[i * 16 * LSTR];
@@ -189,7 +192,10 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     };
 
     Frags<NMT> f;
-    frags_prime<NMT>(f, a_base, wstream(blockIdx.y, 0));
+    frags_prime_b<NMT>(f, wstream(blockIdx.y, 0));     // weight fragments on their way while the bank DMA lands
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA pieces of the bank (not tracked by hipcc)
+    __syncthreads();                                    // ... and every other wave's
+    frags_prime_a<NMT>(f, a_base);
 
     for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
         const int h = hp * 2 + hp_wave;
@@ -323,14 +329,25 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : MT;
     const int rows_live = n_sel * 16;
 
-    // ---- stage X (bf16) once: rows >= L are zero --------------------------------------------------------
-    for (int q = tid; q < rows_live * CH; q += NTHR) {
-        const int row = q / CH, c = q - row * CH;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < L) v = xb[(size_t)row * CH + c];
-        Xs[row * LSTR + c] = v;
+    // ---- stage X (bf16) once by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, every piece in flight at
+    //      once).  A DMA instruction fills 1 KiB of CONTIGUOUS LDS (M0 base + lane*16) from per-lane addresses, so
+    //      the padded [row][42-chunk] image is walked linearly: lanes that fall on the 2 pad chunks of a row are
+    //      switched off, rows >= L read a zero chunk (the zero padding at the end of bank row 0).
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int total = rows_live * LSTR;
+        for (int pc = wave; pc * 64 < total; pc += NTHR / 64) {
+            const int g = pc * 64 + lane;
+            const int row = g / LSTR, c = g - row * LSTR;
+            if (g < total && c < CH) {
+                const uint4* src = row < L ? xb + (size_t)row * CH + c : xb + (CH - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)pc * 1024),
+                                                 16, 0, 0);
+            }
+        }
     }
-    __syncthreads();
+    (void)Xs;
 
     switch (n_sel) {
         case 1: mha_body<1>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
