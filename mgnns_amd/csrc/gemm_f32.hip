@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restric
 // K-split factor: enough workgroups to cover the chip, slices of at least 2 x BK, bounded by the workspace
 int choose_split(int M, int N, int K, size_t ws_floats) {
     const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
-    if (tiles >= 192 || K < 4 * BK) return 1;
+    // short reductions (K < 512: <= 16 slices of BK) finish in a few us on their own; a K split would only add the
+    // reduce launch (~4.5 us inside a graph)
+    if (tiles >= 192 || K < 512) return 1;
     int s = (384 + tiles - 1) / tiles;
     const int smax = K / (2 * BK);
     if (s > smax) s = smax;

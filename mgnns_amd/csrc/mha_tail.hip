@@ -320,7 +320,7 @@ __device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* _
     }
     const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
     const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
-    constexpr int PF = 2;
+    constexpr int PF = TERMS == 1 ? 6 : 3;      // k-steps of weight fragments in flight (L2 latency ~1 us, a k-step of MFMAs ~50 ns)
     uint4 rh[PF][TPW], rl[PF][TPW];
 #pragma unroll
     for (int d = 0; d < PF; ++d)

@@ -70,6 +70,24 @@ def imgbank(B=256):
         print("imgbank_pool bf16 B=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s (map read)" % (B, ms * 1e3, fl / ms / 1e9, by / ms / 1e6))
 
 
+def tail(B=256, H=8):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    r = lambda *shape: torch.randn(*shape, device=DEV, generator=g) * 0.05
+    o, q = torch.randn(B, H * 128, device=DEV, generator=g), torch.randn(B, 300, device=DEV, generator=g)
+    fc, w1, w2, wq = r(300, H * 128), r(300, 300), r(300, 300), r(H * 128, 300)
+    common = {"fc_b": r(300), "g1": r(300) + 1, "be1": r(300), "b1": r(300), "b2": r(300), "g2": r(300) + 1, "be2": r(300)}
+    bq = r(H * 128)
+    pk32 = dict(common, fc_wp=ops.pack_weight_f32(fc), w1_wp=ops.pack_weight_f32(w1), w2_wp=ops.pack_weight_f32(w2))
+    nx32 = (ops.pack_weight_f32(wq), bq, H * 128)
+    print("mha_tail fp32 (+next wq): %.1f us" % (timeit(lambda: ops.mha_tail(o, q, pk32, 1e-6, nx32)) * 1e3))
+    print("mha_tail fp32 (last layer): %.1f us" % (timeit(lambda: ops.mha_tail(o, q, pk32, 1e-6, None)) * 1e3))
+    pkbf = dict(common, fc=ops.pack_weight_bf16_split(fc), w1=ops.pack_weight_bf16_split(w1), w2=ops.pack_weight_bf16_split(w2))
+    nxbf = (ops.pack_weight_bf16_split(wq), bq, H * 128)
+    for terms in (1, 3):
+        print("mha_tail bf16 terms=%d (+next wq): %.1f us" % (terms, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=terms)) * 1e3))
+        print("mha_tail bf16 terms=%d (last layer): %.1f us" % (terms, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, None, terms=terms)) * 1e3))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["mha_bf16", "mha_f32", "imgbank"]
     if "mha_bf16" in what:
@@ -80,3 +98,9 @@ if __name__ == "__main__":
         mha("f32", L=100, masked=True)
     if "imgbank" in what:
         imgbank()
+    if "tail" in what:
+        tail()
+    if "tail_h" in what:
+        for h in (1, 2, 4, 8):
+            print("H =", h)
+            tail(H=h)
