@@ -90,3 +90,87 @@ class PmiCsr:
             self._dev[key] = tuple(
                 torch.from_numpy(a).to(device) for a in (self.row_ptr, self.col, self.eid))
         return self._dev[key]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Building the edge map from a corpus (the reference's cal_PMI, utils/pmi.py:28-105) without the three dense
+# [V,V] matrices and the four O(V^2) Python loops: pair counts are accumulated as sorted (src*V + dst) keys.
+# Every quirk of the reference is kept, because edge ids index a learned embedding (seq_edge_w):
+#   * sentences are padded with 'PAD' to 100 tokens, sentences of >= 100 tokens are dropped (pmi.py:7-15);
+#   * the window is asymmetric: j in [i-window, i+window) (pmi.py:50-52);
+#   * a PAD *target* is counted (it is a vocabulary word), an out-of-vocabulary source or target is skipped;
+#     PAD never is a source and has word count 0, so its PMI is 0 (pmi.py:44-59,75-77);
+#   * pairs seen fewer than min_cooccurence times are zeroed (pmi.py:60-66);
+#   * PMI = log(p_ij / (p_i * p_j)) with counts normalised by the total word count, kept where > 0;
+#   * ids are handed out in row-major (i, j) order starting at 1; id 0 = "no edge" (pmi.py:86-97).
+# ---------------------------------------------------------------------------------------------------------
+def build_pmi(texts, vocab, window_size=6, min_cooccurence=2, max_len=100, chunk=4096):
+    """texts: iterable of whitespace-tokenised strings (the train split); vocab: list with 'PAD' at 0.
+    Returns (edges_weights float32 [count, 1], PmiCsr, count) -- the reference's return triple with the
+    dense edges_mappings replaced by its CSR."""
+    V = len(vocab)
+    d = {w: i for i, w in enumerate(vocab)}
+    pad = d['PAD']
+    rows = []
+    for text in texts:
+        words = text.split(' ')
+        if len(words) >= max_len:
+            continue
+        ids = np.full(max_len, pad, dtype=np.int64)
+        ids[:len(words)] = [d.get(w, -1) for w in words]
+        # the reference compares the *string* with 'PAD': a literal "PAD" token in the text is padding too
+        rows.append(ids)
+    word_count = np.zeros(V, dtype=np.int64)
+    keys_acc, cnts_acc = [], []
+    offs = [o for o in range(-window_size, window_size) if o != 0]
+    for c0 in range(0, len(rows), chunk):
+        S = np.stack(rows[c0:c0 + chunk])                       # [n, max_len]
+        src_ok = (S != pad) & (S >= 0)
+        np.add.at(word_count, S[src_ok], 1)
+        ks = []
+        for o in offs:
+            if o > 0:
+                a, b, m = S[:, :-o], S[:, o:], src_ok[:, :-o]
+            else:
+                a, b, m = S[:, -o:], S[:, :o], src_ok[:, -o:]
+            m = m & (b >= 0)
+            ks.append(a[m] * V + b[m])
+        k, c = np.unique(np.concatenate(ks), return_counts=True)
+        keys_acc.append(k)
+        cnts_acc.append(c)
+    if keys_acc:
+        allk = np.concatenate(keys_acc)
+        allc = np.concatenate(cnts_acc)
+        keys, inv = np.unique(allk, return_inverse=True)
+        counts = np.zeros(keys.shape[0], dtype=np.int64)
+        np.add.at(counts, inv, allc)
+    else:
+        keys = np.zeros(0, dtype=np.int64)
+        counts = np.zeros(0, dtype=np.int64)
+    keep = counts >= min_cooccurence
+    keys, counts = keys[keep], counts[keep]
+    total = np.sum(word_count)
+    wc = word_count / total
+    pij = counts / total
+    i, j = keys // V, keys % V
+    denom = wc[i] * wc[j]
+    pmi = np.zeros(keys.shape[0], dtype=np.float64)
+    ok = denom != 0
+    pmi[ok] = np.log(pij[ok] / denom[ok])
+    pmi = np.maximum(np.nan_to_num(pmi), 0.0)
+    nz = pmi != 0
+    i, j, pmi = i[nz], j[nz], pmi[nz]                            # keys are sorted -> row-major order
+    eids = np.arange(1, pmi.shape[0] + 1)
+    weights = np.concatenate([[0.0], pmi]).astype(np.float32).reshape(-1, 1)
+    return weights, PmiCsr.from_coo(i, j, eids, V), int(pmi.shape[0] + 1)
+
+
+def save_pmi(path, weights, pmi, count):
+    """Compact on-disk form of (edges_weights, edges_mappings, count): one .npz, ~12 B per edge."""
+    np.savez_compressed(path, row_ptr=pmi.row_ptr, col=pmi.col, eid=pmi.eid, weights=np.asarray(weights, np.float32),
+                        n_rows=np.int64(pmi.n_rows), count=np.int64(count))
+
+
+def load_pmi(path):
+    z = np.load(path)
+    return z["weights"], PmiCsr(z["row_ptr"], z["col"], z["eid"], int(z["n_rows"])), int(z["count"])

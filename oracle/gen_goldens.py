@@ -250,6 +250,52 @@ def gold_text_bank(ns):
     save("text_bank.npz", tok=tok, lens=lens, bank=bank, V=cfg.V)
 
 
+def gold_hostside(ns):
+    """Reference host-side data prep on a small slice of the shipped val split: build_vocab + cal_PMI
+    (utils/vocab_new.py, utils/pmi.py) and the dataset's word2id/_padding (utils/Multi_GCN_Co_att_dataset.py)."""
+    print("[host side] vocab, PMI edge map, batch padding")
+    import importlib
+    import tempfile
+    texts = []
+    with open(os.path.join(REF, "data/all_anno_json/val_all_anno.json")) as f:
+        for line in f:
+            texts.append(json.loads(line)["text"])
+            if len(texts) == 300:
+                break
+    texts.append(" ".join("w%d" % (i % 7) for i in range(100)))      # >= 100 tokens: dropped by cal_PMI's padding
+    texts.append(" ".join(texts[0].split(" ")[:6]))
+    root = tempfile.mkdtemp(prefix="mgnns_pmi_")
+    os.makedirs(os.path.join(root, "all_anno_json"))
+    os.makedirs(os.path.join(root, "vocab"))
+    with open(os.path.join(root, "all_anno_json", "train_all_anno.json"), "w") as f:
+        for t in texts:
+            f.write(json.dumps({"text": t}) + "\n")
+    VOC = importlib.import_module("utils.vocab_new")
+    PMI = importlib.import_module("utils.pmi")
+    vocab = VOC.get_vocab_list(root, root, 2)                       # builds + writes vocab-2.txt
+    weights, mappings, count = PMI.cal_PMI(root, root, min_count=2, phase="train", window_size=5, min_cooccurence=2)
+    r, c = np.nonzero(mappings)
+    print("   V=%d, edges=%d" % (len(vocab), count - 1))
+    # dataset padding
+    DS = importlib.import_module("utils.Multi_GCN_Co_att_dataset")
+    ds = DS.Tumblr_Dataset.__new__(DS.Tumblr_Dataset)
+    ds.vocab = vocab
+    ds.d = dict(zip(vocab, range(len(vocab))))
+    ds.pad_idx = ds.d["PAD"]
+    ds.text_max_length = 40
+    sample = [t for t in texts[:40] if len(t.split(" ")) <= 40][:12] + ["zzzz_unknown_word " + texts[1].split(" ")[0]]
+    ids, lens, masks = [], [], []
+    for t in sample:
+        content = list(map(lambda x: ds.word2id(x), t.split(" ")))
+        cp, n, m = ds._padding(content)
+        ids.append(cp.numpy())
+        lens.append(n)
+        masks.append(m.numpy())
+    save("hostside.npz", texts=np.array(texts), vocab=np.array(vocab), pmi_rows=r, pmi_cols=c, pmi_eids=mappings[r, c],
+         pmi_weights=weights.numpy(), pmi_count=count, pad_texts=np.array(sample), pad_ids=np.stack(ids),
+         pad_lens=np.array(lens), pad_mask=np.stack(masks))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -262,6 +308,7 @@ def main():
     gold_text_gcn(ns)
     gold_text_bank(ns)
     gold_full(ns)
+    gold_hostside(ns)
     print("done")
 
 

@@ -1,0 +1,61 @@
+"""Host-side rows either side of the path: vocabulary, sparse PMI edge-map builder
+and batch assembly against goldens produced by the reference's own build_vocab / cal_PMI / dataset padding
+(oracle/gen_goldens.py::gold_hostside) on a slice of the shipped val split.  CPU only, bit-exact."""
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from mgnns_amd.batching import BatchAssembler
+from mgnns_amd.pmi import PmiCsr, build_pmi, load_pmi, save_pmi
+from mgnns_amd.vocab import Word2Id, build_vocab
+from tests import helpers as H
+
+
+def _g():
+    return H.load_golden("hostside.npz")
+
+
+def test_build_vocab_equals_reference():
+    g = _g()
+    vocab = build_vocab([str(t) for t in g["texts"]], 2)
+    assert vocab == [str(w) for w in g["vocab"]]
+    assert vocab[0] == "PAD" and vocab[1] == "UNK"
+
+
+def test_sparse_pmi_builder_equals_reference_cal_PMI():
+    g = _g()
+    texts = [str(t) for t in g["texts"]]
+    vocab = [str(w) for w in g["vocab"]]
+    weights, pmi, count = build_pmi(texts, vocab, window_size=5, min_cooccurence=2)
+    assert count == int(g["pmi_count"])
+    ref = PmiCsr.from_coo(g["pmi_rows"], g["pmi_cols"], g["pmi_eids"], len(vocab))
+    assert np.array_equal(pmi.row_ptr, ref.row_ptr)
+    assert np.array_equal(pmi.col, ref.col)
+    assert np.array_equal(pmi.eid, ref.eid)                       # same ids: they index the learned seq_edge_w
+    assert np.array_equal(weights, g["pmi_weights"])              # same float32 PMI values
+    assert pmi[0, 0] == 0 and pmi.row_ptr[1] == 0                 # PAD is never a source
+    # round trip through the compact on-disk form
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "pmi.npz")
+        save_pmi(path, weights, pmi, count)
+        w2, p2, c2 = load_pmi(path)
+        assert c2 == count and np.array_equal(w2, weights) and np.array_equal(p2.col, pmi.col) and np.array_equal(p2.eid, pmi.eid)
+
+
+def test_batch_assembler_equals_reference_padding():
+    g = _g()
+    vocab = [str(w) for w in g["vocab"]]
+    texts = [str(t) for t in g["pad_texts"]]
+    T = g["pad_ids"].shape[1]
+    asm = BatchAssembler(vocab, max_len=T, batch_size=len(texts) + 3)
+    text, lens, mask = asm.encode(texts)
+    assert np.array_equal(text.numpy(), g["pad_ids"])
+    assert np.array_equal(lens.numpy(), g["pad_lens"])
+    assert np.array_equal(mask.numpy(), g["pad_mask"])
+    assert text.dtype == torch.int64 and mask.dtype == torch.float32
+    w2i = Word2Id(vocab)
+    assert w2i("zzzz_unknown_word") == 1                           # UNK
+    # unused tail rows of the fixed-size buffers are all PAD / length 0 / mask 0
+    assert int(asm.text[len(texts):].abs().sum()) == 0 and int(asm.lens[len(texts):].sum()) == 0

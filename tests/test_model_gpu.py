@@ -101,3 +101,31 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
         assert torch.equal(gf.replay(), ref1)
         assert torch.equal(gf(*a2), ref2)          # copy-in + replay on new inputs
         assert torch.equal(gf(*a1), ref1)
+
+
+def test_real_text_pipeline_vocab_pmi_batching_forward():
+    """Rows f2+f3 feeding the path: vocabulary + sparse PMI edge map built from real (val-split) texts, batch
+    assembled in pinned buffers, copied to the device, forward == CPU oracle on the same ids."""
+    from mgnns_amd.batching import BatchAssembler
+    from mgnns_amd.pmi import build_pmi
+    g = H.load_golden("hostside.npz")
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    texts = [str(t) for t in g["texts"]]
+    vocab = [str(w) for w in g["vocab"]]
+    weights, pmi, count = build_pmi(texts, vocab, window_size=5, min_cooccurence=2)
+    batch = [t for t in texts if len(t.split(" ")) <= 60][:24]
+    cfg = synth.Config("realtext", B=len(batch), T=60, V=len(vocab), NL=7, n_head=4, stack_num=2, ngram=4, seed=77)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    asm = BatchAssembler(vocab, max_len=cfg.T, batch_size=len(batch), device=DEV)
+    asm.encode(batch)
+    text, lens, mask = asm.to_device()
+    inp = synth.make_inputs(cfg, B=len(batch), pmi=pmi)
+    inp["text"], inp["text_lens"], inp["text_mask"] = asm.text.numpy().copy(), asm.lens.numpy().copy(), asm.mask.numpy().copy()
+    args = list(call_args(inp, DEV))
+    args[0], args[1], args[2] = text, lens, mask
+    logits = model(*args).cpu()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ti = {k: torch.from_numpy(v) for k, v in inp.items()}
+    ref = R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=torch.from_numpy(lq))
+    assert H.maxabs(logits, ref) < TOL
