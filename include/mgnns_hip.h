@@ -183,6 +183,20 @@ int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const flo
                                const void* Wp, const float* bk, const float* bv,
                                float* o, float* attn, mgnns_stream_t stream);
 
+/* ---- a8, folded variant: the K/V projections folded into the query side ---------------------------------
+ * Same inputs and outputs as mgnns_sq_mha_core_fwd (submodules.py:55-119, len_q == 1) computed as
+ *   U_h = Wk_h^T qh_h;   p = softmax_l(U_h . bank[b,l,:] / sqrt(dk)) (masked);   o_h = Wv_h (sum_l p_l bank[b,l,:]) + bv_h
+ * which is algebraically the reference's result (q.bk is constant over l and drops out of the softmax; sum_l p_l = 1
+ * carries bv through) at 1/100 of the FLOPs, all in fp32 (f32 MFMA).  Selected explicitly; the faithful kernels
+ * above are what the MFMA-utilisation target is measured on.
+ * bank: fp32 [B, L, D] (bank_is_bf16 == 0, ld_bank == D) or bf16 [B, L, ld_bank] zero padded (bank_is_bf16 == 1).
+ * workspace: mgnns_sq_mha_folded_workspace_bytes(B, D, H) bytes.  D <= 320, D % 4 == 0, H <= 8, dk % 4 == 0, L <= 208.
+ */
+size_t mgnns_sq_mha_folded_workspace_bytes(int B, int D, int H);
+int mgnns_sq_mha_folded_fwd(const float* qh, const void* bank, int bank_is_bf16, int ld_bank, const float* mask,
+                            int B, int L, int D, int H, int dk, const float* Wk, const float* Wv, const float* bv,
+                            void* workspace, size_t workspace_bytes, float* o, float* attn, mgnns_stream_t stream);
+
 /* ---- a8, rest of the layer: fc + residual + LayerNorm + position-wise FFN + residual + LayerNorm in ONE launch ----
  * MultiHeadAttention.forward after the attention (submodules.py:88-94) and PositionwiseFeedForward.forward
  * (submodules.py:132-139), optionally followed by the NEXT layer's query projection w_qs (submodules.py:68):

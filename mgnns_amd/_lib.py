@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c = ctypes
 _P = _c.c_void_p
@@ -37,11 +37,23 @@ SIGNATURES = {
     "mgnns_sq_mha_pack_weights_bf16": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_cast_pad_bf16": [_P, _L, _I, _I, _P, _P],
     "mgnns_sq_mha_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_sq_mha_folded_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _P],
     "mgnns_pack_weight_f32": [_P, _I, _I, _P, _P],
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
     "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
+}
+
+# size_t-returning helpers (buffer sizes the caller allocates)
+SIZE_GETTERS = {
+    "mgnns_packed_bf16_weight_bytes": [_I, _I],
+    "mgnns_packed_f32_weight_bytes": [_I, _I],
+    "mgnns_gemm_workspace_bytes": [],
+    "mgnns_imgbank_packed_weight_bytes": [_I],
+    "mgnns_sq_mha_packed_weight_bytes": [_I],
+    "mgnns_sq_mha_folded_workspace_bytes": [_I, _I, _I],
+    "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
 }
 
 _lib = None
@@ -67,18 +79,10 @@ def lib():
     L.mgnns_abi_version.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
-    L.mgnns_packed_bf16_weight_bytes.restype = _SZ
-    L.mgnns_packed_bf16_weight_bytes.argtypes = [_I, _I]
-    L.mgnns_packed_f32_weight_bytes.restype = _SZ
-    L.mgnns_packed_f32_weight_bytes.argtypes = [_I, _I]
-    L.mgnns_gemm_workspace_bytes.restype = _SZ
-    L.mgnns_gemm_workspace_bytes.argtypes = []
-    L.mgnns_imgbank_packed_weight_bytes.restype = _SZ
-    L.mgnns_imgbank_packed_weight_bytes.argtypes = [_I]
-    L.mgnns_sq_mha_packed_weight_bytes.restype = _SZ
-    L.mgnns_sq_mha_packed_weight_bytes.argtypes = [_I]
-    L.mgnns_bilstm_workspace_bytes.restype = _SZ
-    L.mgnns_bilstm_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    for name, args in SIZE_GETTERS.items():
+        fn = getattr(L, name)
+        fn.restype = _SZ
+        fn.argtypes = args
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)      # AttributeError if the symbol is missing
         fn.restype = _I

@@ -1,5 +1,8 @@
 // Error channel + ABI version of libmgnns_hip.so.
 #include "common.hpp"
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -10,5 +13,23 @@ void mgnns_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute lives on the device's code object, so a
+// process that drives several GPUs has to set it on each of them.
+int mg_ensure_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MGNNS_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        mgnns_set_error("hipFuncSetAttribute(dynamic LDS = %d B) failed: %s", bytes, hipGetErrorString(e));
+        return MGNNS_ERR_LAUNCH;
+    }
+    done.insert({fn, dev});
+    return 0;
+}
+
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 3; }
+extern "C" int mgnns_abi_version(void) { return 4; }

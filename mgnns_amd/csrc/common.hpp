@@ -10,6 +10,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void mgnns_set_error(const char* fmt, ...);
+int mg_ensure_dyn_lds(const void* fn, int bytes);   // api.hip; 0 or MGNNS_ERR_LAUNCH (error text set)
+#define MG_DYN_LDS(fn, bytes)                                                              \
+    do {                                                                                   \
+        if (int r_ = mg_ensure_dyn_lds(reinterpret_cast<const void*>(fn), (int)(bytes))) return r_; \
+    } while (0)
 
 #define MG_REQUIRE(cond, ...)                         \
     do {                                              \

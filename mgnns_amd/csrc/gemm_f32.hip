@@ -28,6 +28,9 @@ __device__ __forceinline__ f32x4 load4(const float* p, int n_valid, bool vec_ok)
     return v;
 }
 
+// strided batch descriptor (element strides between consecutive problems); n == 0: plain / K-split launch
+struct GemmBatch { int n; long sx, sw, sy, sb; };
+
 // grid (ceil(N/64), ceil(M/64), S).  S == 1: full epilogue here.  S > 1: raw partial sums of K-slice z go to
 // part[z][M][N] and gemm_reduce_kernel finishes.
 template <bool W_IS_KN>
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        float* __restrict__ Y, int ldy, int act, int vecX, int vecW,
                                                        const int32_t* __restrict__ gather_idx,
                                                        const int32_t* __restrict__ m_dev, int kslice,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, int ldx, GemmBatch bt) {
     __shared__ __attribute__((aligned(16))) float As[BM * SA];
     __shared__ __attribute__((aligned(16))) float Bs[W_IS_KN ? BK * SBN : BN * SA];
 
@@ -51,7 +54,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         M = min(M, *m_dev);
         if (m0 >= M) return;
     }
-    const int kbeg = blockIdx.z * kslice;
+    if (bt.n) {                       // strided batch: blockIdx.z selects the problem, no K split
+        X += (size_t)blockIdx.z * bt.sx;
+        W += (size_t)blockIdx.z * bt.sw;
+        Y += (size_t)blockIdx.z * bt.sy;
+        if (bias) bias += (size_t)blockIdx.z * bt.sb;
+    }
+    const int kbeg = bt.n ? 0 : blockIdx.z * kslice;
     const int kend = min(K, kbeg + kslice);
 
     f32x4 acc[2][2];
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int u = 0; u < 2; ++u) {
             const int gm = m0 + s_row + 32 * u, gk = k0 + s_k4;
             ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gm < M) ra[u] = load4(X + a_row[u] * K + gk, kend - gk, vecX);
+            if (gm < M) ra[u] = load4(X + a_row[u] * ldx + gk, kend - gk, vecX);
             if (!W_IS_KN) {
                 const int gn = n0 + s_row + 32 * u;
                 rb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 
     // epilogue: C layout col = lane&15, row = (lane>>4)*4 + r
-    const bool partial = gridDim.z > 1;
+    const bool partial = !bt.n && gridDim.z > 1;
     float* pz = partial ? part + (size_t)blockIdx.z * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -200,7 +209,7 @@ int launch_gemm(const float* X, int M, int K, const float* W, int N, const float
     }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, S);
     hipLaunchKernelGGL(gemm_f32_kernel<W_IS_KN>, grid, dim3(256), 0, stream, X, M, K, W, N, bias, residual, Y, ldy, act,
-                       vecX, vecW, gather_idx, m_dev, kslice, ws);
+                       vecX, vecW, gather_idx, m_dev, kslice, ws, K, GemmBatch{0, 0, 0, 0, 0});
     if (S > 1) {
         size_t blocks = ((size_t)M * N + 255) / 256;
         if (blocks > 1024) blocks = 1024;
@@ -216,6 +225,25 @@ int launch_gemm(const float* X, int M, int K, const float* W, int N, const float
 int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                      const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream) {
     return launch_gemm<false>(X, M, K, W, N, bias, nullptr, Y, ldy, MGNNS_ACT_NONE, gather_idx, m_dev, nullptr, 0, stream);
+}
+
+// internal strided-batch launcher (sq_mha_folded.hip): for z < nbatch
+//   Y_z[m, 0:N] (row stride ldy) = X_z[m, 0:K] (row stride ldx) . W_z (+ bias_z),  P_z = P + z * stride_P
+// W_z is [N,K] (w_is_kn == 0, the nn.Linear layout) or [K,N] (w_is_kn == 1).
+int mg_launch_gemm_batched(const float* X, int ldx, long sx, int M, int K, const float* W, long sw, int w_is_kn,
+                           const float* bias, long sb, int N, float* Y, int ldy, long sy, int nbatch,
+                           hipStream_t stream) {
+    const int vecX = (K % 4 == 0) && (ldx % 4 == 0) && (sx % 4 == 0) && mg_aligned16(X);
+    const int vecW = (sw % 4 == 0) && mg_aligned16(W) && (w_is_kn ? (N % 4 == 0) : (K % 4 == 0));
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch);
+    const GemmBatch bt{nbatch, sx, sw, sy, sb};
+    if (w_is_kn)
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, X, M, K, W, N, bias, nullptr, Y, ldy,
+                           MGNNS_ACT_NONE, vecX, vecW, nullptr, nullptr, K, nullptr, ldx, bt);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, X, M, K, W, N, bias, nullptr, Y, ldy,
+                           MGNNS_ACT_NONE, vecX, vecW, nullptr, nullptr, K, nullptr, ldx, bt);
+    return 0;
 }
 
 extern "C" size_t mgnns_gemm_workspace_bytes(void) { return (size_t)16 << 20; }   // 16 MiB of K-split partials

@@ -251,12 +251,7 @@ extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int 
     MG_REQUIRE(mg_aligned16(feat) && mg_aligned16(Wp) && mg_aligned16(bank_bf16),
                "mgnns_imgbank_pool_bf16_fwd: feat/Wp/bank must be 16-byte aligned");
     if (B == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imgbank_pool_bf16_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
-        attr_set = true;
-    }
+    MG_DYN_LDS(imgbank_pool_bf16_kernel, SMEM_BYTES);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ((B + 7) / 8) * 16;      // pairs laid out XCD-major, padded to a multiple of 8 samples
     hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(nblk), dim3(NTHR), SMEM_BYTES, s, feat, B, K, P,

@@ -247,12 +247,7 @@ extern "C" int mgnns_mha_tail_fwd(const float* o, int HK, const float* q, int B,
     const int so = HK + 2 + ((32 - (HK % 32)) % 32);
     const size_t lds = ((size_t)ROWS * so + 2 * (size_t)ROWS * SD) * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_fwd: needs %zu B of LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    MG_DYN_LDS(mha_tail_kernel, 160 * 1024);
     hipLaunchKernelGGL(mha_tail_kernel, dim3((B + ROWS - 1) / ROWS), dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, fc_wp,
                        fc_b, ln1_gamma, ln1_beta, w1_wp, b1, w2_wp, b2, ln2_gamma, ln2_beta, eps, out, wq_next_wp, bq_next,
                        HK_next, qh_next);
@@ -523,12 +518,8 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     const int so = (HK >> 3) + 2;
     const size_t lds = (size_t)(2 * ROWS * so + 2 * ROWS * SCD) * 16 + 2 * (size_t)ROWS * SD * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_bf16_fwd: needs %zu B of LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_tail_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_tail_bf16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    MG_DYN_LDS(mha_tail_bf16_kernel<1>, 160 * 1024);
+    MG_DYN_LDS(mha_tail_bf16_kernel<3>, 160 * 1024);
     dim3 grid((B + ROWS - 1) / ROWS);
     if (terms == 3)
         hipLaunchKernelGGL(mha_tail_bf16_kernel<3>, grid, dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w, eps, out, HK_next, qh_next);

@@ -397,12 +397,7 @@ extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16
     MG_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= LMAX, "mgnns_sq_mha_core_bf16_fwd: L=%d unsupported (1..%d)", L, LMAX);
     MG_REQUIRE(mg_aligned16(bank_bf16) && mg_aligned16(Wp), "mgnns_sq_mha_core_bf16_fwd: bank/Wp must be 16-byte aligned");
     if (B == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sq_mha_core_bf16_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
-        attr_set = true;
-    }
+    MG_DYN_LDS(sq_mha_core_bf16_kernel, SMEM_BYTES);
     // one workgroup per sample owns all head pairs when the batch fills the chip; small batches split the pairs
     const int pairs = (H + 1) / 2;
     int gy = 1;

@@ -134,12 +134,7 @@ extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* 
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_textgcn_fwd: min(T,max_length)=%d needs %zu B of LDS (> 160 KiB)", Tm, lds);
     const int vec = (D % 4 == 0) && mg_aligned16(node_hidden);
     const int threads = ((D + 63) / 64) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(textgcn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr_set = true;
-    }
+    MG_DYN_LDS(textgcn_kernel, 160 * 1024);
     hipLaunchKernelGGL(textgcn_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, tok, T, Tm, node_hidden, V, D,
                        edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec);
     MG_CHECK_LAUNCH("mgnns_textgcn_fwd");

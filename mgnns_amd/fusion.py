@@ -70,6 +70,7 @@ class MultiHeadAttention(nn.Module):
             raise ValueError("d_k must equal d_v (the reference always passes d_kv for both)")
         self.n_head, self.d_k, self.d_v, self.is_regu = n_head, d_k, d_v, is_regu
         self.precision = 'fp32'      # 'fp32' (exact-f32 MFMA) | 'bf16' (bf16 operands, fp32 accumulate)
+        self.attention = 'faithful'  # 'faithful' (K/V projected as the reference does) | 'folded' (see _folded)
         self._wp = None
         self.w_qs = nn.Linear(d_model, n_head * d_k)
         self.w_ks = nn.Linear(d_model, n_head * d_k)
@@ -97,7 +98,9 @@ class MultiHeadAttention(nn.Module):
         q2 = q.reshape(B, -1).contiguous()
         m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
         qh = ops.linear(q2, self.w_qs.weight.detach(), self.w_qs.bias.detach())
-        if self.precision == 'bf16':
+        if self.attention == 'folded':
+            o, attn = self._folded(qh, bank, m2, True)
+        elif self.precision == 'bf16':
             o, attn = ops.sq_mha_core_bf16(qh, bank.bf16, m2, self.n_head, self.d_k, self._packed_kv(),
                                            self.w_ks.bias.detach(), self.w_vs.bias.detach())
         else:
@@ -110,6 +113,13 @@ class MultiHeadAttention(nn.Module):
         y = self.layer_norm(y)
         return y.view(B, 1, -1), attn
 
+
+    def _folded(self, qh, bank, m2, want_attn):
+        """K/V projections folded into the query side (csrc/sq_mha_folded.hip): algebraically the reference's
+        attention, fp32 throughout, reads whichever copy of the memory bank exists (fp32 preferred)."""
+        x = bank.f32 if bank.f32 is not None else bank.bf16
+        return ops.sq_mha_folded(qh, x, m2, self.n_head, self.d_k, self.w_ks.weight.detach(),
+                                 self.w_vs.weight.detach(), self.w_vs.bias.detach(), want_attn=want_attn)
 
     def _packed_kv(self):
         """w_ks / w_vs in the MFMA-fragment-major bf16 layout, rebuilt when either weight changes."""
@@ -244,7 +254,9 @@ def run_stack(layers, q, bank, mask=None):
     qh = ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
     for i, layer in enumerate(layers):
         a = layer.slf_attn
-        if a.precision == 'bf16':
+        if a.attention == 'folded':
+            o, _ = a._folded(qh, bank, m2, False)
+        elif a.precision == 'bf16':
             o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
                                         a.w_vs.bias.detach(), want_attn=False)
         else:

@@ -192,6 +192,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.use_streams = bool(opt.get('use_streams', True))
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
+        self.attention = 'faithful'
+        self.set_attention(opt.get('attention', 'faithful'))
 
     def set_precision(self, precision):
         """'fp32': every contraction on the exact-f32 MFMA (the parity path, <=1e-4 on logits).
@@ -203,6 +205,18 @@ class Multi_GCN_Multihead_Att(nn.Module):
         for m in self.modules():
             if isinstance(m, MultiHeadAttention):
                 m.precision = precision
+        return self
+
+    def set_attention(self, attention):
+        """'faithful': the fusion attention projects K and V from the memory bank as the reference does (the MFMA
+        kernels the utilisation target is quoted on).  'folded': the same attention with both projections folded
+        into the query side (fp32, ~1/100 of the FLOPs; a separately reported variant)."""
+        if attention not in ('faithful', 'folded'):
+            raise ValueError("attention must be 'faithful' or 'folded'")
+        self.attention = attention
+        for m in self.modules():
+            if isinstance(m, MultiHeadAttention):
+                m.attention = attention
         return self
 
     # ---- construction helpers -------------------------------------------------------------------

@@ -404,6 +404,37 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     return o, attn
 
 
+def sq_mha_folded(qh, bank, mask, n_head, d_kv, wk, wv, bv, want_attn=True):
+    """Folded single-query attention (mgnns_sq_mha_folded_fwd): same result as sq_mha_core, K and V never formed.
+    bank: fp32 [B, L, D] or bf16 [B, L, ld] (zero padded).  b_k is not needed (it drops out of the softmax)."""
+    _chk(qh, "qh", ndim=2)
+    is_bf16 = bank.dtype == torch.bfloat16
+    _chk(bank, "memory bank", torch.bfloat16 if is_bf16 else torch.float32, 3)
+    B, L_, ld = bank.shape
+    for n, t in (("w_ks.weight", wk), ("w_vs.weight", wv)):
+        _chk(t, n, ndim=2)
+    D = wk.shape[1]
+    if qh.shape != (B, n_head * d_kv):
+        raise ValueError("qh shape %s, expected %s" % (tuple(qh.shape), (B, n_head * d_kv)))
+    if wk.shape != (n_head * d_kv, D) or wv.shape != (n_head * d_kv, D):
+        raise ValueError("w_ks %s / w_vs %s, expected %s" % (tuple(wk.shape), tuple(wv.shape), (n_head * d_kv, D)))
+    if (ld != D) if not is_bf16 else (ld < D):
+        raise ValueError("memory bank last dim %d does not match d_model %d" % (ld, D))
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
+    attn = torch.empty(n_head * B, 1, L_, device=qh.device, dtype=torch.float32) if want_attn else None
+    L = _lib.lib()
+    nbytes = L.mgnns_sq_mha_folded_workspace_bytes(B, D, n_head)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=qh.device)     # per call: stacks run on four streams
+    _launch("mgnns_sq_mha_folded_fwd", ("mgnns_sq_mha_folded_fwd", L_, is_bf16), L.mgnns_sq_mha_folded_fwd,
+            _p(qh), _p(bank), int(is_bf16), ld, _p(mask), B, L_, D, n_head, d_kv, _p(wk), _p(wv), _p(bv), _p(ws), nbytes,
+            _p(o), _p(attn), _stream())
+    return o, attn
+
+
 def pack_weight_f32(w):
     """[N, K] fp32 (nn.Linear layout) -> MFMA-fragment-major fp32 buffer for mha_tail."""
     _chk(w, "weight", ndim=2)

@@ -142,6 +142,63 @@ def test_sq_mha_core_against_goldens(Hn, tag, L, masked):
     assert H.maxabs(out.cpu(), g[name + "_out"]) < 2e-5
 
 
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_sq_mha_folded_against_goldens(Hn, tag, L, masked):
+    """Folded attention (K/V projections folded into the query) reproduces the reference's attention weights and
+    layer output (same goldens, same bounds as the faithful fp32 kernel) and agrees with the faithful kernel's o."""
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+    dm = None if mask is None else dev(mask)
+    a = name + ".slf_attn."
+    qh = ops.linear(dev(q), p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    o, attn = ops.sq_mha_folded(qh, dev(bank), dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_vs.weight"],
+                                p[a + "w_vs.bias"])
+    assert H.maxabs(attn.cpu(), g[name + "_attn"]) < 1e-5
+    o_f, _ = ops.sq_mha_core(qh, dev(bank), dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_ks.bias"],
+                             p[a + "w_vs.weight"], p[a + "w_vs.bias"])
+    assert H.relerr(o.cpu(), o_f.cpu()) < 1e-5
+    y = ops.linear(o, p[a + "fc.weight"], p[a + "fc.bias"], residual=dev(q))
+    y = ops.layernorm(y, p[a + "layer_norm.gamma"], p[a + "layer_norm.beta"])
+    f = name + ".pos_ffn."
+    h1 = ops.linear(y, p[f + "w_1.weight"].squeeze(-1).contiguous(), p[f + "w_1.bias"], act=ops.ACT_RELU)
+    z = ops.linear(h1, p[f + "w_2.weight"].squeeze(-1).contiguous(), p[f + "w_2.bias"], residual=y)
+    out = ops.layernorm(z, p[f + "layer_norm.gamma"], p[f + "layer_norm.beta"])
+    assert H.maxabs(out.cpu(), g[name + "_out"]) < 2e-5
+    # without the attn output, and from the bf16 copy of the bank (exact on the bf16-rounded bank)
+    o2, none = ops.sq_mha_folded(qh, dev(bank), dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_vs.weight"],
+                                 p[a + "w_vs.bias"], want_attn=False)
+    assert none is None and torch.equal(o2, o)
+    bank_bf = ops.cast_pad_bf16(dev(bank))
+    o3, attn3 = ops.sq_mha_folded(qh, bank_bf, dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_vs.weight"], p[a + "w_vs.bias"])
+    o4, attn4 = ops.sq_mha_folded(qh, bank_bf[..., :300].float().contiguous(), dm, Hn, 128, p[a + "w_ks.weight"],
+                                  p[a + "w_vs.weight"], p[a + "w_vs.bias"])
+    assert H.maxabs(attn3.cpu(), attn4.cpu()) < 1e-6 and H.relerr(o3.cpu(), o4.cpu()) < 1e-6
+
+
+def test_sq_mha_folded_ragged_lengths_and_fully_masked_tail():
+    """L not a multiple of 16, L < 8 tiles (idle waves), masks that blank whole 16-row tiles."""
+    rs = np.random.RandomState(77)
+    for L, Hn, B in ((1, 8, 3), (17, 4, 2), (100, 8, 5), (208, 1, 2)):
+        qh = dev(rs.standard_normal((B, Hn * 128)).astype(np.float32))
+        bank = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+        wk = dev((0.05 * rs.standard_normal((Hn * 128, 300))).astype(np.float32))
+        wv = dev((0.05 * rs.standard_normal((Hn * 128, 300))).astype(np.float32))
+        bk = dev(rs.standard_normal(Hn * 128).astype(np.float32))
+        bv = dev(rs.standard_normal(Hn * 128).astype(np.float32))
+        mask = np.ones((B, L), np.float32)
+        for b in range(B):
+            mask[b, rs.randint(1, L + 1):] = 0.0
+        mask[0, :] = 1.0
+        dm = dev(mask)
+        o, attn = ops.sq_mha_folded(qh, bank, dm, Hn, 128, wk, wv, bv)
+        o_f, attn_f = ops.sq_mha_core(qh, bank, dm, Hn, 128, wk, bk, wv, bv)
+        assert H.maxabs(attn.cpu(), attn_f.cpu()) < 1e-5, L
+        assert H.relerr(o.cpu(), o_f.cpu()) < 1e-5, L
+
+
 @pytest.mark.parametrize("ngram", [1, 4])
 def test_textgcn_against_goldens(ngram):
     g = H.load_golden("text_gcn.npz")

@@ -14,9 +14,28 @@ DEV = "cuda:0"
 
 
 def timeit(fn, n=20, warm=5):
+    """Time per call.  MGNNS_BENCH_GRAPH=1: n calls captured in one hipGraph and replayed (no host launch cost)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("MGNNS_BENCH_GRAPH") == "1":
+        st = torch.cuda.Stream()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            fn()
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(n):
+                    fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                gr.replay()
+            b.record()
+            torch.cuda.synchronize()
+        return a.elapsed_time(b) / (5 * n)
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
     a.record()
@@ -48,6 +67,13 @@ def mha(kind, B=256, L=196, H=8, masked=False):
         bb = ops.cast_pad_bf16(bank)
         wp = ops.pack_kv_weights_bf16(wk, wv, H, 128)
         ms = timeit(lambda: ops.sq_mha_core_bf16(qh, bb, mask, H, 128, wp, bk, bv))
+    elif kind in ("folded", "folded_bf16"):
+        x = ops.cast_pad_bf16(bank) if kind == "folded_bf16" else bank
+        ms = timeit(lambda: ops.sq_mha_folded(qh, x, mask, H, 128, wk, wv, bv, want_attn=False))
+        by = x.numel() * x.element_size()
+        print("sq_mha_folded (%s bank) B=%d L=%d H=%d masked=%s: %.1f us (3 launches)  %.0f GB/s (one bank read)"
+              % (kind, B, L, H, masked, ms * 1e3, by / ms / 1e6))
+        return
     else:
         ms = timeit(lambda: ops.sq_mha_core(qh, bank, mask, H, 128, wk, bk, wv, bv))
     print("sq_mha_core_%s B=%d L=%d H=%d masked=%s: %.1f us  %.1f TFLOP/s (full-L algorithmic)"
@@ -96,6 +122,11 @@ if __name__ == "__main__":
     if "mha_f32" in what:
         mha("f32")
         mha("f32", L=100, masked=True)
+    if "mha_folded" in what:
+        for k in ("folded", "folded_bf16"):
+            mha(k)
+            mha(k, L=100, masked=True)
+            mha(k, H=1)
     if "imgbank" in what:
         imgbank()
     if "tail" in what:
