@@ -164,6 +164,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
 }
 
+// Small problems (a few hundred rows, K of a few hundred): latency, not throughput, decides.  One wave per 16x16
+// output tile, no LDS and no barrier: the wave fetches its A rows and B columns straight into MFMA operand registers
+// -- with K walked in the permuted order (16j + 4g + e) every lane's fetch is 16 contiguous bytes -- so all loads of
+// a 80-deep K chunk are in flight together and the MFMAs follow back to back.  Operand tiles are re-read by
+// neighbouring waves from L2, which is irrelevant at these sizes.  Requires K % 4 == 0 and 16-byte aligned rows.
+// grid (ceil(N/64), ceil(M/16), nbatch or 1), 4 waves = 4 adjacent column tiles.
+template <bool W_IS_KN>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ X, int M, int K,
+                                                         const float* __restrict__ W, int N,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ residual, float* __restrict__ Y,
+                                                         int ldy, int act, int ldx, GemmBatch bt) {
+    if (bt.n) {
+        X += (size_t)blockIdx.z * bt.sx;
+        W += (size_t)blockIdx.z * bt.sw;
+        Y += (size_t)blockIdx.z * bt.sy;
+        if (bias) bias += (size_t)blockIdx.z * bt.sb;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= N) return;
+    const int row = m0 + n, col = n0 + n;
+    const bool rv = row < M, cv = col < N;
+    const float* xr = X + (size_t)(rv ? row : 0) * ldx;
+    const float* wr = W_IS_KN ? W + (cv ? col : 0) : W + (size_t)(cv ? col : 0) * K;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    constexpr int CH = 5;                             // k-groups of 16 per chunk
+    for (int k0 = 0; k0 < K; k0 += 16 * CH) {
+        f32x4 a[CH], w[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int kk = k0 + 16 * j + 4 * g;
+            a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            w[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kk < K) {                             // K % 4 == 0: the whole group of four is inside
+                if (rv) a[j] = *reinterpret_cast<const f32x4*>(xr + kk);
+                if (cv) {
+                    if (W_IS_KN) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[j][e] = wr[(size_t)(kk + e) * N];
+                    } else {
+                        w[j] = *reinterpret_cast<const f32x4*>(wr + kk);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], w[j][e], acc[e & 1], 0, 0, 0);
+    }
+    // C layout: col = lane & 15, rows 4g + r
+    if (!cv) return;
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + 4 * g + r;
+        if (gm >= M) continue;
+        float v = mg_act(acc[0][r] + acc[1][r] + bv, act);
+        if (residual) v += residual[(size_t)gm * N + col];
+        Y[(size_t)gm * ldy + col] = v;
+    }
+}
+
+// the small-problem kernel pays when the tiled kernel could not fill the chip anyway
+static bool use_small(int M, int N, int K, int ldx, const float* X, const float* W, bool w_is_kn, long sx, long sw) {
+    if (K % 4 || ldx % 4 || sx % 4 || !mg_aligned16(X) || K > 512) return false;
+    if (!w_is_kn && (sw % 4 || !mg_aligned16(W))) return false;
+    return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) <= 96;
+}
+
 // Y = act(sum_z part[z] + bias) + residual, slices summed in ascending z (deterministic)
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int S, int M, int N,
                                                           const float* __restrict__ bias,
@@ -199,6 +272,11 @@ template <bool W_IS_KN>
 int launch_gemm(const float* X, int M, int K, const float* W, int N, const float* bias, const float* residual, float* Y,
                 int ldy, int act, const int32_t* gather_idx, const int32_t* m_dev, float* ws, size_t ws_floats,
                 hipStream_t stream) {
+    if (!gather_idx && !m_dev && use_small(M, N, K, K, X, W, W_IS_KN, 0, 0)) {
+        hipLaunchKernelGGL(gemm_small_kernel<W_IS_KN>, dim3((N + 63) / 64, (M + 15) / 16, 1), dim3(256), 0, stream, X, M, K, W,
+                           N, bias, residual, Y, ldy, act, K, GemmBatch{0, 0, 0, 0, 0});
+        return 0;
+    }
     const int vecX = (K % 4 == 0) && mg_aligned16(X);
     const int vecW = W_IS_KN ? ((N % 4 == 0) && mg_aligned16(W)) : ((K % 4 == 0) && mg_aligned16(W));
     int S = (ws && !m_dev) ? choose_split(M, N, K, ws_floats) : 1;
@@ -237,6 +315,16 @@ int mg_launch_gemm_batched(const float* X, int ldx, long sx, int M, int K, const
     const int vecW = (sw % 4 == 0) && mg_aligned16(W) && (w_is_kn ? (N % 4 == 0) : (K % 4 == 0));
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch);
     const GemmBatch bt{nbatch, sx, sw, sy, sb};
+    if (use_small(M, N, K, ldx, X, W, w_is_kn != 0, sx, sw)) {
+        dim3 gs((N + 63) / 64, (M + 15) / 16, nbatch);
+        if (w_is_kn)
+            hipLaunchKernelGGL(gemm_small_kernel<true>, gs, dim3(256), 0, stream, X, M, K, W, N, bias, nullptr, Y, ldy,
+                               MGNNS_ACT_NONE, ldx, bt);
+        else
+            hipLaunchKernelGGL(gemm_small_kernel<false>, gs, dim3(256), 0, stream, X, M, K, W, N, bias, nullptr, Y, ldy,
+                               MGNNS_ACT_NONE, ldx, bt);
+        return 0;
+    }
     if (w_is_kn)
         hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, X, M, K, W, N, bias, nullptr, Y, ldy,
                            MGNNS_ACT_NONE, vecX, vecW, nullptr, nullptr, K, nullptr, ldx, bt);

@@ -8,14 +8,16 @@
 // the bank.  It is NOT the formulation the north-star's MFMA-utilisation metric is quoted on; the faithful
 // kernels (sq_mha.hip, sq_mha_bf16.hip) stay the default and this one is selected explicitly.
 //
-// folded_attn_kernel: one workgroup (8 waves) per sample; wave w owns the 16-row bank tiles w, w+8, ...
-//   GEMM1  S[16 rows, 16 heads] = X_tile[16, D] . U^T      (heads 8..15 are zero padding)
+// folded_attn_kernel: one workgroup (8 waves) per sample; wave w owns the 16-row bank tiles w, w+8, ... and reads
+// each of them from memory exactly once:
+//   GEMM1  S[16 rows, 16 heads] = X_tile[16, D] . U^T      (heads 8..15 are zero padding; U from LDS)
 //   online softmax over rows per head (running max m, running partial sum z per lane)
 //   GEMM2  Cacc[16 heads, D] += P^T[16 heads, 16 rows] . X_tile[16 rows, D]
-// The K index of GEMM1 and the N index of GEMM2 are permuted so that every lane fetches 16 contiguous bytes of a
-// bank row per load (the MFMA result does not depend on the order K is walked in, and N only renames columns);
-// P leaves GEMM1 in the C layout (col = head, rows 4g+r), which is exactly GEMM2's A operand for k-step r.
-// The eight per-wave partial results are merged through LDS with the usual exp(m_w - M) factors.
+// GEMM1 wants a lane to hold one bank ROW (K = features walked in the permuted order 16j + 4g + e, so every fetch is
+// 16 contiguous bytes); GEMM2 wants a lane to hold one feature COLUMN.  The tile therefore goes through a
+// wave-private LDS slab, 64 features at a time, between the two (no workgroup barrier: LDS operations of one wave
+// execute in order).  P leaves GEMM1 in the C layout (col = head, rows 4g+r), which is exactly GEMM2's A operand
+// for k-step r.  The eight per-wave partial results are merged through LDS with the usual exp(m_w - M) factors.
 #include "common.hpp"
 
 int mg_launch_gemm_batched(const float* X, int ldx, long sx, int M, int K, const float* W, long sw, int w_is_kn,
@@ -32,9 +34,9 @@ constexpr int WAVES = 8;
 constexpr int MAXL = 208;
 
 template <bool BF16>
-__device__ __forceinline__ f32x4 load_x4(const void* bank, size_t row_off, int dim, int dmax) {
-    // four consecutive features of one bank row, zero beyond dmax
-    if (dim >= dmax) return f32x4{0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x4 load_x4(const void* bank, size_t row_off, int dim, bool ok) {
+    // four consecutive features of one bank row (zero when !ok)
+    if (!ok) return f32x4{0.f, 0.f, 0.f, 0.f};
     if (BF16) {
         const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(bank) + row_off + dim);
         return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
@@ -43,14 +45,25 @@ __device__ __forceinline__ f32x4 load_x4(const void* bank, size_t row_off, int d
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(bank) + row_off + dim);
 }
 
+constexpr int USTR = FD + 4;      // U row stride in LDS (floats)
+constexpr int XSTR = 68;          // slab row stride (floats): 64 features + pad
+constexpr int SLAB = 16 * XSTR;   // floats per slab (16 rows x 64 features)
+constexpr size_t LDS_LOOP = sizeof(float) * (MAXH * USTR + WAVES * 2 * SLAB);
+constexpr size_t LDS_COMB = sizeof(float) * WAVES * MAXH * FD;
+constexpr size_t LDS_MAIN = LDS_LOOP > LDS_COMB ? LDS_LOOP : LDS_COMB;
+constexpr size_t LDS_BYTES = LDS_MAIN + sizeof(float) * (2 * WAVES * 16 + WAVES * MAXH + MAXH * MAXL);
+
 template <bool BF16>
 __global__ __launch_bounds__(WAVES * 64) void folded_attn_kernel(const float* __restrict__ U, const void* __restrict__ bank,
                                                                  int ld, const float* __restrict__ mask, int B, int L,
                                                                  int D, int H, float inv_temp, float* __restrict__ C,
                                                                  float* __restrict__ attn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // loop phase: U + the wave-private transposition slabs; merge phase: comb (aliases both, after a barrier)
+    float (*Us)[USTR] = reinterpret_cast<float (*)[USTR]>(smem);
+    float* slabs = reinterpret_cast<float*>(smem) + MAXH * USTR;
     float (*comb)[MAXH][FD] = reinterpret_cast<float (*)[MAXH][FD]>(smem);              // per-wave sum_l p_l x_l   80 KB
-    float (*mz)[WAVES][16] = reinterpret_cast<float (*)[WAVES][16]>(comb + WAVES);      // [2]: running max / sum
+    float (*mz)[WAVES][16] = reinterpret_cast<float (*)[WAVES][16]>(smem + LDS_MAIN);   // [2]: running max / sum
     float (*fac)[MAXH] = reinterpret_cast<float (*)[MAXH]>(mz + 2);                     // exp(m_w - M) / Z
     float (*s_all)[MAXL] = reinterpret_cast<float (*)[MAXL]>(fac + WAVES);              // scaled scores (attn output)
 
@@ -59,44 +72,42 @@ __global__ __launch_bounds__(WAVES * 64) void folded_attn_kernel(const float* __
     const int n = lane & 15, g = lane >> 4;
     const int dmax = BF16 ? ld : D;                // readable width of a bank row
     const size_t bank_b = (size_t)b * L * ld;
+    const int ntiles = (L + 15) / 16;
+    float* slab = slabs + wave * 2 * SLAB;
 
-    // GEMM1 B operand: ub[j][e] = U[head n][16j + 4g + e]
-    f32x4 ub[NJ];
+    auto load_tile = [&](int t, f32x4 (&xa)[NJ]) {           // lane (n, g): row 16t + n, features 16j + 4g .. + 3
+        const int row = 16 * t + n;
+        const bool rv = t < ntiles && row < L;
+        const size_t ro = bank_b + (size_t)(rv ? row : 0) * ld;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int dim = 16 * j + 4 * g;
-        ub[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n < H && dim < D) ub[j] = *reinterpret_cast<const f32x4*>(U + ((size_t)n * B + b) * D + dim);
+        for (int j = 0; j < NJ; ++j) xa[j] = load_x4<BF16>(bank, ro, 16 * j + 4 * g, rv && 16 * j + 4 * g < dmax);
+    };
+
+    f32x4 xa[NJ];
+    load_tile(wave, xa);
+    for (int i = tid; i < MAXH * (FD / 4); i += WAVES * 64) {
+        const int h = i / (FD / 4), d = (i - h * (FD / 4)) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (h < H && d < D) v = *reinterpret_cast<const f32x4*>(U + ((size_t)h * B + b) * D + d);
+        *reinterpret_cast<f32x4*>(&Us[h][d]) = v;
     }
+    __syncthreads();
 
     f32x4 acc[NQ * 4];
 #pragma unroll
     for (int t = 0; t < NQ * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, z_run = 0.f;          // head n; z_run is this lane's share (rows 4g+r) of the sum
 
-    const int ntiles = (L + 15) / 16;
     for (int t = wave; t < ntiles; t += WAVES) {
         const int row0 = 16 * t;
-        // ---- GEMM1: S = X_tile . U^T
+        // ---- GEMM1: S = X_tile . U^T ; A = X[row0 + n][16j + 4g + e], B = U[head n][16j + 4g + e]
         f32x4 s4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        {
-            const int row = row0 + n;
-            const bool rv = row < L;
-            const size_t ro = bank_b + (size_t)(rv ? row : 0) * ld;
 #pragma unroll
-            for (int j0 = 0; j0 < NJ; j0 += 5) {
-                f32x4 xa[5];
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 ub = *reinterpret_cast<const f32x4*>(&Us[n & 7][16 * j + 4 * g]);
+            if (n >= MAXH) ub = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                    xa[jj] = load_x4<BF16>(bank, ro, 16 * (j0 + jj) + 4 * g, dmax);
-                    if (!rv) xa[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        s4[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[jj][e], ub[j0 + jj][e], s4[e & 1], 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e) s4[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j][e], ub[e], s4[e & 1], 0, 0, 0);
         }
         // lane: head n, rows row0 + 4g + r
         float s[4];
@@ -132,25 +143,29 @@ __global__ __launch_bounds__(WAVES * 64) void folded_attn_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[tt][r] *= scr[r];
         }
-        // ---- GEMM2: Cacc += P^T . X_tile ; k-step r pairs p[r] (head n, row 4g+r) with X[row 4g+r][64q + 4n + e]
+        // ---- GEMM2: Cacc += P^T . X_tile, 64 features at a time through the slab:
+        //      write lane (n, g): row n, features 64q + 16jj + 4g ..; read lane (n, g): row 4g + e, features 64q + 4n ..
+        //      k-step e pairs p[e] (head n, row 4g+e) with X[row 4g+e][64q + 4n + c]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 4 * g + r;
-            const bool rv = row < L;
-            const size_t ro = bank_b + (size_t)(rv ? row : 0) * ld;
-            f32x4 xb[NQ];
+        for (int q = 0; q < NQ; ++q) {
+            float* sb = slab + (q & 1) * SLAB;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                xb[q] = load_x4<BF16>(bank, ro, 64 * q + 4 * n, dmax);
-                if (!rv) xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(&sb[n * XSTR + 16 * jj + 4 * g]) = xa[4 * q + jj];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x4 xb[4];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+            for (int e = 0; e < 4; ++e) xb[e] = *reinterpret_cast<const f32x4*>(&sb[(4 * g + e) * XSTR + 4 * n]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], xb[q][e], acc[4 * q + e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[4 * q + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[e], xb[e][c], acc[4 * q + c], 0, 0, 0);
         }
+        if (t + WAVES < ntiles) load_tile(t + WAVES, xa);
     }
+    __syncthreads();              // every wave is done with U and its slabs: comb may overwrite them
 
     // ---- merge the eight waves
     // acc[4q+e][r] at lane (n, g): head 4g + r, feature 64q + 4n + e
@@ -231,7 +246,7 @@ extern "C" int mgnns_sq_mha_folded_fwd(const float* qh, const void* bank, int ba
     mg_launch_gemm_batched(qh, H * dk, dk, B, dk, Wk, (long)dk * D, 1, nullptr, 0, D, Uw, D, (long)B * D, H, s);
     MG_CHECK_LAUNCH("mgnns_sq_mha_folded_fwd(U)");
     const float inv_temp = 1.0f / sqrtf((float)dk);
-    constexpr size_t LDS = sizeof(float) * (WAVES * MAXH * FD + 2 * WAVES * 16 + WAVES * MAXH + MAXH * MAXL);
+    constexpr size_t LDS = LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS");
     MG_DYN_LDS(folded_attn_kernel<true>, LDS);
     MG_DYN_LDS(folded_attn_kernel<false>, LDS);
