@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgnns_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MGNNS_HIPCC_FLAGS", "").split()      # e.g. -DMG_MHA_TRACE for the in-kernel phase timer
 
 
 def sources():

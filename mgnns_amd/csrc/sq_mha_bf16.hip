@@ -14,6 +14,18 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef MG_MHA_TRACE
+// profiling aid (off by default): s_memtime stamps of wave 0 / wave 4 of two workgroups at every phase boundary
+__device__ unsigned long long g_mha_trace[4][64];
+#define MG_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        if ((threadIdx.x & 255) == 0 && (blockIdx.x == 0 || blockIdx.x == 129) && blockIdx.y == 0)  \
+            g_mha_trace[(blockIdx.x ? 2 : 0) + (threadIdx.x >> 8)][(slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define MG_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int MT = 13;                  // row tiles of 16 (L <= 208)
@@ -24,6 +36,7 @@ constexpr int CH = KP / 8;              // 40 16-byte chunks per row
 constexpr int LSTR = 42;                // LDS row stride in chunks (672 B)
 constexpr int DK = 128;
 constexpr int NTHR = 512;
+constexpr int QMAX = 2048;              // floats of the projected query kept in LDS (H * 128 <= QMAX)
 
 __device__ __forceinline__ unsigned short f2bf(float x) {      // round-to-nearest-even
     unsigned int u = __float_as_uint(x);
@@ -77,6 +90,18 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
     }
 }
 
+// sum over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), result in every lane: two
+// v_permlane{32,16}_swap + add steps, pure VALU (the ds_bpermute form costs an LDS round trip per step)
+__device__ __forceinline__ float rows4_sum(float v) {
+    // inline asm: both registers of a swap are read AND written (hipcc 7.2's builtin loses the second result here);
+    // s_nop 1 covers the VALU-write -> permlane-swap read hazard the assembler does not see inside an asm block
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = [lo, lo], b = [hi, hi]
+    float c = a + b, d = c;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = [r0 r0 r2 r2], d = [r1 r1 r3 r3]
+    return c + d;
+}
+
 // Fragments that are in flight ACROSS a phase boundary: the first k-step's A fragments (the staged bank is the
 // same for every head and phase) and the first BD k-steps' B fragments of the NEXT weight stream are requested at
 // the tail of the current GEMM, so the score / softmax / weighted-sum epilogue and its barriers run with the next
@@ -92,12 +117,24 @@ struct Frags {
     uint4 bq[BD][2];
 };
 
+// The packed weights are read through a buffer resource: one VGPR (lane * 16) addresses every fragment, the
+// fragment itself is selected by a wave-uniform byte offset in an SGPR.  (64-bit per-lane pointers for the two live
+// weight streams cost the 13-tile class enough registers to spill its head-pair loop state.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;                                   // lane * 16
+};
+__device__ __forceinline__ uint4 wfrag(const WStream& w, int soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, soff, 0));
+}
+constexpr int FRAG = 1024;                      // bytes per fragment
 template <int NMT>
-__device__ __forceinline__ void frags_prime_b(Frags<NMT>& f, const uint4* __restrict__ wb) {
+__device__ __forceinline__ void frags_prime_b(Frags<NMT>& f, const WStream& w, int wb) {
 #pragma unroll
     for (int d = 0; d < Frags<NMT>::BD; ++d) {
-        f.bq[d][0] = wb[(size_t)d * 64];
-        f.bq[d][1] = wb[(size_t)(KSTEPS + d) * 64];
+        f.bq[d][0] = wfrag(w, wb + d * FRAG);
+        f.bq[d][1] = wfrag(w, wb + (KSTEPS + d) * FRAG);
     }
 }
 template <int NMT>
@@ -118,7 +155,7 @@ __device__ __forceinline__ void frags_prime_a(Frags<NMT>& f, const uint4* __rest
 // sched_barrier(0) fences keep the compiler from sinking the prefetches back to their uses.
 template <int NMT>
 __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, const uint4* __restrict__ a_base,
-                                        const uint4* __restrict__ wb, const uint4* __restrict__ wb_next) {
+                                        const WStream& w, int wb, int wb_next, int trace_base = -1) {
     constexpr int HA = Frags<NMT>::HA, HB = Frags<NMT>::HB, BD = Frags<NMT>::BD;
     if (!Frags<NMT>::CROSS_A) {
 #pragma unroll
@@ -131,6 +168,9 @@ __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, cons
     for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][0]);
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][1]);
+#ifdef MG_MHA_TRACE
+        if (trace_base >= 0) MG_STAMP(trace_base + ks);
+#endif
         const int ksn = (ks + 1) % KSTEPS;          // k-step whose A fragments are requested next (wraps to the next phase)
         // ---- half A: MFMAs on ga (k-step ks), then refill ga ---------------------------------------------------
 #pragma unroll
@@ -158,11 +198,11 @@ __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, cons
             for (int i = 0; i < HB; ++i) f.gb[i] = a_base[(HA + i) * 16 * LSTR + ksn * 4];
         }
         if (ks + BD < KSTEPS) {
-            f.bq[ks % BD][0] = wb[(size_t)(ks + BD) * 64];
-            f.bq[ks % BD][1] = wb[(size_t)(KSTEPS + ks + BD) * 64];
+            f.bq[ks % BD][0] = wfrag(w, wb + (ks + BD) * FRAG);
+            f.bq[ks % BD][1] = wfrag(w, wb + (KSTEPS + ks + BD) * FRAG);
         } else {                                     // next phase's k-steps 0..BD-1
-            f.bq[ks % BD][0] = wb_next[(size_t)(ks + BD - KSTEPS) * 64];
-            f.bq[ks % BD][1] = wb_next[(size_t)(KSTEPS + ks + BD - KSTEPS) * 64];
+            f.bq[ks % BD][0] = wfrag(w, wb_next + (ks + BD - KSTEPS) * FRAG);
+            f.bq[ks % BD][1] = wfrag(w, wb_next + (KSTEPS + ks + BD - KSTEPS) * FRAG);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -178,32 +218,45 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
     float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
     float* s_red = s_p + 2 * LMAX;                                                // [16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s_q = s_red + 16 + 4;                                            // [QMAX] this sample's projected query
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values live in SGPRs
     const int b = blockIdx.x;
     const int hp_wave = wave >> 2, wq = wave & 3;
     const uint4* a_base = Xs + (lane & 15) * LSTR + (lane >> 4);     // + i*16*LSTR + ks*4
-    const int pos = tid & 255, hh = tid >> 8;
+    const int pos = tid & 255, hh = wave >> 2;
     const bool pos_masked = mask && pos < L && mask[(size_t)b * L + pos] == 0.0f;
-    // weight stream of (head, phase) for this wave; heads beyond H (odd H) read head 0's stream and are discarded
+    // weight stream of (head, phase) for this wave (byte offset of its first fragment, wave-uniform); heads beyond H
+    // (odd H) read head 0's stream and are discarded
+    const int hp_wave_s = hp_wave, wq_s = wq;
+    WStream wsr;
+    wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wp), 0, 0x7fffffff, 0x00027000);
+    wsr.voff = lane * 16;
     auto wstream = [&](int hp, int phase) {
-        int h = hp * 2 + hp_wave;
+        int h = hp * 2 + hp_wave_s;
         if (h >= H) h = 0;
-        return reinterpret_cast<const uint4*>(Wp) + ((((size_t)h * 2 + phase) * 8 + wq * 2) * KSTEPS) * 64 + lane;
+        return (((h * 2 + phase) * 8 + wq_s * 2) * KSTEPS) * FRAG;
     };
-
+    // o row of this sample / b_v: buffer resources (uniform base, 32-bit per-lane offsets)
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o + (size_t)b * H * DK, 0, H * DK * 4, 0x00027000);
+    const __amdgpu_buffer_rsrc_t bv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bv), 0, bv ? H * DK * 4 : 0, 0x00027000);
+    const __amdgpu_buffer_rsrc_t attn_rsrc = __builtin_amdgcn_make_buffer_rsrc(attn, 0, attn ? 0x7fffffff : 0, 0x00027000);
     Frags<NMT> f;
-    frags_prime_b<NMT>(f, wstream(blockIdx.y, 0));     // weight fragments on their way while the bank DMA lands
+    frags_prime_b<NMT>(f, wsr, wstream(blockIdx.y, 0));     // weight fragments on their way while the bank DMA lands
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA pieces of the bank (not tracked by hipcc)
     __syncthreads();                                    // ... and every other wave's
     frags_prime_a<NMT>(f, a_base);
+    MG_STAMP(2);
+    int stamp = 3;
+    (void)stamp;
 
     for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
         const int h = hp * 2 + hp_wave;
         const bool head_on = h < H;
-        const float* qv = qh + (size_t)b * H * DK + (size_t)(head_on ? h : 0) * DK;
+        // the query row sits in LDS since the prologue: no global read (and no 64-bit address) in the head-pair loop
+        const float* qv = s_q + (head_on ? h : 0) * DK;
         // the tiles are computed TRANSPOSED (rows = head dims, columns = bank rows): this lane's accumulator element
         // [i][j][r] is head dim d(j,r) = wq*32 + 16j + 4*(lane>>4) + r of bank row 16i + (lane&15)
-        const int hb = head_on ? h : 0;
         const int dbase = wq * 32 + (lane >> 4) * 4;
         const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv + dbase), qd1 = *reinterpret_cast<const f32x4*>(qv + dbase + 16);
         // Biases: q.(K_l + b_k) = q.K_l + q.b_k shifts every score of the head by the same constant, which the
@@ -219,7 +272,13 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                 acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            kv_gemm<NMT>(acc, f, a_base, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0));
+#ifdef MG_MHA_TRACE
+            kv_gemm<NMT>(acc, f, a_base, wsr, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0),
+                         hp == 1 ? 32 + 12 * phase : -1);
+#else
+            kv_gemm<NMT>(acc, f, a_base, wsr, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0));
+#endif
+            MG_STAMP(stamp++);
 
             if (phase == 0) {
                 // ---- partial scores of this wave's 32 head dims: in-register over the 8 dims of the lane, then
@@ -233,8 +292,12 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                             v = fmaf(qd0[r], acc[i][0][r], v);
                             v = fmaf(qd1[r], acc[i][1][r], v);
                         }
+#ifdef MG_NO_PERMLANE
                         v += __shfl_xor(v, 16, 64);
                         v += __shfl_xor(v, 32, 64);
+#else
+                        v = rows4_sum(v);
+#endif
                         if (lane < 16) s_part[wave * LMAX + i * 16 + lane] = v;
                     }
                 }
@@ -258,8 +321,10 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                 z = (s_red[8 + hh * 4] + s_red[8 + hh * 4 + 1]) + (s_red[8 + hh * 4 + 2] + s_red[8 + hh * 4 + 3]);
                 const float p = (hs < H) ? e / z : 0.f;
                 if (pos < LMAX) s_p[hh * LMAX + pos] = p;
-                if (attn && hs < H && pos < L) attn[((size_t)hs * B + b) * L + pos] = p;
+                if (attn && hs < H && pos < L)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, p), attn_rsrc, pos * 4, (hs * B + b) * L * 4, 0);
                 __syncthreads();
+                MG_STAMP(stamp++);
             } else {
                 // ---- o[d] = sum_l p[l] * (V[l,d] + bv[d]): p is per column here, 8 dims per lane accumulate in
                 //      registers over the row tiles, one 16-lane DPP sum per dim at the end ---------------------------
@@ -281,18 +346,19 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                         t1[r] = row16_sum(t1[r]);
                     }
                     if ((lane & 15) == 0) {
+                        const int hoff = (hp * 2 + hp_wave_s) * DK * 4;          // wave-uniform byte offset of the head
                         if (bv) {
-                            const f32x4 vb0 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase);
-                            const f32x4 vb1 = *reinterpret_cast<const f32x4*>(bv + hb * DK + dbase + 16);
+                            const f32x4 vb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4, hoff, 0));
+                            const f32x4 vb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4 + 64, hoff, 0));
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { t0[r] += vb0[r]; t1[r] += vb1[r]; }
                         }
-                        float* ob = o + (size_t)b * H * DK + h * DK + dbase;
-                        *reinterpret_cast<f32x4*>(ob) = t0;
-                        *reinterpret_cast<f32x4*>(ob + 16) = t1;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t0), o_rsrc, dbase * 4, hoff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, 0);
                     }
                 }
                 __syncthreads();      // s_p / s_part are rewritten by the next head pair
+                MG_STAMP(stamp++);
             }
         }
     }
@@ -311,6 +377,7 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const uint4* xb = reinterpret_cast<const uint4*>(bank) + (size_t)b * L * CH;
+    MG_STAMP(0);
 
     // ---- live rows -------------------------------------------------------------------------------------
     if (tid == 0) *s_lvalid = mask ? 0 : L;
@@ -348,6 +415,11 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
         }
     }
     (void)Xs;
+    {                                   // this sample's query row -> LDS (visible after the staging barrier in mha_body)
+        float* s_q = reinterpret_cast<float*>(s_lvalid) + 4;
+        for (int i = tid * 4; i < H * DK; i += NTHR * 4)
+            *reinterpret_cast<f32x4*>(s_q + i) = *reinterpret_cast<const f32x4*>(qh + (size_t)b * H * DK + i);
+    }
 
     switch (n_sel) {
         case 1: mha_body<1>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
@@ -358,9 +430,16 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     }
 }
 
-constexpr size_t SMEM_BYTES = (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float) + 16;
+constexpr size_t SMEM_BYTES = (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float) + 16 + QMAX * sizeof(float);
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 
 }  // namespace
+
+#ifdef MG_MHA_TRACE
+extern "C" int mgnns_debug_mha_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mha_trace), sizeof(unsigned long long) * 4 * 64) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t mgnns_sq_mha_packed_weight_bytes(int H) { return (size_t)H * 2 * 8 * KSTEPS * 64 * 16; }
 
@@ -395,6 +474,8 @@ extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16
     MG_REQUIRE(dk == DK, "mgnns_sq_mha_core_bf16_fwd: d_kv=%d unsupported (128 only)", dk);
     MG_REQUIRE(ld == KP, "mgnns_sq_mha_core_bf16_fwd: bank row length %d must be %d (bf16, zero padded)", ld, KP);
     MG_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= LMAX, "mgnns_sq_mha_core_bf16_fwd: L=%d unsupported (1..%d)", L, LMAX);
+    MG_REQUIRE((double)H * B * L * 4 < 2147483648.0, "mgnns_sq_mha_core_bf16_fwd: attn output beyond 2 GiB (B=%d)", B);
+    MG_REQUIRE(H * DK <= QMAX, "mgnns_sq_mha_core_bf16_fwd: n_head=%d unsupported (<= %d)", H, QMAX / DK);
     MG_REQUIRE(mg_aligned16(bank_bf16) && mg_aligned16(Wp), "mgnns_sq_mha_core_bf16_fwd: bank/Wp must be 16-byte aligned");
     if (B == 0) return 0;
     MG_DYN_LDS(sq_mha_core_bf16_kernel, SMEM_BYTES);
