@@ -34,3 +34,7 @@ for w in range(4):
     print("  " + "  ".join("%s %d" % (names[i], t[i] - t[i - 1]) for i in range(1, len(names))))
     print("  pair 1 K gemm k-steps: " + " ".join(str(t[32 + k + 1] - t[32 + k]) for k in range(9)) + "  (from epilogue end to k0: %d)" % (t[32] - t[6]))
     print("  pair 1 V gemm k-steps: " + " ".join(str(t[44 + k + 1] - t[44 + k]) for k in range(9)) + "  (from epilogue end to k0: %d)" % (t[44] - t[8]))
+base = buf[2 * 64 + 0]
+for w in (2, 3):
+    t = list(buf[w * 64:(w + 1) * 64])
+    print("wg129 wave %d absolute (k cycles): " % (0 if w == 2 else 4) + " ".join("%.1f" % ((t[i] - base) / 1e3) for i in range(2, 19)))
