@@ -96,49 +96,160 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const float* __restrict__
     }
 }
 
-// Y[i, :] = act(sum_p val[p] * X[col[p], :]) over the CSR row i.  Work unit = (row, 256-feature chunk) = one
-// wave (64 lanes x 16 B); waves walk the units grid-stride so a CU always has many independent 1-KiB row-segment
-// loads in flight (the rows of a PMI-like graph have ~4 non-zeros: a block per row is launch/latency bound).
-// The non-zeros of a row are consumed four at a time (four gathers in flight per wave), in ascending order.
+// Y[i, :] = act(sum_p val[p] * X[col[p], :]) over the CSR row i.  One wave per row, walking the rows grid-stride.
+// The row index is wave-uniform, so row_ptr / col / val come through the scalar cache (s_load, no vector-memory
+// round trip and no VGPRs) and only the row segments of X are vector loads: 64 lanes x 16 B = one 1-KiB segment
+// per (non-zero, 256-feature chunk).  A wave keeps up to 4 non-zeros x 4 chunks = 16 independent segment loads in
+// flight (the rows of a PMI-like graph have ~4 non-zeros; a dependent row_ptr -> col -> X chain per 256 features,
+// as a (row, chunk) work unit has it, is latency bound).  Non-zeros are accumulated in ascending order (fmaf chain).
+template <int NCH>
+__device__ __forceinline__ void spmm_row(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                         const float* __restrict__ X, int F, int f0, int lo, int hi, int row,
+                                         float* __restrict__ Y, int act, int lane) {
+    f32x4 acc[NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        on[c] = f0 + c * 256 + lane * 4 < F;
+    }
+    const float* xb = X + f0 + lane * 4;
+    int p = lo;
+    for (; p + 4 <= hi; p += 4) {
+        const int c0 = col[p], c1 = col[p + 1], c2 = col[p + 2], c3 = col[p + 3];
+        const float w0 = val[p], w1 = val[p + 1], w2 = val[p + 2], w3 = val[p + 3];
+        f32x4 x[4][NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            x[0][c] = x[1][c] = x[2][c] = x[3][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (on[c]) {
+                x[0][c] = *reinterpret_cast<const f32x4*>(xb + (size_t)c0 * F + c * 256);
+                x[1][c] = *reinterpret_cast<const f32x4*>(xb + (size_t)c1 * F + c * 256);
+                x[2][c] = *reinterpret_cast<const f32x4*>(xb + (size_t)c2 * F + c * 256);
+                x[3][c] = *reinterpret_cast<const f32x4*>(xb + (size_t)c3 * F + c * 256);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[c][j] = fmaf(w0, x[0][c][j], acc[c][j]);
+                acc[c][j] = fmaf(w1, x[1][c][j], acc[c][j]);
+                acc[c][j] = fmaf(w2, x[2][c][j], acc[c][j]);
+                acc[c][j] = fmaf(w3, x[3][c][j], acc[c][j]);
+            }
+    }
+    for (; p < hi; ++p) {
+        const int c0 = col[p];
+        const float w = val[p];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (on[c]) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(xb + (size_t)c0 * F + c * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w, x[j], acc[c][j]);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (on[c]) {
+            const f32x4 o = {mg_act(acc[c][0], act), mg_act(acc[c][1], act), mg_act(acc[c][2], act), mg_act(acc[c][3], act)};
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row * F + f0 + c * 256 + lane * 4));
+        }
+}
+
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ row_ptr,
                                                        const int32_t* __restrict__ col,
                                                        const float* __restrict__ val,
                                                        const float* __restrict__ X, int n_rows, int F,
                                                        float* __restrict__ Y, int act) {
     const int lane = threadIdx.x & 63;
-    const int chunks = (F + 255) >> 8;
-    const long long units = (long long)n_rows * chunks;
-    const long long wstride = (long long)gridDim.x * 4;
-    for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += wstride) {
-        const int i = (int)(u / chunks);
-        const int f = ((int)(u - (long long)i * chunks) << 8) + lane * 4;
-        const int lo = row_ptr[i], hi = row_ptr[i + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (f < F) {
-            int p = lo;
-            for (; p + 4 <= hi; p += 4) {
-                const int c0 = col[p], c1 = col[p + 1], c2 = col[p + 2], c3 = col[p + 3];
-                const float w0 = val[p], w1 = val[p + 1], w2 = val[p + 2], w3 = val[p + 3];
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (size_t)c0 * F + f);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (size_t)c1 * F + f);
-                const f32x4 x2 = *reinterpret_cast<const f32x4*>(X + (size_t)c2 * F + f);
-                const f32x4 x3 = *reinterpret_cast<const f32x4*>(X + (size_t)c3 * F + f);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * 4;
+    for (int row = wave; row < n_rows; row += nwaves) {
+        const int lo = row_ptr[row], hi = row_ptr[row + 1];
+        int f0 = 0;
+        for (; f0 + 1024 <= F || (f0 < F && F - f0 > 512); f0 += 1024)
+            spmm_row<4>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
+        if (f0 < F) {
+            if (F - f0 > 256) spmm_row<2>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
+            else spmm_row<1>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
+        }
+    }
+}
+
+// Large graphs (X = [n_rows, F] well beyond one XCD's 4-MiB L2): the same product walked in feature SLABS of 64
+// floats.  A slab of X is n_rows x 256 B (2.5 MB at 10 000 nodes) and stays resident in the L2 of the XCD that works
+// on it, so every gather after the first touch of a row segment is an L2 hit and X crosses the fabric once instead of
+// once per non-zero.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx & 7 = XCD), slab s belongs to
+// XCD s & 7.  A wave handles four rows at a time (16 lanes x 16 B = one 256-B row segment each), up to four
+// gathers per lane in flight, non-zeros in ascending order exactly like spmm_csr_kernel.
+__global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val,
+                                                            const float* __restrict__ X, int n_rows, int F,
+                                                            float* __restrict__ Y, int act) {
+    const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    const int wave = bj * 4 + (threadIdx.x >> 6), nwaves = nb * 4;
+    const int nslabs = (F + 63) >> 6;
+    for (int slab = xcd; slab < nslabs; slab += 8) {
+        const int f = slab * 64 + l * 4;
+        const bool fon = f < F;
+        // two independent row chains per 16-lane group (rows r0 + g and r0 + 4 + g): the row_ptr -> col/val -> X
+        // dependent round trips of one overlap the other's
+        constexpr int RU = 2;
+        for (int r0 = wave * 4 * RU; r0 < n_rows; r0 += nwaves * 4 * RU) {
+            int p[RU], hi[RU], row[RU];
+            bool on[RU];
+            f32x4 acc[RU];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j] = fmaf(w0, x0[j], acc[j]);
-                    acc[j] = fmaf(w1, x1[j], acc[j]);
-                    acc[j] = fmaf(w2, x2[j], acc[j]);
-                    acc[j] = fmaf(w3, x3[j], acc[j]);
+            for (int u = 0; u < RU; ++u) {
+                row[u] = r0 + 4 * u + g;
+                on[u] = fon && row[u] < n_rows;
+                p[u] = hi[u] = 0;
+                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (on[u]) {
+                    p[u] = row_ptr[row[u]];
+                    hi[u] = row_ptr[row[u] + 1];
                 }
             }
-            for (; p < hi; ++p) {
-                const float w = val[p];
-                const f32x4 x = *reinterpret_cast<const f32x4*>(X + (size_t)col[p] * F + f);
+            while (__any(p[0] < hi[0] || p[1] < hi[1])) {
+                int c[RU][4];
+                float w[RU][4];
+                f32x4 x[RU][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, x[j], acc[j]);
+                for (int u = 0; u < RU; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool live = p[u] + k < hi[u];
+                        c[u][k] = live ? col[p[u] + k] : 0;
+                        w[u][k] = live ? val[p[u] + k] : 0.f;
+                    }
+#pragma unroll
+                for (int u = 0; u < RU; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p[u] + k < hi[u]) x[u][k] = *reinterpret_cast<const f32x4*>(X + (size_t)c[u][k] * F + f);
+                    }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p[u] + k < hi[u]) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[u][j] = fmaf(w[u][k], x[u][k][j], acc[u][j]);
+                        }
+                    p[u] += 4;
+                }
             }
-            f32x4 o = {mg_act(acc[0], act), mg_act(acc[1], act), mg_act(acc[2], act), mg_act(acc[3], act)};
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)i * F + f));
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                if (on[u]) {
+                    const f32x4 o = {mg_act(acc[u][0], act), mg_act(acc[u][1], act), mg_act(acc[u][2], act), mg_act(acc[u][3], act)};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row[u] * F + f));
+                }
         }
     }
 }
@@ -184,9 +295,16 @@ extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, co
     MG_REQUIRE(mg_aligned16(X) && mg_aligned16(Y), "mgnns_spmm_csr_fwd: X/Y must be 16-byte aligned");
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_spmm_csr_fwd: unknown activation %d", act);
     if (n_rows == 0) return 0;
-    const long long units = (long long)n_rows * ((F + 255) / 256);
-    long long blocks = (units + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;          // 16 workgroups (64 waves) per CU, grid-stride beyond
+    if (F % 4 == 0 && (size_t)n_rows * F * sizeof(float) > ((size_t)6 << 20) && (size_t)n_rows * 256 <= ((size_t)3 << 20)) {
+        // X does not fit an XCD's L2 but a 64-float slab of it does: slab-resident walk
+        // 192 workgroups per XCD (6 per CU): measured plateau at 10 000 nodes (128: -8 %, 64: -35 %)
+        hipLaunchKernelGGL(spmm_csr_slab_kernel, dim3(8 * 192), dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X, n_rows,
+                           F, Y, act);
+        MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
+        return 0;
+    }
+    long long blocks = ((long long)n_rows + 3) / 4;    // one wave per row
+    if (blocks > 256 * 8) blocks = 256 * 8;            // 8 workgroups (32 waves) per CU, grid-stride beyond
     hipLaunchKernelGGL(spmm_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X,
                        n_rows, F, Y, act);
     MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");

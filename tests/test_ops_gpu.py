@@ -73,6 +73,30 @@ def test_gen_adj_and_csr_against_reference_goldens():
             assert np.array_equal(dense, adj.numpy())
 
 
+@pytest.mark.parametrize("N,F", [(37, 300), (500, 1000), (3000, 1024), (2500, 1348)])
+def test_spmm_csr_ragged_rows_both_kernels(N, F):
+    """CSR SpMM vs an fp64 dense product: empty rows, rows longer than the 4-wide gather group, a feature width
+    that is not a multiple of the 64-float slab / 256-float chunk.  (3000,1024) and (2500,1348) take the
+    L2-resident slab kernel, the others the wave-per-row kernel."""
+    rs = np.random.RandomState(N + F)
+    per = rs.poisson(4.0, size=N)
+    per[::7] = 0
+    per[1] = min(N, 23)
+    rp = np.zeros(N + 1, np.int32)
+    rp[1:] = np.cumsum(per)
+    col = np.concatenate([np.sort(rs.choice(N, size=k, replace=False)) for k in per] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rs.uniform(-1.0, 1.0, size=col.size).astype(np.float32)
+    x = rs.standard_normal((N, F)).astype(np.float32)
+    y = ops.spmm_csr((dev(rp), dev(col), dev(val)), dev(x), act=ops.ACT_LRELU2).cpu().double()
+    A = torch.zeros(N, N, dtype=torch.float64)
+    for i in range(N):
+        A[i, col[rp[i]:rp[i + 1]].astype(np.int64)] = torch.from_numpy(val[rp[i]:rp[i + 1]]).double()
+    ref = torch.nn.functional.leaky_relu(A @ torch.from_numpy(x).double(), 0.2)
+    assert y.shape == (N, F)
+    assert float((y - ref).abs().max()) < 1e-5
+    assert float(y[::7].abs().max()) == 0.0          # empty rows produce exact zeros
+
+
 def test_image_gcn_chain_against_goldens():
     g = H.load_golden("image_gcn.npz")
     adjg = H.load_golden("adjacency.npz")

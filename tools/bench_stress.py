@@ -64,6 +64,13 @@ def main():
             gathered = nnz * (8.0 + F * 4.0) + N * F * 4.0
             out["spmm_d%g_F%d" % (dens, F)] = {"nnz": nnz, "ms": round(ms, 4), "algorithmic_GBps": round(by / ms / 1e6, 1),
                                                  "gathered_GBps": round(gathered / ms / 1e6, 1)}
+    # practical streaming ceiling at these sizes: a device-to-device copy of one [N,F] operand (read + write = the
+    # same 2*N*F*4 algorithmic bytes as the SpMM, no gathers)
+    for F in (1024, 2048):
+        src = torch.randn(N, F, device=DEV, generator=g)
+        dst = torch.empty_like(src)
+        ms = timeit(lambda: dst.copy_(src))
+        out["copy_F%d" % F] = {"ms": round(ms, 4), "GBps": round(2.0 * N * F * 4 / ms / 1e6, 1)}
     H1 = torch.randn(N, 1024, device=DEV, generator=g)
     ms = timeit(lambda: ops.matmul(H1, W2))
     out["hw2_ms"] = round(ms, 4); out["hw2_tflops"] = round(2.0 * N * 1024 * 2048 / ms / 1e9, 1)
