@@ -15,24 +15,25 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef MG_IMG_TRACE
+// profiling aid (off by default): per-phase cycle sums of wave 0 / wave 7 of two workgroups
+__device__ unsigned long long g_img_trace[4][8];
+#define IMG_T() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 
 constexpr int BK = 128;                 // k-slice (4 MFMA k-steps): every lane of a wave streams 8 feature rows
 constexpr int MTH = 7;                  // row tiles per half (112 rows)
 constexpr int ROWS = MTH * 16;
 constexpr int FSTR = 18;                // LDS row stride of the staged slice in 16-B chunks (16 data + 2 pad)
-constexpr int NTW = 3;                  // column tiles per wave (max)
 constexpr int NT = 19;                  // 304 / 16
 constexpr int OUT_LD = 320;             // bank row length (bf16)
 constexpr int OCH = OUT_LD / 8;         // 40 chunks per output row
+constexpr int OSTR = OUT_LD * 2 + 16;   // epilogue LDS row stride in bytes (656: rows land on distinct banks)
 constexpr int NTHR = 512;
 constexpr int P_SPLIT = 104;            // half 0: regions [0,104) (tiles 0..6), half 1: [104,196) (tiles 0..5)
 
-__device__ __forceinline__ unsigned short f2bf(float x) {
-    unsigned int u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
 // two fp32 -> packed bf16x2 (round to nearest even) in ONE instruction; there is no builtin for it on gfx950
 __device__ __forceinline__ unsigned int pack2(float a, float b) {
     unsigned int r;
@@ -106,10 +107,14 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
             if (ld_on) st[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(fsrc + ((size_t)c * BK + i) * P));
         }
     };
-    auto lstore = [&](int c, int buf) {
-        // max-pool of the 8 feature rows this wave just loaded (exact fp32), then transpose-write as bf16
-        // (each half-wave = two DPP rows holds one 8-row group: lanes 0/16 and 32/48 carry the row maxima; lane i
-        // keeps the result of feature row i of the wave's 16, so they leave as ONE 64-byte store per wave)
+    // A slice goes global -> st (fp32) -> pk (max-pool taken, packed bf16, half the registers) -> LDS.  Converting at
+    // the TOP of an iteration frees st for the next slice's loads before the MFMAs start, so those loads have the
+    // whole iteration (MFMAs + LDS write + barrier) to land and the memory pipe idles only during the conversion.
+    uint4 pk[4];
+    auto convert = [&](int c) {
+        // max-pool of the 8 feature rows this wave just loaded (exact fp32): each half-wave = two DPP rows holds one
+        // 8-row group: lanes 0/16 and 32/48 carry the row maxima; lane i keeps the result of feature row i of the
+        // wave's 16, so they leave as ONE 64-byte store per wave
         float mine = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -123,82 +128,150 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
             if (lane == 8 + i) mine = fmaxf(b0, b1);
         }
         if (lane < 16) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 16 * wave + lane] = mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pk[j].x = pack2(st[0][j], st[1][j]);
+            pk[j].y = pack2(st[2][j], st[3][j]);
+            pk[j].z = pack2(st[4][j], st[5][j]);
+            pk[j].w = pack2(st[6][j], st[7][j]);
+        }
+    };
+    auto lstore = [&](int buf) {          // transpose-write of the packed slice
         if (st_on) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint4 o;
-                o.x = pack2(st[0][j], st[1][j]);
-                o.y = pack2(st[2][j], st[3][j]);
-                o.z = pack2(st[4][j], st[5][j]);
-                o.w = pack2(st[6][j], st[7][j]);
-                const int row = 4 * pq + j;
-                Fs[(buf * ROWS + row) * FSTR + (kc ^ (pq & 7))] = o;
-            }
+            for (int j = 0; j < 4; ++j) Fs[(buf * ROWS + 4 * pq + j) * FSTR + (kc ^ (pq & 7))] = pk[j];
         }
     };
 
     const uint4* wb = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64 + lane;
     const int nchunk = K / BK;
-    // B fragments (L2) run one k-step ahead of the MFMAs that consume them
-    uint4 bq[2][NTN];
+    // B fragments (L2) of ALL four k-steps of a slice are requested at the top of its iteration, BEFORE the next map
+    // slice is requested: vector-memory results return in order, so a W fragment requested after the map loads
+    // would not be usable until those (HBM latency) have landed -- that stall, once per slice, used to be ~60 % of
+    // the MFMA phase
+    uint4 bq[BK / 32][NTN];
+    constexpr int HA = 4, HB = MTH - HA;
+    uint4 ga[HA], gb[HB];
+    auto afrag_a = [&](const uint4* fb, int kk) {
 #pragma unroll
-    for (int j = 0; j < NTN; ++j) bq[0][j] = wb[((size_t)j * KS) * 64];
+        for (int i = 0; i < HA; ++i) {
+            const int row = i * 16 + (lane & 15);
+            ga[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
+        }
+    };
+    auto afrag_b = [&](const uint4* fb, int kk) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int row = (HA + i) * 16 + (lane & 15);
+            gb[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
+        }
+    };
     gload(0);
-    lstore(0, 0);
+    convert(0);
+    lstore(0);
+    if (nchunk > 1) gload(1);
     __syncthreads();
+#ifdef MG_IMG_TRACE
+    unsigned long long tc = 0, tm = 0, tb = 0, t_start = IMG_T();
+#endif
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
+#ifdef MG_IMG_TRACE
+        const unsigned long long t0 = IMG_T();
+#endif
         const uint4* fb = Fs + (size_t)buf * ROWS * FSTR;
 #pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) bq[kk][j] = wb[((size_t)j * KS + c * (BK / 32) + kk) * 64];
+        afrag_a(fb, 0);                           // first k-step's fragments fly under the conversion below
+        afrag_b(fb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunk) {
+            convert(c + 1);                       // waits for slice c+1 (requested one iteration ago)
+            if (c + 2 < nchunk) gload(c + 2);     // ... and its registers take slice c+2 at once
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MG_IMG_TRACE
+        const unsigned long long t1 = IMG_T();
+#endif
+        // MFMAs of the slice, software pipelined in two half-groups of row tiles: while one half's MFMAs run, the
+        // other half's A fragments (ds_read_b128) for the same / next k-step are in flight, so an LDS round trip is
+        // exposed once per slice (and that one overlaps the conversion above) instead of once per k-step
+#pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            const int ks_next = c * (BK / 32) + kk + 1;
-            if (ks_next < KS) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NTN; ++j) bq[(kk + 1) & 1][j] = wb[((size_t)j * KS + ks_next) * 64];
-            }
-            uint4 a[MTH];
-#pragma unroll
-            for (int i = 0; i < MTH; ++i) {
-                const int row = i * 16 + (lane & 15);
-                a[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
-            }
-#pragma unroll
-            for (int i = 0; i < MTH; ++i) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
+            for (int i = 0; i < HA; ++i) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, ga[i]);
 #pragma unroll
                 for (int j = 0; j < NTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bq[kk & 1][j]),
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[kk][j]), av,
                                                                        acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < BK / 32) afrag_a(fb, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, gb[i]);
+#pragma unroll
+                for (int j = 0; j < NTN; ++j)
+                    acc[HA + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[kk][j]), av,
+                                                                            acc[HA + i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < BK / 32) afrag_b(fb, kk + 1);
         }
-        if (c + 1 < nchunk) lstore(c + 1, buf ^ 1);
+#ifdef MG_IMG_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t2 = IMG_T();
+#endif
+        if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
+#ifdef MG_IMG_TRACE
+        const unsigned long long t3 = IMG_T();
+        tc += t1 - t0; tm += t2 - t1; tb += t3 - t2;
+#endif
     }
+#ifdef MG_IMG_TRACE
+    if ((lane == 0) && (wave == 0 || wave == 7) && (blockIdx.x == 0 || blockIdx.x == 301)) {
+        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + (wave ? 1 : 0)];
+        g[0] = tc; g[1] = tm; g[2] = tb; g[3] = IMG_T() - t_start;
+    }
+#endif
 
-    // ---- epilogue: + bias, bf16, transpose through LDS, 16-B row stores; columns N..319 are zero ------------
-    unsigned short* os = reinterpret_cast<unsigned short*>(Os);
+    // ---- epilogue: + bias, bf16, through LDS, 16-B row stores; columns N..319 are zero -----------------------
+    // The tiles were computed TRANSPOSED (A operand = W fragment, B operand = map fragment): this lane's accumulator
+    // element [i][j][r] is output column (nt0+j)*16 + 4*(lane>>4) + r of region row 16i + (lane&15), i.e. four
+    // CONSECUTIVE bank columns per tile -> one 8-byte LDS write (the untransposed layout needs four 2-byte writes).
+    unsigned char* osb = reinterpret_cast<unsigned char*>(Os);
 #pragma unroll
     for (int j = 0; j < NTN; ++j) {
-        const int n = (nt0 + j) * 16 + (lane & 15);
-        const float bv = (bias && n < N) ? bias[n] : 0.f;
+        const int n = (nt0 + j) * 16 + (lane >> 4) * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (n + r < N) ? bias[n + r] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < MTH; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i * 16 + (lane >> 4) * 4 + r;
-                os[row * OUT_LD + n] = (n < N) ? f2bf(acc[i][j][r] + bv) : (unsigned short)0;
-            }
+            const int row = i * 16 + (lane & 15);
+            uint2 o;
+            o.x = pack2(n + 0 < N ? acc[i][j][0] + bv[0] : 0.f, n + 1 < N ? acc[i][j][1] + bv[1] : 0.f);
+            o.y = pack2(n + 2 < N ? acc[i][j][2] + bv[2] : 0.f, n + 3 < N ? acc[i][j][3] + bv[3] : 0.f);
+            *reinterpret_cast<uint2*>(osb + (size_t)row * OSTR + n * 2) = o;
         }
     }
     // zero the pad columns 304..319 (two chunks per row)
-    for (int q = tid; q < ROWS * 2; q += NTHR) Os[(q >> 1) * OCH + (NT * 2) + (q & 1)] = make_uint4(0u, 0u, 0u, 0u);
+    for (int q = tid; q < ROWS * 2; q += NTHR)
+        *reinterpret_cast<uint4*>(osb + (size_t)(q >> 1) * OSTR + (NT * 2 + (q & 1)) * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)b * P * OCH;
     const int nrows = p_store_end - p0;
     for (int q = tid; q < nrows * OCH; q += NTHR) {
         const int row = q / OCH, ch = q - row * OCH;
-        ob[(size_t)(p0 + row) * OCH + ch] = Os[row * OCH + ch];
+        ob[(size_t)(p0 + row) * OCH + ch] = *reinterpret_cast<const uint4*>(osb + (size_t)row * OSTR + ch * 16);
     }
 }
 
@@ -223,9 +296,15 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
     }
 }
 
-constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR + ROWS * OCH) * 16;
+constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR) * 16 + (size_t)ROWS * OSTR;
 
 }  // namespace
+
+#ifdef MG_IMG_TRACE
+extern "C" int mgnns_debug_img_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_img_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t mgnns_imgbank_packed_weight_bytes(int K) { return (size_t)NT * (K / 32) * 64 * 16; }
 
