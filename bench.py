@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timing of the folded-attention variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="with --no-graph: every kernel on one stream (no concurrent kernels) -- the setting the rocprofv3 "
+                         "per-kernel averages under profiles/ are taken in, comparable with roofline.avg_launch_ms")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +107,8 @@ def main():
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
     model.set_precision("bf16" if args.dtype == "bf16" else "fp32")
     model.set_attention(args.attn)
+    if args.single_stream:
+        model.use_streams = False
     core = "mgnns_sq_mha_core_bf16_fwd" if args.dtype == "bf16" else "mgnns_sq_mha_core_fwd"
     if args.attn == "folded":
         core = "mgnns_sq_mha_folded_fwd"
@@ -144,7 +149,7 @@ def main():
         for _ in range(min(args.steps, 10)):
             model(*call)
         torch.cuda.synchronize()
-        model.use_streams = True
+        model.use_streams = not args.single_stream
         ops.set_timer(None)
         # separately reported variant (single GPU only): same step with attention='folded', its own graph
         variant = None

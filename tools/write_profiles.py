@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Assemble the judged summaries under profiles/ from what tools/round_profiles.sh left in gpurun_out/.
+
+    python tools/write_profiles.py <run-tag> <profile-prefix>      e.g.  r01e r01_e
+Writes  profiles/<prefix>_{bf16,f32,folded}_kernel_stats.md, <prefix>_pmc_summary.md, <prefix>_bench_{bf16,f32}.json,
+<prefix>_stress_gcn.json and refreshes profiles/r01_pmc_traffic.json (read by bench.py for roofline.traffic)."""
+import json
+import os
+import shutil
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GO = os.path.join(ROOT, "gpurun_out")
+PR = os.path.join(ROOT, "profiles")
+
+
+def tables(cur):
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    return lambda p: [x for x in tabs if x.startswith(p)][0]
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    t = tables(cur)
+    disp, sym = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
+    rows = cur.execute("select s.kernel_name, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), "
+                       "max(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by 1 order by 3 desc"
+                       % (disp, sym)).fetchall()
+    total = sum(r[2] for r in rows)
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for name, n, tot, avg, mn, mx in rows:
+        short = name if len(name) < 90 else name[:87] + "..."
+        lines.append("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (short, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    # the attention core runs on two problem sizes (image banks L=196 / text bank L=100) with one grid: split at the median
+    split = {}
+    for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "folded_attn_kernel"):
+        v = sorted(r[0] for r in cur.execute("select d.end - d.start from %s d join %s s on d.kernel_id = s.id where s.kernel_name like ?"
+                                             % (disp, sym), ("%" + sub + "%",)))
+        if len(v) >= 2:
+            h = len(v) // 2
+            split[sub] = (sum(v[:h]) / h / 1e3, sum(v[h:]) / (len(v) - h) / 1e3, len(v))
+    return "\n".join(lines), split
+
+
+def pmc(db, sub):
+    cur = sqlite3.connect(db).cursor()
+    t = tables(cur)
+    q = ("select sum(p.value) from %s p join %s d on p.event_id = d.event_id join %s s on d.kernel_id = s.id "
+         "where s.kernel_name like ? group by d.event_id order by 1" % (t("rocpd_pmc_event"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")))
+    v = [r[0] for r in cur.execute(q, ("%" + sub + "%",))]
+    return v
+
+
+def main():
+    tag, pre = sys.argv[1], sys.argv[2]
+    cmds = {"bf16": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants",
+            "bf16_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream",
+            "f32": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32",
+            "folded": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded"}
+    for m, args in cmds.items():
+        db = os.path.join(GO, "prof_%s_%s" % (tag, m), "%s_%s_results.db" % (tag, m))
+        if not os.path.exists(db):
+            continue
+        table, split = kernel_stats(db)
+        log = open(os.path.join(GO, "prof_%s_%s.log" % (tag, m))).read().strip().splitlines()
+        line = [x for x in log if x.startswith('{"metric"')]
+        with open(os.path.join(PR, "%s_%s_kernel_stats.md" % (pre, m)), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats, %s, mode %s\n\n" % (pre, m))
+            f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py %s` (hipGraph replays + the eager timing "
+                    "forwards; in the graph replays kernels of the four streams overlap, so a kernel's duration there includes "
+                    "what it shares the chip with -- the `bf16_serial` file has every kernel alone on one stream, which is the "
+                    "setting bench.py's roofline leg times; summarised from the rocpd database by tools/write_profiles.py).\n\n" % args)
+            if line:
+                f.write("bench line under the profiler: `%s`\n\n" % line[-1][:400])
+            for sub, (lo, hi, n) in split.items():
+                f.write("`%s`: %d launches on two problem sizes -- text-bank launches (L=100, masked) mean %.2f us, "
+                        "image-bank launches (L=196) mean **%.2f us**.\n\n" % (sub, n, lo, hi))
+            f.write(table + "\n")
+    # ---- PMC summary -------------------------------------------------------------------------------------------
+    rows = []
+    traffic = {}
+    def half(v, upper):
+        h = len(v) // 2
+        w = v[h:] if upper else v[:h]
+        return sum(w) / max(len(w), 1)
+    dbs = {c: os.path.join(GO, "pmc_%s_%s" % (tag, c), "%s_%s_results.db" % (tag, c)) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES")}
+    if all(os.path.exists(p) for p in dbs.values()):
+        kern = [("sq_mha_core_bf16_kernel L=196 (image banks)", "sq_mha_core_bf16_kernel", True, "32.1 bank + 1.3 W + 1.0 q + 1.0 out"),
+                ("sq_mha_core_bf16_kernel L=100 (text bank, masked)", "sq_mha_core_bf16_kernel", False, "16.4 bank + 1.3 W + 1.0 q + 1.0 out"),
+                ("imgbank_pool_bf16", "imgbank_pool_bf16", None, "411.0 map + 1.2 W + 32.1 bank"),
+                ("lstm_rec", "lstm_rec", None, "Gx + h"),
+                ("mha_tail_bf16", "mha_tail_bf16", None, "1.6 W per WG (L2)"),
+                ("textgcn", "textgcn", None, "~5")]
+        for label, sub, upper, alg in kern:
+            f, w = pmc(dbs["FETCH_SIZE"], sub), pmc(dbs["WRITE_SIZE"], sub)
+            if not f:
+                continue
+            fv = half(f, upper) if upper is not None else sum(f) / len(f)
+            wv = half(w, upper) if upper is not None else sum(w) / len(w)
+            n = len(f) // 2 if upper is not None else len(f)
+            rows.append("| %s | %d | %.0f | %.1f | %.0f | %.1f | %s |" % (label, n, fv, 2 * fv * 1024 / 1e6, wv, wv * 1024 / 1e6, alg))
+            if label.startswith("sq_mha_core_bf16_kernel L=196"):
+                traffic["sq_mha_core_bf16_kernel@L196"] = {
+                    "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
+                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre}
+        busy = pmc(dbs["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_mha_core_bf16_kernel")
+        with open(os.path.join(PR, "%s_pmc_summary.md" % pre), "w") as f:
+            f.write("# rocprofv3 PMC passes, %s (bf16 mode, eager single forwards: `bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                    "--no-variants --no-graph`)\n\n" % pre)
+            f.write("One counter per pass (`rocprofv3 --pmc <ctr> --kernel-trace`, tools/pmc.sh). FETCH_SIZE/WRITE_SIZE are in KiB; per "
+                    "MI355X_MICROARCH.md the gfx950 FETCH_SIZE of a wide coalesced read is HALF the bytes (checked on `cast_pad_bf16`: "
+                    "15.2 MB raw for a 30.7 MB read), so `hbm_read = 2 x FETCH_SIZE x 1024`; WRITE_SIZE is exact. Values are per launch "
+                    "(sum over the counter instances of a dispatch, mean over launches).\n\n")
+            f.write("| kernel | launches | FETCH_SIZE raw KiB | read MB (x2) | WRITE_SIZE KiB | write MB | algorithmic MB |\n|---|---|---|---|---|---|---|\n")
+            f.write("\n".join(rows) + "\n\n")
+            if busy:
+                hi = half(busy, True)
+                f.write("MFMA pipe: `SQ_VALU_MFMA_BUSY_CYCLES` = %.4e per L=196 launch of sq_mha_core_bf16 (= 256 WG x 8 waves x 2080 MFMA x "
+                        "16 cycles: every issued 16x16x32 MFMA, padding included). Divide by 1024 SIMDs x launch time x clock for the pipe "
+                        "occupancy; algorithmic utilisation (61.86 GFLOP / time / 2.5 PF) is what bench.py reports.\n" % hi)
+        if traffic:
+            with open(os.path.join(PR, "r01_pmc_traffic.json"), "w") as f:
+                json.dump(traffic, f, indent=1)
+    for name in ("bench_bf16", "bench_f32", "stress_gcn"):
+        src = os.path.join(GO, "%s_%s.json" % (tag, name))
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(PR, "%s_%s.json" % (pre, name)))
+    print("wrote", sorted(x for x in os.listdir(PR) if x.startswith(pre)))
+
+
+if __name__ == "__main__":
+    main()
