@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
 // v_permlane{32,16}_swap + add steps, pure VALU (the ds_bpermute form costs an LDS round trip per step)
 __device__ __forceinline__ float rows4_sum(float v) {
     // inline asm: both registers of a swap are read AND written (hipcc 7.2's builtin loses the second result here);
-    // s_nop 1 covers the VALU-write -> permlane-swap read hazard the assembler does not see inside an asm block
+    // the s_nop 1 on either side cover the VALU-write -> swap-read and swap-write -> VALU-read hazards, which the
+    // compiler's hazard recogniser does not see through an asm block
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = [lo, lo], b = [hi, hi]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));      // a = [lo, lo], b = [hi, hi]
     float c = a + b, d = c;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = [r0 r0 r2 r2], d = [r1 r1 r3 r3]
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));      // c = [r0 r0 r2 r2], d = [r1 r1 r3 r3]
     return c + d;
 }
 

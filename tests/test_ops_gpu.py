@@ -349,6 +349,29 @@ def test_sq_mha_core_bf16(Hn, tag, L, masked):
     assert err < 5e-2, err
 
 
+@pytest.mark.parametrize("Hn", [1, 3, 8])
+def test_sq_mha_core_bf16_random_batches_vs_fp32_core(Hn):
+    """bf16 core vs the exact-fp32 core on random banks: odd head counts (a half-workgroup without a head), a batch
+    that fills the chip (one workgroup owns all heads) and one that does not (head pairs split over workgroups)."""
+    name = "h%d_img" % (Hn if Hn in (1, 4, 8) else 8)
+    pc = H.params_for(H.mha_shapes(8 if Hn == 3 else Hn), prefix=name + ".")
+    p = dparams(pc)
+    a = name + ".slf_attn."
+    wq, wk, wv = (p[a + k][:Hn * 128].contiguous() for k in ("w_qs.weight", "w_ks.weight", "w_vs.weight"))
+    bq, bk, bv = (p[a + k][:Hn * 128].contiguous() for k in ("w_qs.bias", "w_ks.bias", "w_vs.bias"))
+    wp = ops.pack_kv_weights_bf16(wk, wv, Hn, 128)
+    for B, L in ((5, 196), (256, 196), (256, 37)):
+        rs = np.random.RandomState(B + L + Hn)
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        bank32 = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+        qh = ops.linear(q, wq, bq)
+        o, attn = ops.sq_mha_core_bf16(qh, ops.cast_pad_bf16(bank32), None, Hn, 128, wp, bk, bv)
+        o32, attn32 = ops.sq_mha_core(qh, bank32, None, Hn, 128, wk, bk, wv, bv)
+        assert torch.isfinite(attn).all() and torch.isfinite(o).all()
+        assert H.maxabs(attn.cpu(), attn32.cpu()) < 5e-3, (B, L)
+        assert H.maxabs(o.cpu(), o32.cpu()) < 2e-2, (B, L)
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_imgbank_pool_bf16(B):
     """bf16-operand bank kernel vs fp64 math on the SAME bf16-rounded operands (tight), exact fp32 max-pool,
