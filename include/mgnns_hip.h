@@ -235,6 +235,12 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
 int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                         float eps, float* y, mgnns_stream_t stream);
 
+/* ---- measurement aid: a one-thread kernel that writes the GPU's constant-rate real-time counter (s_memrealtime,
+ * 100 MHz) into slots[idx] when the stream reaches it.  Captured into the forward's hipGraph it gives the REAL
+ * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.
+ */
+int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

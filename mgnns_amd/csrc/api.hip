@@ -33,3 +33,14 @@ int mg_ensure_dyn_lds(const void* fn, int bytes) {
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
 extern "C" int mgnns_abi_version(void) { return 4; }
+
+namespace {
+__global__ void stamp_kernel(unsigned long long* slots, int idx) { slots[idx] = __builtin_amdgcn_s_memrealtime(); }
+}  // namespace
+
+extern "C" int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream) {
+    MG_REQUIRE(slots && idx >= 0, "mgnns_debug_stamp: bad arguments");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(slots), idx);
+    MG_CHECK_LAUNCH("mgnns_debug_stamp");
+    return 0;
+}

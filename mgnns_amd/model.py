@@ -337,7 +337,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
         _, csr = gen_adj_csr(A)
         x = self.gc1(inp[0].float().contiguous(), csr, act=ops.ACT_LRELU2)
         G = self.gc2(x, csr)                                     # [C, 2048]
+        ops.stamp("  label GCN end")
         bank, pooled = self._img_bank_and_pool(feats, lin)
+        ops.stamp("  image bank end")
         x = ops.linear(pooled, G)                                # pooled @ G^T -> [B, C]
         att = attention(query=self.label_query, key=x, value=x)  # [B, NLQ, 300]
         att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(feats.shape[0], -1)
@@ -383,45 +385,74 @@ class Multi_GCN_Multihead_Att(nn.Module):
         for st in (s_aux,):
             st.wait_stream(main)
         # -- text channel: the text-level GCN (aux stream) and the BiLSTM memory bank (main stream) ---------------
+        ops.stamp("main: start")
         with torch.cuda.stream(s_aux):
+            ops.stamp("aux: text GCN start")
             text_feature = self.text_features(text)
+            ops.stamp("aux: text GCN end")
             ev_text_feature = torch.cuda.Event()
             ev_text_feature.record(s_aux)
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
         text_memory_bank = self._text_bank(text, text_lens)
+        ops.stamp("main: text bank (LSTM) end")
+        ev_text_bank = torch.cuda.Event()
+        ev_text_bank.record(main)
         text_mask = text_mask.float().contiguous()
 
         # -- object / place channels ------------------------------------------------------------------------------
         with torch.cuda.stream(s_obj):
+            ops.stamp("obj: channel start")
             self.object_feature = self._features(self.object_features, object_feature)
             bank_obj, att_obj = self._channel(self.object_feature, self.liner_img_object, self.object_A, object_inp,
                                               self.object_attention, self.object_linear_5, self.object_x_linear)
+            ops.stamp("obj: channel end")
+            ev_obj = torch.cuda.Event()
+            ev_obj.record(s_obj)                 # bank_obj / att_obj ready (the stream goes on with the iot stack)
         with torch.cuda.stream(s_place):
+            ops.stamp("place: channel start")
             self.place_feature = self._features(self.place_features, place_feature)
             bank_place, att_place = self._channel(self.place_feature, self.liner_img_place, self.place_A, place_inp,
                                                   self.place_attention, self.place_linear_5, self.place_x_linear)
+            ops.stamp("place: channel end")
+            ev_place = torch.cuda.Event()
+            ev_place.record(s_place)
 
-        # -- four fusion stacks: image->text on the channel streams, text->image on main / aux --------------------
-        s_obj.wait_stream(main)                  # needs the text bank
+        # -- four fusion stacks: image->text on the channel streams, text->image on main / aux.  Every wait is on an EVENT
+        #    recorded right behind the producer: waiting on a whole stream would also wait for the stack queued behind
+        #    the producer on that stream (tools/graph_timeline.py showed tio idling until iot had finished).
+        s_obj.wait_event(ev_text_bank)
         with torch.cuda.stream(s_obj):
+            ops.stamp("obj: iot stack start")
             iot = run_stack(self.img_object_text_multi_head_att, att_obj, text_memory_bank, text_mask)
-        s_place.wait_stream(main)
-        with torch.cuda.stream(s_place):
-            ipt = run_stack(self.img_place_text_multi_head_att, att_place, text_memory_bank, text_mask)
-        s_aux.wait_stream(s_place)               # place bank (its stream also carries ipt; ordering is harmless)
-        with torch.cuda.stream(s_aux):
-            tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
-        main.wait_stream(s_obj)
+            ops.stamp("obj: iot stack end")
+        main.wait_event(ev_obj)                  # the object bank only -- NOT the iot stack that follows it on s_obj
         main.wait_event(ev_text_feature)         # text_feature was produced on the aux stream
+        ops.stamp("main: tio stack start")
         tio = run_stack(self.text_img_object_multi_head_att, text_feature, bank_obj)
+        ops.stamp("main: tio stack end")
+        s_place.wait_event(ev_text_bank)
+        with torch.cuda.stream(s_place):
+            ops.stamp("place: ipt stack start")
+            ipt = run_stack(self.img_place_text_multi_head_att, att_place, text_memory_bank, text_mask)
+            ops.stamp("place: ipt stack end")
+        # (the hipGraph runtime still runs this fourth branch after its sibling ipt -- both hang off the place channel;
+        #  see DESIGN.md section 6)
+        s_aux.wait_event(ev_place)               # the place bank only
+        with torch.cuda.stream(s_aux):
+            ops.stamp("aux: tip stack start")
+            tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
+            ops.stamp("aux: tip stack end")
 
+        main.wait_stream(s_obj)
         main.wait_stream(s_place)
         main.wait_stream(s_aux)
         multi_feature = torch.cat([tio, tip, iot, ipt], dim=1)
         multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
                                    self.multi_linear_1.bias.detach())
-        return ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
+        logits = ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
+        ops.stamp("main: logits")
+        return logits
 
     def get_config_optim(self, lr, lrp):
         return [

@@ -515,3 +515,30 @@ def layernorm(x, gamma, beta, eps=1e-6):
     _lib.check(L.mgnns_layernorm_fwd(_p(x2), x2.shape[0], D, _p(gamma), _p(beta), float(eps), _p(y), _stream()),
                "mgnns_layernorm_fwd")
     return y.view(x.shape)
+
+
+# ---- measurement aid: in-graph timestamps --------------------------------------------------------------------------
+_timeline = None          # (slots tensor [uint64 as int64], names list) while tools/graph_timeline.py is recording
+
+
+def timeline_begin(device, n=64):
+    global _timeline
+    _timeline = (torch.zeros(n, dtype=torch.int64, device=device), [])
+    return _timeline
+
+
+def timeline_end():
+    global _timeline
+    t, _timeline = _timeline, None
+    return t
+
+
+def stamp(name):
+    """Record `name` at the current point of the current stream (no-op unless a timeline is being recorded)."""
+    if _timeline is None:
+        return
+    slots, names = _timeline
+    if len(names) >= slots.numel():
+        raise RuntimeError("timeline full")
+    names.append(name)
+    _lib.check(_lib.lib().mgnns_debug_stamp(_p(slots), len(names) - 1, _stream()), "mgnns_debug_stamp")
