@@ -235,6 +235,15 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
 int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                         float eps, float* y, mgnns_stream_t stream);
 
+/* ---- f4 (metrics half): the evaluation tail after the logits (ENGINE:828-838) -------------------------------------
+ * probs = softmax(logits, dim=1) (max-subtracted), pred = first arg-max of probs; when target (int64 [B]) and
+ * confusion (int32 [NL, NL], rows = target, columns = prediction; ACCUMULATED, zero it per epoch) are given the batch
+ * is added to the confusion matrix, from which accuracy and the micro / macro / weighted F1 of the engine follow
+ * (mgnns_amd/metrics.py).  probs, pred, target + confusion may each be NULL.  NL <= 64.
+ */
+int mgnns_softmax_argmax_fwd(const float* logits, int B, int NL, float* probs, int32_t* pred, const int64_t* target,
+                             int32_t* confusion, mgnns_stream_t stream);
+
 /* ---- measurement aid: a one-thread kernel that writes the GPU's constant-rate real-time counter (s_memrealtime,
  * 100 MHz) into slots[idx] when the stream reaches it.  Captured into the forward's hipGraph it gives the REAL
  * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.

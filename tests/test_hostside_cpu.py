@@ -59,3 +59,26 @@ def test_batch_assembler_equals_reference_padding():
     assert w2i("zzzz_unknown_word") == 1                           # UNK
     # unused tail rows of the fixed-size buffers are all PAD / length 0 / mask 0
     assert int(asm.text[len(texts):].abs().sum()) == 0 and int(asm.lens[len(texts):].sum()) == 0
+
+
+def test_metric_scores_from_confusion_match_sklearn():
+    """mgnns_amd.metrics.scores_from_confusion == accuracy_score / f1_score(micro, macro, weighted) as the engine
+    computes them (ENGINE:833-838), including classes absent from the targets or from the predictions."""
+    from sklearn.metrics import accuracy_score, f1_score
+    from mgnns_amd.metrics import scores_from_confusion
+    rs = np.random.RandomState(0)
+    for NL in (3, 7):
+        for trial in range(6):
+            y = rs.randint(0, NL, size=257)
+            p = rs.randint(0, NL if trial else NL - 1, size=257)       # trial 0: the last class is never predicted
+            if trial == 3:
+                y[y == NL - 1] = 0                                       # ... and here never a target
+            if trial == 4:
+                p = y.copy()                                             # perfect
+            conf = np.zeros((NL, NL), np.int64)
+            np.add.at(conf, (y, p), 1)
+            s = scores_from_confusion(conf)
+            ref = {"acc": accuracy_score(y, p), "micro_f1": f1_score(y, p, average="micro"),
+                   "macro_f1": f1_score(y, p, average="macro"), "weighted_f1": f1_score(y, p, average="weighted")}
+            for k, v in ref.items():
+                assert abs(s[k] - v) < 1e-12, (NL, trial, k)

@@ -453,3 +453,35 @@ def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
     out1, qh1 = ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=1)
     e1 = H.maxabs(out1.cpu(), out32.cpu())
     assert 1e-4 < e1 < 5e-2
+
+
+def test_metrics_tail_softmax_argmax_confusion():
+    """The evaluation tail on the device (ENGINE:828-838): softmax == torch.softmax, pred == argmax(softmax) incl. ties
+    (first maximum), confusion matrix accumulated over batches, scores == sklearn's on the concatenated predictions."""
+    from sklearn.metrics import accuracy_score, f1_score
+    from mgnns_amd.metrics import Metrics, predict
+    rs = np.random.RandomState(3)
+    for NL in (3, 7):
+        met = Metrics(NL, DEV)
+        ys, ps = [], []
+        for B in (1, 255, 600):
+            logits = (3.0 * rs.standard_normal((B, NL))).astype(np.float32)
+            logits[0, :] = 1.25                                       # an exact tie: the first class wins
+            y = rs.randint(0, NL, size=B).astype(np.int64)
+            probs, pred = met.update(dev(logits), dev(y), want_probs=True)
+            ref = torch.softmax(torch.from_numpy(logits), dim=1)
+            assert H.maxabs(probs.cpu(), ref) < 1e-6
+            assert np.array_equal(pred.cpu().numpy(), ref.argmax(dim=1).numpy().astype(np.int32))
+            assert int(pred[0]) == 0
+            ys.append(y)
+            ps.append(pred.cpu().numpy())
+        y, p = np.concatenate(ys), np.concatenate(ps)
+        conf = np.zeros((NL, NL), np.int64)
+        np.add.at(conf, (y, p), 1)
+        assert np.array_equal(met.conf.cpu().numpy(), conf)
+        s = met.result()
+        assert abs(s["acc"] - accuracy_score(y, p)) < 1e-12
+        for avg in ("micro", "macro", "weighted"):
+            assert abs(s[avg + "_f1"] - f1_score(y, p, average=avg)) < 1e-12
+        _, pred_only = predict(dev(logits), want_probs=False)
+        assert np.array_equal(pred_only.cpu().numpy(), ps[-1])
