@@ -235,6 +235,15 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
 int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                         float eps, float* y, mgnns_stream_t stream);
 
+/* ---- dense bf16 GEMM (BASELINE configs[4] (i): dense [N,N] adjacency x support on the bf16 MFMA; any large X.W) ------
+ * C[M,N] = act(A[M,K] . Bt[N,K]^T + bias): A and Bt are bf16 with K-contiguous rows of Kp elements (Kp % 64 == 0, zero
+ * padded: build A with mgnns_cast_pad_bf16, Bt from a [K,N] fp32 matrix with mgnns_transpose_cast_bf16), C fp32 with
+ * row stride ldc.  N % 4 == 0, ldc % 4 == 0.  UTIL:421-426 (`adj @ support`), MODEL:52-58.
+ */
+int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int ld, void* y, mgnns_stream_t stream);
+int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc,
+                           int act, mgnns_stream_t stream);
+
 /* ---- f4 (metrics half): the evaluation tail after the logits (ENGINE:828-838) -------------------------------------
  * probs = softmax(logits, dim=1) (max-subtracted), pred = first arg-max of probs; when target (int64 [B]) and
  * confusion (int32 [NL, NL], rows = target, columns = prediction; ACCUMULATED, zero it per epoch) are given the batch

@@ -42,6 +42,8 @@ SIGNATURES = {
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
     "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
+    "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
+    "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "mgnns_debug_stamp": [_P, _I, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],

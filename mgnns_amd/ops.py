@@ -517,6 +517,42 @@ def layernorm(x, gamma, beta, eps=1e-6):
     return y.view(x.shape)
 
 
+# ---- dense bf16 GEMM (large graphs / large X.W) -------------------------------------------------------------------------
+def _kpad(k):
+    return (k + 63) // 64 * 64
+
+
+def transpose_cast_bf16(x):
+    """[K, N] fp32 -> bf16 [N, Kp] (K-contiguous, zero padded to a multiple of 64): the Bt operand of gemm_bf16_nt."""
+    _chk(x, "x", ndim=2)
+    K, N = x.shape
+    y = torch.empty(N, _kpad(K), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().mgnns_transpose_cast_bf16(_p(x), K, N, y.shape[1], _p(y), _stream()), "mgnns_transpose_cast_bf16")
+    return y
+
+
+def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None):
+    """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 [M, N]."""
+    _chk(a_bf16, "A", torch.bfloat16, 2)
+    _chk(bt_bf16, "Bt", torch.bfloat16, 2)
+    M, Kp = a_bf16.shape
+    N = bt_bf16.shape[0]
+    if bt_bf16.shape[1] != Kp or Kp % 64:
+        raise ValueError("A %s / Bt %s: K rows must match and be a multiple of 64" % (tuple(a_bf16.shape), tuple(bt_bf16.shape)))
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+    c = torch.empty(M, N, device=a_bf16.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), N, act, _stream()),
+               "mgnns_gemm_bf16_nt_fwd")
+    return c
+
+
+def dense_adj_matmul_bf16(adj_bf16, support, act=ACT_NONE):
+    """act(adj @ support) with the DENSE adjacency kept in bf16 ([C, Kp], from cast_pad_bf16(adj, ld=Kp)) and the fp32
+    support [C, F] transposed + cast on the fly: the dense counterpart of spmm_csr for graphs that are not sparse."""
+    return gemm_bf16_nt(adj_bf16, transpose_cast_bf16(support), None, act)
+
+
 # ---- measurement aid: in-graph timestamps --------------------------------------------------------------------------
 _timeline = None          # (slots tensor [uint64 as int64], names list) while tools/graph_timeline.py is recording
 

@@ -485,3 +485,29 @@ def test_metrics_tail_softmax_argmax_confusion():
             assert abs(s[avg + "_f1"] - f1_score(y, p, average=avg)) < 1e-12
         _, pred_only = predict(dev(logits), want_probs=False)
         assert np.array_equal(pred_only.cpu().numpy(), ps[-1])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 132, 1000), (37, 4, 64), (1030, 520, 333)])
+def test_gemm_bf16_nt_vs_fp64_on_rounded_operands(M, N, K):
+    """Dense bf16 GEMM (LDS-DMA ring, XCD-aware tile map) vs an fp64 product of the SAME bf16-rounded operands: ragged
+    M / N / K (rows beyond M and N are clamped loads, K is zero padded to 64), bias + LeakyReLU epilogue, and the
+    adjacency helper built from cast_pad_bf16 + transpose_cast_bf16."""
+    rs = np.random.RandomState(M + N + K)
+    a = rs.standard_normal((M, K)).astype(np.float32)
+    b = rs.standard_normal((K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    kp = (K + 63) // 64 * 64
+    a_bf = ops.cast_pad_bf16(dev(a), ld=kp)
+    bt_bf = ops.transpose_cast_bf16(dev(b))
+    assert a_bf.shape == (M, kp) and bt_bf.shape == (N, kp)
+    assert torch.equal(bt_bf[:, :K].float().cpu(), _bf16_round(b).t())
+    assert float(bt_bf[:, K:].float().abs().max()) == 0.0 if kp > K else True
+    ref = _bf16_round(a).double() @ _bf16_round(b).double()
+    c = ops.gemm_bf16_nt(a_bf, bt_bf).cpu().double()
+    assert float((c - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max())) * 1e-1
+    c2 = ops.gemm_bf16_nt(a_bf, bt_bf, dev(bias), act=ops.ACT_LRELU2).cpu().double()
+    ref2 = torch.nn.functional.leaky_relu(ref + torch.from_numpy(bias).double(), 0.2)
+    assert float((c2 - ref2).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    if M == K:
+        c3 = ops.dense_adj_matmul_bf16(a_bf, dev(b)).cpu().double()
+        assert torch.equal(c3, c)

@@ -2,7 +2,7 @@
 """configs[4]-style stress of the label-graph GCN step on ONE GPU: N = 10 000-node graph, X [N,300],
 W1 [300,1024], W2 [1024,2048], adjacency in CSR at PMI-like (4e-4) and dense-ish (1e-2) density, read-out
 [512,2048] x [2048,N].  Reports per-kernel time and the algorithmic HBM rate of the sparse step
-(nnz*8 + 2*N*F*4 bytes per SpMM).  The dense-bf16 [N,N] GEMM variant is not built yet.
+(nnz*8 + 2*N*F*4 bytes per SpMM), and (i) the dense-bf16 [N,N] adjacency x support GEMM.
 
     python tools/bench_stress.py [N] [batch]
 """
@@ -71,6 +71,27 @@ def main():
         dst = torch.empty_like(src)
         ms = timeit(lambda: dst.copy_(src))
         out["copy_F%d" % F] = {"ms": round(ms, 4), "GBps": round(2.0 * N * F * 4 / ms / 1e6, 1)}
+    # (i) dense adjacency kept in bf16 ([N, Kp], 200 MB at N = 10 000): adj @ support on the bf16 MFMA GEMM
+    #     (workgroup tile 256 x 128, BK = 64, three 48-KB LDS stages); the support is transposed + cast per call
+    adj = torch.rand(N, N, device=DEV, generator=g) * (2.0 / N)
+    adj_bf = ops.cast_pad_bf16(adj, ld=(N + 63) // 64 * 64)
+    del adj
+    for F in (1024, 2048):
+        S = torch.randn(N, F, device=DEV, generator=g)
+        ms_t = timeit(lambda: ops.transpose_cast_bf16(S))
+        St = ops.transpose_cast_bf16(S)
+        ms = timeit(lambda: ops.gemm_bf16_nt(adj_bf, St, None, ops.ACT_LRELU2))
+        out["dense_adj_bf16_F%d" % F] = {"gemm_ms": round(ms, 4), "tflops": round(2.0 * N * N * F / ms / 1e9, 1),
+                                         "transpose_cast_ms": round(ms_t, 4),
+                                         "A_stream_GBps": round(adj_bf.numel() * 2 / ms / 1e6, 1)}
+        del S, St
+    # the dense X.W products of the layer on the same kernel (weights / activations cast per call are not timed)
+    for nm, (mm, kk, nn) in (("xw1_bf16", (N, 300, 1024)), ("hw2_bf16", (N, 1024, 2048))):
+        a = ops.cast_pad_bf16(torch.randn(mm, kk, device=DEV, generator=g), ld=(kk + 63) // 64 * 64)
+        bt = ops.transpose_cast_bf16(torch.randn(kk, nn, device=DEV, generator=g))
+        ms = timeit(lambda: ops.gemm_bf16_nt(a, bt))
+        out[nm] = {"ms": round(ms, 4), "tflops": round(2.0 * mm * kk * nn / ms / 1e9, 1)}
+    del adj_bf
     H1 = torch.randn(N, 1024, device=DEV, generator=g)
     ms = timeit(lambda: ops.matmul(H1, W2))
     out["hw2_ms"] = round(ms, 4); out["hw2_tflops"] = round(2.0 * N * 1024 * 2048 / ms / 1e9, 1)
