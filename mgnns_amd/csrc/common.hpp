@@ -41,6 +41,12 @@ __device__ __forceinline__ float mg_act(float v, int act) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler
+// lowers to s_waitcnt vmcnt(0) lgkmcnt(0): every global load in flight -- including a prefetch requested on purpose
+// for a LATER iteration -- has to land before the barrier.  Use this one where the barrier only publishes LDS writes /
+// retires LDS reads and global loads are meant to stay in flight across it.
+__device__ __forceinline__ void mg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- DPP (pure VALU, no LDS crossbar) reductions -----------------------------------------------------------
 // 16-lane row reductions: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -> all 16 lanes
 #define MG_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))

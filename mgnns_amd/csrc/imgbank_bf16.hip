@@ -228,7 +228,7 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
         const unsigned long long t2 = IMG_T();
 #endif
         if (c + 1 < nchunk) lstore(buf ^ 1);
-        __syncthreads();
+        mg_lds_barrier();        // NOT __syncthreads(): its vmcnt(0) would wait for the map slice requested above
 #ifdef MG_IMG_TRACE
         const unsigned long long t3 = IMG_T();
         tc += t1 - t0; tm += t2 - t1; tb += t3 - t2;

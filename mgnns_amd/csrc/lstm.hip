@@ -169,7 +169,8 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
             a0 = fmaf(w[i][KW - 1], hv[KW - 1], a0);
             sp[wr_idx + 64 * i] = a0 + a1;
         }
-        __syncthreads();
+        mg_lds_barrier();        // LDS-only barriers in the step loop: __syncthreads() implies s_waitcnt vmcnt(0), i.e. every
+                                 // step would wait for the Gx prefetch and for the h stores to reach memory
         // ---- 2. every gate row: ordered sum of the 12 partials, + W_ih x + b_ih (Gx) + b_hh, activation ----------
         if (gate_on) {
             float sum = sp[rd_idx];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
             if (s + 1 < len) gx = gx_base[(size_t)(dir ? len - 2 - s : s + 1) * (2 * G4)];   // next step, in flight
             s_act[tid] = is_tanh ? tanhf_(pre) : sigmoidf_(pre);
         }
-        __syncthreads();
+        mg_lds_barrier();
         // ---- 3. cell update by the 150 unit threads -------------------------------------------------------------------
         if (cell) {
             const float ig = s_act[tid], fg = s_act[HID + tid], gg = s_act[2 * HID + tid], og = s_act[3 * HID + tid];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
             out[((size_t)b * T + t) * (2 * HID) + dir * HID + tid] = hh;
             if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + tid] = f2bf_rne(hh);
         }
-        __syncthreads();
+        mg_lds_barrier();
         cur ^= 1;
     }
     // pad_packed_sequence(total_length=T): zeros behind the sample's length

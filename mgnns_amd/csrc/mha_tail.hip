@@ -119,6 +119,38 @@ __device__ __forceinline__ void ln_rows(float* __restrict__ buf, const float* __
     }
 }
 
+// the same with gamma / beta of this lane's five columns already in registers (loaded at kernel start: inside the
+// LayerNorm they are a global round trip right behind the reduction)
+__device__ __forceinline__ void ln_rows_r(float* __restrict__ buf, const float (&gamma)[5], const float (&beta)[5], float eps,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        float* row = buf + (2 * wave + rr) * SD;
+        float v[5];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < D ? row[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < D ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float inv = 1.0f / (sqrtf(wave_sum(q) / (float)(D - 1)) + eps);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) row[c] = gamma[i] * (v[i] - mean) * inv + beta[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict__ o, int HK, const float* __restrict__ q, int B,
                                                         const float* __restrict__ fc_wp, const float* __restrict__ fc_b,
                                                         const float* __restrict__ g1, const float* __restrict__ be1,
@@ -315,7 +347,7 @@ __device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* _
     }
     const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
     const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
-    constexpr int PF = TERMS == 1 ? 6 : 3;      // k-steps of weight fragments in flight (L2 latency ~1 us, a k-step of MFMAs ~50 ns)
+    constexpr int PF = TERMS == 1 ? 10 : 3;     // k-steps of weight fragments in flight (L2 latency ~1-2 us, a k-step of MFMAs ~50 ns)
     uint4 rh[PF][TPW], rl[PF][TPW];
 #pragma unroll
     for (int d = 0; d < PF; ++d)
@@ -379,19 +411,57 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     const int r0 = blockIdx.x * ROWS;
     const int KSo = (HK + 31) / 32, KSd = (D + 31) / 32;
 
-    // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
-    for (int i = tid; i < ROWS * so; i += NTHR) {
-        const int r = i / so, c = i - r * so;
-        unsigned short h[8], l[8];
+    // per-lane parameter vectors first: b_1 / b_2 of this lane's output columns, gamma / beta of its LayerNorm columns
+    const int ccol0 = lane & 15;
+    float pb1[3], pb2[3], lg1[5], lb1[5], lg2[5], lb2[5];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = c * 8 + j;
-            const float x = (r0 + r < B && col < HK) ? o[(size_t)(r0 + r) * HK + col] : 0.f;
-            h[j] = f2bf_t(x);
-            l[j] = f2bf_t(x - bf2f_t(h[j]));
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol0;
+        const bool ok = wave + 8 * t < DT && n < D;
+        pb1[t] = ok ? w.b1[n] : 0.f;
+        pb2[t] = ok ? w.b2[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c = lane + 64 * i;
+        lg1[i] = c < D ? w.g1[c] : 0.f;
+        lb1[i] = c < D ? w.be1[c] : 0.f;
+        lg2[i] = c < D ? w.g2[c] : 0.f;
+        lb2[i] = c < D ? w.be2[c] : 0.f;
+    }
+    // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
+    // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
+    // item by item: ~30 % of the kernel), converted afterwards
+    {
+        constexpr int MAXIT = (ROWS * (2048 / 8 + 2) + NTHR - 1) / NTHR;      // HK <= 2048
+        f32x4 v[MAXIT][2];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * NTHR;
+            const int r = i / so, c = i - r * so;
+            v[it][0] = v[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < ROWS * so && r0 + r < B && c * 8 < HK) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(o + (size_t)(r0 + r) * HK + c * 8);
+                v[it][0] = src[0];
+                v[it][1] = src[1];
+            }
         }
-        s_oh[i] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
-        s_ol[i] = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < ROWS * so) {
+                unsigned short h[8], l[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = v[it][j >> 2][j & 3];
+                    h[j] = f2bf_t(x);
+                    l[j] = TERMS == 3 ? f2bf_t(x - bf2f_t(h[j])) : (unsigned short)0;
+                }
+                s_oh[i] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
+                if (TERMS == 3)
+                    s_ol[i] = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
+            }
+        }
     }
     for (int i = tid; i < 2 * ROWS * SCD; i += NTHR) s_ah[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -401,21 +471,32 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     const int crow = (lane >> 4) * 4, ccol = lane & 15;
     f32x4 acc[3];
     // ---- 1. y = LN1(fc(o) + q) ----------------------------------------------------------------------------------------
-    tile_gemm_bf16<3, TERMS>(acc, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+    // residual + bias of this lane's 12 outputs requested BEFORE the GEMM (they used to be a global round trip after it)
+    f32x4 qb[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
+        qb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wave + 8 * t < DT && n < D) {
             const float bv = w.fc_b[n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gr = r0 + crow + r;
-                s_y[(crow + r) * SD + n] = acc[t][r] + bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
+                qb[t][r] = bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
             }
         }
     }
+    tile_gemm_bf16<3, TERMS>(acc, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol;
+        if (wave + 8 * t < DT && n < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_y[(crow + r) * SD + n] = acc[t][r] + qb[t][r];
+        }
+    }
     __syncthreads();
-    ln_rows(s_y, w.g1, w.be1, eps, wave, lane);
+    ln_rows_r(s_y, lg1, lb1, eps, wave, lane);
     __syncthreads();
     for (int i = tid; i < ROWS * D; i += NTHR) {
         const int r = i / D, c = i - r * D;
@@ -429,7 +510,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
-            const float bv = w.b1[n];
+            const float bv = pb1[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) split_store(ah16, al16, (crow + r) * SCD * 8 + n, fmaxf(acc[t][r] + bv, 0.f));
         }
@@ -441,13 +522,13 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
-            const float bv = w.b2[n];
+            const float bv = pb2[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_t[(crow + r) * SD + n] = acc[t][r] + bv + s_y[(crow + r) * SD + n];
         }
     }
     __syncthreads();
-    ln_rows(s_t, w.g2, w.be2, eps, wave, lane);
+    ln_rows_r(s_t, lg2, lb2, eps, wave, lane);
     __syncthreads();
     for (int i = tid; i < ROWS * D; i += NTHR) {
         const int r = i / D, c = i - r * D;
