@@ -134,7 +134,7 @@ __device__ __forceinline__ void ln_rows_r(float* __restrict__ buf, const float (
             v[i] = c < D ? row[c] : 0.f;
             s += v[i];
         }
-        const float mean = wave_sum(s) / (float)D;
+        const float mean = wave_sum_dpp(s) / (float)D;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void ln_rows_r(float* __restrict__ buf, const float (
             const float d = c < D ? v[i] - mean : 0.f;
             q += d * d;
         }
-        const float inv = 1.0f / (sqrtf(wave_sum(q) / (float)(D - 1)) + eps);
+        const float inv = 1.0f / (sqrtf(wave_sum_dpp(q) / (float)(D - 1)) + eps);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int c = lane + 64 * i;
@@ -357,6 +357,15 @@ __device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* _
             if (TERMS == 3) rl[d][t] = d < KS ? Wl[woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
         }
     for (int ks0 = 0; ks0 < KS; ks0 += PF) {
+        // the chunk's A fragments (activations in LDS) all at once: read one k-step at a time right before its MFMAs,
+        // every k-step exposed an LDS round trip (3 MFMAs per wave and k-step hide nothing)
+        uint4 ahq[PF], alq[TERMS == 3 ? PF : 1];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int ks = ks0 + d < KS ? ks0 + d : KS - 1;
+            ahq[d] = Ahi[aoff + ks * 4];
+            if (TERMS == 3) alq[d] = Alo[aoff + ks * 4];
+        }
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int ks = ks0 + d;
@@ -374,9 +383,9 @@ __device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* _
                         if (TERMS == 3) rl[d][t] = Wl[woff[t] + (size_t)(ks + PF) * 64];
                     }
                 }
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi[aoff + ks * 4]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, ahq[d]);
                 bf16x8 al = ah;
-                if (TERMS == 3) al = __builtin_bit_cast(bf16x8, Alo[aoff + ks * 4]);
+                if (TERMS == 3) al = __builtin_bit_cast(bf16x8, alq[d]);
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, ch[t]), acc[t], 0, 0, 0);
