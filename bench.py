@@ -118,8 +118,21 @@ def main():
         fwd = ShardedForward(lambda *a: model(*a))
     else:
         from mgnns_amd.graph import GraphedForward
-        gf = GraphedForward(model, call)          # inputs are resident in the graph's static buffers
-        fwd = ShardedForward(lambda *a: gf.replay())
+        sf = ShardedForward(lambda *a: gf.replay())
+        launch = "hipGraph replay"
+        # opt-in (MGNNS_GRAPH_COLLECTIVE=1): verified here with one rank only -- the multi-rank capture could not be run in
+        # this round's single-GPU boxes, so the default keeps the all-gather behind the replay
+        if dist is not None and os.environ.get("MGNNS_GRAPH_COLLECTIVE", "0") == "1":
+            try:                                  # the logits all-gather as a node of the same graph
+                gf = GraphedForward(model, call, post=sf.gather)
+                fwd = lambda *a: gf.replay()
+                launch = "hipGraph replay (RCCL all-gather captured)"
+            except Exception as e:                # capture of the collective unsupported: gather after the replay
+                print("collective capture failed (%s); gathering after the replay" % type(e).__name__, file=sys.stderr)
+                gf = None
+        if gf is None:
+            gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
+            fwd = sf
 
     def barrier():
         if dist is not None:
@@ -238,7 +251,7 @@ def main():
                                "feature maps [B,2048,14,14] fp32 resident in HBM, logits all-gathered"
                                % (cfg.name, B, cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
                    "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
-                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+                   "launch": "eager" if args.no_graph else launch},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     line["config"]["attention"] = args.attn

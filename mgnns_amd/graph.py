@@ -9,8 +9,10 @@ import torch
 
 
 class GraphedForward:
-    def __init__(self, model, example_args, warmup=3):
-        """example_args: the 7 forward arguments on the GPU (text_lens included, int64 on the device)."""
+    def __init__(self, model, example_args, warmup=3, post=None):
+        """example_args: the 7 forward arguments on the GPU (text_lens included, int64 on the device).
+        post: optional callable applied to the logits INSIDE the capture (e.g. ShardedForward.gather: the RCCL
+        all-gather becomes a node of the same graph)."""
         self.model = model
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         for a in self.static_in:
@@ -21,11 +23,15 @@ class GraphedForward:
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):                 # builds weight caches / workspaces / function attributes
                 self.static_out = model(*self.static_in)
+                if post is not None:
+                    self.static_out = post(self.static_out)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = model(*self.static_in)
+            if post is not None:
+                self.static_out = post(self.static_out)
 
     def copy_inputs(self, *args):
         for dst, src in zip(self.static_in, args):

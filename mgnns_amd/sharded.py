@@ -25,7 +25,11 @@ class ShardedForward:
         self._out = None
 
     def __call__(self, *local_args):
-        logits = self.forward_fn(*local_args)
+        return self.gather(self.forward_fn(*local_args))
+
+    def gather(self, logits):
+        """The collective alone (also usable as GraphedForward's `post` hook: RCCL collectives capture into the
+        forward's hipGraph, so a step is one graph launch including the all-gather)."""
         if self.world == 1 and not dist.is_initialized():
             return logits
         shape = (self.world * logits.shape[0],) + tuple(logits.shape[1:])
