@@ -184,40 +184,49 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
 // once per non-zero.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx & 7 = XCD), slab s belongs to
 // XCD s & 7.  A wave handles four rows at a time (16 lanes x 16 B = one 256-B row segment each), up to four
 // gathers per lane in flight, non-zeros in ascending order exactly like spmm_csr_kernel.
+// LPR lanes x 16 B = one row segment (slab width 4 * LPR floats); a pass walks NS slabs (s, s + 8, ...) of the XCD at
+// once with ONE fetch of the row's col / val for all of them; RU independent rows per lane group.
+template <int LPR, int NS, int RU>
 __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float* __restrict__ X, int n_rows, int F,
                                                             float* __restrict__ Y, int act) {
+    constexpr int SW = 4 * LPR;                 // slab width in floats
+    constexpr int GPW = 64 / LPR;               // row groups per wave
     const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3, nb = gridDim.x >> 3;
-    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const int wave = bj * 4 + (threadIdx.x >> 6), nwaves = nb * 4;
-    const int nslabs = (F + 63) >> 6;
-    for (int slab = xcd; slab < nslabs; slab += 8) {
-        const int f = slab * 64 + l * 4;
-        const bool fon = f < F;
-        // two independent row chains per 16-lane group (rows r0 + g and r0 + 4 + g): the row_ptr -> col/val -> X
-        // dependent round trips of one overlap the other's
-        constexpr int RU = 2;
-        for (int r0 = wave * 4 * RU; r0 < n_rows; r0 += nwaves * 4 * RU) {
+    const int nslabs = (F + SW - 1) / SW;
+    for (int slab0 = xcd; slab0 < nslabs; slab0 += 8 * NS) {
+        int f[NS];
+        bool fon[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            f[q] = (slab0 + 8 * q) * SW + l * 4;
+            fon[q] = slab0 + 8 * q < nslabs && f[q] < F;
+        }
+        for (int r0 = wave * GPW * RU; r0 < n_rows; r0 += nwaves * GPW * RU) {
             int p[RU], hi[RU], row[RU];
-            bool on[RU];
-            f32x4 acc[RU];
+            f32x4 acc[RU][NS];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                row[u] = r0 + 4 * u + g;
-                on[u] = fon && row[u] < n_rows;
+                row[u] = r0 + GPW * u + g;
                 p[u] = hi[u] = 0;
-                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (on[u]) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) acc[u][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (fon[0] && row[u] < n_rows) {
                     p[u] = row_ptr[row[u]];
                     hi[u] = row_ptr[row[u] + 1];
                 }
             }
-            while (__any(p[0] < hi[0] || p[1] < hi[1])) {
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) more |= p[u] < hi[u];
+            while (__any(more)) {
                 int c[RU][4];
                 float w[RU][4];
-                f32x4 x[RU][4];
+                f32x4 x[RU][4][NS];
 #pragma unroll
                 for (int u = 0; u < RU; ++u)
 #pragma unroll
@@ -229,27 +238,36 @@ __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __res
 #pragma unroll
                 for (int u = 0; u < RU; ++u)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (p[u] + k < hi[u]) x[u][k] = *reinterpret_cast<const f32x4*>(X + (size_t)c[u][k] * F + f);
-                    }
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) {
+                            x[u][k][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (p[u] + k < hi[u] && fon[q]) x[u][k][q] = *reinterpret_cast<const f32x4*>(X + (size_t)c[u][k] * F + f[q]);
+                        }
+                more = false;
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (p[u] + k < hi[u]) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[u][j] = fmaf(w[u][k], x[u][k][j], acc[u][j]);
+                            for (int q = 0; q < NS; ++q)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[u][q][j] = fmaf(w[u][k], x[u][k][q][j], acc[u][q][j]);
                         }
                     p[u] += 4;
+                    more |= p[u] < hi[u];
                 }
             }
 #pragma unroll
             for (int u = 0; u < RU; ++u)
-                if (on[u]) {
-                    const f32x4 o = {mg_act(acc[u][0], act), mg_act(acc[u][1], act), mg_act(acc[u][2], act), mg_act(acc[u][3], act)};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row[u] * F + f));
-                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    if (fon[q] && row[u] < n_rows) {
+                        const f32x4 o = {mg_act(acc[u][q][0], act), mg_act(acc[u][q][1], act), mg_act(acc[u][q][2], act),
+                                         mg_act(acc[u][q][3], act)};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row[u] * F + f[q]));
+                    }
         }
     }
 }
@@ -297,9 +315,17 @@ extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, co
     if (n_rows == 0) return 0;
     if (F % 4 == 0 && (size_t)n_rows * F * sizeof(float) > ((size_t)6 << 20) && (size_t)n_rows * 256 <= ((size_t)3 << 20)) {
         // X does not fit an XCD's L2 but a 64-float slab of it does: slab-resident walk
-        // 192 workgroups per XCD (6 per CU): measured plateau at 10 000 nodes (128: -8 %, 64: -35 %)
-        hipLaunchKernelGGL(spmm_csr_slab_kernel, dim3(8 * 192), dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X, n_rows,
-                           F, Y, act);
+        // slabs per XCD walked in ONE pass share a single fetch of the row's col / val (measured at 10 000 nodes: two slabs
+        // per pass 20.1 us vs 24.2 us one at a time at F = 1024; four per pass 46.9 us vs 48.9 us at F = 2048)
+        const int spx = ((F + 63) / 64 + 7) / 8;
+        const dim3 grid(8 * 192), blk(256);
+        hipStream_t st = (hipStream_t)stream;
+        if (spx >= 4)
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 4, 1>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+        else if (spx >= 2)
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 2, 1>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+        else
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 1, 2>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
         MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
         return 0;
     }

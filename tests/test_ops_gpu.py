@@ -73,11 +73,11 @@ def test_gen_adj_and_csr_against_reference_goldens():
             assert np.array_equal(dense, adj.numpy())
 
 
-@pytest.mark.parametrize("N,F", [(37, 300), (500, 1000), (3000, 1024), (2500, 1348)])
+@pytest.mark.parametrize("N,F", [(37, 300), (500, 1000), (3000, 1024), (2500, 1348), (1500, 2048), (4000, 512)])
 def test_spmm_csr_ragged_rows_both_kernels(N, F):
     """CSR SpMM vs an fp64 dense product: empty rows, rows longer than the 4-wide gather group, a feature width
-    that is not a multiple of the 64-float slab / 256-float chunk.  (3000,1024) and (2500,1348) take the
-    L2-resident slab kernel, the others the wave-per-row kernel."""
+    that is not a multiple of the 64-float slab / 256-float chunk.  (37,300) and (500,1000) take the wave-per-row
+    kernel, the others the L2-resident slab kernel with 2, 2, 4 and 1 slabs per pass."""
     rs = np.random.RandomState(N + F)
     per = rs.poisson(4.0, size=N)
     per[::7] = 0
