@@ -152,3 +152,41 @@ def test_real_text_pipeline_vocab_pmi_batching_forward():
     ti = {k: torch.from_numpy(v) for k, v in inp.items()}
     ref = R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=torch.from_numpy(lq))
     assert H.maxabs(logits, ref) < TOL
+
+
+def test_full_size_b256_properties():
+    """BASELINE's full size (mvsa_multiple_b256, B = 256, T = 100, 8 heads) through size-independent properties, fp32 mode:
+    (a) a 16-sample subset equals the CPU oracle run on those 16 samples alone (<= 1e-4: the oracle cannot run 256
+    samples in test time, and no operation couples samples), (b) permutation equivariance over the batch, (c) run-to-run
+    bit determinism, (d) the hipGraph replay equals the eager forward, (e) the folded-attention variant stays inside the
+    same gate at this size."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["mvsa_multiple_b256"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("full_mvsa_multiple_b256.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    B = 256
+    inp = synth.make_inputs(cfg, B=B, seed=4242, pmi=pmi)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    call = call_args(inp, DEV)
+    logits = model(*call).cpu()
+    assert logits.shape == (B, cfg.NL) and torch.isfinite(logits).all()
+    # (a) subset vs oracle
+    idx = np.arange(0, B, 16)
+    sub = {k: (v[idx] if k != "label_query" else v) for k, v in inp.items()}
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in sub.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                    label_query=torch.from_numpy(lq))
+    assert H.maxabs(logits[idx], ref) < TOL
+    # (b) permutation equivariance
+    perm = np.random.RandomState(1).permutation(B)
+    pin = {k: (v[perm] if k != "label_query" else v) for k, v in inp.items()}
+    lp = model(*call_args(pin, DEV)).cpu()
+    assert H.maxabs(lp, logits[perm]) < 2e-5
+    # (c) determinism, (d) graph replay == eager
+    assert torch.equal(model(*call).cpu(), logits)
+    gf = GraphedForward(model, call)
+    assert H.maxabs(gf.replay().cpu(), logits) < 1e-6
+    # (e) folded attention at full size
+    model.set_attention("folded")
+    assert H.maxabs(model(*call).cpu()[idx], ref) < TOL
