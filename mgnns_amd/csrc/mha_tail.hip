@@ -167,15 +167,61 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * ROWS;
 
-    // ---- stage o rows (zero beyond B), zero the pads the k-loops may touch --------------------------------------
-    for (int i = tid; i < ROWS * so; i += NTHR) {
-        const int r = i / so, c = i - r * so;
-        s_o[i] = (r0 + r < B && c < HK) ? o[(size_t)(r0 + r) * HK + c] : 0.f;
+    // per-lane parameter vectors and the residual first (see the bf16 kernel: each was a global round trip behind a GEMM)
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    float pb1[3], pb2[3], lg1[5], lb1[5], lg2[5], lb2[5];
+    f32x4 qb[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = (wave + 8 * t) * 16 + ccol;
+        const bool ok = wave + 8 * t < DT && n < D;
+        pb1[t] = ok ? b1[n] : 0.f;
+        pb2[t] = ok ? b2[n] : 0.f;
+        qb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float bv = fc_b[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = r0 + crow + r;
+                qb[t][r] = bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c = lane + 64 * i;
+        lg1[i] = c < D ? g1[c] : 0.f;
+        lb1[i] = c < D ? be1[c] : 0.f;
+        lg2[i] = c < D ? g2[c] : 0.f;
+        lb2[i] = c < D ? be2[c] : 0.f;
+    }
+    // ---- stage o rows (zero beyond B), zero the pads the k-loops may touch: 16-B loads, all in flight first -------------
+    {
+        const int hk4 = HK >> 2;                                   // HK % 4 == 0 (checked by the launcher)
+        constexpr int MAXIT = (ROWS * (2048 / 4) + NTHR - 1) / NTHR;
+        f32x4 v[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * NTHR;
+            const int r = i / hk4, c4 = i - r * hk4;
+            v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < ROWS * hk4 && r0 + r < B) v[it] = *reinterpret_cast<const f32x4*>(o + (size_t)(r0 + r) * HK + 4 * c4);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < ROWS * hk4) {
+                const int r = i / hk4, c4 = i - r * hk4;
+                float* d = s_o + r * so + 4 * c4;                  // so is even: 8-byte aligned
+                *reinterpret_cast<float2*>(d) = float2{v[it][0], v[it][1]};
+                *reinterpret_cast<float2*>(d + 2) = float2{v[it][2], v[it][3]};
+            }
+        }
+        for (int i = tid; i < ROWS * (so - HK); i += NTHR) s_o[(i / (so - HK)) * so + HK + i % (so - HK)] = 0.f;
     }
     for (int i = tid; i < 2 * ROWS * SD; i += NTHR) s_y[i] = 0.f;
     __syncthreads();
 
-    const int crow = (lane >> 4) * 4, ccol = lane & 15;
     f32x4 acc[3];
     // ---- 1. y = LN1(fc(o) + q) --------------------------------------------------------------------------------------
     tile_gemm<3>(acc, s_o, so, HK, fc_wp, DT, wave, lane, 0);
@@ -183,16 +229,12 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
-            const float bv = fc_b[n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = r0 + crow + r;
-                s_y[(crow + r) * SD + n] = acc[t][r] + bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
-            }
+            for (int r = 0; r < 4; ++r) s_y[(crow + r) * SD + n] = acc[t][r] + qb[t][r];
         }
     }
     __syncthreads();
-    ln_rows(s_y, g1, be1, eps, wave, lane);
+    ln_rows_r(s_y, lg1, lb1, eps, wave, lane);
     __syncthreads();
     // ---- 2. h = relu(w_1 y + b_1) ------------------------------------------------------------------------------------
     tile_gemm<3>(acc, s_y, SD, D, w1_wp, DT, wave, lane, 0);
@@ -200,7 +242,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
-            const float bv = b1[n];
+            const float bv = pb1[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_h[(crow + r) * SD + n] = fmaxf(acc[t][r] + bv, 0.f);
         }
@@ -213,13 +255,13 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
-            const float bv = b2[n];
+            const float bv = pb2[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_h[(crow + r) * SD + n] = acc[t][r] + bv + s_y[(crow + r) * SD + n];
         }
     }
     __syncthreads();
-    ln_rows(s_h, g2, be2, eps, wave, lane);
+    ln_rows_r(s_h, lg2, lb2, eps, wave, lane);
     __syncthreads();
     for (int i = tid; i < ROWS * D; i += NTHR) {
         const int r = i / D, c = i - r * D;
