@@ -253,6 +253,30 @@ int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, 
 int mgnns_softmax_argmax_fwd(const float* logits, int B, int NL, float* probs, int32_t* pred, const int64_t* target,
                              int32_t* confusion, mgnns_stream_t stream);
 
+/* ---- f4 (trunk half): torchvision-style ResNet trunks cut after layer4 (MODEL:274-294 `object_features` /
+ * `place_features`, MODEL:586-595, 629-630), eval mode.  Activations NHWC bf16, fp32 accumulation.
+ *  mgnns_conv_fold_bn_bf16   one-off: wt[o, k] = bf16(w[o,c,kh,kw] * gamma[o] / sqrt(var[o] + eps)) with k = (kh, kw, c)
+ *                            (k_order 0, rows of ld >= KH*KW*Cin elements, zero padded) or k = (c, kh, kw) (k_order 1: the
+ *                            stem, ld = 160); bias[o] = beta[o] + (conv_bias[o] - mean[o]) * scale.  gamma == NULL: no
+ *                            BatchNorm (scale 1, bias = conv_bias or 0); conv_bias may be NULL.
+ *  mgnns_stem_conv7_fwd      conv1 (7x7, stride 2, pad 3, 3 -> 64) + bn1 + ReLU: img [B,3,H,W] fp32 NCHW ->
+ *                            y [B, H/2, W/2, 64] bf16 NHWC (OH = (H - 1) / 2 + 1).
+ *  mgnns_maxpool3x3s2_nhwc_fwd  MaxPool2d(3, 2, 1): [B,H,W,C] -> [B,(H-1)/2+1,(W-1)/2+1,C], C % 8 == 0.
+ *  mgnns_conv_bf16_nhwc_fwd  y = relu?(conv(x; wt) + bias + residual?) as an implicit GEMM: 1x1 or 3x3, any stride,
+ *                            pad <= K/2, Cin a power of two >= 64, Cout % 4 == 0; residual [B,OH,OW,Cout] bf16 or NULL;
+ *                            y [B,OH,OW,Cout] bf16, or -- out_nchw_f32 != 0 -- [B,Cout,OH,OW] fp32, the feature-map
+ *                            layout mgnns_imgbank_pool_* read.
+ */
+int mgnns_conv_fold_bn_bf16(const float* w, const float* conv_bias, int Cout, int Cin, int KH, int KW,
+                            const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                            int k_order, int ld, void* wt, float* bias, mgnns_stream_t stream);
+int mgnns_stem_conv7_fwd(const float* img, int B, int H, int W, const void* wt, const float* bias, void* y,
+                         mgnns_stream_t stream);
+int mgnns_maxpool3x3s2_nhwc_fwd(const void* x, int B, int H, int W, int C, void* y, mgnns_stream_t stream);
+int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int Cin, const void* wt, const float* bias, int Cout,
+                             int KH, int KW, int stride, int pad, const void* residual, int relu, int out_nchw_f32,
+                             void* y, mgnns_stream_t stream);
+
 /* ---- measurement aid: a one-thread kernel that writes the GPU's constant-rate real-time counter (s_memrealtime,
  * 100 MHz) into slots[idx] when the stream reaches it.  Captured into the forward's hipGraph it gives the REAL
  * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.

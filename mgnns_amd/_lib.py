@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c = ctypes
 _P = _c.c_void_p
@@ -45,6 +45,10 @@ SIGNATURES = {
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
     "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "mgnns_conv_fold_bn_bf16": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P],
+    "mgnns_stem_conv7_fwd": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "mgnns_maxpool3x3s2_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P],
+    "mgnns_conv_bf16_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     "mgnns_debug_stamp": [_P, _I, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
 }

@@ -553,6 +553,91 @@ def dense_adj_matmul_bf16(adj_bf16, support, act=ACT_NONE):
     return gemm_bf16_nt(adj_bf16, transpose_cast_bf16(support), None, act)
 
 
+# ---- f4: ResNet trunks (NHWC bf16 activations) ------------------------------------------------------------------
+STEM_LD = 160      # stem weight rows: K = 3*7*7 = 147 zero padded to 5 MFMA k-steps
+
+
+def conv_fold_bn(weight, conv_bias=None, bn=None, stem=False):
+    """Fold an eval-mode BatchNorm (tuple gamma, beta, running_mean, running_var, eps -- or None) into a convolution
+    weight [Cout, Cin, KH, KW] fp32 -> (bf16 [Cout, ld] with k = (kh, kw, c), or (c, kh, kw) padded to 160 for the stem;
+    fp32 bias [Cout])."""
+    _chk(weight, "weight", ndim=4)
+    Cout, Cin, KH, KW = weight.shape
+    ld = STEM_LD if stem else KH * KW * Cin
+    if stem and (Cin, KH, KW) != (3, 7, 7):
+        raise ValueError("stem weight must be [Cout, 3, 7, 7], got %s" % (tuple(weight.shape),))
+    g = b = m = v = None
+    eps = 0.0
+    if bn is not None:
+        g, b, m, v, eps = bn
+        for t, n in ((g, "bn.weight"), (b, "bn.bias"), (m, "bn.running_mean"), (v, "bn.running_var")):
+            _chk(t, n, ndim=1)
+            if t.shape[0] != Cout:
+                raise ValueError("%s has %d entries for %d output channels" % (n, t.shape[0], Cout))
+    if conv_bias is not None:
+        _chk(conv_bias, "conv_bias", ndim=1)
+    wt = torch.empty(Cout, ld, device=weight.device, dtype=torch.bfloat16)
+    bias = torch.empty(Cout, device=weight.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mgnns_conv_fold_bn_bf16(_p(weight), _p(conv_bias), Cout, Cin, KH, KW, _p(g), _p(b), _p(m), _p(v),
+                                                  float(eps), 1 if stem else 0, ld, _p(wt), _p(bias), _stream()),
+               "mgnns_conv_fold_bn_bf16")
+    return wt, bias
+
+
+def stem_conv7(img, wt, bias):
+    """relu(bn1(conv1(img))): img [B,3,H,W] fp32 NCHW -> [B, OH, OW, 64] bf16 NHWC."""
+    _chk(img, "img", ndim=4)
+    _chk(wt, "wt", torch.bfloat16, 2)
+    _chk(bias, "bias", ndim=1)
+    B, C, H, W = img.shape
+    if C != 3 or tuple(wt.shape) != (64, STEM_LD) or bias.shape[0] != 64:
+        raise ValueError("stem expects img [B,3,H,W], wt [64,%d], bias [64]; got %s %s %s"
+                         % (STEM_LD, tuple(img.shape), tuple(wt.shape), tuple(bias.shape)))
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=img.device, dtype=torch.bfloat16)
+    L = _lib.lib()
+    _launch("mgnns_stem_conv7_fwd", ("mgnns_stem_conv7_fwd",), L.mgnns_stem_conv7_fwd, _p(img), B, H, W, _p(wt), _p(bias),
+            _p(y), _stream())
+    return y
+
+
+def maxpool3x3s2_nhwc(x):
+    _chk(x, "x", torch.bfloat16, 4)
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, device=x.device, dtype=torch.bfloat16)
+    L = _lib.lib()
+    _launch("mgnns_maxpool3x3s2_nhwc_fwd", ("mgnns_maxpool3x3s2_nhwc_fwd",), L.mgnns_maxpool3x3s2_nhwc_fwd, _p(x), B, H, W, C,
+            _p(y), _stream())
+    return y
+
+
+def conv_bf16_nhwc(x, wt, bias, ksize, stride=1, pad=0, residual=None, relu=True, out_nchw_f32=False):
+    """relu?(conv(x) + bias + residual?): x [B,H,W,Cin] bf16, wt [Cout, k*k*Cin] bf16 (conv_fold_bn) -> [B,OH,OW,Cout]
+    bf16, or [B,Cout,OH,OW] fp32 when out_nchw_f32."""
+    _chk(x, "x", torch.bfloat16, 4)
+    _chk(wt, "wt", torch.bfloat16, 2)
+    _chk(bias, "bias", ndim=1)
+    B, H, W, Cin = x.shape
+    Cout = wt.shape[0]
+    if wt.shape[1] != ksize * ksize * Cin or bias.shape[0] != Cout:
+        raise ValueError("wt %s / bias %s do not match a %dx%d convolution of %d channels"
+                         % (tuple(wt.shape), tuple(bias.shape), ksize, ksize, Cin))
+    OH = (H + 2 * pad - ksize) // stride + 1
+    OW = (W + 2 * pad - ksize) // stride + 1
+    if residual is not None:
+        _chk(residual, "residual", torch.bfloat16, 4)
+        if tuple(residual.shape) != (B, OH, OW, Cout):
+            raise ValueError("residual %s != output %s" % (tuple(residual.shape), (B, OH, OW, Cout)))
+    if out_nchw_f32:
+        y = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.bfloat16)
+    L = _lib.lib()
+    _launch("mgnns_conv_bf16_nhwc_fwd", ("mgnns_conv_bf16_nhwc_fwd", ksize, Cin, Cout, stride, OH), L.mgnns_conv_bf16_nhwc_fwd,
+            _p(x), B, H, W, Cin, _p(wt), _p(bias), Cout, ksize, ksize, stride, pad, _p(residual), 1 if relu else 0,
+            1 if out_nchw_f32 else 0, _p(y), _stream())
+    return y
+
+
 # ---- measurement aid: in-graph timestamps --------------------------------------------------------------------------
 _timeline = None          # (slots tensor [uint64 as int64], names list) while tools/graph_timeline.py is recording
 

@@ -55,6 +55,39 @@ def fill_state_dict(shapes, skip=(), salt=0):
     return {k: param_value(k, s, salt) for k, s in shapes.items() if k not in skip}
 
 
+def trunk_param_value(name, shape, salt=0):
+    """Seeded values for a ResNet trunk state_dict entry (torchvision key names): He-scaled convolution weights and
+    BatchNorm statistics that keep activations O(1) through 33 residual blocks (the last BatchNorm of a block and
+    of a projection get a small scale, as trained networks have)."""
+    shape = tuple(int(s) for s in shape)
+    rs = _rs(name, salt)
+    leaf = name.rsplit(".", 1)[-1]
+    owner = name.rsplit(".", 2)[-2] if name.count(".") else ""
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if len(shape) == 4:
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (np.sqrt(2.0 / fan_in) * rs.standard_normal(shape)).astype(np.float32)
+    if leaf == "running_var":
+        return rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    if leaf == "running_mean":
+        return (0.1 * rs.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight" and len(shape) == 1:
+        small = owner == "bn3"
+        return rs.uniform(0.2, 0.4, size=shape).astype(np.float32) if small else rs.uniform(0.6, 1.0, size=shape).astype(np.float32)
+    if leaf == "bias" and len(shape) == 1:
+        return (0.1 * rs.standard_normal(shape)).astype(np.float32)
+    return (0.02 * rs.standard_normal(shape)).astype(np.float32)
+
+
+def fill_trunk_(module, salt=0):
+    """Load trunk_param_value() into every entry of module.state_dict() (in place); returns the module."""
+    import torch
+    sd = module.state_dict()
+    module.load_state_dict({k: torch.from_numpy(trunk_param_value(k, v.shape, salt)) for k, v in sd.items()})
+    return module
+
+
 # ---------------------------------------------------------------------------
 # adjacency (gen_A formula) and PMI map
 # ---------------------------------------------------------------------------
