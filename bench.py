@@ -65,6 +65,36 @@ def cpu_baseline(cfg, model, inp, pmi, budget_s=20.0):
                            "(torch-CPU fp32, %d threads; median %.3f s)" % (len(times), B, cores, best)}
 
 
+def trunk_leg(dev, batch=32, size=448, iters=5):
+    """ResNet-101 (objects) + ResNet-50/365 (places) features of `batch` 448x448 images on the HIP
+    implicit-GEMM kernels (seeded weights), eager launches; MFMA utilisation on the algorithmic convolution FLOPs."""
+    try:
+        from mgnns_amd import trunk
+        res = {}
+        for name, ctor in (("resnet101", trunk.resnet101), ("resnet50_places365", lambda: trunk.resnet50(365))):
+            feats = trunk.ResNetFeatures(synth.fill_trunk_(ctor(), 3).eval()).to(dev).eval()
+            img = torch.randn(batch, 3, size, size, device=dev)
+            for _ in range(2):
+                feats(img)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                feats(img)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            fl = trunk.features_flops(feats, size) * batch
+            res[name] = {"ms_per_batch": round(ms, 3), "images_per_s": round(batch / ms * 1e3, 1),
+                         "achieved_tflops": round(fl / ms / 1e9, 1), "frac_of_bf16_mfma_peak": round(fl / ms / 1e9 / 2500.0, 4)}
+            del feats, img
+        both = sum(v["ms_per_batch"] for v in res.values())
+        res["what"] = ("the two CNN trunks in front of the path (MODEL:274-294), batch %d of %dx%d images each, bf16 NHWC "
+                       "implicit-GEMM convolutions; not part of `value`" % (batch, size, size))
+        res["images_per_s_both_trunks"] = round(batch / both * 1e3, 1)
+        return res
+    except Exception as e:     # the headline line must survive a failure of this extra leg
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +213,11 @@ def main():
                        "_out": vout[:B].float().cpu()}
             model.set_attention("faithful")
 
+    # row f4 (reported beside the headline, never part of `value`): the two CNN trunks in front of the path
+    trunks = None
+    if world == 1 and dist is None and not args.no_variants:
+        trunks = trunk_leg(dev)
+
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,6 +292,8 @@ def main():
     line["config"]["attention"] = args.attn
     if variant is not None:
         line["variants"] = {"attention=folded": variant}
+    if trunks is not None:
+        line["trunks"] = trunks
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

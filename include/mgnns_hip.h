@@ -263,7 +263,7 @@ int mgnns_softmax_argmax_fwd(const float* logits, int B, int NL, float* probs, i
  *                            y [B, H/2, W/2, 64] bf16 NHWC (OH = (H - 1) / 2 + 1).
  *  mgnns_maxpool3x3s2_nhwc_fwd  MaxPool2d(3, 2, 1): [B,H,W,C] -> [B,(H-1)/2+1,(W-1)/2+1,C], C % 8 == 0.
  *  mgnns_conv_bf16_nhwc_fwd  y = relu?(conv(x; wt) + bias + residual?) as an implicit GEMM: 1x1 or 3x3, any stride,
- *                            pad <= K/2, Cin a power of two >= 64, Cout % 4 == 0; residual [B,OH,OW,Cout] bf16 or NULL;
+ *                            pad <= K/2, Cin a power of two >= 64, Cout % 8 == 0; residual [B,OH,OW,Cout] bf16 or NULL;
  *                            y [B,OH,OW,Cout] bf16, or -- out_nchw_f32 != 0 -- [B,Cout,OH,OW] fp32, the feature-map
  *                            layout mgnns_imgbank_pool_* read.
  */

@@ -313,41 +313,71 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: acc[i][jj][r] = Y[m0 + wr*64 + 16 i + fr][n0 + wc*16*NJ + 16 jj + 4 fg + r]
+    // ---- epilogue.  acc[i][jj][r] = Y[m0 + wr*64 + 16 i + fr][n0 + wc*16*NJ + 16 jj + 4 fg + r]: a lane holds 4 consecutive
+    // channels of a pixel per tile.  One v_permlane16_swap per register between the tiles of a pair (2 jp, 2 jp + 1)
+    // trades the odd 16-lane rows of the first with the even rows of the second, after which lane (fr, fg) holds EIGHT
+    // consecutive channels -- (fg & 1) * 16 + (fg >> 1) * 8 .. + 7 of the 32-channel pair -- so residual loads and
+    // output stores are 16 bytes per lane in 64-byte runs per pixel (the 8-byte form cost as much as the GEMM itself).
     const int ohw = a.OH * a.OW;
+    const int ncol = n0 + wc * 16 * NJ + (fg & 1) * 16 + (fg >> 1) * 8;
+    uint4 rv[NJ / 2][4];
+    if (a.res) {
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int n = n0 + wc * 16 * NJ + jj * 16 + fg * 4;
-        if (n >= a.Cout) continue;
-        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n);
+        for (int jp = 0; jp < NJ / 2; ++jp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wr * 64 + i * 16 + fr, n = ncol + jp * 32;
+                rv[jp][i] = uint4{0u, 0u, 0u, 0u};
+                if (m < a.M && n < a.Cout) rv[jp][i] = *reinterpret_cast<const uint4*>(a.res + (size_t)m * a.Cout + n);
+            }
+    }
+#pragma unroll
+    for (int jp = 0; jp < NJ / 2; ++jp) {
+        const int n = ncol + jp * 32;
+        const bool ncok = n < a.Cout;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (ncok) {
+            b0 = *reinterpret_cast<const f32x4*>(a.bias + n);
+            b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                         "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
             const int m = m0 + wr * 64 + i * 16 + fr;
-            if (m >= a.M) continue;
-            float o[4];
+            if (m >= a.M || !ncok) continue;
+            float o[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[i][jj][r] + bs[r];
+            for (int r = 0; r < 4; ++r) {
+                o[r] = lo[r] + b0[r];
+                o[4 + r] = hi[r] + b1[r];
+            }
             if (a.res) {
-                const uint2 rv = *reinterpret_cast<const uint2*>(a.res + (size_t)m * a.Cout + n);
-                o[0] += bf2f(rv.x & 0xFFFFu);
-                o[1] += bf2f(rv.x >> 16);
-                o[2] += bf2f(rv.y & 0xFFFFu);
-                o[3] += bf2f(rv.y >> 16);
+                const unsigned int u[4] = {rv[jp][i].x, rv[jp][i].y, rv[jp][i].z, rv[jp][i].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[2 * r] += bf2f(u[r] & 0xFFFFu);
+                    o[2 * r + 1] += bf2f(u[r] >> 16);
+                }
             }
             if (a.relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+                for (int r = 0; r < 8; ++r) o[r] = fmaxf(o[r], 0.f);
             }
             if (a.out_nchw) {
                 const int b = m / ohw, p = m - b * ohw;
                 float* dst = reinterpret_cast<float*>(a.y) + ((size_t)b * a.Cout + n) * ohw + p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(size_t)r * ohw] = o[r];
+                for (int r = 0; r < 8; ++r) dst[(size_t)r * ohw] = o[r];
             } else {
-                uint2 ov;
+                uint4 ov;
                 ov.x = f2bf(o[0]) | (f2bf(o[1]) << 16);
                 ov.y = f2bf(o[2]) | (f2bf(o[3]) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.y) + (size_t)m * a.Cout + n) = ov;
+                ov.z = f2bf(o[4]) | (f2bf(o[5]) << 16);
+                ov.w = f2bf(o[6]) | (f2bf(o[7]) << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.y) + (size_t)m * a.Cout + n) = ov;
             }
         }
     }
@@ -420,7 +450,7 @@ extern "C" int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int 
     MG_REQUIRE(x && wt && bias && y, "mgnns_conv_bf16_nhwc_fwd: null pointer");
     MG_REQUIRE(B >= 0 && H > 0 && W > 0, "mgnns_conv_bf16_nhwc_fwd: bad dims B=%d H=%d W=%d", B, H, W);
     MG_REQUIRE(Cin >= 64 && (Cin & (Cin - 1)) == 0, "mgnns_conv_bf16_nhwc_fwd: C_in must be a power of two >= 64 (got %d)", Cin);
-    MG_REQUIRE(Cout > 0 && Cout % 4 == 0, "mgnns_conv_bf16_nhwc_fwd: C_out %% 4 != 0 (got %d)", Cout);
+    MG_REQUIRE(Cout > 0 && Cout % 8 == 0, "mgnns_conv_bf16_nhwc_fwd: C_out %% 8 != 0 (got %d)", Cout);
     MG_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3), "mgnns_conv_bf16_nhwc_fwd: kernel must be 1x1 or 3x3 (got %dx%d)", KH, KW);
     MG_REQUIRE(stride >= 1 && pad >= 0 && pad <= KH / 2, "mgnns_conv_bf16_nhwc_fwd: bad stride %d / padding %d", stride, pad);
     MG_REQUIRE(mg_aligned16(x) && mg_aligned16(wt) && mg_aligned16(bias) && mg_aligned16(y) && (!residual || mg_aligned16(residual)),

@@ -11,9 +11,15 @@ def make_vocab(V):
     return ["PAD", "UNK"] + ["w%d" % i for i in range(2, V)]
 
 
-def build_model(cfg, pmi, count, A_obj, A_place, label_query, device=None):
+def build_model(cfg, pmi, count, A_obj, A_place, label_query, device=None, trunks=False):
+    """trunks=True also builds the reference's CNN trunks (MODEL:629-630: ResNet-101 for objects, ResNet-50 with 365
+    classes for places) with seeded weights, so the model accepts raw [B,3,448,448] images."""
     tm = Text_model(make_vocab(cfg.V), pmi, count, cfg.NL, cfg.ngram, 0.5)
-    m = Multi_GCN_Multihead_Att(cfg.opt(), cfg.NL, tm, None, None, cfg.C_obj, cfg.C_place,
+    obj = place = None
+    if trunks:
+        from . import trunk
+        obj, place = trunk.resnet101(), trunk.resnet50(num_classes=365)
+    m = Multi_GCN_Multihead_Att(cfg.opt(), cfg.NL, tm, obj, place, cfg.C_obj, cfg.C_place,
                                 label_glove=torch.as_tensor(label_query))
     sd = {}
     for k, v in m.state_dict().items():
@@ -21,6 +27,8 @@ def build_model(cfg, pmi, count, A_obj, A_place, label_query, device=None):
             sd[k] = torch.as_tensor(A_obj).float()
         elif k == "place_A":
             sd[k] = torch.as_tensor(A_place).float()
+        elif k.startswith("object_features.") or k.startswith("place_features."):
+            sd[k] = torch.from_numpy(synth.trunk_param_value(k, tuple(v.shape)))
         else:
             sd[k] = torch.from_numpy(synth.param_value(k, tuple(v.shape)))
     m.load_state_dict(sd, strict=True)

@@ -94,9 +94,12 @@ class _NoTrunk(nn.Module):
 
 
 def _trunk(m):
+    """MODEL:274-294: Sequential(conv1, bn1, relu, maxpool, layer1..4) of the given ResNet -- same child indices, so the
+    same state_dict keys -- with the HIP forward of mgnns_amd.trunk (row f4)."""
     if m is None:
         return _NoTrunk()
-    return nn.Sequential(m.conv1, m.bn1, m.relu, m.maxpool, m.layer1, m.layer2, m.layer3, m.layer4)
+    from .trunk import ResNetFeatures
+    return ResNetFeatures(m)
 
 
 class Multi_GCN_Multihead_Att(nn.Module):

@@ -163,3 +163,23 @@ class ResNetFeatures(nn.Sequential):
             w, b, k, s, p = convs[2]
             y = ops.conv_bf16_nhwc(o, w, b, k, s, p, residual=idn, out_nchw_f32=last)
         return y
+
+
+def features_flops(feats, size):
+    """Algorithmic FLOPs (2 x MACs of the stem and of every bottleneck convolution) of ONE size x size image through a
+    ResNetFeatures -- the figure the trunk's MFMA utilisation is quoted on (62.4 GFLOP for ResNet-101 at 448)."""
+    h = (size - 1) // 2 + 1
+    total = 2 * 64 * 147 * h * h
+    h = (h - 1) // 2 + 1
+    for li in range(4, 8):
+        for blk in feats[li]:
+            hin = h
+            for conv in (blk.conv1, blk.conv2, blk.conv3):
+                k, s, p = _one(conv.kernel_size), _one(conv.stride), _one(conv.padding)
+                h = (h + 2 * p - k) // s + 1
+                total += 2 * conv.out_channels * conv.in_channels * k * k * h * h
+            if blk.downsample is not None:
+                d = blk.downsample[0]
+                ho = (hin - 1) // _one(d.stride) + 1
+                total += 2 * d.out_channels * d.in_channels * ho * ho
+    return total

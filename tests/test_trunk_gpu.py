@@ -60,7 +60,7 @@ def test_conv_fold_bn_is_the_oracle_fold():
     (3, 1, 512, 512, 1, 14, 14, False, True, False),   # K = 4608
     (1, 1, 512, 2048, 2, 14, 14, True, True, True),    # last layer: fp32 NCHW output + residual
     (1, 1, 256, 1024, 1, 3, 5, True, True, True),      # tiny M (one partial tile), NCHW
-    (1, 1, 128, 100, 2, 9, 9, False, True, False),     # C_out not a multiple of the tile
+    (1, 1, 128, 104, 2, 9, 9, False, True, False),     # C_out not a multiple of the tile
 ])
 def test_conv_igemm_vs_conv2d_on_rounded_operands(k, stride, Cin, Cout, B, H, W, res, relu, nchw):
     pad = k // 2
@@ -164,3 +164,29 @@ def test_state_dict_surface_matches_reference_sequential_names():
               "6.22.bn3.weight", "7.2.conv3.weight"):
         assert k in keys, k
     assert len([k for k in keys if k.endswith("conv2.weight")]) == 33
+
+
+def test_model_from_raw_images_equals_model_from_trunk_features():
+    """ENGINE:825 hands the model raw images; the benchmark entry hands it the [B,2048,14,14] maps.  Both
+    must be the same computation: run the two trunks alone, feed their maps to the model, compare with the model run
+    on the images (bit exact), and check the state_dict carries the reference's trunk key names."""
+    from mgnns_amd.harness import build_model, call_args, synthetic_adjacencies
+    cfg = synth.CONFIGS["mvsa_multiple_b256"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    A_obj, A_place = synthetic_adjacencies(cfg)
+    B = 4
+    inp = synth.make_inputs(cfg, B=B, seed=99, pmi=pmi)
+    model = build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], DEV, trunks=True)
+    keys = model.state_dict().keys()
+    assert "object_features.6.22.conv3.weight" in keys and "place_features.6.5.bn3.running_var" in keys
+    assert "place_features.6.6.conv1.weight" not in keys                      # ResNet-50: six blocks in layer3
+    args = list(call_args(inp, DEV))
+    imgs_o, imgs_p = _rnd((B, 3, 448, 448), 41).to(DEV), _rnd((B, 3, 448, 448), 42).to(DEV)
+    fo, fp = model.object_features(imgs_o), model.place_features(imgs_p)
+    assert tuple(fo.shape) == tuple(fp.shape) == (B, 2048, 14, 14)
+    args[3], args[4] = fo, fp
+    ref = model(*args)
+    args[3], args[4] = imgs_o, imgs_p
+    out = model(*args)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref)

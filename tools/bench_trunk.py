@@ -16,25 +16,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mgnns_amd import ops, synth, trunk  # noqa: E402
 
 
-def conv_flops(feats, S):
-    """2 * MACs of one image through the trunk (stem + every bottleneck convolution), from the module geometry."""
-    h = (S - 1) // 2 + 1
-    total = 2 * 64 * 147 * h * h
-    h = (h - 1) // 2 + 1
-    for li in range(4, 8):
-        for blk in feats[li]:
-            hin = h
-            for conv in (blk.conv1, blk.conv2, blk.conv3):
-                k, s = conv.kernel_size[0], conv.stride[0]
-                h = (h + 2 * conv.padding[0] - k) // s + 1
-                total += 2 * conv.out_channels * conv.in_channels * k * k * h * h
-            if blk.downsample is not None:
-                d = blk.downsample[0]
-                ho = (hin - 1) // d.stride[0] + 1
-                total += 2 * d.out_channels * d.in_channels * ho * ho
-    return total
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
@@ -47,7 +28,7 @@ def main():
     m = synth.fill_trunk_(getattr(trunk, a.arch)(), 3).eval()
     feats = trunk.ResNetFeatures(m).to(dev).eval()
     img = torch.randn(a.batch, 3, a.size, a.size, device=dev)
-    fl = conv_flops(feats, a.size)
+    fl = trunk.features_flops(feats, a.size)
     for _ in range(2):
         y = feats(img)
     torch.cuda.synchronize()
