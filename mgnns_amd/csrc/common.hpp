@@ -8,6 +8,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 void mgnns_set_error(const char* fmt, ...);
 int mg_ensure_dyn_lds(const void* fn, int bytes);   // api.hip; 0 or MGNNS_ERR_LAUNCH (error text set)
@@ -46,6 +47,26 @@ __device__ __forceinline__ float mg_act(float v, int act) {
 // for a LATER iteration -- has to land before the barrier.  Use this one where the barrier only publishes LDS writes /
 // retires LDS reads and global loads are meant to stay in flight across it.
 __device__ __forceinline__ void mg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16-byte LDS read the compiler does not see as an LDS access.  hipcc puts s_waitcnt vmcnt(0) in front of every ds_read
+// it knows about while an LDS-DMA (global_load_lds) is outstanding -- it cannot tell that the ring stage being read is not
+// the one being filled -- which serialises a multi-stage DMA ring into "request a slice, wait for it".  Reads issued
+// through this helper carry no such wait; the CALLER orders them: s_waitcnt lgkmcnt(n) through mg_lds_wait<n>(regs...)
+// before the first use (LDS operations of a wave complete in order).
+template <int OFF>
+__device__ __forceinline__ u32x4 mg_lds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned mg_lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // generic -> LDS offset
+// s_waitcnt lgkmcnt(N) for fragments read with mg_lds_read128.  Nothing ties the consumer MFMAs to the wait (tying the fragment
+// or accumulator registers as in/out asm operands made hipcc copy them around the wait -- some copies BEFORE it, i.e. before the
+// data had landed): follow it with __builtin_amdgcn_sched_barrier(0), which no instruction is scheduled across.
+template <int N>
+__device__ __forceinline__ void mg_lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // ---- DPP (pure VALU, no LDS crossbar) reductions -----------------------------------------------------------
 // 16-lane row reductions: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -> all 16 lanes

@@ -177,8 +177,21 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const unsigned short*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, persistent form.  One workgroup per CU walks its tiles (XCD-aware order: the 32
+// workgroups of an XCD work on one super tile of row blocks x all column tiles at a time) and treats the BK slices of ALL
+// its tiles as one stream through the three-stage LDS-DMA ring: the slices of the next tile are requested while the
+// current tile still computes, and the epilogue's residual loads / output stores overlap the next tile's first slices.
+// (The one-tile-per-workgroup form spent as long in prologue + epilogue as in the MFMA loop on the K <= 256 layers.)
+//
+// Every vector-memory operation of a wave is issued UNCONDITIONALLY and in a fixed order -- DMA pieces beyond the end of
+// the stream fetch the zero source into a free stage, residual loads use clamped addresses, output stores are buffer
+// stores whose offset is pushed out of range for rows / channels outside the tensor -- so the number of operations
+// behind a given DMA slice is known at compile time and s_waitcnt vmcnt(N) can wait for exactly that slice (memory
+// operations complete in order) while younger DMA slices, loads and stores stay in flight.
 constexpr int TM = 256, BK = 64, NSTAGE = 3, NTHR = 512, NWAVE = NTHR / 64;
 constexpr int A_BYTES = TM * BK * 2, A_PIECES = A_BYTES / 1024;      // 32 KB = 32 DMA pieces of 8 rows x 128 B
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const unsigned short* x;      // [B, H, W, Cin] bf16
@@ -186,52 +199,99 @@ struct ConvArgs {
     const float* bias;            // [Cout]
     const unsigned short* res;    // [M, Cout] bf16 or null
     void* y;                      // [M, Cout] bf16, or [B, Cout, OH*OW] fp32 when out_nchw
-    int H, W, Cin, cin_shift, OH, OW, Cout, KH, KW, stride, pad, M, relu, out_nchw;
-    int nrb, nct, rps;
+    int H, W, Cin, cin_shift, OH, OW, Cout, KH, KW, stride, pad, M, relu;
+    float inv_ohw, inv_ow;
+    unsigned int ybytes;
+    int nrb, nct, rps, jmax;      // tile map: row blocks, column tiles, row blocks per super tile, virtual tiles per XCD
 };
 
-template <int NJ>
+// s_waitcnt vmcnt(N) + workgroup barrier, N = PPW + NS * stores_behind + NR * loads_behind (see the kernel)
+template <int PPW, int NS, int NR>   // NR: tile-closing loads
+__device__ __forceinline__ void slice_wait(int l0, int l1, int l2) {
+#define MG_W(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((n) > 63 ? 63 : (n)) : "memory")
+    switch (l2 * 4 + l1 * 2 + l0) {
+        case 0: MG_W(PPW); break;
+        case 1: MG_W(PPW + NR); break;
+        case 2: MG_W(PPW + NS + NR); break;
+        case 3: MG_W(PPW + NS + 2 * NR); break;
+        case 4: MG_W(PPW + NS); break;
+        case 5: MG_W(PPW + NS + NR); break;
+        case 6: MG_W(PPW + 2 * NS + NR); break;
+        default: MG_W(PPW + 2 * NS + 2 * NR); break;
+    }
+#undef MG_W
+}
+
+template <int NJ, bool HAS_RES, bool OUT_NCHW>
 __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int TN = 32 * NJ, B_BYTES = TN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVE;          // 48 / 6 (NJ = 4), 40 / 5 (NJ = 2)
+    constexpr int NL = NJ + (HAS_RES ? 2 * NJ : 0);                           // tile-closing loads per wave: bias, residual
+    constexpr int NS = OUT_NCHW ? 16 * NJ : 2 * NJ;                           // output stores per wave and tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- XCD-aware tile map (gemm_bf16.hip)
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
     const int per = a.rps * a.nct;
-    const int sl = j / per, within = j - sl * per;
-    const int rb = (sl * 8 + xcd) * a.rps + within / a.nct, ct = within % a.nct;
-    if (rb >= a.nrb) return;
-    const int m0 = rb * TM, n0 = ct * TN;
-    const int wr = wave >> 1, wc = wave & 1;                       // wave tile: rows wr*64.., cols wc*16*NJ..
     const int K = a.KH * a.KW * a.Cin, nk = K / BK;
+    const int ohw = a.OH * a.OW;
 
-    // ---- the four A rows this lane feeds (pieces wave + 8 i): input pixel of tap (0, 0) and its element offset
+    // virtual tile j of this XCD -> (m0, n0); false when it lies beyond the last row block
+    auto decode = [&](int j, int& m0, int& n0) {
+        const int sl = j / per, within = j - sl * per;
+        const int rb = (sl * 8 + xcd) * a.rps + within / a.nct, ct = within % a.nct;
+        m0 = rb * TM;
+        n0 = ct * TN;
+        return j < a.jmax && rb < a.nrb;
+    };
+    auto next_valid = [&](int j, int& m0, int& n0) {     // first valid tile at or after j (stride jstep), or >= jmax
+        while (j < a.jmax && !decode(j, m0, n0)) j += jstep;
+        return j;
+    };
+    int ntiles = 0;
+    {
+        int m0, n0;
+        for (int j = jj0; j < a.jmax; j += jstep) ntiles += decode(j, m0, n0) ? 1 : 0;
+    }
+    if (ntiles == 0) return;
+    const int S = ntiles * nk;                          // slices in this workgroup's stream
+
+    // ---- issue side: tile, slice within the tile, and the four A rows this lane feeds (pieces wave + 8 i)
     const int row_in = lane >> 3, slot = lane & 7;
+    int ij, im0 = 0, in0 = 0, ikt = 0, ig = 0;
     int ih0[4], iw0[4];
     long long base[4];
+    auto rows_of_tile = [&]() {
+        const int b0 = im0 / ohw, rem0 = im0 - b0 * ohw;          // uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (wave + NWAVE * i) * 8 + row_in;
-        if (m < a.M) {
-            const int ohw = a.OH * a.OW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oh = rem / a.OW, ow = rem - oh * a.OW;
-            ih0[i] = oh * a.stride - a.pad;
-            iw0[i] = ow * a.stride - a.pad;
-            base[i] = (((long long)b * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
-        } else {
-            ih0[i] = -(1 << 20);
-            iw0[i] = 0;
-            base[i] = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int off = (wave + NWAVE * i) * 8 + row_in;
+            if (im0 + off < a.M) {
+                int x = rem0 + off;                                // < ohw + 256 < 2^24: float quotient +-1
+                int kb = (int)((float)x * a.inv_ohw);
+                int r = x - kb * ohw;
+                if (r < 0) { r += ohw; --kb; } else if (r >= ohw) { r -= ohw; ++kb; }
+                int oh = (int)((float)r * a.inv_ow);
+                int ow = r - oh * a.OW;
+                if (ow < 0) { ow += a.OW; --oh; } else if (ow >= a.OW) { ow -= a.OW; ++oh; }
+                ih0[i] = oh * a.stride - a.pad;
+                iw0[i] = ow * a.stride - a.pad;
+                base[i] = (((long long)(b0 + kb) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+            } else {
+                ih0[i] = -(1 << 20);
+                iw0[i] = 0;
+                base[i] = 0;
+            }
         }
-    }
+    };
+    ij = next_valid(jj0, im0, in0);
+    rows_of_tile();
     const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
 
-    auto issue = [&](int kt, int stage) {
-        unsigned char* sb = smem + (size_t)stage * STAGE_BYTES;
-        const int k0 = kt * BK;
+    auto issue = [&]() {                                 // DMA of stream slice ig into stage ig % NSTAGE, then advance
+        unsigned char* sb = smem + (size_t)(ig % NSTAGE) * STAGE_BYTES;
+        const bool live = ig < S;
+        const int k0 = ikt * BK;
         const int tap = k0 >> a.cin_shift, c0 = k0 & (a.Cin - 1);
         const int kh = a.KW == 3 ? (tap * 11) >> 5 : 0, kw = tap - kh * a.KW;   // KW in {1, 3}
         const int toff = (kh * a.W + kw) * a.Cin + c0;
@@ -244,40 +304,55 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
         for (int i = 0; i < 4; ++i) {                             // A pieces p = wave + 8 i < 32
             const int p = wave + NWAVE * i;
             const int chunk = slot ^ (4 * (p & 1) + (row_in >> 1));
-            const bool ok = (unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W;
+            const bool ok = live && (unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W;
             dma(ok ? a.x + (base[i] + toff + chunk * 8) : zsrc, p);
         }
 #pragma unroll
         for (int i = 4; i < PPW; ++i) {                           // weight pieces
             const int p = wave + NWAVE * i;
             const int chunk = slot ^ (4 * (p & 1) + (row_in >> 1));
-            int row = n0 + (p - A_PIECES) * 8 + row_in;
+            int row = in0 + (p - A_PIECES) * 8 + row_in;
             row = row < a.Cout ? row : a.Cout - 1;
-            dma(a.wt + (size_t)row * K + k0 + chunk * 8, p);
+            dma(live ? a.wt + (size_t)row * K + k0 + chunk * 8 : zsrc, p);
+        }
+        ++ig;
+        if (++ikt == nk && ig < S) {                              // uniform: the stream moves on to the next tile
+            ikt = 0;
+            ij = next_valid(ij + jstep, im0, in0);
+            rows_of_tile();
         }
     };
 
+    const int wr = wave >> 1, wc = wave & 1;                       // wave tile: rows wr*64.., cols wc*16*NJ..
     f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fragment reads through mg_lds_read128 (common.hpp): as ordinary ds_reads hipcc guards each group with
+    // s_waitcnt vmcnt(0) against the LDS-DMA in flight, and the ring never overlaps anything
     const int fr = lane & 15, fg = lane >> 4;
-    auto afrag = [&](const unsigned char* sb, int i, int s) {
-        const int row = wr * 64 + i * 16 + fr;
-        return *reinterpret_cast<const uint4*>(sb + ((size_t)row * 8 + ((4 * s + fg) ^ ((fr >> 1) & 7))) * 16);
-    };
-    auto bfrag = [&](const unsigned char* sb, int jj, int s) {
-        const int row = wc * 16 * NJ + jj * 16 + fr;
-        return *reinterpret_cast<const uint4*>(sb + A_BYTES + ((size_t)row * 8 + ((4 * s + fg) ^ ((fr >> 1) & 7))) * 16);
-    };
-    uint4 av[2][4], bv[2][NJ];
-    auto reads = [&](const unsigned char* sb, int s, int buf) {
+    const unsigned lds0 = mg_lds_addr(smem);
+    unsigned aoff[2], boff[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[buf][i] = afrag(sb, i, s);
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) bv[buf][jj] = bfrag(sb, jj, s);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+        boff[s2] = lds0 + A_BYTES + ((wc * 16 * NJ + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+    }
+    u32x4 av[2][4], bv[2][NJ];
+    auto reads = [&](int stage, int s2, int buf) {
+        const unsigned so = (unsigned)stage * STAGE_BYTES;
+        av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
+        av[buf][1] = mg_lds_read128<2048>(aoff[s2] + so);
+        av[buf][2] = mg_lds_read128<4096>(aoff[s2] + so);
+        av[buf][3] = mg_lds_read128<6144>(aoff[s2] + so);
+        bv[buf][0] = mg_lds_read128<0>(boff[s2] + so);
+        bv[buf][1] = mg_lds_read128<2048>(boff[s2] + so);
+        if constexpr (NJ == 4) {
+            bv[buf][2] = mg_lds_read128<4096>(boff[s2] + so);
+            bv[buf][3] = mg_lds_read128<6144>(boff[s2] + so);
+        }
     };
     auto mmas = [&](int buf) {
 #pragma unroll
@@ -287,107 +362,139 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[buf][jj]),
                                                                     __builtin_bit_cast(bf16x8, av[buf][i]), acc[i][jj], 0, 0, 0);
     };
-    // pipeline: see gemm_bf16.hip (mid-iteration bare barrier, waves 0-3 / 4-7 issue their DMA pieces at different points)
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (nk > 2) issue(2, 2);
-    reads(smem, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* sb = smem + (size_t)(kt % NSTAGE) * STAGE_BYTES;
-        reads(sb, 1, 1);
+
+    // ---- compute side
+    int cj, cm0 = 0, cn0 = 0, ckt = 0;
+    cj = next_valid(jj0, cm0, cn0);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00027000);
+    const int ncl = wc * 16 * NJ + (fg & 1) * 16 + (fg >> 1) * 8;   // this lane's 8 channels of pair jp: cn0 + ncl + 32 jp ..
+    // tile-closing loads (residual, bias): inline asm, so that the compiler -- which would wait for them with vmcnt(0), i.e.
+    // for every DMA slice in flight -- does not see them; the epilogue waits with vmcnt(PPW): exactly one DMA slice is
+    // issued between these loads and their use
+    u32x4 rv[NJ / 2][4];
+    f32x4 bs[NJ / 2][2];
+    auto gload = [&](const void* ptr) {
+        u32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+
+    issue();
+    issue();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
+    issue();
+    reads(0, 0, 0);
+    int l1 = 0, l2 = 0;                                            // "slice g-1 / g-2 closed a tile"
+    for (int g = 0; g < S; ++g) {
+        const int l0 = ckt == nk - 1 ? 1 : 0;
+        if (l0) {
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                int n = cn0 + ncl + jp * 32;
+                n = n < a.Cout ? n : a.Cout - 8;                   // clamped: always a valid address, never a skipped load
+                bs[jp][0] = __builtin_bit_cast(f32x4, gload(a.bias + n));
+                bs[jp][1] = __builtin_bit_cast(f32x4, gload(a.bias + n + 4));
+                if (HAS_RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int m = cm0 + wr * 64 + i * 16 + fr;
+                        m = m < a.M ? m : a.M - 1;
+                        rv[jp][i] = gload(a.res + (size_t)m * a.Cout + n);
+                    }
+                }
+            }
+        }
+        reads(g % NSTAGE, 1, 1);
+        mg_lds_wait<4 + NJ>();                                     // k-step 0 landed (the reads of k-step 1 are behind it)
         __builtin_amdgcn_sched_barrier(0);
         mmas(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (wave < 4 && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
-            reads(smem + (size_t)((kt + 1) % NSTAGE) * STAGE_BYTES, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // slice g+1 landed: behind it are DMA slice g+2 and whatever the tile ends at g-2, g-1, g put in between
+        slice_wait<PPW, NS, NL>(l0, l1, l2);
+        // the two waves of a SIMD issue their DMA pieces (~100+ cycles each, MFMA issue blocked meanwhile) at
+        // DIFFERENT points of the iteration: waves 0-3 here, waves 4-7 after their second k-step
+        if (wave < 4) issue();
+        reads((g + 1) % NSTAGE, 0, 0);
+        mg_lds_wait<4 + NJ>();                                     // k-step 1 landed at the barrier (lgkmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
         mmas(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (wave >= 4 && kt + 1 < nk && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
+        if (wave >= 4) issue();
         __builtin_amdgcn_sched_barrier(0);
-    }
+        l2 = l1;
+        l1 = l0;
+        if (++ckt < nk) continue;
+        ckt = 0;
 
-    // ---- epilogue.  acc[i][jj][r] = Y[m0 + wr*64 + 16 i + fr][n0 + wc*16*NJ + 16 jj + 4 fg + r]: a lane holds 4 consecutive
-    // channels of a pixel per tile.  One v_permlane16_swap per register between the tiles of a pair (2 jp, 2 jp + 1)
-    // trades the odd 16-lane rows of the first with the even rows of the second, after which lane (fr, fg) holds EIGHT
-    // consecutive channels -- (fg & 1) * 16 + (fg >> 1) * 8 .. + 7 of the 32-channel pair -- so residual loads and
-    // output stores are 16 bytes per lane in 64-byte runs per pixel (the 8-byte form cost as much as the GEMM itself).
-    const int ohw = a.OH * a.OW;
-    const int ncol = n0 + wc * 16 * NJ + (fg & 1) * 16 + (fg >> 1) * 8;
-    uint4 rv[NJ / 2][4];
-    if (a.res) {
+        // ---- epilogue of tile (cm0, cn0).  acc[i][jj][r] = Y[cm0 + wr*64 + 16 i + fr][cn0 + wc*16*NJ + 16 jj + 4 fg + r]: a
+        // lane holds 4 consecutive channels of a pixel per tile.  One v_permlane16_swap per register between the tiles of a
+        // pair (2 jp, 2 jp + 1) trades the odd 16-lane rows of the first with the even rows of the second, after which lane
+        // (fr, fg) holds EIGHT consecutive channels -- (fg & 1) * 16 + (fg >> 1) * 8 .. + 7 of the 32-channel pair -- so
+        // residual loads and output stores are 16 bytes per lane in 64-byte runs per pixel.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // bias / residual landed; DMA slice g+3 stays in flight
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jp = 0; jp < NJ / 2; ++jp)
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            const int n = cn0 + ncl + jp * 32;
+            const bool ncok = n < a.Cout;
+            const f32x4 b0 = bs[jp][0], b1 = bs[jp][1];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wr * 64 + i * 16 + fr, n = ncol + jp * 32;
-                rv[jp][i] = uint4{0u, 0u, 0u, 0u};
-                if (m < a.M && n < a.Cout) rv[jp][i] = *reinterpret_cast<const uint4*>(a.res + (size_t)m * a.Cout + n);
-            }
-    }
-#pragma unroll
-    for (int jp = 0; jp < NJ / 2; ++jp) {
-        const int n = ncol + jp * 32;
-        const bool ncok = n < a.Cout;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (ncok) {
-            b0 = *reinterpret_cast<const f32x4*>(a.bias + n);
-            b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                         "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
-            const int m = m0 + wr * 64 + i * 16 + fr;
-            if (m >= a.M || !ncok) continue;
-            float o[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = lo[r] + b0[r];
-                o[4 + r] = hi[r] + b1[r];
-            }
-            if (a.res) {
-                const unsigned int u[4] = {rv[jp][i].x, rv[jp][i].y, rv[jp][i].z, rv[jp][i].w};
+                f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                             "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+                acc[i][2 * jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * jp + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int m = cm0 + wr * 64 + i * 16 + fr;
+                const bool ok = ncok && m < a.M;
+                float o[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o[2 * r] += bf2f(u[r] & 0xFFFFu);
-                    o[2 * r + 1] += bf2f(u[r] >> 16);
+                    o[r] = lo[r] + b0[r];
+                    o[4 + r] = hi[r] + b1[r];
+                }
+                if (HAS_RES) {
+                    const unsigned int u[4] = {rv[jp][i][0], rv[jp][i][1], rv[jp][i][2], rv[jp][i][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[2 * r] += bf2f(u[r] & 0xFFFFu);
+                        o[2 * r + 1] += bf2f(u[r] >> 16);
+                    }
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = fmaxf(o[r], 0.f);
+                }
+                if (OUT_NCHW) {
+                    const int mm = ok ? m : 0;
+                    const int b = mm / ohw, p = mm - b * ohw;
+                    const unsigned int off = ok ? (unsigned int)((((size_t)b * a.Cout + n) * ohw + p) * 4) : 0xFFFFFFF0u;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[r]), y_rsrc, ok ? off + (unsigned)(r * ohw * 4) : off, 0, 0);
+                } else {
+                    i32x4 ov;
+                    ov[0] = (int)(f2bf(o[0]) | (f2bf(o[1]) << 16));
+                    ov[1] = (int)(f2bf(o[2]) | (f2bf(o[3]) << 16));
+                    ov[2] = (int)(f2bf(o[4]) | (f2bf(o[5]) << 16));
+                    ov[3] = (int)(f2bf(o[6]) | (f2bf(o[7]) << 16));
+                    const unsigned int off = ok ? (unsigned int)(((size_t)m * a.Cout + n) * 2) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, y_rsrc, off, 0, 0);
                 }
             }
-            if (a.relu) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = fmaxf(o[r], 0.f);
-            }
-            if (a.out_nchw) {
-                const int b = m / ohw, p = m - b * ohw;
-                float* dst = reinterpret_cast<float*>(a.y) + ((size_t)b * a.Cout + n) * ohw + p;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) dst[(size_t)r * ohw] = o[r];
-            } else {
-                uint4 ov;
-                ov.x = f2bf(o[0]) | (f2bf(o[1]) << 16);
-                ov.y = f2bf(o[2]) | (f2bf(o[3]) << 16);
-                ov.z = f2bf(o[4]) | (f2bf(o[5]) << 16);
-                ov.w = f2bf(o[6]) | (f2bf(o[7]) << 16);
-                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.y) + (size_t)m * a.Cout + n) = ov;
-            }
         }
+        cj = next_valid(cj + jstep, cm0, cn0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dummy DMA pieces must not outlive the workgroup's LDS
 }
 
-template <int NJ>
-int launch_conv(ConvArgs& a, hipStream_t stream) {
+template <int NJ, bool HAS_RES, bool OUT_NCHW>
+int launch_conv3(ConvArgs& a, hipStream_t stream, int n_cu) {
     constexpr int TN = 32 * NJ;
     constexpr size_t SMEM = (size_t)NSTAGE * (A_BYTES + TN * BK * 2);
-    MG_DYN_LDS(conv_igemm_kernel<NJ>, SMEM);
+    auto kern = conv_igemm_kernel<NJ, HAS_RES, OUT_NCHW>;
+    MG_DYN_LDS(kern, SMEM);
     a.nrb = (a.M + TM - 1) / TM;
     a.nct = (a.Cout + TN - 1) / TN;
     int rps = 32 / a.nct;
@@ -395,9 +502,18 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
     if (rps > a.nrb) rps = a.nrb;
     a.rps = rps;
     const int supers = (a.nrb + rps - 1) / rps;
-    const int blocks = 8 * ((supers + 7) / 8) * rps * a.nct;
-    hipLaunchKernelGGL(conv_igemm_kernel<NJ>, dim3(blocks), dim3(NTHR), SMEM, stream, a);
+    a.jmax = ((supers + 7) / 8) * rps * a.nct;                    // virtual tiles per XCD
+    int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
+    if (per_xcd < 1) per_xcd = 1;
+    if (per_xcd > a.jmax) per_xcd = a.jmax;
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NTHR), SMEM, stream, a);
     return 0;
+}
+
+template <int NJ>
+int launch_conv(ConvArgs& a, bool out_nchw, hipStream_t stream, int n_cu) {
+    if (out_nchw) return a.res ? launch_conv3<NJ, true, true>(a, stream, n_cu) : launch_conv3<NJ, false, true>(a, stream, n_cu);
+    return a.res ? launch_conv3<NJ, true, false>(a, stream, n_cu) : launch_conv3<NJ, false, false>(a, stream, n_cu);
 }
 
 }  // namespace
@@ -469,10 +585,21 @@ extern "C" int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int 
     MG_REQUIRE(a.OH > 0 && a.OW > 0, "mgnns_conv_bf16_nhwc_fwd: empty output");
     const long long M = (long long)B * a.OH * a.OW;
     MG_REQUIRE(M < (1ll << 31) - TM, "mgnns_conv_bf16_nhwc_fwd: B*OH*OW = %lld does not fit 31 bits", M);
+    const long long ybytes = M * Cout * (out_nchw_f32 ? 4 : 2);
+    MG_REQUIRE(ybytes < 0xFFFFFFF0ll, "mgnns_conv_bf16_nhwc_fwd: output of %lld bytes exceeds the 4 GiB buffer-store range; split the batch", ybytes);
+    MG_REQUIRE((long long)a.OH * a.OW + TM < (1 << 24), "mgnns_conv_bf16_nhwc_fwd: OH*OW = %d too large", a.OH * a.OW);
     a.M = (int)M;
+    a.ybytes = (unsigned int)ybytes;
+    a.inv_ohw = 1.0f / (float)(a.OH * a.OW);
+    a.inv_ow = 1.0f / (float)a.OW;
     a.relu = relu ? 1 : 0;
-    a.out_nchw = out_nchw_f32 ? 1 : 0;
-    const int rc = Cout <= 64 ? launch_conv<2>(a, (hipStream_t)stream) : launch_conv<4>(a, (hipStream_t)stream);
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+        mgnns_set_error("mgnns_conv_bf16_nhwc_fwd: cannot query the CU count");
+        return MGNNS_ERR_LAUNCH;
+    }
+    const int rc = Cout <= 64 ? launch_conv<2>(a, out_nchw_f32 != 0, (hipStream_t)stream, n_cu)
+                              : launch_conv<4>(a, out_nchw_f32 != 0, (hipStream_t)stream, n_cu);
     if (rc) return rc;
     MG_CHECK_LAUNCH("mgnns_conv_bf16_nhwc_fwd");
     return 0;

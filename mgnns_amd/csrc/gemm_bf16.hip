@@ -95,29 +95,36 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment addresses: lane (r = lane & 15, g = lane >> 4) reads chunk (4 s + g) ^ ((r >> 1) & 7) of row (tile * 16 + r)
+    // fragment addresses: lane (r = lane & 15, g = lane >> 4) reads chunk (4 s + g) ^ ((r >> 1) & 7) of row (tile * 16 + r);
+    // tile i of a wave lies i * 2 KiB further on (immediate offset).  The reads go through mg_lds_read128 (inline asm):
+    // as ordinary ds_reads hipcc guards each group with s_waitcnt vmcnt(0) against the LDS-DMA in flight, i.e. it
+    // waits for the slice that was requested a moment ago and the three-stage ring never overlaps anything.
     const int fr = lane & 15, fg = lane >> 4;
-    auto afrag = [&](const unsigned char* sb, int i, int s) {
-        const int row = wr * 64 + i * 16 + fr;
-        return *reinterpret_cast<const uint4*>(sb + ((size_t)row * 8 + ((4 * s + fg) ^ ((fr >> 1) & 7))) * 16);
-    };
-    auto bfrag = [&](const unsigned char* sb, int jj, int s) {
-        const int row = wc * 64 + jj * 16 + fr;
-        return *reinterpret_cast<const uint4*>(sb + A_BYTES + ((size_t)row * 8 + ((4 * s + fg) ^ ((fr >> 1) & 7))) * 16);
-    };
+    const unsigned lds0 = mg_lds_addr(smem);
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+        boff[s2] = lds0 + A_BYTES + ((wc * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+    }
 
-    // Software pipeline (one wave per SIMD, so nothing else hides a latency): fragments are double buffered per k-step;
-    // the reads of k-step 1 are issued before the MFMAs of k-step 0, and -- behind the slice barrier placed in the
-    // MIDDLE of an iteration -- the reads of the NEXT slice's k-step 0 before the MFMAs of k-step 1.  The barrier also
-    // frees the current slice's stage (both k-steps are in registers by then) for the DMA of slice kt + 3.
-    // Barriers are bare s_barrier + the s_waitcnt actually needed: __syncthreads() carries a workgroup fence, i.e.
-    // s_waitcnt vmcnt(0), which would wait for DMA slices that were only just requested.
-    uint4 a[2][4], b[2][4];
-    auto reads = [&](const unsigned char* sb, int s, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[buf][i] = afrag(sb, i, s);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) b[buf][jj] = bfrag(sb, jj, s);
+    // Software pipeline: fragments are double buffered per k-step; the reads of k-step 1 are issued before the MFMAs
+    // of k-step 0, and -- behind the slice barrier placed in the MIDDLE of an iteration -- the reads of the NEXT
+    // slice's k-step 0 before the MFMAs of k-step 1.  The barrier also frees the current slice's stage (both k-steps
+    // are in registers by then) for the DMA of slice kt + 3.  Barriers are bare s_barrier + the s_waitcnt actually
+    // needed: __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0), which would wait for DMA slices
+    // that were only just requested.
+    u32x4 a[2][4], b[2][4];
+    auto reads = [&](int stage, int s, int buf) {
+        const unsigned so = (unsigned)stage * STAGE_BYTES;
+        a[buf][0] = mg_lds_read128<0>(aoff[s] + so);
+        a[buf][1] = mg_lds_read128<2048>(aoff[s] + so);
+        a[buf][2] = mg_lds_read128<4096>(aoff[s] + so);
+        a[buf][3] = mg_lds_read128<6144>(aoff[s] + so);
+        b[buf][0] = mg_lds_read128<0>(boff[s] + so);
+        b[buf][1] = mg_lds_read128<2048>(boff[s] + so);
+        b[buf][2] = mg_lds_read128<4096>(boff[s] + so);
+        b[buf][3] = mg_lds_read128<6144>(boff[s] + so);
     };
     auto mmas = [&](int buf) {
 #pragma unroll
@@ -132,10 +139,10 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
     if (nk > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (nk > 2) issue(2, 2);
-    reads(smem, 0, 0);
+    reads(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* sb = smem + (size_t)(kt % NSTAGE) * STAGE_BYTES;
-        reads(sb, 1, 1);
+        reads(kt % NSTAGE, 1, 1);
+        mg_lds_wait<8>();                                     // k-step 0 landed (the 8 reads of k-step 1 are behind it)
         __builtin_amdgcn_sched_barrier(0);
         mmas(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -147,9 +154,12 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
             // the two waves of a SIMD issue their DMA pieces (~100+ cycles each, MFMA issue blocked meanwhile) at
             // DIFFERENT points of the iteration: waves 0-3 here, waves 4-7 after their second k-step
             if (wave < 4 && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
-            reads(smem + (size_t)((kt + 1) % NSTAGE) * STAGE_BYTES, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            reads((kt + 1) % NSTAGE, 0, 0);
+            mg_lds_wait<8>();                                 // k-step 1 landed at the barrier (lgkmcnt(0)); orders the MFMAs
+        } else {
+            mg_lds_wait<0>();
         }
+        __builtin_amdgcn_sched_barrier(0);
         mmas(1);
         __builtin_amdgcn_sched_barrier(0);
         if (wave >= 4 && kt + 1 < nk && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
