@@ -65,7 +65,7 @@ def cpu_baseline(cfg, model, inp, pmi, budget_s=20.0):
                            "(torch-CPU fp32, %d threads; median %.3f s)" % (len(times), B, cores, best)}
 
 
-def trunk_leg(dev, batch=32, size=448, iters=5):
+def trunk_leg(dev, batch=128, size=448, iters=3):
     """ResNet-101 (objects) + ResNet-50/365 (places) features of `batch` 448x448 images on the HIP
     implicit-GEMM kernels (seeded weights), eager launches; MFMA utilisation on the algorithmic convolution FLOPs."""
     try:

@@ -29,6 +29,13 @@ __device__ __forceinline__ unsigned int f2bf(float f) {       // round to neares
     return u >> 16;
 }
 __device__ __forceinline__ float bf2f(unsigned int h) { return __uint_as_float(h << 16); }
+// two fp32 -> packed bf16x2 (round to nearest even) in ONE instruction (no builtin for it on gfx950); the shift / add form
+// above costs five VALU operations per value, which made the convolution epilogue VALU-bound
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ cbias,
@@ -70,13 +77,22 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict
     const int b = blockIdx.z, or0 = blockIdx.y * ST_ROWS, oc0 = blockIdx.x * ST_COLS;
     const int ir0 = 2 * or0 - 3, ic0 = 2 * oc0 - 3;
     const float* src = img + (size_t)b * 3 * H * W;
-    for (int e = tid; e < 3 * ST_PR * ST_PC; e += 256) {
+    // all loads of the patch in flight before the first conversion (a rolled loop pays one HBM round trip per element)
+    constexpr int NE = 3 * ST_PR * ST_PC, NIT = (NE + 255) / 256;
+    float pv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e = tid + 256 * i;
         const int c = e / (ST_PR * ST_PC), rem = e - c * (ST_PR * ST_PC);
         const int r = rem / ST_PC, cc = rem - r * ST_PC;
         const int ir = ir0 + r, ic = ic0 + cc;
-        float v = 0.f;
-        if ((unsigned)ir < (unsigned)H && (unsigned)ic < (unsigned)W) v = src[((size_t)c * H + ir) * W + ic];
-        patch[e] = (unsigned short)f2bf(v);
+        pv[i] = 0.f;
+        if (e < NE && (unsigned)ir < (unsigned)H && (unsigned)ic < (unsigned)W) pv[i] = src[((size_t)c * H + ir) * W + ic];
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e = tid + 256 * i;
+        if (e < NE) patch[e] = (unsigned short)pack2(pv[i], 0.f);
     }
     const int fr = lane & 15, fg = lane >> 4;
     // weights: lane (n = fr, k-group fg) of column tile jt, k-step s
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict
                 const int n = jt * 16 + fg * 4;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
                 uint2 o;
-                o.x = f2bf(fmaxf(acc[jt][0] + bv[0], 0.f)) | (f2bf(fmaxf(acc[jt][1] + bv[1], 0.f)) << 16);
-                o.y = f2bf(fmaxf(acc[jt][2] + bv[2], 0.f)) | (f2bf(fmaxf(acc[jt][3] + bv[3], 0.f)) << 16);
+                o.x = pack2(fmaxf(acc[jt][0] + bv[0], 0.f), fmaxf(acc[jt][1] + bv[1], 0.f));
+                o.y = pack2(fmaxf(acc[jt][2] + bv[2], 0.f), fmaxf(acc[jt][3] + bv[3], 0.f));
                 *reinterpret_cast<uint2*>(dst + n) = o;
             }
         }
@@ -192,6 +208,18 @@ constexpr int TM = 256, BK = 64, NSTAGE = 3, NTHR = 512, NWAVE = NTHR / 64;
 constexpr int A_BYTES = TM * BK * 2, A_PIECES = A_BYTES / 1024;      // 32 KB = 32 DMA pieces of 8 rows x 128 B
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef MG_CONV_TRACE
+// in-kernel phase timer (tools/conv_trace.py): cycles (s_memtime) wave 0 and wave 4 of workgroup 0 spend in each part of the
+// slice loop, accumulated over the launch: [wave][0 total, 1 DMA issue, 2 k-step-0 wait + MFMAs, 3 slice barrier wait,
+// 4 k-step-1 reads + MFMAs, 5 epilogue, 6 slices, 7 tiles, 8 tile-closing loads]
+__device__ unsigned long long g_conv_trace[2][16];
+#define MG_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define MG_TACC(slot, t0, t1) if (trace_on) tr[slot] += (t1) - (t0)
+#else
+#define MG_T(var)
+#define MG_TACC(slot, t0, t1)
+#endif
 
 struct ConvArgs {
     const unsigned short* x;      // [B, H, W, Cin] bf16
@@ -342,6 +370,9 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
     }
     u32x4 av[2][4], bv[2][NJ];
     auto reads = [&](int stage, int s2, int buf) {
+#if defined(MG_CONV_EXP) && (MG_CONV_EXP & 1)
+        return;
+#endif
         const unsigned so = (unsigned)stage * STAGE_BYTES;
         av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
         av[buf][1] = mg_lds_read128<2048>(aoff[s2] + so);
@@ -355,6 +386,9 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     auto mmas = [&](int buf) {
+#if defined(MG_CONV_EXP) && (MG_CONV_EXP & 2)
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -379,6 +413,11 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
         return v;
     };
 
+#ifdef MG_CONV_TRACE
+    const bool trace_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
+    unsigned long long tr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MG_T(t_begin);
     issue();
     issue();
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
@@ -387,6 +426,7 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
     int l1 = 0, l2 = 0;                                            // "slice g-1 / g-2 closed a tile"
     for (int g = 0; g < S; ++g) {
         const int l0 = ckt == nk - 1 ? 1 : 0;
+        MG_T(t0);
         if (l0) {
 #pragma unroll
             for (int jp = 0; jp < NJ / 2; ++jp) {
@@ -404,23 +444,38 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
                 }
             }
         }
+        MG_T(t1);
         reads(g % NSTAGE, 1, 1);
         mg_lds_wait<4 + NJ>();                                     // k-step 0 landed (the reads of k-step 1 are behind it)
         __builtin_amdgcn_sched_barrier(0);
         mmas(0);
         __builtin_amdgcn_sched_barrier(0);
+        MG_T(t2);
         // slice g+1 landed: behind it are DMA slice g+2 and whatever the tile ends at g-2, g-1, g put in between
         slice_wait<PPW, NS, NL>(l0, l1, l2);
+        MG_T(t3);
         // the two waves of a SIMD issue their DMA pieces (~100+ cycles each, MFMA issue blocked meanwhile) at
         // DIFFERENT points of the iteration: waves 0-3 here, waves 4-7 after their second k-step
         if (wave < 4) issue();
+        MG_T(t4);
         reads((g + 1) % NSTAGE, 0, 0);
         mg_lds_wait<4 + NJ>();                                     // k-step 1 landed at the barrier (lgkmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
         mmas(1);
         __builtin_amdgcn_sched_barrier(0);
+        MG_T(t5);
         if (wave >= 4) issue();
         __builtin_amdgcn_sched_barrier(0);
+        MG_T(t6);
+        MG_TACC(8, t0, t1);
+        MG_TACC(2, t1, t2);
+        MG_TACC(3, t2, t3);
+        MG_TACC(1, t3, t4);
+        MG_TACC(4, t4, t5);
+        MG_TACC(1, t5, t6);
+#ifdef MG_CONV_TRACE
+        tr[6] += 1;
+#endif
         l2 = l1;
         l1 = l0;
         if (++ckt < nk) continue;
@@ -458,8 +513,8 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
                     const unsigned int u[4] = {rv[jp][i][0], rv[jp][i][1], rv[jp][i][2], rv[jp][i][3]};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        o[2 * r] += bf2f(u[r] & 0xFFFFu);
-                        o[2 * r + 1] += bf2f(u[r] >> 16);
+                        o[2 * r] += __uint_as_float(u[r] << 16);
+                        o[2 * r + 1] += __uint_as_float(u[r] & 0xFFFF0000u);
                     }
                 }
                 if (a.relu) {
@@ -475,18 +530,29 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[r]), y_rsrc, ok ? off + (unsigned)(r * ohw * 4) : off, 0, 0);
                 } else {
                     i32x4 ov;
-                    ov[0] = (int)(f2bf(o[0]) | (f2bf(o[1]) << 16));
-                    ov[1] = (int)(f2bf(o[2]) | (f2bf(o[3]) << 16));
-                    ov[2] = (int)(f2bf(o[4]) | (f2bf(o[5]) << 16));
-                    ov[3] = (int)(f2bf(o[6]) | (f2bf(o[7]) << 16));
+                    ov[0] = (int)pack2(o[0], o[1]);
+                    ov[1] = (int)pack2(o[2], o[3]);
+                    ov[2] = (int)pack2(o[4], o[5]);
+                    ov[3] = (int)pack2(o[6], o[7]);
                     const unsigned int off = ok ? (unsigned int)(((size_t)m * a.Cout + n) * 2) : 0xFFFFFFF0u;
                     __builtin_amdgcn_raw_buffer_store_b128(ov, y_rsrc, off, 0, 0);
                 }
             }
         }
         cj = next_valid(cj + jstep, cm0, cn0);
+        MG_T(t7);
+        MG_TACC(5, t6, t7);
+#ifdef MG_CONV_TRACE
+        tr[7] += 1;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dummy DMA pieces must not outlive the workgroup's LDS
+#ifdef MG_CONV_TRACE
+    if (trace_on && lane == 0) {
+        tr[0] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 9; ++i) g_conv_trace[wave >> 2][i] = tr[i];
+    }
+#endif
 }
 
 template <int NJ, bool HAS_RES, bool OUT_NCHW>
@@ -517,6 +583,12 @@ int launch_conv(ConvArgs& a, bool out_nchw, hipStream_t stream, int n_cu) {
 }
 
 }  // namespace
+
+#ifdef MG_CONV_TRACE
+extern "C" int mgnns_debug_conv_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int mgnns_conv_fold_bn_bf16(const float* w, const float* conv_bias, int Cout, int Cin, int KH, int KW,
                                        const float* gamma, const float* beta, const float* mean, const float* var, float eps,
