@@ -370,9 +370,6 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
     }
     u32x4 av[2][4], bv[2][NJ];
     auto reads = [&](int stage, int s2, int buf) {
-#if defined(MG_CONV_EXP) && (MG_CONV_EXP & 1)
-        return;
-#endif
         const unsigned so = (unsigned)stage * STAGE_BYTES;
         av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
         av[buf][1] = mg_lds_read128<2048>(aoff[s2] + so);
@@ -386,9 +383,6 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     auto mmas = [&](int buf) {
-#if defined(MG_CONV_EXP) && (MG_CONV_EXP & 2)
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

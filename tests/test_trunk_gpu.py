@@ -156,16 +156,6 @@ def test_full_size_trunk_448_properties():
     assert torch.equal(y1[0], y[1])
 
 
-def test_state_dict_surface_matches_reference_sequential_names():
-    f = trunk.ResNetFeatures(trunk.resnet101())
-    keys = set(f.state_dict().keys())
-    # MODEL:274-283: children 0 = conv1, 1 = bn1, 4..7 = layer1..4
-    for k in ("0.weight", "1.running_var", "4.0.conv1.weight", "4.0.downsample.0.weight", "4.0.downsample.1.running_mean",
-              "6.22.bn3.weight", "7.2.conv3.weight"):
-        assert k in keys, k
-    assert len([k for k in keys if k.endswith("conv2.weight")]) == 33
-
-
 def test_model_from_raw_images_equals_model_from_trunk_features():
     """ENGINE:825 hands the model raw images; the benchmark entry hands it the [B,2048,14,14] maps.  Both
     must be the same computation: run the two trunks alone, feed their maps to the model, compare with the model run
