@@ -549,11 +549,267 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Warp-specialised form: twelve waves, three per SIMD.  Waves 8..11 (one per SIMD) are PRODUCERS -- they only issue the
+// LDS-DMA pieces of the slice stream (a quarter of every slice each) and wait for them; waves 0..7 only read fragments,
+// issue MFMAs and run the epilogue.  In the eight-wave form a compute wave spent ~1.2-1.4 k cycles per slice stalled in
+// the issue of its six DMA pieces (the vector-memory path was backed up) against ~0.7 k cycles of its own MFMA work;
+// here that stall sits in waves that have nothing else to do.  One s_barrier per slice still publishes slice g+1 and
+// frees the stage of slice g.  Compute waves have no DMA in their vector-memory queue, so their waits are plain.
+constexpr int NTHR_WS = 768, NPROD = 4;
+
+template <int NJ, bool HAS_RES, bool OUT_NCHW>
+__global__ __launch_bounds__(NTHR_WS) void conv_igemm_ws_kernel(const ConvArgs a) {
+    constexpr int TN = 32 * NJ, B_BYTES = TN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int B_PIECES = B_BYTES / 1024;
+    constexpr int APP = A_PIECES / NPROD, BPP = B_PIECES / NPROD, PPP = APP + BPP;   // pieces per producer and slice: 8 + 4 (2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
+    const int per = a.rps * a.nct;
+    const int K = a.KH * a.KW * a.Cin, nk = K / BK;
+    const int ohw = a.OH * a.OW;
+
+    auto decode = [&](int j, int& m0, int& n0) {
+        const int sl = j / per, within = j - sl * per;
+        const int rb = (sl * 8 + xcd) * a.rps + within / a.nct, ct = within % a.nct;
+        m0 = rb * TM;
+        n0 = ct * TN;
+        return j < a.jmax && rb < a.nrb;
+    };
+    auto next_valid = [&](int j, int& m0, int& n0) {
+        while (j < a.jmax && !decode(j, m0, n0)) j += jstep;
+        return j;
+    };
+    int ntiles = 0;
+    {
+        int m0, n0;
+        for (int j = jj0; j < a.jmax; j += jstep) ntiles += decode(j, m0, n0) ? 1 : 0;
+    }
+    if (ntiles == 0) return;
+    const int S = ntiles * nk;
+
+    if (wave >= 8) {
+        // =============================== producer ===============================
+        const int q = wave - 8;
+        const int row_in = lane >> 3, slot = lane & 7;
+        const int chunk = slot ^ (4 * (q & 1) + (row_in >> 1));    // pieces q + 4 i: p & 1 == q & 1
+        int im0 = 0, in0 = 0, ikt = 0, ig = 0;
+        int ij = next_valid(jj0, im0, in0);
+        int ih0[APP], iw0[APP];
+        long long base[APP];
+        auto rows_of_tile = [&]() {
+            const int b0 = im0 / ohw, rem0 = im0 - b0 * ohw;
+#pragma unroll
+            for (int i = 0; i < APP; ++i) {
+                const int off = (q + NPROD * i) * 8 + row_in;
+                if (im0 + off < a.M) {
+                    int x = rem0 + off;
+                    int kb = (int)((float)x * a.inv_ohw);
+                    int r = x - kb * ohw;
+                    if (r < 0) { r += ohw; --kb; } else if (r >= ohw) { r -= ohw; ++kb; }
+                    int oh = (int)((float)r * a.inv_ow);
+                    int ow = r - oh * a.OW;
+                    if (ow < 0) { ow += a.OW; --oh; } else if (ow >= a.OW) { ow -= a.OW; ++oh; }
+                    ih0[i] = oh * a.stride - a.pad;
+                    iw0[i] = ow * a.stride - a.pad;
+                    base[i] = (((long long)(b0 + kb) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+                } else {
+                    ih0[i] = -(1 << 20);
+                    iw0[i] = 0;
+                    base[i] = 0;
+                }
+            }
+        };
+        rows_of_tile();
+        const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
+        auto issue = [&]() {
+            unsigned char* sb = smem + (size_t)(ig % NSTAGE) * STAGE_BYTES;
+            const bool live = ig < S;
+            const int k0 = ikt * BK;
+            const int tap = k0 >> a.cin_shift, c0 = k0 & (a.Cin - 1);
+            const int kh = a.KW == 3 ? (tap * 11) >> 5 : 0, kw = tap - kh * a.KW;
+            const int toff = (kh * a.W + kw) * a.Cin + c0;
+            auto dma = [&](const unsigned short* src, int p) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, 0, 0);
+            };
+#pragma unroll
+            for (int i = 0; i < APP; ++i) {
+                const bool ok = live && (unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W;
+                dma(ok ? a.x + (base[i] + toff + chunk * 8) : zsrc, q + NPROD * i);
+            }
+#pragma unroll
+            for (int i = 0; i < BPP; ++i) {
+                int row = in0 + (q + NPROD * i) * 8 + row_in;
+                row = row < a.Cout ? row : a.Cout - 1;
+                dma(live ? a.wt + (size_t)row * K + k0 + chunk * 8 : zsrc, A_PIECES + q + NPROD * i);
+            }
+            ++ig;
+            if (++ikt == nk && ig < S) {
+                ikt = 0;
+                ij = next_valid(ij + jstep, im0, in0);
+                rows_of_tile();
+            }
+        };
+        issue();
+        issue();
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPP) : "memory");     // slice 0 landed
+        issue();
+        for (int g = 0; g < S; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPP) : "memory"); // slice g+1 landed; stage of slice g is free
+            issue();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // dummy pieces must not outlive the workgroup's LDS
+        return;
+    }
+
+    // =============================== compute ===============================
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+        boff[s2] = lds0 + A_BYTES + ((wc * 16 * NJ + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+    }
+    u32x4 av[2][4], bv[2][NJ];
+    auto reads = [&](int stage, int s2, int buf) {
+        const unsigned so = (unsigned)stage * STAGE_BYTES;
+        av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
+        av[buf][1] = mg_lds_read128<2048>(aoff[s2] + so);
+        av[buf][2] = mg_lds_read128<4096>(aoff[s2] + so);
+        av[buf][3] = mg_lds_read128<6144>(aoff[s2] + so);
+        bv[buf][0] = mg_lds_read128<0>(boff[s2] + so);
+        bv[buf][1] = mg_lds_read128<2048>(boff[s2] + so);
+        if constexpr (NJ == 4) {
+            bv[buf][2] = mg_lds_read128<4096>(boff[s2] + so);
+            bv[buf][3] = mg_lds_read128<6144>(boff[s2] + so);
+        }
+    };
+    auto mmas = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[buf][jj]),
+                                                                    __builtin_bit_cast(bf16x8, av[buf][i]), acc[i][jj], 0, 0, 0);
+    };
+    int cm0 = 0, cn0 = 0, ckt = 0;
+    int cj = next_valid(jj0, cm0, cn0);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00027000);
+    const int ncl = wc * 16 * NJ + (fg & 1) * 16 + (fg >> 1) * 8;
+    u32x4 rv[NJ / 2][4];
+    f32x4 bs[NJ / 2][2];
+    // ordinary loads (the compiler places their waits): no DMA sits in a compute wave's vector-memory queue, and an
+    // inline-asm load is only safe while nothing spills -- under register pressure hipcc reuses the destination
+    // registers of a load it cannot see is still in flight
+    auto gload = [&](const void* ptr) { return *reinterpret_cast<const u32x4*>(ptr); };
+
+    asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
+    reads(0, 0, 0);
+    for (int g = 0; g < S; ++g) {
+        const bool last = ckt == nk - 1;
+        if (last) {                                                // bias / residual of the tile this slice closes, a slice ahead of their use
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                int n = cn0 + ncl + jp * 32;
+                n = n < a.Cout ? n : a.Cout - 8;
+                bs[jp][0] = __builtin_bit_cast(f32x4, gload(a.bias + n));
+                bs[jp][1] = __builtin_bit_cast(f32x4, gload(a.bias + n + 4));
+                if (HAS_RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int m = cm0 + wr * 64 + i * 16 + fr;
+                        m = m < a.M ? m : a.M - 1;
+                        rv[jp][i] = gload(a.res + (size_t)m * a.Cout + n);
+                    }
+                }
+            }
+        }
+        reads(g % NSTAGE, 1, 1);
+        mg_lds_wait<4 + NJ>();
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this wave is done with the stage of slice g; slice g+1 landed
+        reads((g + 1) % NSTAGE, 0, 0);
+        mg_lds_wait<4 + NJ>();
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++ckt < nk) continue;
+        ckt = 0;
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            const int n = cn0 + ncl + jp * 32;
+            const bool ncok = n < a.Cout;
+            const f32x4 b0 = bs[jp][0], b1 = bs[jp][1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                             "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+                acc[i][2 * jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * jp + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int m = cm0 + wr * 64 + i * 16 + fr;
+                const bool ok = ncok && m < a.M;
+                float o[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = lo[r] + b0[r];
+                    o[4 + r] = hi[r] + b1[r];
+                }
+                if (HAS_RES) {
+                    const unsigned int u[4] = {rv[jp][i][0], rv[jp][i][1], rv[jp][i][2], rv[jp][i][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[2 * r] += __uint_as_float(u[r] << 16);
+                        o[2 * r + 1] += __uint_as_float(u[r] & 0xFFFF0000u);
+                    }
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = fmaxf(o[r], 0.f);
+                }
+                if (OUT_NCHW) {
+                    const int mm = ok ? m : 0;
+                    const int b = mm / ohw, p = mm - b * ohw;
+                    const unsigned int off = ok ? (unsigned int)((((size_t)b * a.Cout + n) * ohw + p) * 4) : 0xFFFFFFF0u;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[r]), y_rsrc, ok ? off + (unsigned)(r * ohw * 4) : off, 0, 0);
+                } else {
+                    i32x4 ov;
+                    ov[0] = (int)pack2(o[0], o[1]);
+                    ov[1] = (int)pack2(o[2], o[3]);
+                    ov[2] = (int)pack2(o[4], o[5]);
+                    ov[3] = (int)pack2(o[6], o[7]);
+                    const unsigned int off = ok ? (unsigned int)(((size_t)m * a.Cout + n) * 2) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, y_rsrc, off, 0, 0);
+                }
+            }
+        }
+        cj = next_valid(cj + jstep, cm0, cn0);
+    }
+}
+
 template <int NJ, bool HAS_RES, bool OUT_NCHW>
 int launch_conv3(ConvArgs& a, hipStream_t stream, int n_cu) {
     constexpr int TN = 32 * NJ;
     constexpr size_t SMEM = (size_t)NSTAGE * (A_BYTES + TN * BK * 2);
-    auto kern = conv_igemm_kernel<NJ, HAS_RES, OUT_NCHW>;
+    // residual layers stay on the eight-wave form: with the 64 x 64 bf16 residual tile prefetched (32 registers) the compute
+    // waves of the twelve-wave form do not fit the 168 registers three waves per SIMD leave them (measured 10-30 % slower)
+    constexpr bool use_ws = !HAS_RES;
+    auto kern = use_ws ? conv_igemm_ws_kernel<NJ, HAS_RES, OUT_NCHW> : conv_igemm_kernel<NJ, HAS_RES, OUT_NCHW>;
     MG_DYN_LDS(kern, SMEM);
     a.nrb = (a.M + TM - 1) / TM;
     a.nct = (a.Cout + TN - 1) / TN;
@@ -566,7 +822,7 @@ int launch_conv3(ConvArgs& a, hipStream_t stream, int n_cu) {
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > a.jmax) per_xcd = a.jmax;
-    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NTHR), SMEM, stream, a);
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(use_ws ? NTHR_WS : NTHR), SMEM, stream, a);
     return 0;
 }
 

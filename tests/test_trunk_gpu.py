@@ -180,3 +180,11 @@ def test_model_from_raw_images_equals_model_from_trunk_features():
     out = model(*args)
     assert torch.isfinite(out).all()
     assert torch.equal(out, ref)
+    # images -> logits as ONE hipGraph (both trunks + the path, four streams): replay == eager
+    from mgnns_amd.graph import GraphedForward
+    g = GraphedForward(model, args)
+    assert torch.equal(g.replay(), ref)
+    imgs2 = _rnd((B, 3, 448, 448), 43).to(DEV)
+    args2 = list(args)
+    args2[3] = imgs2
+    assert torch.equal(g(*args2), model(*args2))

@@ -17,7 +17,7 @@ fn.argtypes = [ctypes.c_void_p]
 NAMES = ["total", "DMA issue", "k0: reads k1 + wait + 16 MFMA", "slice barrier", "k1: reads k0' + 16 MFMA", "epilogue", "slices", "tiles", "tile loads"]
 
 
-def run(k, cin, cout, hw, B=32, res=True):
+def run(k, cin, cout, hw, B=128, res=True):
     x = torch.randn(B, hw, hw, cin, device=DEV).to(torch.bfloat16)
     w = (torch.randn(cout, k * k * cin, device=DEV) * 0.05).to(torch.bfloat16)
     b = torch.randn(cout, device=DEV)
