@@ -2,8 +2,9 @@
 // [N,N] adjacency path of the label / vocabulary graph GCN, UTIL:421-426 `adj @ support`, and any large X.W):
 //   C[M,N] = act(A[M,K] . Bt[N,K]^T + bias),  A and Bt bf16, K-contiguous rows of Kp elements (Kp % 64 == 0, zero padded)
 //
-// Workgroup tile 256 x 128, eight waves 4 x 2 = two per SIMD (wave tile 64 x 64 = 4 x 4 MFMA tiles; with one wave per
-// SIMD and a 128 x 64 wave tile the MFMAs issued at ~36 cycles instead of ~17 next to the fragment reads),
+// Workgroup tile 256 x 128, eight compute waves 4 x 2 = two per SIMD (wave tile 64 x 64 = 4 x 4 MFMA tiles; with one wave per
+// SIMD and a 128 x 64 wave tile the MFMAs issued at ~36 cycles instead of ~17 next to the fragment reads) plus four producer
+// waves that issue the LDS-DMA stream (persistent workgroups, see the kernel),
 // BK = 64.  Both operand tiles go global -> LDS by LDS-DMA (no VGPR round trip) through a three-stage ring (48 KB
 // per stage: rows of 8 16-B chunks, chunk index XOR ((row >> 1) & 7) so that the ds_read_b128 fragment pattern -- 16 rows
 // x one chunk column -- is bank-conflict free without padding, which LDS-DMA could not write); one barrier per
@@ -20,9 +21,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int TM = 256, TN = 128, BK = 64, NSTAGE = 3, NTHR = 512, NWAVE = NTHR / 64;
-constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 32 KB + 16 KB
-constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVE;                               // 48 DMA pieces, 6 per wave
+constexpr int TM = 256, TN = 128, BK = 64, NSTAGE = 3;
+constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 32 KB + 16 KB = 48 DMA pieces
 constexpr size_t SMEM_BYTES = (size_t)NSTAGE * STAGE_BYTES;
 
 // y[c, 0:ld] = bf16(x[0:rows, c]) (transpose + cast, zero padded to ld): the K-contiguous Bt operand from a [K,N] matrix
@@ -46,49 +46,97 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ A,
-                                                            const unsigned short* __restrict__ Bt, int M, int N, int Kp,
-                                                            const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                            int act, int nrb, int nct, int rps) {
+// Persistent, warp specialised (the structure measured on the convolutions, conv_bf16.hip): one workgroup per CU walks its
+// tiles in XCD-aware order; waves 8..11 (one per SIMD) only issue the LDS-DMA pieces of the slice stream -- the slices of ALL
+// the workgroup's tiles, one after the other, through the three-stage ring -- and wait for them; waves 0..7 only read
+// fragments, issue MFMAs and store.  (With the DMA issue inside the compute waves each of them stalled ~1.2 k cycles per slice
+// in the backed-up vector-memory path against ~0.7 k cycles of MFMA work.)
+constexpr int NTHR_WS = 768, NPROD = 4, A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;
+constexpr int APP = A_PIECES / NPROD, BPP = B_PIECES / NPROD, PPP = APP + BPP;     // 8 + 4 pieces per producer and slice
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ A,
+                                                               const unsigned short* __restrict__ Bt, int M, int N, int Kp,
+                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                               int act, int nrb, int nct, int rps, int jmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- XCD-aware tile map
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
     const int per = rps * nct;
-    const int sl = j / per, within = j - sl * per;
-    const int rb = (sl * 8 + xcd) * rps + within / nct, ct = within % nct;
-    if (rb >= nrb) return;
-    const int m0 = rb * TM, n0 = ct * TN;
-    const int wr = wave >> 1, wc = wave & 1;                       // wave tile: rows wr*64.., cols wc*64..
     const int nk = Kp / BK;
-
-    // ---- LDS-DMA of one BK slice: piece p covers 8 rows x 128 B; lane (row_in = lane >> 3, slot = lane & 7) fetches
-    //      the chunk that belongs in its slot (rows r and r + 8 of a fragment sit 1 KiB apart = the same banks, so the
-    //      swizzle has to tell them apart: it uses row bits 1..3; row bit 0 already selects the 128-B half of a bank row)
-    const int row_in = lane >> 3, slot = lane & 7;
-    auto issue = [&](int kt, int stage) {
-        unsigned char* sb = smem + (size_t)stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave + NWAVE * i;                       // wave-uniform
-            // slot = chunk ^ ((row >> 1) & 7); a piece starts at a multiple of 8 rows: (row >> 1) & 7 = 4 (p & 1) + (row_in >> 1)
-            const int chunk = slot ^ (4 * (p & 1) + (row_in >> 1));   // p & 1 == (p - 32) & 1: same rule for the Bt pieces
-            const unsigned short* src;
-            if (p < A_BYTES / 1024) {
-                int row = m0 + p * 8 + row_in;
-                row = row < M ? row : M - 1;                      // rows beyond M: any valid row (never stored)
-                src = A + (size_t)row * Kp + (size_t)kt * BK + chunk * 8;
-            } else {
-                int row = n0 + (p - A_BYTES / 1024) * 8 + row_in;
-                row = row < N ? row : N - 1;
-                src = Bt + (size_t)row * Kp + (size_t)kt * BK + chunk * 8;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, 0, 0);
-        }
+    // virtual tile j of this XCD -> (m0, n0); false beyond the last row block
+    auto decode = [&](int j, int& m0, int& n0) {
+        const int sl = j / per, within = j - sl * per;
+        const int rb = (sl * 8 + xcd) * rps + within / nct, ct = within % nct;
+        m0 = rb * TM;
+        n0 = ct * TN;
+        return j < jmax && rb < nrb;
     };
+    auto next_valid = [&](int j, int& m0, int& n0) {
+        while (j < jmax && !decode(j, m0, n0)) j += jstep;
+        return j;
+    };
+    int ntiles = 0;
+    {
+        int m0, n0;
+        for (int j = jj0; j < jmax; j += jstep) ntiles += decode(j, m0, n0) ? 1 : 0;
+    }
+    if (ntiles == 0) return;
+    const int S = ntiles * nk;                                     // slices in this workgroup's stream
 
+    if (wave >= 8) {
+        // ---- producer q: A pieces q + 4 i, Bt pieces 32 + q + 4 i of every slice.  Piece p covers 8 rows x 128 B; lane
+        //      (row_in = lane >> 3, slot = lane & 7) fetches the chunk that belongs in its slot: slot = chunk ^ ((row >> 1) & 7),
+        //      and a piece starts at a multiple of 8 rows, so (row >> 1) & 7 = 4 (p & 1) + (row_in >> 1), p & 1 == q & 1.
+        const int q = wave - 8;
+        const int row_in = lane >> 3, slot = lane & 7;
+        const int chunk = slot ^ (4 * (q & 1) + (row_in >> 1));
+        int im0 = 0, in0 = 0, ikt = 0, ig = 0;
+        int ij = next_valid(jj0, im0, in0);
+        const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
+        auto issue = [&]() {                                       // slice ig of the stream -> stage ig % NSTAGE; then advance
+            unsigned char* sb = smem + (size_t)(ig % NSTAGE) * STAGE_BYTES;
+            const bool live = ig < S;                              // past the end: dummy pieces keep the operation count fixed
+            const size_t koff = (size_t)ikt * BK + chunk * 8;
+            auto dma = [&](const unsigned short* src, int p) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, 0, 0);
+            };
+#pragma unroll
+            for (int i = 0; i < APP; ++i) {
+                int row = im0 + (q + NPROD * i) * 8 + row_in;
+                row = row < M ? row : M - 1;                       // rows beyond M: any valid row (never stored)
+                dma(live ? A + (size_t)row * Kp + koff : zsrc, q + NPROD * i);
+            }
+#pragma unroll
+            for (int i = 0; i < BPP; ++i) {
+                int row = in0 + (q + NPROD * i) * 8 + row_in;
+                row = row < N ? row : N - 1;
+                dma(live ? Bt + (size_t)row * Kp + koff : zsrc, A_PIECES + q + NPROD * i);
+            }
+            ++ig;
+            if (++ikt == nk && ig < S) {
+                ikt = 0;
+                ij = next_valid(ij + jstep, im0, in0);
+            }
+        };
+        // bare s_waitcnt + s_barrier: __syncthreads() carries vmcnt(0) and would wait for the slices just requested
+        issue();
+        issue();
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPP) : "memory");      // slice 0 landed
+        issue();
+        for (int g = 0; g < S; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPP) : "memory");  // slice g+1 landed; the stage of slice g is free
+            issue();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // dummy pieces must not outlive the workgroup's LDS
+        return;
+    }
+
+    // ---- compute wave: tile rows wr*64.., columns wc*64.. (4 x 4 MFMA tiles)
+    const int wr = wave >> 1, wc = wave & 1;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -97,8 +145,7 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
 
     // fragment addresses: lane (r = lane & 15, g = lane >> 4) reads chunk (4 s + g) ^ ((r >> 1) & 7) of row (tile * 16 + r);
     // tile i of a wave lies i * 2 KiB further on (immediate offset).  The reads go through mg_lds_read128 (inline asm):
-    // as ordinary ds_reads hipcc guards each group with s_waitcnt vmcnt(0) against the LDS-DMA in flight, i.e. it
-    // waits for the slice that was requested a moment ago and the three-stage ring never overlaps anything.
+    // as ordinary ds_reads hipcc guards each group with s_waitcnt vmcnt(0) against the LDS-DMA in flight.
     const int fr = lane & 15, fg = lane >> 4;
     const unsigned lds0 = mg_lds_addr(smem);
     unsigned aoff[2], boff[2];
@@ -107,13 +154,6 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
         aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
         boff[s2] = lds0 + A_BYTES + ((wc * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
     }
-
-    // Software pipeline: fragments are double buffered per k-step; the reads of k-step 1 are issued before the MFMAs
-    // of k-step 0, and -- behind the slice barrier placed in the MIDDLE of an iteration -- the reads of the NEXT
-    // slice's k-step 0 before the MFMAs of k-step 1.  The barrier also frees the current slice's stage (both k-steps
-    // are in registers by then) for the DMA of slice kt + 3.  Barriers are bare s_barrier + the s_waitcnt actually
-    // needed: __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0), which would wait for DMA slices
-    // that were only just requested.
     u32x4 a[2][4], b[2][4];
     auto reads = [&](int stage, int s, int buf) {
         const unsigned so = (unsigned)stage * STAGE_BYTES;
@@ -126,6 +166,7 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
         b[buf][2] = mg_lds_read128<4096>(boff[s] + so);
         b[buf][3] = mg_lds_read128<6144>(boff[s] + so);
     };
+    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns
     auto mmas = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -134,54 +175,43 @@ __global__ __launch_bounds__(NTHR) void gemm_bf16_nt_kernel(const unsigned short
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
                                                                     __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
     };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (nk > 2) issue(2, 2);
+    int cm0 = 0, cn0 = 0, ckt = 0;
+    int cj = next_valid(jj0, cm0, cn0);
+    asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
     reads(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        reads(kt % NSTAGE, 1, 1);
-        mg_lds_wait<8>();                                     // k-step 0 landed (the 8 reads of k-step 1 are behind it)
+    // software pipeline: the reads of k-step 1 are issued before the MFMAs of k-step 0 and -- behind the slice barrier in the
+    // MIDDLE of the iteration -- the reads of the next slice's k-step 0 before the MFMAs of k-step 1
+    for (int g = 0; g < S; ++g) {
+        reads(g % NSTAGE, 1, 1);
+        mg_lds_wait<8>();                                          // k-step 0 landed (the 8 reads of k-step 1 are behind it)
         __builtin_amdgcn_sched_barrier(0);
         mmas(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            // slice kt+1 landed: of this wave's DMA pieces at most those of slice kt+2 may still be in flight; this wave's
-            // fragment reads of slice kt are complete (lgkmcnt) so its stage may be overwritten after the barrier
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // the two waves of a SIMD issue their DMA pieces (~100+ cycles each, MFMA issue blocked meanwhile) at
-            // DIFFERENT points of the iteration: waves 0-3 here, waves 4-7 after their second k-step
-            if (wave < 4 && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
-            reads((kt + 1) % NSTAGE, 0, 0);
-            mg_lds_wait<8>();                                 // k-step 1 landed at the barrier (lgkmcnt(0)); orders the MFMAs
-        } else {
-            mg_lds_wait<0>();
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done with the stage of slice g; slice g+1 landed
+        reads((g + 1) % NSTAGE, 0, 0);
+        mg_lds_wait<8>();
         __builtin_amdgcn_sched_barrier(0);
         mmas(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (wave >= 4 && kt + 1 < nk && kt + 3 < nk) issue(kt + 3, kt % NSTAGE);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue: acc[i][jj][r] = C[m0 + wr*64 + 16 i + (lane & 15)][n0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
+        if (++ckt < nk) continue;
+        ckt = 0;
+        // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*64 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int n = n0 + wc * 64 + jj * 16 + fg * 4;
-        if (n >= N) continue;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = cn0 + wc * 64 + jj * 16 + fg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + fr;
-            if (m >= M) continue;
-            f32x4 o;
+            for (int i = 0; i < 4; ++i) {
+                const int m = cm0 + wr * 64 + i * 16 + fr;
+                f32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
-            *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+                for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+                acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && n < N) *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+            }
         }
+        cj = next_valid(cj + jstep, cm0, cn0);
     }
 }
 
@@ -212,10 +242,18 @@ extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int 
     if (rps < 1) rps = 1;
     if (rps > nrb) rps = nrb;
     const int supers = (nrb + rps - 1) / rps;
-    const int blocks = 8 * ((supers + 7) / 8) * rps * nct;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(blocks), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream,
+    const int jmax = ((supers + 7) / 8) * rps * nct;               // virtual tiles per XCD
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+        mgnns_set_error("mgnns_gemm_bf16_nt_fwd: cannot query the CU count");
+        return MGNNS_ERR_LAUNCH;
+    }
+    int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
+    if (per_xcd < 1) per_xcd = 1;
+    if (per_xcd > jmax) per_xcd = jmax;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM_BYTES, (hipStream_t)stream,
                        reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
-                       ldc, act, nrb, nct, rps);
+                       ldc, act, nrb, nct, rps, jmax);
     MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd");
     return 0;
 }
