@@ -5,11 +5,11 @@
 //                           w'[o, (kh, kw, c)] = bf16(w[o, c, kh, kw] * gamma[o] / sqrt(var[o] + eps)), b'[o] = beta - mean * scale
 //   stem_conv7_kernel       conv1 7x7 / stride 2 / pad 3 (3 -> 64) + bn1 + ReLU, NCHW fp32 image -> NHWC bf16
 //   maxpool3x3s2_kernel     MaxPool2d(3, 2, 1) on NHWC bf16
-//   conv_igemm_kernel       every 1x1 / 3x3 convolution of the bottlenecks as an implicit GEMM on
+//   conv_igemm_ws_kernel    every 1x1 / 3x3 convolution of the bottlenecks as an implicit GEMM on
 //                           v_mfma_f32_16x16x32_bf16:  Y[m, o] = relu?( sum_k X[pixel(m, tap(k)), c(k)] * w'[o, k] + b'[o] + R[m, o] )
 //
 // Activations are NHWC bf16 ([B, H, W, C], C contiguous = the GEMM's K axis), accumulation fp32.  The implicit GEMM is
-// the dense bf16 GEMM of gemm_bf16.hip (256 x 128 workgroup tile, 8 waves, BK = 64, three-stage LDS-DMA ring, XOR chunk
+// the dense bf16 GEMM of gemm_bf16.hip (256 x 128 workgroup tile, 8 compute + 4 producer waves, BK = 64, three-stage LDS-DMA ring, XOR chunk
 // swizzle, XCD-aware super tiles) with the A rows resolved per BK slice: C_in is a power of two >= 64, so one BK slice
 // lies inside one filter tap (kh, kw) and an A row of the slice is 128 contiguous bytes of the input pixel
 // (oh*s - p + kh, ow*s - p + kw), or 16 zero bytes from g_zero16 when that pixel is padding.  No im2col buffer exists.
@@ -193,33 +193,22 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const unsigned short*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Implicit-GEMM convolution, persistent form.  One workgroup per CU walks its tiles (XCD-aware order: the 32
-// workgroups of an XCD work on one super tile of row blocks x all column tiles at a time) and treats the BK slices of ALL
-// its tiles as one stream through the three-stage LDS-DMA ring: the slices of the next tile are requested while the
-// current tile still computes, and the epilogue's residual loads / output stores overlap the next tile's first slices.
-// (The one-tile-per-workgroup form spent as long in prologue + epilogue as in the MFMA loop on the K <= 256 layers.)
-//
-// Every vector-memory operation of a wave is issued UNCONDITIONALLY and in a fixed order -- DMA pieces beyond the end of
-// the stream fetch the zero source into a free stage, residual loads use clamped addresses, output stores are buffer
-// stores whose offset is pushed out of range for rows / channels outside the tensor -- so the number of operations
-// behind a given DMA slice is known at compile time and s_waitcnt vmcnt(N) can wait for exactly that slice (memory
-// operations complete in order) while younger DMA slices, loads and stores stay in flight.
-constexpr int TM = 256, BK = 64, NSTAGE = 3, NTHR = 512, NWAVE = NTHR / 64;
+// Implicit-GEMM convolution: persistent and warp specialised.  One workgroup per CU walks its tiles (XCD-aware order: the 32
+// workgroups of an XCD work on one super tile of row blocks x all column tiles at a time) and treats the BK slices of ALL its
+// tiles as one stream through the three-stage LDS-DMA ring, so the slices of the next tile are requested while the current
+// tile still computes and the epilogue's loads / stores overlap the next tile's first slices.  Twelve waves, three per SIMD:
+// waves 8..11 (one per SIMD) are PRODUCERS -- they only issue the LDS-DMA pieces of the slice stream (a quarter of every
+// slice each; pieces past the end of the stream fetch a zero source so the operation count behind a slice is fixed and
+// s_waitcnt vmcnt(N) is exact) and wait for them; waves 0..7 only read fragments, issue MFMAs and run the epilogue.  One
+// s_barrier per slice publishes slice g+1 and frees the stage of slice g.
+// History (all measured): one tile per workgroup with the DMA issue inside the eight compute waves: 6.96 ms per
+// 32 ResNet-101 images; 16-byte epilogue 6.12; persistent stream + inline-asm LDS reads 5.19 (a compute wave still stalled
+// ~1.2-1.4 k cycles per slice in the issue of its six DMA pieces -- the vector-memory path was backed up -- against ~0.7 k
+// cycles of its own MFMA work, in-kernel timer); v_cvt_pk_bf16_f32 epilogue 4.96; producer waves 4.73.
+constexpr int TM = 256, BK = 64, NSTAGE = 3;
 constexpr int A_BYTES = TM * BK * 2, A_PIECES = A_BYTES / 1024;      // 32 KB = 32 DMA pieces of 8 rows x 128 B
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-#ifdef MG_CONV_TRACE
-// in-kernel phase timer (tools/conv_trace.py): cycles (s_memtime) wave 0 and wave 4 of workgroup 0 spend in each part of the
-// slice loop, accumulated over the launch: [wave][0 total, 1 DMA issue, 2 k-step-0 wait + MFMAs, 3 slice barrier wait,
-// 4 k-step-1 reads + MFMAs, 5 epilogue, 6 slices, 7 tiles, 8 tile-closing loads]
-__device__ unsigned long long g_conv_trace[2][16];
-#define MG_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define MG_TACC(slot, t0, t1) if (trace_on) tr[slot] += (t1) - (t0)
-#else
-#define MG_T(var)
-#define MG_TACC(slot, t0, t1)
-#endif
 
 struct ConvArgs {
     const unsigned short* x;      // [B, H, W, Cin] bf16
@@ -233,329 +222,6 @@ struct ConvArgs {
     int nrb, nct, rps, jmax;      // tile map: row blocks, column tiles, row blocks per super tile, virtual tiles per XCD
 };
 
-// s_waitcnt vmcnt(N) + workgroup barrier, N = PPW + NS * stores_behind + NR * loads_behind (see the kernel)
-template <int PPW, int NS, int NR>   // NR: tile-closing loads
-__device__ __forceinline__ void slice_wait(int l0, int l1, int l2) {
-#define MG_W(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((n) > 63 ? 63 : (n)) : "memory")
-    switch (l2 * 4 + l1 * 2 + l0) {
-        case 0: MG_W(PPW); break;
-        case 1: MG_W(PPW + NR); break;
-        case 2: MG_W(PPW + NS + NR); break;
-        case 3: MG_W(PPW + NS + 2 * NR); break;
-        case 4: MG_W(PPW + NS); break;
-        case 5: MG_W(PPW + NS + NR); break;
-        case 6: MG_W(PPW + 2 * NS + NR); break;
-        default: MG_W(PPW + 2 * NS + 2 * NR); break;
-    }
-#undef MG_W
-}
-
-template <int NJ, bool HAS_RES, bool OUT_NCHW>
-__global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int TN = 32 * NJ, B_BYTES = TN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVE;          // 48 / 6 (NJ = 4), 40 / 5 (NJ = 2)
-    constexpr int NL = NJ + (HAS_RES ? 2 * NJ : 0);                           // tile-closing loads per wave: bias, residual
-    constexpr int NS = OUT_NCHW ? 16 * NJ : 2 * NJ;                           // output stores per wave and tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
-    const int per = a.rps * a.nct;
-    const int K = a.KH * a.KW * a.Cin, nk = K / BK;
-    const int ohw = a.OH * a.OW;
-
-    // virtual tile j of this XCD -> (m0, n0); false when it lies beyond the last row block
-    auto decode = [&](int j, int& m0, int& n0) {
-        const int sl = j / per, within = j - sl * per;
-        const int rb = (sl * 8 + xcd) * a.rps + within / a.nct, ct = within % a.nct;
-        m0 = rb * TM;
-        n0 = ct * TN;
-        return j < a.jmax && rb < a.nrb;
-    };
-    auto next_valid = [&](int j, int& m0, int& n0) {     // first valid tile at or after j (stride jstep), or >= jmax
-        while (j < a.jmax && !decode(j, m0, n0)) j += jstep;
-        return j;
-    };
-    int ntiles = 0;
-    {
-        int m0, n0;
-        for (int j = jj0; j < a.jmax; j += jstep) ntiles += decode(j, m0, n0) ? 1 : 0;
-    }
-    if (ntiles == 0) return;
-    const int S = ntiles * nk;                          // slices in this workgroup's stream
-
-    // ---- issue side: tile, slice within the tile, and the four A rows this lane feeds (pieces wave + 8 i)
-    const int row_in = lane >> 3, slot = lane & 7;
-    int ij, im0 = 0, in0 = 0, ikt = 0, ig = 0;
-    int ih0[4], iw0[4];
-    long long base[4];
-    auto rows_of_tile = [&]() {
-        const int b0 = im0 / ohw, rem0 = im0 - b0 * ohw;          // uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (wave + NWAVE * i) * 8 + row_in;
-            if (im0 + off < a.M) {
-                int x = rem0 + off;                                // < ohw + 256 < 2^24: float quotient +-1
-                int kb = (int)((float)x * a.inv_ohw);
-                int r = x - kb * ohw;
-                if (r < 0) { r += ohw; --kb; } else if (r >= ohw) { r -= ohw; ++kb; }
-                int oh = (int)((float)r * a.inv_ow);
-                int ow = r - oh * a.OW;
-                if (ow < 0) { ow += a.OW; --oh; } else if (ow >= a.OW) { ow -= a.OW; ++oh; }
-                ih0[i] = oh * a.stride - a.pad;
-                iw0[i] = ow * a.stride - a.pad;
-                base[i] = (((long long)(b0 + kb) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
-            } else {
-                ih0[i] = -(1 << 20);
-                iw0[i] = 0;
-                base[i] = 0;
-            }
-        }
-    };
-    ij = next_valid(jj0, im0, in0);
-    rows_of_tile();
-    const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
-
-    auto issue = [&]() {                                 // DMA of stream slice ig into stage ig % NSTAGE, then advance
-        unsigned char* sb = smem + (size_t)(ig % NSTAGE) * STAGE_BYTES;
-        const bool live = ig < S;
-        const int k0 = ikt * BK;
-        const int tap = k0 >> a.cin_shift, c0 = k0 & (a.Cin - 1);
-        const int kh = a.KW == 3 ? (tap * 11) >> 5 : 0, kw = tap - kh * a.KW;   // KW in {1, 3}
-        const int toff = (kh * a.W + kw) * a.Cin + c0;
-        auto dma = [&](const unsigned short* src, int p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, 0, 0);
-        };
-        // slot = chunk ^ ((row >> 1) & 7); a piece starts at a multiple of 8 rows: (row >> 1) & 7 = 4 (p & 1) + (row_in >> 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                             // A pieces p = wave + 8 i < 32
-            const int p = wave + NWAVE * i;
-            const int chunk = slot ^ (4 * (p & 1) + (row_in >> 1));
-            const bool ok = live && (unsigned)(ih0[i] + kh) < (unsigned)a.H && (unsigned)(iw0[i] + kw) < (unsigned)a.W;
-            dma(ok ? a.x + (base[i] + toff + chunk * 8) : zsrc, p);
-        }
-#pragma unroll
-        for (int i = 4; i < PPW; ++i) {                           // weight pieces
-            const int p = wave + NWAVE * i;
-            const int chunk = slot ^ (4 * (p & 1) + (row_in >> 1));
-            int row = in0 + (p - A_PIECES) * 8 + row_in;
-            row = row < a.Cout ? row : a.Cout - 1;
-            dma(live ? a.wt + (size_t)row * K + k0 + chunk * 8 : zsrc, p);
-        }
-        ++ig;
-        if (++ikt == nk && ig < S) {                              // uniform: the stream moves on to the next tile
-            ikt = 0;
-            ij = next_valid(ij + jstep, im0, in0);
-            rows_of_tile();
-        }
-    };
-
-    const int wr = wave >> 1, wc = wave & 1;                       // wave tile: rows wr*64.., cols wc*16*NJ..
-    f32x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment reads through mg_lds_read128 (common.hpp): as ordinary ds_reads hipcc guards each group with
-    // s_waitcnt vmcnt(0) against the LDS-DMA in flight, and the ring never overlaps anything
-    const int fr = lane & 15, fg = lane >> 4;
-    const unsigned lds0 = mg_lds_addr(smem);
-    unsigned aoff[2], boff[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
-        boff[s2] = lds0 + A_BYTES + ((wc * 16 * NJ + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
-    }
-    u32x4 av[2][4], bv[2][NJ];
-    auto reads = [&](int stage, int s2, int buf) {
-        const unsigned so = (unsigned)stage * STAGE_BYTES;
-        av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
-        av[buf][1] = mg_lds_read128<2048>(aoff[s2] + so);
-        av[buf][2] = mg_lds_read128<4096>(aoff[s2] + so);
-        av[buf][3] = mg_lds_read128<6144>(aoff[s2] + so);
-        bv[buf][0] = mg_lds_read128<0>(boff[s2] + so);
-        bv[buf][1] = mg_lds_read128<2048>(boff[s2] + so);
-        if constexpr (NJ == 4) {
-            bv[buf][2] = mg_lds_read128<4096>(boff[s2] + so);
-            bv[buf][3] = mg_lds_read128<6144>(boff[s2] + so);
-        }
-    };
-    auto mmas = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[buf][jj]),
-                                                                    __builtin_bit_cast(bf16x8, av[buf][i]), acc[i][jj], 0, 0, 0);
-    };
-
-    // ---- compute side
-    int cj, cm0 = 0, cn0 = 0, ckt = 0;
-    cj = next_valid(jj0, cm0, cn0);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00027000);
-    const int ncl = wc * 16 * NJ + (fg & 1) * 16 + (fg >> 1) * 8;   // this lane's 8 channels of pair jp: cn0 + ncl + 32 jp ..
-    // tile-closing loads (residual, bias): inline asm, so that the compiler -- which would wait for them with vmcnt(0), i.e.
-    // for every DMA slice in flight -- does not see them; the epilogue waits with vmcnt(PPW): exactly one DMA slice is
-    // issued between these loads and their use
-    u32x4 rv[NJ / 2][4];
-    f32x4 bs[NJ / 2][2];
-    auto gload = [&](const void* ptr) {
-        u32x4 v;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-        return v;
-    };
-
-#ifdef MG_CONV_TRACE
-    const bool trace_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
-    unsigned long long tr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    MG_T(t_begin);
-    issue();
-    issue();
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
-    issue();
-    reads(0, 0, 0);
-    int l1 = 0, l2 = 0;                                            // "slice g-1 / g-2 closed a tile"
-    for (int g = 0; g < S; ++g) {
-        const int l0 = ckt == nk - 1 ? 1 : 0;
-        MG_T(t0);
-        if (l0) {
-#pragma unroll
-            for (int jp = 0; jp < NJ / 2; ++jp) {
-                int n = cn0 + ncl + jp * 32;
-                n = n < a.Cout ? n : a.Cout - 8;                   // clamped: always a valid address, never a skipped load
-                bs[jp][0] = __builtin_bit_cast(f32x4, gload(a.bias + n));
-                bs[jp][1] = __builtin_bit_cast(f32x4, gload(a.bias + n + 4));
-                if (HAS_RES) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int m = cm0 + wr * 64 + i * 16 + fr;
-                        m = m < a.M ? m : a.M - 1;
-                        rv[jp][i] = gload(a.res + (size_t)m * a.Cout + n);
-                    }
-                }
-            }
-        }
-        MG_T(t1);
-        reads(g % NSTAGE, 1, 1);
-        mg_lds_wait<4 + NJ>();                                     // k-step 0 landed (the reads of k-step 1 are behind it)
-        __builtin_amdgcn_sched_barrier(0);
-        mmas(0);
-        __builtin_amdgcn_sched_barrier(0);
-        MG_T(t2);
-        // slice g+1 landed: behind it are DMA slice g+2 and whatever the tile ends at g-2, g-1, g put in between
-        slice_wait<PPW, NS, NL>(l0, l1, l2);
-        MG_T(t3);
-        // the two waves of a SIMD issue their DMA pieces (~100+ cycles each, MFMA issue blocked meanwhile) at
-        // DIFFERENT points of the iteration: waves 0-3 here, waves 4-7 after their second k-step
-        if (wave < 4) issue();
-        MG_T(t4);
-        reads((g + 1) % NSTAGE, 0, 0);
-        mg_lds_wait<4 + NJ>();                                     // k-step 1 landed at the barrier (lgkmcnt(0))
-        __builtin_amdgcn_sched_barrier(0);
-        mmas(1);
-        __builtin_amdgcn_sched_barrier(0);
-        MG_T(t5);
-        if (wave >= 4) issue();
-        __builtin_amdgcn_sched_barrier(0);
-        MG_T(t6);
-        MG_TACC(8, t0, t1);
-        MG_TACC(2, t1, t2);
-        MG_TACC(3, t2, t3);
-        MG_TACC(1, t3, t4);
-        MG_TACC(4, t4, t5);
-        MG_TACC(1, t5, t6);
-#ifdef MG_CONV_TRACE
-        tr[6] += 1;
-#endif
-        l2 = l1;
-        l1 = l0;
-        if (++ckt < nk) continue;
-        ckt = 0;
-
-        // ---- epilogue of tile (cm0, cn0).  acc[i][jj][r] = Y[cm0 + wr*64 + 16 i + fr][cn0 + wc*16*NJ + 16 jj + 4 fg + r]: a
-        // lane holds 4 consecutive channels of a pixel per tile.  One v_permlane16_swap per register between the tiles of a
-        // pair (2 jp, 2 jp + 1) trades the odd 16-lane rows of the first with the even rows of the second, after which lane
-        // (fr, fg) holds EIGHT consecutive channels -- (fg & 1) * 16 + (fg >> 1) * 8 .. + 7 of the 32-channel pair -- so
-        // residual loads and output stores are 16 bytes per lane in 64-byte runs per pixel.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // bias / residual landed; DMA slice g+3 stays in flight
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jp = 0; jp < NJ / 2; ++jp) {
-            const int n = cn0 + ncl + jp * 32;
-            const bool ncok = n < a.Cout;
-            const f32x4 b0 = bs[jp][0], b1 = bs[jp][1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                             "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
-                acc[i][2 * jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[i][2 * jp + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int m = cm0 + wr * 64 + i * 16 + fr;
-                const bool ok = ncok && m < a.M;
-                float o[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o[r] = lo[r] + b0[r];
-                    o[4 + r] = hi[r] + b1[r];
-                }
-                if (HAS_RES) {
-                    const unsigned int u[4] = {rv[jp][i][0], rv[jp][i][1], rv[jp][i][2], rv[jp][i][3]};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        o[2 * r] += __uint_as_float(u[r] << 16);
-                        o[2 * r + 1] += __uint_as_float(u[r] & 0xFFFF0000u);
-                    }
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = fmaxf(o[r], 0.f);
-                }
-                if (OUT_NCHW) {
-                    const int mm = ok ? m : 0;
-                    const int b = mm / ohw, p = mm - b * ohw;
-                    const unsigned int off = ok ? (unsigned int)((((size_t)b * a.Cout + n) * ohw + p) * 4) : 0xFFFFFFF0u;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[r]), y_rsrc, ok ? off + (unsigned)(r * ohw * 4) : off, 0, 0);
-                } else {
-                    i32x4 ov;
-                    ov[0] = (int)pack2(o[0], o[1]);
-                    ov[1] = (int)pack2(o[2], o[3]);
-                    ov[2] = (int)pack2(o[4], o[5]);
-                    ov[3] = (int)pack2(o[6], o[7]);
-                    const unsigned int off = ok ? (unsigned int)(((size_t)m * a.Cout + n) * 2) : 0xFFFFFFF0u;
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, y_rsrc, off, 0, 0);
-                }
-            }
-        }
-        cj = next_valid(cj + jstep, cm0, cn0);
-        MG_T(t7);
-        MG_TACC(5, t6, t7);
-#ifdef MG_CONV_TRACE
-        tr[7] += 1;
-#endif
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dummy DMA pieces must not outlive the workgroup's LDS
-#ifdef MG_CONV_TRACE
-    if (trace_on && lane == 0) {
-        tr[0] = __builtin_readcyclecounter() - t_begin;
-        for (int i = 0; i < 9; ++i) g_conv_trace[wave >> 2][i] = tr[i];
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Warp-specialised form: twelve waves, three per SIMD.  Waves 8..11 (one per SIMD) are PRODUCERS -- they only issue the
-// LDS-DMA pieces of the slice stream (a quarter of every slice each) and wait for them; waves 0..7 only read fragments,
-// issue MFMAs and run the epilogue.  In the eight-wave form a compute wave spent ~1.2-1.4 k cycles per slice stalled in
-// the issue of its six DMA pieces (the vector-memory path was backed up) against ~0.7 k cycles of its own MFMA work;
-// here that stall sits in waves that have nothing else to do.  One s_barrier per slice still publishes slice g+1 and
-// frees the stage of slice g.  Compute waves have no DMA in their vector-memory queue, so their waits are plain.
 constexpr int NTHR_WS = 768, NPROD = 4;
 
 template <int NJ, bool HAS_RES, bool OUT_NCHW>
@@ -680,7 +346,11 @@ __global__ __launch_bounds__(NTHR_WS) void conv_igemm_ws_kernel(const ConvArgs a
         aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
         boff[s2] = lds0 + A_BYTES + ((wc * 16 * NJ + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
     }
-    u32x4 av[2][4], bv[2][NJ];
+    // with a residual the 64 x 64 bf16 residual tile is prefetched a slice ahead (32 registers): the fragments are then
+    // single buffered (read k-step, MFMAs, read k-step, MFMAs) so that the wave stays inside the 168 registers three waves
+    // per SIMD leave it; these layers (1x1, K <= 512, + residual) are bound by their activation traffic, not by the MFMAs
+    constexpr int NBUF = HAS_RES ? 1 : 2;
+    u32x4 av[NBUF][4], bv[NBUF][NJ];
     auto reads = [&](int stage, int s2, int buf) {
         const unsigned so = (unsigned)stage * STAGE_BYTES;
         av[buf][0] = mg_lds_read128<0>(aoff[s2] + so);
@@ -714,7 +384,7 @@ __global__ __launch_bounds__(NTHR_WS) void conv_igemm_ws_kernel(const ConvArgs a
     auto gload = [&](const void* ptr) { return *reinterpret_cast<const u32x4*>(ptr); };
 
     asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
-    reads(0, 0, 0);
+    if constexpr (NBUF == 2) reads(0, 0, 0);
     for (int g = 0; g < S; ++g) {
         const bool last = ckt == nk - 1;
         if (last) {                                                // bias / residual of the tile this slice closes, a slice ahead of their use
@@ -734,17 +404,31 @@ __global__ __launch_bounds__(NTHR_WS) void conv_igemm_ws_kernel(const ConvArgs a
                 }
             }
         }
-        reads(g % NSTAGE, 1, 1);
-        mg_lds_wait<4 + NJ>();
-        __builtin_amdgcn_sched_barrier(0);
-        mmas(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this wave is done with the stage of slice g; slice g+1 landed
-        reads((g + 1) % NSTAGE, 0, 0);
-        mg_lds_wait<4 + NJ>();
-        __builtin_amdgcn_sched_barrier(0);
-        mmas(1);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NBUF == 2) {
+            reads(g % NSTAGE, 1, 1);
+            mg_lds_wait<4 + NJ>();
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this wave is done with the stage of slice g; slice g+1 landed
+            reads((g + 1) % NSTAGE, 0, 0);
+            mg_lds_wait<4 + NJ>();
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            reads(g % NSTAGE, 0, 0);
+            mg_lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(0);
+            __builtin_amdgcn_sched_barrier(0);
+            reads(g % NSTAGE, 1, 0);
+            mg_lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            mmas(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");                // done with the stage of slice g; slice g+1 landed
+        }
         if (++ckt < nk) continue;
         ckt = 0;
 #pragma unroll
@@ -806,10 +490,7 @@ template <int NJ, bool HAS_RES, bool OUT_NCHW>
 int launch_conv3(ConvArgs& a, hipStream_t stream, int n_cu) {
     constexpr int TN = 32 * NJ;
     constexpr size_t SMEM = (size_t)NSTAGE * (A_BYTES + TN * BK * 2);
-    // residual layers stay on the eight-wave form: with the 64 x 64 bf16 residual tile prefetched (32 registers) the compute
-    // waves of the twelve-wave form do not fit the 168 registers three waves per SIMD leave them (measured 10-30 % slower)
-    constexpr bool use_ws = !HAS_RES;
-    auto kern = use_ws ? conv_igemm_ws_kernel<NJ, HAS_RES, OUT_NCHW> : conv_igemm_kernel<NJ, HAS_RES, OUT_NCHW>;
+    auto kern = conv_igemm_ws_kernel<NJ, HAS_RES, OUT_NCHW>;
     MG_DYN_LDS(kern, SMEM);
     a.nrb = (a.M + TM - 1) / TM;
     a.nct = (a.Cout + TN - 1) / TN;
@@ -822,7 +503,7 @@ int launch_conv3(ConvArgs& a, hipStream_t stream, int n_cu) {
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > a.jmax) per_xcd = a.jmax;
-    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(use_ws ? NTHR_WS : NTHR), SMEM, stream, a);
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM, stream, a);
     return 0;
 }
 
@@ -833,12 +514,6 @@ int launch_conv(ConvArgs& a, bool out_nchw, hipStream_t stream, int n_cu) {
 }
 
 }  // namespace
-
-#ifdef MG_CONV_TRACE
-extern "C" int mgnns_debug_conv_trace(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" int mgnns_conv_fold_bn_bf16(const float* w, const float* conv_bias, int Cout, int Cin, int KH, int KW,
                                        const float* gamma, const float* beta, const float* mean, const float* var, float eps,
