@@ -82,6 +82,15 @@ int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
                      const float* const* w_hh, const float* const* b_hh,
                      void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
                      mgnns_stream_t stream);
+/* Same contract, bf16-mode recurrence: the per-step W_hh . h on v_mfma_f32_4x4x4_16b_bf16 (W_hh and h rounded to bf16 for
+ * the product; fp32 accumulation, gates and cell state; fast exp / rcp): ~2e-3 absolute on the bank, 2.5x shorter chain.  The
+ * input projections stay on the exact-f32 GEMM. */
+int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
+                     const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
+                     const float* const* w_ih_cat, const float* const* b_ih_cat,
+                     const float* const* w_hh, const float* const* b_hh,
+                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                     mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].

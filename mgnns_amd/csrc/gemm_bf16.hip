@@ -59,8 +59,14 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ A,
                                                                const unsigned short* __restrict__ Bt, int M, int N, int Kp,
                                                                const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                               int act, int nrb, int nct, int rps, int jmax) {
+                                                               int act, int nrb, int nct, int rps, int jmax,
+                                                               const int32_t* __restrict__ m_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (m_dev) {                                                   // row count produced on the device (ragged batches): M is its bound
+        const int md = *m_dev;
+        M = md < M ? (md < 0 ? 0 : md) : M;
+        nrb = (M + TM - 1) / TM;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
@@ -227,8 +233,10 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
     return 0;
 }
 
-extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc,
-                                      int act, mgnns_stream_t stream) {
+// internal launcher (also used by the bf16-mode LSTM input projections): m_dev != nullptr -> the row count is read on the
+// device and M is only its upper bound
+int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
+                        const int32_t* m_dev, hipStream_t stream) {
     MG_REQUIRE(A && Bt && C, "mgnns_gemm_bf16_nt_fwd: null pointer");
     MG_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && Kp > 0 && Kp % BK == 0 && ldc >= N && ldc % 4 == 0,
                "mgnns_gemm_bf16_nt_fwd: need N %% 4 == 0, Kp %% %d == 0, ldc %% 4 == 0 (M=%d N=%d Kp=%d ldc=%d)", BK, M, N, Kp, ldc);
@@ -251,9 +259,14 @@ extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int 
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > jmax) per_xcd = jmax;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM_BYTES, stream,
                        reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
-                       ldc, act, nrb, nct, rps, jmax);
+                       ldc, act, nrb, nct, rps, jmax, m_dev);
     MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd");
     return 0;
+}
+
+extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc,
+                                      int act, mgnns_stream_t stream) {
+    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, C, ldc, act, nullptr, (hipStream_t)stream);
 }

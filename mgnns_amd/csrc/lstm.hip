@@ -19,6 +19,8 @@
 
 int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                      const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream);
+int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
+                        const int32_t* m_dev, hipStream_t stream);
 
 namespace {
 
@@ -101,6 +103,24 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + expf(-2
 // values of h (four 16-B LDS broadcasts instead of 38 for a row-per-thread split, which made the LDS the
 // bottleneck), and leaves 600 partial sums in LDS; after one barrier the 150 cell threads add the 10 partials of
 // their four gate rows in a fixed order (12 partials each), apply the cell update and publish h (LDS + the output row).
+// The h rows of a chain leave through LDS in bursts of OCH steps.  A store per step sits in the wave's vector-memory queue
+// between the input-projection loads of consecutive steps: memory operations retire in order and the store is conditional,
+// so the compiler's wait for the NEXT step's projection row was s_waitcnt vmcnt(0) -- every step paid a store round trip
+// (~1.4 us; no change to the arithmetic of a step ever moved the kernel's time).
+constexpr int OCH = 32;
+__device__ __forceinline__ void flush_rows(const float (*s_out)[HPAD], int s0, int s1, int len, int dir, int b, int T,
+                                           float* __restrict__ out, unsigned short* __restrict__ out_bf16, int ld_bf16, int tid,
+                                           int nthr) {
+    for (int e = tid; e < (s1 - s0) * HID; e += nthr) {
+        const int s = s0 + e / HID, j = e % HID;
+        const int t = dir ? len - 1 - s : s;
+        const float hh = s_out[s % OCH][j];
+        out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = hh;
+        if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + j] = f2bf_rne(hh);
+    }
+    mg_lds_barrier();                                                    // the rows may be overwritten by the next steps
+}
+
 constexpr int KW = 13;               // hidden units per wave (12 x 13 = 156 >= 150, the tail is zero)
 constexpr int NWAVE = 12;
 constexpr int RPL = 10;              // gate rows per lane (ceil(600 / 64))
@@ -115,6 +135,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) float s_h[2][NWAVE][16];     // h, chunked per owning wave (15 + 1 pad)
     __shared__ float s_part[NWAVE][PSTR];
     __shared__ float s_act[G4];
+    __shared__ float s_out[OCH][HPAD];                                   // h of the last OCH steps, flushed in bursts
     // workgroup id -> (rank, direction): both directions of the longest sample first
     const int b = order[blockIdx.x >> 1], dir = blockIdx.x & 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,7 +172,6 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     float* const sp = &s_part[0][0];
     int wr_idx = wave * PSTR + lane, rd_idx = tid;
     for (int s = 0; s < len; ++s) {
-        const int t = dir ? len - 1 - s : s;
         asm volatile("" : "+v"(wr_idx), "+v"(rd_idx));
         // ---- 1. partial GEMV over this wave's 13 hidden units ---------------------------------------------------
         const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h[cur][wave]);
@@ -187,11 +207,11 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
             c = fg * c + ig * gg;
             const float hh = og * tanhf_(c);
             s_h[cur ^ 1][tid / KW][tid % KW] = hh;
-            out[((size_t)b * T + t) * (2 * HID) + dir * HID + tid] = hh;
-            if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + tid] = f2bf_rne(hh);
+            s_out[s % OCH][tid] = hh;
         }
         mg_lds_barrier();
         cur ^= 1;
+        if ((s + 1) % OCH == 0 || s + 1 == len) flush_rows(s_out, s - s % OCH, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, REC_THREADS);
     }
     // pad_packed_sequence(total_length=T): zeros behind the sample's length
     for (int i = tid; i < (T - len) * HID; i += REC_THREADS) {
@@ -207,6 +227,166 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
     }
 }
 
+// ---- bf16-mode recurrence: the per-step GEMV on the MFMA ----------------------------------------------------------------
+// Same one-workgroup-per-(sample, direction) chain as above, but gates[600] = W_hh . h runs on v_mfma_f32_4x4x4_16b_bf16
+// (16 independent 4x4x4 blocks per instruction).  The gate rows are PERMUTED to n' = 4 unit + gate and wave w owns rows
+// 64 w .. 64 w + 63: lane l = 4 b + j is row n' = 64 w + l = gate j of unit 16 w + b.  Its 152 weights sit in registers
+// as the B operand (B_b[k][j] = W'[n'][4 ks + k], bf16); the A operand is h[4 ks .. 4 ks + 3] in every row of every block
+// (one LDS broadcast read), so after 38 accumulating MFMAs every lane holds the COMPLETE pre-activation of its own row
+// (four identical registers): no partial sums, no cross-wave reduction, one activation per lane; the four gates of a unit
+// sit in one quad and meet through DPP, the cell state lives in a register, and the only LDS traffic and the only
+// barrier of a step is the new h.  ~1.2 k cycles per step against 3.0 k of the fp32 kernel; W_hh and h are rounded to bf16
+// for the product (fp32 accumulation, gates and cell state), which is what "bf16 mode" means for this kernel.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+constexpr int MW = 10;                // waves: 10 x 64 = 640 >= 600 permuted gate rows
+constexpr int MTHR = MW * 64;
+constexpr int MKS = 38;               // k-steps of 4 (150 -> 152)
+constexpr int MH = 160;               // h row in LDS (bf16), zero padded
+
+__device__ __forceinline__ unsigned int pack2_bf16(float a, float b) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#define MG_QUAD_BCAST(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (q) * 0x55, 0xF, 0xF, true))
+
+// bf16-mode input projection, A side: Xb[r, 0:Kp] = bf16(X[gidx[r], 0:K]) (zero padded to Kp) for the r < *m_dev packed
+// token rows -- the embedding / layer-0 rows gathered once, as the K-contiguous bf16 operand of the dense bf16 GEMM
+constexpr int XKP = 320;              // 300 -> 5 BK slices of 64
+__global__ __launch_bounds__(256) void lstm_gather_cast_kernel(const float* __restrict__ X, int K, const int32_t* __restrict__ gidx,
+                                                               const int32_t* __restrict__ m_dev, int rows_max,
+                                                               unsigned short* __restrict__ Xb) {
+    const int per = XKP / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int r = i / per, c = (i - r * per) * 8;
+    int m = *m_dev;
+    m = m < rows_max ? m : rows_max;
+    if (r >= m) return;
+    const float* src = X + (size_t)gidx[r] * K + c;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        if (c + 4 * h + 4 <= K) q = *reinterpret_cast<const f32x4*>(src + 4 * h);      // K % 4 == 0 (checked on the host)
+        v[4 * h] = q[0]; v[4 * h + 1] = q[1]; v[4 * h + 2] = q[2]; v[4 * h + 3] = q[3];
+    }
+    *reinterpret_cast<uint4*>(Xb + (size_t)r * XKP + c) =
+        uint4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+}
+
+// W_hh of both directions in the register layout of the kernel below: packed[((dir * MW + wave) * MKS + ks) * 64 + lane] =
+// the four bf16 weights W'[64 wave + lane][4 ks .. 4 ks + 3] (gate rows permuted to n' = 4 unit + gate), so a workgroup
+// fetches its 194 KB with 38 coalesced 8-byte loads per lane instead of 152 strided scalar ones.
+__global__ __launch_bounds__(MTHR) void lstm_pack_whh_kernel(const float* __restrict__ Whh_f, const float* __restrict__ Whh_b,
+                                                             uint2* __restrict__ packed) {
+    const int dir = blockIdx.y, ks = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Whh = dir ? Whh_b : Whh_f;
+    const int unit = wave * 16 + (lane >> 2), gate = lane & 3;
+    const bool row_on = unit < HID;
+    const float* wrow = Whh + (size_t)(gate * HID + (row_on ? unit : 0)) * HID;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (row_on && 4 * ks + e < HID) ? wrow[4 * ks + e] : 0.f;
+    packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane] = uint2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+}
+
+// Persistent: workgroup w walks the (rank, direction) pairs w, 2G-1-w, 2G+w, ... of the length-sorted order (long chains
+// first, each paired with a short one), the weights stay in registers across its samples.
+__global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __restrict__ Gx, const int32_t* __restrict__ offs,
+                                                             const int64_t* __restrict__ lens, int B, int T,
+                                                             const uint2* __restrict__ packed,
+                                                             const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
+                                                             const int32_t* __restrict__ order, float* __restrict__ out,
+                                                             unsigned short* __restrict__ out_bf16, int ld_bf16) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_h[2][MH];
+    __shared__ float s_out[OCH][HPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x, npair = 2 * B;
+    const int unit = wave * 16 + (lane >> 2), gate = lane & 3;
+    const bool row_on = unit < HID;
+    const int row = gate * HID + (row_on ? unit : 0);              // PyTorch row (gate order i, f, g, o)
+    const bool is_tanh = gate == 2;
+    // pairs are numbered p = 2 rank + direction; with an even grid the walk below keeps a workgroup on ONE direction, so its
+    // weights are fetched once (a grid that is not even reloads them per sample -- from L2, coalesced)
+    int wdir = -1;
+    s16x4_t w[MKS];
+    float bias = 0.f;
+    for (int r = 0;; ++r) {
+        // even rounds ascend, odd rounds descend (long chains meet short ones); the ^ 1 keeps the pair's parity = direction
+        const int p = r * G + ((r & 1) ? ((G - 1 - (int)blockIdx.x) ^ 1) : (int)blockIdx.x);
+        if (p >= npair) break;                                     // (the next round's index is larger still)
+        const int b = order[p >> 1], dir = p & 1;
+        if (dir != wdir) {
+            wdir = dir;
+#pragma unroll
+            for (int ks = 0; ks < MKS; ++ks) {
+                const uint2 v = packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane];
+                w[ks] = s16x4_t{(short)(v.x & 0xFFFFu), (short)(v.x >> 16), (short)(v.y & 0xFFFFu), (short)(v.y >> 16)};
+            }
+            bias = row_on ? (dir ? bhh_b : bhh_f)[row] : 0.f;
+        }
+        long long l = lens[b];
+        const int len = (int)(l < 0 ? 0 : (l > T ? T : l));
+        const int off = offs[b];
+        if (tid < 2 * MH) (&s_h[0][0])[tid] = 0;
+        float c = 0.f;
+        __syncthreads();
+
+        // input-projection rows of the next three steps in flight; the loads are UNCONDITIONAL (index clamped to the last
+        // step; padding lanes read row 0 of their gate) so that the compiler knows how many are outstanding and waits with
+        // vmcnt(2) instead of vmcnt(0) -- behind a burst of output stores a vmcnt(0) costs a store round trip
+        const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + row;
+        const int lm1 = len > 0 ? len - 1 : 0;
+        auto gx_at = [&](int st) {
+            const int sc = st < lm1 ? st : lm1;
+            return gx_base[(size_t)(dir ? lm1 - sc : sc) * (2 * G4)];
+        };
+        float gx = gx_at(0), gx1 = gx_at(1), gx2 = gx_at(2);
+        int cur = 0;
+        for (int s = 0; s < len; ++s) {
+            // h as the A operand: the same four values in every lane (LDS broadcast), 16 B = two k-steps per read
+            const uint4* h4 = reinterpret_cast<const uint4*>(s_h[cur]);
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < MKS / 2; ++kp) {
+                const uint4 hv = h4[kp];
+                const s16x4_t ha = {(short)(hv.x & 0xFFFFu), (short)(hv.x >> 16), (short)(hv.y & 0xFFFFu), (short)(hv.y >> 16)};
+                const s16x4_t hb = {(short)(hv.z & 0xFFFFu), (short)(hv.z >> 16), (short)(hv.w & 0xFFFFu), (short)(hv.w >> 16)};
+                a0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ha, w[2 * kp], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hb, w[2 * kp + 1], a1, 0, 0, 0);
+            }
+            const float pre = (gx + bias) + (a0[0] + a1[0]);
+            gx = gx1;
+            gx1 = gx2;
+            gx2 = gx_at(s + 3);
+            // one activation per lane: sigmoid(x), or tanh(x) = 2 sigmoid(2x) - 1 on the g rows
+            const float sg = __frcp_rn(1.0f + __expf(is_tanh ? -2.0f * pre : -pre));
+            const float act = is_tanh ? 2.0f * sg - 1.0f : sg;
+            const float ig = MG_QUAD_BCAST(act, 0), fgt = MG_QUAD_BCAST(act, 1), gg = MG_QUAD_BCAST(act, 2), og = MG_QUAD_BCAST(act, 3);
+            c = fgt * c + ig * gg;
+            const float hh = og * (2.0f * __frcp_rn(1.0f + __expf(-2.0f * c)) - 1.0f);
+            if (gate == 0 && row_on) {
+                s_h[cur ^ 1][unit] = (unsigned short)(pack2_bf16(hh, 0.f) & 0xFFFFu);
+                s_out[s % OCH][unit] = hh;
+            }
+            mg_lds_barrier();
+            cur ^= 1;
+            if ((s + 1) % OCH == 0 || s + 1 == len) flush_rows(s_out, s - s % OCH, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
+        }
+        // pad_packed_sequence(total_length=T): zeros behind the sample's length
+        for (int i = tid; i < (T - len) * HID; i += MTHR) {
+            const int t = len + i / HID, j = i % HID;
+            out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = 0.f;
+            if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + j] = 0;
+        }
+        if (out_bf16 && dir == 0) {
+            const int padw = ld_bf16 - 2 * HID;
+            for (int i = tid; i < T * padw; i += MTHR) out_bf16[((size_t)b * T + i / padw) * ld_bf16 + 2 * HID + i % padw] = 0;
+        }
+        __syncthreads();                                           // s_h / s_out are reused by the next sample
+    }
+}
+
 }  // namespace
 
 extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers) {
@@ -215,14 +395,19 @@ extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num
     size_t bytes = rows * 8 * (size_t)hidden * sizeof(float);   // Gx [rows, 2*4*hidden]
     bytes += rows * 2 * (size_t)hidden * sizeof(float);          // layer-0 output [rows, 2*hidden]
     bytes += (2 * rows + 2 * (size_t)B + 1 + 8) * sizeof(int32_t);   // pack_tok, pack_pos, offs, order
+    bytes = (bytes + 255) & ~(size_t)255;
+    bytes += (size_t)2 * MW * MKS * 64 * sizeof(uint2);              // W_hh of one layer in the bf16 recurrence's register layout
+    bytes = (bytes + 255) & ~(size_t)255;
+    bytes += (rows + 8 * (size_t)hidden) * XKP * sizeof(unsigned short);   // bf16 mode: gathered input rows + W_ih, [*, 320] bf16
     return (bytes + 255) & ~(size_t)255;
 }
 
-extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
-                                int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
-                                const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
-                                void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                                mgnns_stream_t stream) {
+
+static int bilstm_impl(bool bf16_rec, const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+                       int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
+                       const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
+                       void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                       mgnns_stream_t stream) {
     MG_REQUIRE(tok && lens && emb_table && w_ih_cat && w_hh && b_ih_cat && b_hh && workspace && out,
                "mgnns_bilstm_fwd: null pointer");
     MG_REQUIRE(!out_bf16 || (ld_bf16 >= 2 * hidden && ld_bf16 % 8 == 0), "mgnns_bilstm_fwd: bad bf16 row length %d", ld_bf16);
@@ -242,6 +427,22 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
     int32_t* pack_pos = pack_tok + rows;
     int32_t* offs = pack_pos + rows;
     int32_t* order = offs + B + 1;
+    uint2* packed = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(workspace) +
+                                             ((((unsigned char*)(order + B + 8) - (unsigned char*)workspace) + 255) & ~(size_t)255));
+    unsigned short* xb = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(packed) +
+                                                           (((size_t)2 * MW * MKS * 64 * sizeof(uint2) + 255) & ~(size_t)255));
+    unsigned short* wb = xb + rows * XKP;
+    int grid_rec = 2 * B;
+    if (bf16_rec) {                                                  // one persistent workgroup per CU (even count: see the kernel)
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+            mgnns_set_error("mgnns_bilstm_bf16_fwd: cannot query the CU count");
+            return MGNNS_ERR_LAUNCH;
+        }
+        n_cu &= ~1;
+        if (n_cu < 2) n_cu = 2;
+        if (grid_rec > n_cu) grid_rec = n_cu;
+    }
 
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
     hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
@@ -251,13 +452,44 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
         const int32_t* gidx = layer == 0 ? pack_tok : pack_pos;
         float* dst = (layer == num_layers - 1) ? out : mid;
         // both directions' input projections in one GEMM: W_ih = [forward ; reverse] stacked to [2*4H, in]
-        mg_launch_linear(X, (int)rows, K, w_ih_cat[layer], b_ih_cat[layer], 2 * G4, Gx, 2 * G4, gidx, offs + B, s);
-        hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
-                           T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1],
-                           (const int32_t*)order, dst,
-                           (layer == num_layers - 1) ? reinterpret_cast<unsigned short*>(out_bf16) : (unsigned short*)nullptr,
-                           ld_bf16);
+        if (bf16_rec && K % 4 == 0 && K <= XKP) {
+            // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42
+            hipLaunchKernelGGL(lstm_gather_cast_kernel, dim3((unsigned)((rows * (XKP / 8) + 255) / 256)), dim3(256), 0, s, X, K, gidx,
+                               (const int32_t*)(offs + B), (int)rows, xb);
+            if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, K, XKP, wb, stream)) return rc;
+            if (int rc = mg_launch_gemm_bf16(xb, wb, (int)rows, 2 * G4, XKP, b_ih_cat[layer], Gx, 2 * G4, MGNNS_ACT_NONE, offs + B, s)) return rc;
+        } else {
+            mg_launch_linear(X, (int)rows, K, w_ih_cat[layer], b_ih_cat[layer], 2 * G4, Gx, 2 * G4, gidx, offs + B, s);
+        }
+        unsigned short* obf = (layer == num_layers - 1) ? reinterpret_cast<unsigned short*>(out_bf16) : (unsigned short*)nullptr;
+        if (bf16_rec) {
+            hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
+            hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), 0, s, (const float*)Gx, (const int32_t*)offs, lens, B,
+                               T, (const uint2*)packed, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst, obf, ld_bf16);
+        }
+        else
+            hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
+                               T, w_hh[2 * layer], w_hh[2 * layer + 1], b_hh[2 * layer], b_hh[2 * layer + 1],
+                               (const int32_t*)order, dst, obf, ld_bf16);
     }
     MG_CHECK_LAUNCH("mgnns_bilstm_fwd");
     return 0;
+}
+
+extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+                                int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
+                                const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
+                                void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                                mgnns_stream_t stream) {
+    return bilstm_impl(false, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
+                       workspace_bytes, out, out_bf16, ld_bf16, stream);
+}
+
+extern "C" int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+                                     int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
+                                     const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
+                                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                                     mgnns_stream_t stream) {
+    return bilstm_impl(true, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
+                       workspace_bytes, out, out_bf16, ld_bf16, stream);
 }

@@ -267,7 +267,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
         if self.precision == 'bf16':
             f32, bf = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
-                                 self.hidden_size, self.lstm.num_layers, want_bf16=True)
+                                 self.hidden_size, self.lstm.num_layers, want_bf16=True,
+                                 recurrence=os.environ.get("MGNNS_LSTM_REC", "bf16"))
             return MemoryBank(f32=f32, bf16=bf)
         return MemoryBank(f32=ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
                                          self._lstm_weights(), self.hidden_size, self.lstm.num_layers))

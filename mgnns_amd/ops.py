@@ -209,10 +209,11 @@ def _lstm_cat(weights, num_layers):
     return hit
 
 
-def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False):
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32"):
     """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
     (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length
-    (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16)."""
+    (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16).  recurrence="bf16": W_hh . h of every step on the
+    bf16 MFMA (bf16 operands, fp32 accumulation and state) instead of the exact fp32 GEMV."""
     import ctypes
     _chk(tok, "text", torch.int64, 2)
     _chk(lens, "text_lens", torch.int64, 1)
@@ -240,7 +241,10 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False):
     ws = _workspace(nbytes, tok.device)
     out = torch.empty(B, T, 2 * hidden, device=tok.device, dtype=torch.float32)
     out_bf = torch.empty(B, T, BANK_LD, device=tok.device, dtype=torch.bfloat16) if want_bf16 else None
-    _launch("mgnns_bilstm_fwd", ("mgnns_bilstm_fwd",), L.mgnns_bilstm_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
+    if recurrence not in ("f32", "bf16"):
+        raise ValueError("recurrence must be 'f32' or 'bf16', got %r" % (recurrence,))
+    name = "mgnns_bilstm_fwd" if recurrence == "f32" else "mgnns_bilstm_bf16_fwd"
+    _launch(name, (name,), getattr(L, name), _p(tok), _p(lens), B, T, _p(emb_table),
             emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
             _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _stream())
     return (out, out_bf) if want_bf16 else out

@@ -511,3 +511,34 @@ def test_gemm_bf16_nt_vs_fp64_on_rounded_operands(M, N, K):
     if M == K:
         c3 = ops.dense_adj_matmul_bf16(a_bf, dev(b)).cpu().double()
         assert torch.equal(c3, c)
+
+
+def test_bilstm_bf16_mfma_recurrence_vs_fp32_recurrence():
+    """bf16-mode recurrence (W_hh . h of every step on v_mfma_f32_4x4x4_16b_bf16, bf16 operands, fp32 state) against the exact
+    fp32 kernel on ragged batches: same zero padding, same bf16 side copy layout, bank within 5e-3 absolute (|h| < 1)."""
+    import numpy as np
+    rs = np.random.RandomState(5)
+    for B, T in ((37, 100), (256, 100), (5, 24)):
+        V, E, Hh = 500, 300, 150
+        lens = rs.randint(1, T + 1, size=B)
+        lens[0], lens[-1] = T, 1
+        tok = np.zeros((B, T), np.int64)
+        for b in range(B):
+            tok[b, :lens[b]] = rs.randint(1, V, size=lens[b])
+        emb = torch.from_numpy((0.4 * rs.standard_normal((V, E))).astype(np.float32)).to(DEV)
+        weights = []
+        for layer in range(2):
+            for d in range(2):
+                ind = E if layer == 0 else 2 * Hh
+                weights.append(tuple(torch.from_numpy(rs.uniform(-0.08, 0.08, size=s).astype(np.float32)).to(DEV)
+                                     for s in ((4 * Hh, ind), (4 * Hh, Hh), (4 * Hh,), (4 * Hh,))))
+        t, l = torch.from_numpy(tok).to(DEV), torch.from_numpy(lens.astype(np.int64)).to(DEV)
+        ref, ref_bf = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True)
+        out, out_bf = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16")
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape and out_bf.shape == ref_bf.shape
+        err = (out - ref).abs().max().item()
+        assert err < 5e-3, err
+        pad = torch.arange(T, device=DEV)[None, :] >= l[:, None]
+        assert (out[pad] == 0).all() and (out_bf[pad] == 0).all() and (out_bf[:, :, 2 * Hh:] == 0).all()
+        assert (out_bf[:, :, :2 * Hh].float() - out).abs().max().item() <= 2.0 ** -8       # the bf16 copy is the rounded bank
