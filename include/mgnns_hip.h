@@ -89,8 +89,13 @@ int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
                      const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
                      const float* const* w_ih_cat, const float* const* b_ih_cat,
                      const float* const* w_hh, const float* const* b_hh,
-                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16, const void* prepacked,
                      mgnns_stream_t stream);
+/* Weights of the bf16 recurrence / projections in their kernel layouts (depends on the weights only: build once per weight
+ * version, pass as `prepacked`; NULL = packed on the fly inside every call). */
+size_t mgnns_bilstm_bf16_prepack_bytes(int hidden, int num_layers);
+int mgnns_bilstm_bf16_prepack(const float* const* w_ih_cat, const float* const* w_hh, int emb_dim, int hidden, int num_layers,
+                              void* packed, mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].

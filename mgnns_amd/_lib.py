@@ -22,7 +22,8 @@ _PP = _c.POINTER(_c.c_void_p)
 SIGNATURES = {
     "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
     "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P],
-    "mgnns_bilstm_bf16_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P],
+    "mgnns_bilstm_bf16_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P],
+    "mgnns_bilstm_bf16_prepack": [_PP, _PP, _I, _I, _I, _P, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
@@ -63,6 +64,7 @@ SIZE_GETTERS = {
     "mgnns_sq_mha_packed_weight_bytes": [_I],
     "mgnns_sq_mha_folded_workspace_bytes": [_I, _I, _I],
     "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
+    "mgnns_bilstm_bf16_prepack_bytes": [_I, _I],
 }
 
 _lib = None

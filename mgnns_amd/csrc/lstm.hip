@@ -61,11 +61,19 @@ __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restri
     // order[r] = sample with the r-th longest text (ties by index): the recurrence launches 2*B workgroups on
     // 256 CUs, one per CU at a time, so the long chains must start first (rank by counting, O(B^2/1024) per thread)
     __syncthreads();
+    __shared__ int s_len[4096];                                // clamped lengths (LDS: the rank loop reads every one of them per sample)
+    const bool in_lds = B <= 4096;
+    if (in_lds)
+        for (int b = tid; b < B; b += 1024) {
+            long long l = lens[b];
+            s_len[b] = (int)(l < 0 ? 0 : (l > T ? T : l));
+        }
+    __syncthreads();
     for (int b = tid; b < B; b += 1024) {                      // clamped length of sample b = offs[b+1] - offs[b]
-        const int lb = offs[b + 1] - offs[b];
+        const int lb = in_lds ? s_len[b] : offs[b + 1] - offs[b];
         int rank = 0;
         for (int j = 0; j < B; ++j) {
-            const int lj = offs[j + 1] - offs[j];
+            const int lj = in_lds ? s_len[j] : offs[j + 1] - offs[j];
             rank += (lj > lb) || (lj == lb && j < b);
         }
         order[rank] = b;
@@ -108,13 +116,13 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + expf(-2
 // so the compiler's wait for the NEXT step's projection row was s_waitcnt vmcnt(0) -- every step paid a store round trip
 // (~1.4 us; no change to the arithmetic of a step ever moved the kernel's time).
 constexpr int OCH = 32;
-__device__ __forceinline__ void flush_rows(const float (*s_out)[HPAD], int s0, int s1, int len, int dir, int b, int T,
+__device__ __forceinline__ void flush_rows(const float* s_out, int och, int s0, int s1, int len, int dir, int b, int T,
                                            float* __restrict__ out, unsigned short* __restrict__ out_bf16, int ld_bf16, int tid,
                                            int nthr) {
     for (int e = tid; e < (s1 - s0) * HID; e += nthr) {
         const int s = s0 + e / HID, j = e % HID;
         const int t = dir ? len - 1 - s : s;
-        const float hh = s_out[s % OCH][j];
+        const float hh = s_out[(s % och) * HPAD + j];
         out[((size_t)b * T + t) * (2 * HID) + dir * HID + j] = hh;
         if (out_bf16) out_bf16[((size_t)b * T + t) * ld_bf16 + dir * HID + j] = f2bf_rne(hh);
     }
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_rec_kernel(const float* __re
         }
         mg_lds_barrier();
         cur ^= 1;
-        if ((s + 1) % OCH == 0 || s + 1 == len) flush_rows(s_out, s - s % OCH, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, REC_THREADS);
+        if ((s + 1) % OCH == 0 || s + 1 == len) flush_rows(&s_out[0][0], OCH, s - s % OCH, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, REC_THREADS);
     }
     // pad_packed_sequence(total_length=T): zeros behind the sample's length
     for (int i = tid; i < (T - len) * HID; i += REC_THREADS) {
@@ -297,9 +305,9 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                                                              const uint2* __restrict__ packed,
                                                              const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                              const int32_t* __restrict__ order, float* __restrict__ out,
-                                                             unsigned short* __restrict__ out_bf16, int ld_bf16) {
+                                                             unsigned short* __restrict__ out_bf16, int ld_bf16, int och) {
     __shared__ __attribute__((aligned(16))) unsigned short s_h[2][MH];
-    __shared__ float s_out[OCH][HPAD];
+    extern __shared__ __attribute__((aligned(16))) float s_out[];       // [och][HPAD]: the h rows of a whole chain (och = min(T, 200))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, npair = 2 * B;
     const int unit = wave * 16 + (lane >> 2), gate = lane & 3;
@@ -367,11 +375,11 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             const float hh = og * (2.0f * __frcp_rn(1.0f + __expf(-2.0f * c)) - 1.0f);
             if (gate == 0 && row_on) {
                 s_h[cur ^ 1][unit] = (unsigned short)(pack2_bf16(hh, 0.f) & 0xFFFFu);
-                s_out[s % OCH][unit] = hh;
+                s_out[(s % och) * HPAD + unit] = hh;
             }
             mg_lds_barrier();
             cur ^= 1;
-            if ((s + 1) % OCH == 0 || s + 1 == len) flush_rows(s_out, s - s % OCH, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
+            if ((s + 1) % och == 0 || s + 1 == len) flush_rows(s_out, och, s - s % och, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
         }
         // pad_packed_sequence(total_length=T): zeros behind the sample's length
         for (int i = tid; i < (T - len) * HID; i += MTHR) {
@@ -403,7 +411,33 @@ extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num
 }
 
 
-static int bilstm_impl(bool bf16_rec, const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+// bf16 mode, weights only (cache per weight version): per layer [W_hh of both directions in the recurrence's register layout |
+// W_ih of both directions as bf16 [8*hidden, 320]]
+static size_t prepack_whh_bytes() { return ((size_t)2 * MW * MKS * 64 * sizeof(uint2) + 255) & ~(size_t)255; }
+static size_t prepack_wih_bytes() { return ((size_t)2 * G4 * XKP * sizeof(unsigned short) + 255) & ~(size_t)255; }
+extern "C" size_t mgnns_bilstm_bf16_prepack_bytes(int hidden, int num_layers) {
+    (void)hidden;
+    return (size_t)num_layers * (prepack_whh_bytes() + prepack_wih_bytes());
+}
+extern "C" int mgnns_bilstm_bf16_prepack(const float* const* w_ih_cat, const float* const* w_hh, int emb_dim, int hidden,
+                                         int num_layers, void* packed, mgnns_stream_t stream) {
+    MG_REQUIRE(w_ih_cat && w_hh && packed, "mgnns_bilstm_bf16_prepack: null pointer");
+    MG_REQUIRE(hidden == HID && num_layers >= 1 && num_layers <= 2 && emb_dim > 0 && emb_dim <= XKP && emb_dim % 4 == 0,
+               "mgnns_bilstm_bf16_prepack: unsupported hidden=%d layers=%d emb_dim=%d", hidden, num_layers, emb_dim);
+    unsigned char* p = reinterpret_cast<unsigned char*>(packed);
+    for (int layer = 0; layer < num_layers; ++layer) {
+        MG_REQUIRE(w_ih_cat[layer] && w_hh[2 * layer] && w_hh[2 * layer + 1], "mgnns_bilstm_bf16_prepack: null weight pointer");
+        hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, (hipStream_t)stream, w_hh[2 * layer], w_hh[2 * layer + 1],
+                           reinterpret_cast<uint2*>(p));
+        p += prepack_whh_bytes();
+        if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, layer == 0 ? emb_dim : 2 * HID, XKP, p, stream)) return rc;
+        p += prepack_wih_bytes();
+    }
+    MG_CHECK_LAUNCH("mgnns_bilstm_bf16_prepack");
+    return 0;
+}
+
+static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
                        int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                        const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                        void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
@@ -433,7 +467,9 @@ static int bilstm_impl(bool bf16_rec, const int64_t* tok, const int64_t* lens, i
                                                            (((size_t)2 * MW * MKS * 64 * sizeof(uint2) + 255) & ~(size_t)255));
     unsigned short* wb = xb + rows * XKP;
     int grid_rec = 2 * B;
-    if (bf16_rec) {                                                  // one persistent workgroup per CU (even count: see the kernel)
+    const int och = T < 200 ? T : 200;                               // h rows kept in LDS between flushes (one flush per chain for T <= 200)
+    if (bf16_rec) {
+        MG_DYN_LDS(lstm_rec_bf16_kernel, (size_t)och * HPAD * sizeof(float));                                                  // one persistent workgroup per CU (even count: see the kernel)
         int dev = 0, n_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
             mgnns_set_error("mgnns_bilstm_bf16_fwd: cannot query the CU count");
@@ -452,20 +488,27 @@ static int bilstm_impl(bool bf16_rec, const int64_t* tok, const int64_t* lens, i
         const int32_t* gidx = layer == 0 ? pack_tok : pack_pos;
         float* dst = (layer == num_layers - 1) ? out : mid;
         // both directions' input projections in one GEMM: W_ih = [forward ; reverse] stacked to [2*4H, in]
+        const unsigned char* pp = prepacked ? reinterpret_cast<const unsigned char*>(prepacked) + (size_t)layer * (prepack_whh_bytes() + prepack_wih_bytes())
+                                            : nullptr;
         if (bf16_rec && K % 4 == 0 && K <= XKP) {
             // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42
             hipLaunchKernelGGL(lstm_gather_cast_kernel, dim3((unsigned)((rows * (XKP / 8) + 255) / 256)), dim3(256), 0, s, X, K, gidx,
                                (const int32_t*)(offs + B), (int)rows, xb);
-            if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, K, XKP, wb, stream)) return rc;
-            if (int rc = mg_launch_gemm_bf16(xb, wb, (int)rows, 2 * G4, XKP, b_ih_cat[layer], Gx, 2 * G4, MGNNS_ACT_NONE, offs + B, s)) return rc;
+            const void* wih = wb;
+            if (pp) wih = pp + prepack_whh_bytes();
+            else if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, K, XKP, wb, stream)) return rc;
+            if (int rc = mg_launch_gemm_bf16(xb, wih, (int)rows, 2 * G4, XKP, b_ih_cat[layer], Gx, 2 * G4, MGNNS_ACT_NONE, offs + B, s)) return rc;
         } else {
             mg_launch_linear(X, (int)rows, K, w_ih_cat[layer], b_ih_cat[layer], 2 * G4, Gx, 2 * G4, gidx, offs + B, s);
         }
         unsigned short* obf = (layer == num_layers - 1) ? reinterpret_cast<unsigned short*>(out_bf16) : (unsigned short*)nullptr;
         if (bf16_rec) {
-            hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
-            hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), 0, s, (const float*)Gx, (const int32_t*)offs, lens, B,
-                               T, (const uint2*)packed, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst, obf, ld_bf16);
+            const uint2* whh = packed;
+            if (pp) whh = reinterpret_cast<const uint2*>(pp);
+            else hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
+            hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), (size_t)och * HPAD * sizeof(float), s, (const float*)Gx,
+                               (const int32_t*)offs, lens, B, T, whh, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst,
+                               obf, ld_bf16, och);
         }
         else
             hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
@@ -481,7 +524,7 @@ extern "C" int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, 
                                 const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                                 void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
                                 mgnns_stream_t stream) {
-    return bilstm_impl(false, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
+    return bilstm_impl(false, nullptr, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
                        workspace_bytes, out, out_bf16, ld_bf16, stream);
 }
 
@@ -489,7 +532,7 @@ extern "C" int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, in
                                      int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                                      const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                                      void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                                     mgnns_stream_t stream) {
-    return bilstm_impl(true, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
+                                     const void* prepacked, mgnns_stream_t stream) {
+    return bilstm_impl(true, prepacked, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
                        workspace_bytes, out, out_bf16, ld_bf16, stream);
 }

@@ -194,6 +194,7 @@ def _workspace(nbytes, device):
 
 
 _lstm_cat_cache = {}
+_lstm_prepack_cache = {}
 
 
 def _lstm_cat(weights, num_layers):
@@ -243,10 +244,23 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
     out_bf = torch.empty(B, T, BANK_LD, device=tok.device, dtype=torch.bfloat16) if want_bf16 else None
     if recurrence not in ("f32", "bf16"):
         raise ValueError("recurrence must be 'f32' or 'bf16', got %r" % (recurrence,))
-    name = "mgnns_bilstm_fwd" if recurrence == "f32" else "mgnns_bilstm_bf16_fwd"
-    _launch(name, (name,), getattr(L, name), _p(tok), _p(lens), B, T, _p(emb_table),
-            emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
-            _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _stream())
+    if recurrence == "f32":
+        _launch("mgnns_bilstm_fwd", ("mgnns_bilstm_fwd",), L.mgnns_bilstm_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
+                emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
+                _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _stream())
+    else:
+        # weight layouts of the bf16 kernels: packed once per weight version, off the per-forward path
+        key = tuple((t.data_ptr(), t._version) for tup in weights for t in (tup[0], tup[1])) + (str(tok.device),)
+        pre = _lstm_prepack_cache.get(key)
+        if pre is None:
+            _lstm_prepack_cache.clear()
+            pre = torch.empty(L.mgnns_bilstm_bf16_prepack_bytes(hidden, num_layers), dtype=torch.uint8, device=tok.device)
+            _lib.check(L.mgnns_bilstm_bf16_prepack(c_wih, c_whh, emb_table.shape[1], hidden, num_layers, _p(pre), _stream()),
+                       "mgnns_bilstm_bf16_prepack")
+            _lstm_prepack_cache[key] = pre
+        _launch("mgnns_bilstm_bf16_fwd", ("mgnns_bilstm_bf16_fwd",), L.mgnns_bilstm_bf16_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
+                emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
+                _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _stream())
     return (out, out_bf) if want_bf16 else out
 
 
