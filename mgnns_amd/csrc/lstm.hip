@@ -305,7 +305,8 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                                                              const uint2* __restrict__ packed,
                                                              const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                              const int32_t* __restrict__ order, float* __restrict__ out,
-                                                             unsigned short* __restrict__ out_bf16, int ld_bf16, int och) {
+                                                             unsigned short* __restrict__ out_bf16, int ld_bf16, int och,
+                                                             unsigned short* __restrict__ next_x) {
     __shared__ __attribute__((aligned(16))) unsigned short s_h[2][MH];
     extern __shared__ __attribute__((aligned(16))) float s_out[];       // [och][HPAD]: the h rows of a whole chain (och = min(T, 200))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,7 +380,27 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             }
             mg_lds_barrier();
             cur ^= 1;
-            if ((s + 1) % och == 0 || s + 1 == len) flush_rows(s_out, och, s - s % och, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
+            if ((s + 1) % och == 0 || s + 1 == len) {
+                if (next_x) {
+                    // not the last layer: the rows are only the NEXT layer's projection input -- written once, as its packed
+                    // bf16 A operand ([packed row, 320], this direction's 150 columns; direction 0 also zeroes the padding)
+                    const int s0 = s - s % och;
+                    for (int e = tid; e < (s + 1 - s0) * HID; e += MTHR) {
+                        const int ss = s0 + e / HID, j = e % HID;
+                        next_x[(size_t)(off + (dir ? len - 1 - ss : ss)) * XKP + dir * HID + j] = f2bf_rne(s_out[(ss % och) * HPAD + j]);
+                    }
+                    if (dir == 0)
+                        for (int e = tid; e < (s + 1 - s0) * (XKP - 2 * HID); e += MTHR)
+                            next_x[(size_t)(off + s0 + e / (XKP - 2 * HID)) * XKP + 2 * HID + e % (XKP - 2 * HID)] = 0;
+                    mg_lds_barrier();
+                } else {
+                    flush_rows(s_out, och, s - s % och, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
+                }
+            }
+        }
+        if (next_x) {
+            __syncthreads();
+            continue;
         }
         // pad_packed_sequence(total_length=T): zeros behind the sample's length
         for (int i = tid; i < (T - len) * HID; i += MTHR) {
@@ -491,9 +512,11 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
         const unsigned char* pp = prepacked ? reinterpret_cast<const unsigned char*>(prepacked) + (size_t)layer * (prepack_whh_bytes() + prepack_wih_bytes())
                                             : nullptr;
         if (bf16_rec && K % 4 == 0 && K <= XKP) {
-            // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42
-            hipLaunchKernelGGL(lstm_gather_cast_kernel, dim3((unsigned)((rows * (XKP / 8) + 255) / 256)), dim3(256), 0, s, X, K, gidx,
-                               (const int32_t*)(offs + B), (int)rows, xb);
+            // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42.
+            // Layer 0 gathers + casts the embedding rows; the later layers find their operand written by the recurrence below.
+            if (layer == 0)
+                hipLaunchKernelGGL(lstm_gather_cast_kernel, dim3((unsigned)((rows * (XKP / 8) + 255) / 256)), dim3(256), 0, s, X, K, gidx,
+                                   (const int32_t*)(offs + B), (int)rows, xb);
             const void* wih = wb;
             if (pp) wih = pp + prepack_whh_bytes();
             else if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, K, XKP, wb, stream)) return rc;
@@ -508,7 +531,7 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
             else hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
             hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), (size_t)och * HPAD * sizeof(float), s, (const float*)Gx,
                                (const int32_t*)offs, lens, B, T, whh, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst,
-                               obf, ld_bf16, och);
+                               obf, ld_bf16, och, (layer + 1 < num_layers && 2 * HID <= XKP) ? xb : (unsigned short*)nullptr);
         }
         else
             hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
