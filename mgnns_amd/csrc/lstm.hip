@@ -34,6 +34,43 @@ __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restri
                                                          int32_t* __restrict__ offs, int32_t* __restrict__ order) {
     __shared__ int32_t s_off[1025];
     const int tid = threadIdx.x;
+    if (B <= 1024) {
+        // common case, one sample per thread: wave scan (shuffles) + 16 wave totals, lengths in LDS as int4 for the rank count
+        __shared__ __attribute__((aligned(16))) int s_l[1024];
+        __shared__ int s_wave[16];
+        int len = 0;
+        if (tid < B) {
+            long long l = lens[tid];
+            len = (int)(l < 0 ? 0 : (l > T ? T : l));
+        }
+        s_l[tid] = tid < B ? len : -1;                         // -1: never counts as longer
+        int inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if ((tid & 63) >= o) inc += v;
+        }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
+        if (tid < B) offs[tid] = base + inc - len;
+        if (tid == B - 1) offs[B] = base + inc;
+        if (tid < B) {
+            int rank = 0;
+            const int4* l4 = reinterpret_cast<const int4*>(s_l);
+            for (int j4 = 0; j4 < (B + 3) / 4; ++j4) {
+                const int4 v = l4[j4];
+                const int j = 4 * j4;
+                rank += (v.x > len) || (v.x == len && j < tid);
+                rank += (v.y > len) || (v.y == len && j + 1 < tid);
+                rank += (v.z > len) || (v.z == len && j + 2 < tid);
+                rank += (v.w > len) || (v.w == len && j + 3 < tid);
+            }
+            order[rank] = tid;
+        }
+        return;
+    }
     // single workgroup: serial-chunk scan of the (<= a few thousand) lengths
     const int per = (B + 1023) / 1024;
     const int lo = tid * per, hi = min(B, lo + per);
