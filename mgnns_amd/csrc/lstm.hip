@@ -388,7 +388,7 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             return gx_base[(size_t)(dir ? lm1 - sc : sc) * (2 * G4)];
         };
         float gx = gx_at(0), gx1 = gx_at(1), gx2 = gx_at(2);
-        int cur = 0;
+        int cur = 0, sm = 0;                                       // sm = s % och (no integer division in the step loop)
         for (int s = 0; s < len; ++s) {
             // h as the A operand: the same four values in every lane (LDS broadcast), 16 B = two k-steps per read
             const uint4* h4 = reinterpret_cast<const uint4*>(s_h[cur]);
@@ -406,22 +406,24 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             gx1 = gx2;
             gx2 = gx_at(s + 3);
             // one activation per lane: sigmoid(x), or tanh(x) = 2 sigmoid(2x) - 1 on the g rows
-            const float sg = __frcp_rn(1.0f + __expf(is_tanh ? -2.0f * pre : -pre));
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(is_tanh ? -2.0f * pre : -pre));   // v_rcp_f32 (1 ulp), not a division sequence
             const float act = is_tanh ? 2.0f * sg - 1.0f : sg;
             const float ig = MG_QUAD_BCAST(act, 0), fgt = MG_QUAD_BCAST(act, 1), gg = MG_QUAD_BCAST(act, 2), og = MG_QUAD_BCAST(act, 3);
             c = fgt * c + ig * gg;
-            const float hh = og * (2.0f * __frcp_rn(1.0f + __expf(-2.0f * c)) - 1.0f);
+            const float hh = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * c)) - 1.0f);
             if (gate == 0 && row_on) {
                 s_h[cur ^ 1][unit] = (unsigned short)(pack2_bf16(hh, 0.f) & 0xFFFFu);
-                s_out[(s % och) * HPAD + unit] = hh;
+                s_out[sm * HPAD + unit] = hh;
             }
             mg_lds_barrier();
             cur ^= 1;
-            if ((s + 1) % och == 0 || s + 1 == len) {
+            const bool flush = sm + 1 == och || s + 1 == len;
+            const int s0 = s - sm;
+            sm = sm + 1 == och ? 0 : sm + 1;
+            if (flush) {
                 if (next_x) {
                     // not the last layer: the rows are only the NEXT layer's projection input -- written once, as its packed
                     // bf16 A operand ([packed row, 320], this direction's 150 columns; direction 0 also zeroes the padding)
-                    const int s0 = s - s % och;
                     for (int e = tid; e < (s + 1 - s0) * HID; e += MTHR) {
                         const int ss = s0 + e / HID, j = e % HID;
                         next_x[(size_t)(off + (dir ? len - 1 - ss : ss)) * XKP + dir * HID + j] = f2bf_rne(s_out[(ss % och) * HPAD + j]);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                             next_x[(size_t)(off + s0 + e / (XKP - 2 * HID)) * XKP + 2 * HID + e % (XKP - 2 * HID)] = 0;
                     mg_lds_barrier();
                 } else {
-                    flush_rows(s_out, och, s - s % och, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
+                    flush_rows(s_out, och, s0, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
                 }
             }
         }
