@@ -286,7 +286,7 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 constexpr int MW = 10;                // waves: 10 x 64 = 640 >= 600 permuted gate rows
 constexpr int MTHR = MW * 64;
 constexpr int MKS = 38;               // k-steps of 4 (150 -> 152)
-constexpr int MH = 160;               // h row in LDS (bf16), zero padded
+constexpr int MH = 192;               // h row in LDS (bf16), zero padded to 3 x 16 chunks of 4
 
 __device__ __forceinline__ unsigned int pack2_bf16(float a, float b) {
     unsigned int r;
@@ -390,17 +390,23 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
         float gx = gx_at(0), gx1 = gx_at(1), gx2 = gx_at(2);
         int cur = 0, sm = 0;                                       // sm = s % och (no integer division in the step loop)
         for (int s = 0; s < len; ++s) {
-            // h as the A operand: the same four values in every lane (LDS broadcast), 16 B = two k-steps per read
-            const uint4* h4 = reinterpret_cast<const uint4*>(s_h[cur]);
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            // h as the A operand through the MFMA's A-matrix BROADCAST (cbsz = 4: all 16 blocks take their A from block abid):
+            // three 8-byte LDS reads put h[4 (16 c + b) .. + 3] into the four lanes of block b of register pair c, and k-step
+            // ks = 16 c + b names that block -- instead of one 16-byte broadcast read (1 KB into the wave) per two k-steps
+            const uint2* hq = reinterpret_cast<const uint2*>(s_h[cur]);
+            s16x4_t hreg[3];
 #pragma unroll
-            for (int kp = 0; kp < MKS / 2; ++kp) {
-                const uint4 hv = h4[kp];
-                const s16x4_t ha = {(short)(hv.x & 0xFFFFu), (short)(hv.x >> 16), (short)(hv.y & 0xFFFFu), (short)(hv.y >> 16)};
-                const s16x4_t hb = {(short)(hv.z & 0xFFFFu), (short)(hv.z >> 16), (short)(hv.w & 0xFFFFu), (short)(hv.w >> 16)};
-                a0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ha, w[2 * kp], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hb, w[2 * kp + 1], a1, 0, 0, 0);
+            for (int cc = 0; cc < 3; ++cc) {
+                const uint2 hv = hq[16 * cc + (lane >> 2)];
+                hreg[cc] = s16x4_t{(short)(hv.x & 0xFFFFu), (short)(hv.x >> 16), (short)(hv.y & 0xFFFFu), (short)(hv.y >> 16)};
             }
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#define MG_STEP2(ks)                                                                                             \
+            a0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hreg[(ks) >> 4], w[ks], a0, 4, (ks) & 15, 0);                \
+            a1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hreg[((ks) + 1) >> 4], w[(ks) + 1], a1, 4, ((ks) + 1) & 15, 0);
+            MG_STEP2(0) MG_STEP2(2) MG_STEP2(4) MG_STEP2(6) MG_STEP2(8) MG_STEP2(10) MG_STEP2(12) MG_STEP2(14) MG_STEP2(16) MG_STEP2(18)
+            MG_STEP2(20) MG_STEP2(22) MG_STEP2(24) MG_STEP2(26) MG_STEP2(28) MG_STEP2(30) MG_STEP2(32) MG_STEP2(34) MG_STEP2(36)
+#undef MG_STEP2
             const float pre = (gx + bias) + (a0[0] + a1[0]);
             gx = gx1;
             gx1 = gx2;
