@@ -344,11 +344,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
         ops.stamp("  label GCN end")
         bank, pooled = self._img_bank_and_pool(feats, lin)
         ops.stamp("  image bank end")
+        ev_bank = torch.cuda.Event()
+        ev_bank.record(torch.cuda.current_stream())              # the bank alone: all a text->image stack needs of the channel
         x = ops.linear(pooled, G)                                # pooled @ G^T -> [B, C]
         att = attention(query=self.label_query, key=x, value=x)  # [B, NLQ, 300]
         att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(feats.shape[0], -1)
         att = ops.linear(att, x_linear.weight.detach(), x_linear.bias.detach())
-        return bank, att
+        return bank, att, ev_bank
 
     def _features(self, trunk, x):
         if x.dim() == 4 and x.shape[1] == 2048:
@@ -408,19 +410,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
         with torch.cuda.stream(s_obj):
             ops.stamp("obj: channel start")
             self.object_feature = self._features(self.object_features, object_feature)
-            bank_obj, att_obj = self._channel(self.object_feature, self.liner_img_object, self.object_A, object_inp,
+            bank_obj, att_obj, ev_bank_obj = self._channel(self.object_feature, self.liner_img_object, self.object_A, object_inp,
                                               self.object_attention, self.object_linear_5, self.object_x_linear)
             ops.stamp("obj: channel end")
-            ev_obj = torch.cuda.Event()
-            ev_obj.record(s_obj)                 # bank_obj / att_obj ready (the stream goes on with the iot stack)
         with torch.cuda.stream(s_place):
             ops.stamp("place: channel start")
             self.place_feature = self._features(self.place_features, place_feature)
-            bank_place, att_place = self._channel(self.place_feature, self.liner_img_place, self.place_A, place_inp,
+            bank_place, att_place, ev_bank_place = self._channel(self.place_feature, self.liner_img_place, self.place_A, place_inp,
                                                   self.place_attention, self.place_linear_5, self.place_x_linear)
             ops.stamp("place: channel end")
-            ev_place = torch.cuda.Event()
-            ev_place.record(s_place)
 
         # -- four fusion stacks: image->text on the channel streams, text->image on main / aux.  Every wait is on an EVENT
         #    recorded right behind the producer: waiting on a whole stream would also wait for the stack queued behind
@@ -430,7 +428,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             ops.stamp("obj: iot stack start")
             iot = run_stack(self.img_object_text_multi_head_att, att_obj, text_memory_bank, text_mask)
             ops.stamp("obj: iot stack end")
-        main.wait_event(ev_obj)                  # the object bank only -- NOT the iot stack that follows it on s_obj
+        main.wait_event(ev_bank_obj)             # the object bank only -- not the label-attention tail of the channel, nor the iot stack
         main.wait_event(ev_text_feature)         # text_feature was produced on the aux stream
         ops.stamp("main: tio stack start")
         tio = run_stack(self.text_img_object_multi_head_att, text_feature, bank_obj)
@@ -442,7 +440,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             ops.stamp("place: ipt stack end")
         # (the hipGraph runtime still runs this fourth branch after its sibling ipt -- both hang off the place channel;
         #  see DESIGN.md section 6)
-        s_aux.wait_event(ev_place)               # the place bank only
+        s_aux.wait_event(ev_bank_place)          # the place bank only
         with torch.cuda.stream(s_aux):
             ops.stamp("aux: tip stack start")
             tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
