@@ -518,7 +518,7 @@ def test_bilstm_bf16_mfma_recurrence_vs_fp32_recurrence():
     fp32 kernel on ragged batches: same zero padding, same bf16 side copy layout, bank within 5e-3 absolute (|h| < 1)."""
     import numpy as np
     rs = np.random.RandomState(5)
-    for B, T in ((37, 100), (256, 100), (5, 24)):
+    for B, T in ((37, 100), (256, 100), (5, 24), (3, 230)):      # T = 230 > 200: the h rows leave LDS in two bursts
         V, E, Hh = 500, 300, 150
         lens = rs.randint(1, T + 1, size=B)
         lens[0], lens[-1] = T, 1
