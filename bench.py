@@ -1,73 +1,441 @@
 #!/usr/bin/env python
 """bench.py -- forward samples/s of the MGNNS hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--dtype f32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--dtype f32] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward of the whole model (text GCN + BiLSTM text bank + object/scene GCN channels +
 label attention + 4 stacks of single-query multi-head fusion + classifier) over one synthetic
-MVSA-Multiple-shaped batch (configs[2]: B=256 per GPU, T=100, V=20154, 8 heads, 2 layers), entered at
-the [B,2048,14,14] feature maps, inputs resident in HBM.  N>1: one process per GPU, batch-sharded
-(weak scaling: 256 samples per GPU), logits all-gathered over RCCL inside the timed region.
-Rank 0 prints ONE JSON line.
+MVSA-Multiple-shaped batch (configs[2]: B=256, T=100, V=20154, 8 heads, 2 layers), entered at
+the [B,2048,14,14] feature maps, inputs resident in HBM.
+
+N>1: one process per GPU.  `python bench.py --gpus N` WITHOUT a torchrun environment starts the N ranks itself
+(child processes, the parent never touches a GPU) and fails non-zero unless all N join; under torchrun it is one
+rank.  The batch shards over ranks with replicated weights and ONE collective, the RCCL all-gather of the logits,
+inside the timed region (a node of the step's hipGraph when the capture probe passes, else right behind the
+replay).  Both scalings are timed: weak (256 samples per GPU, the headline `value`, "scaling": "weak") and strong
+(configs[3]: the global B=256 batch split 256/N per GPU, reported under "strong_scaling"); `--scaling strong` makes
+the strong figure the headline.  Rank 0 prints ONE JSON line.
+
+`--dry-launch` runs the same launcher / rank seeding / barrier + MAX-over-ranks timing / single-line protocol on
+the gloo backend with no GPU and no model (tests/test_bench_launch_cpu.py).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mgnns_amd import harness, ops, synth          # noqa: E402
-from mgnns_amd.sharded import ShardedForward       # noqa: E402
-
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBPS = 8000.0
+GLOBAL_BATCH = 256                                  # BASELINE.json: "forward samples/sec at batch 256"
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="samples per GPU (weak scaling)")
+    ap.add_argument("--config", default="mvsa_multiple_b256")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="which figure is the headline `value` at N>1 (both are always measured)")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
+    ap.add_argument("--attn", default="faithful", choices=["faithful", "folded"],
+                    help="faithful = K/V projected from the memory bank as the reference does (the headline number); "
+                         "folded = the projections folded into the query side (separately reported variant)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra legs (fp32 parity mode, folded attention, "
+                                                               "configs[4] stress, CNN trunks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="with --no-graph: every kernel on one stream (no concurrent kernels) -- the setting the rocprofv3 "
+                         "per-kernel averages under profiles/ are taken in, comparable with roofline.avg_launch_ms")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher / timing protocol only: gloo backend, no GPU, no model (CPU test of the N-rank path)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are stopped after this many seconds")
+    ap.add_argument("--probe-collective", action="store_true", help=argparse.SUPPRESS)     # internal: capture probe child
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without WORLD_SIZE starts the ranks itself
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Parent of a self-launched run.  Starts one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its
+    environment, exactly what torch.distributed.run would set), passes rank 0's stdout through, and returns non-zero
+    unless every rank exits 0 and the JSON line reports n_gpus == N.  This process makes no GPU call."""
+    n = args.gpus
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "MGNNS_BENCH_SELF_LAUNCHED": "1"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    failed = []
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:                         # a dead rank leaves the others in a barrier: stop them now
+                failed += bad
+                break
+            if time.time() > deadline:
+                failed.append(("timeout_s", args.launch_timeout))
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:                     # exactly the PIDs started here
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    failed += [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0 and (r, p.returncode) not in failed]
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                pass
+        else:
+            print(ln, file=sys.stderr)
+    if failed:
+        print("bench.py: %d-rank launch failed: %s" % (n, failed), file=sys.stderr)
+        return 1
+    if line is None or line.get("n_gpus") != n:
+        print("bench.py: rank 0 reported n_gpus=%r, expected %d" % (None if line is None else line.get("n_gpus"), n),
+              file=sys.stderr)
+        return 1
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# protocol shared by the real and the dry run
+# ------------------------------------------------------------------------------------------------------------------
+def timed_steps(step, steps, warmup, barrier, after_warmup=None):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier() on both sides -> local seconds."""
+    for _ in range(warmup):
+        step()
+    if after_warmup is not None:
+        after_warmup()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(dt, dist, device):
+    import torch
+    if dist is None:
+        return dt, [dt]
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), [float(e.item()) for e in every]
+
+
+def rank_seed(base, rank, scaling):
+    """Weak scaling: every rank draws its own shard (seed + 1000*rank).  Strong: all ranks draw the SAME global batch
+    (seed) and keep their contiguous slice, so the gathered logits equal the single-GPU logits of that batch."""
+    return base + 1000 * rank if scaling == "weak" else base
+
+
+def flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def dry_run(args, rank, world):
+    """The N-rank protocol without a GPU: gloo, a step that sleeps (rank+1) ms and 'logits' that encode rank and seed."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mgnns_amd.sharded import ShardedForward, shard_bounds
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    res = {}
+    for scaling in ("weak", "strong"):
+        if scaling == "weak":
+            b_local, seed = args.batch, rank_seed(1237, rank, "weak")
+            local = np.random.RandomState(seed).standard_normal((b_local, 3)).astype(np.float32)
+        else:
+            lo, hi = shard_bounds(GLOBAL_BATCH, world, rank)
+            b_local, seed = hi - lo, rank_seed(1237, rank, "strong")
+            local = np.random.RandomState(seed).standard_normal((GLOBAL_BATCH, 3)).astype(np.float32)[lo:hi]
+        sf = ShardedForward(lambda x: x)
+        x = torch.from_numpy(local)
+        state = {}
+
+        def step():
+            time.sleep(1e-3 * (rank + 1))
+            state["out"] = sf(x)
+
+        def barrier():
+            if d is not None:
+                d.barrier()
+
+        dt = timed_steps(step, args.steps, args.warmup, barrier)
+        dt_max, dts = max_over_ranks(dt, d, "cpu")
+        seeds = [seed]
+        if d is not None:
+            seeds = [None] * world
+            d.all_gather_object(seeds, seed)
+        total = world * b_local if scaling == "weak" else GLOBAL_BATCH
+        res[scaling] = {"value": total / (dt_max / args.steps), "ms_per_step": dt_max / args.steps * 1e3, "dt_ranks": dts,
+                        "seeds": seeds, "gathered_rows": int(state["out"].shape[0]),
+                        "gathered_checksum": float(state["out"].double().sum())}
+    if d is not None:
+        d.barrier()
+        d.destroy_process_group()
+    if rank != 0:
+        return
+    head = res[args.scaling]
+    line = {"metric": "forward samples/sec at batch 256 (3-channel GCN + fusion)", "value": round(head["value"], 1),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry_launch": True,
+            "config": {"workload": "dry launch (gloo, no GPU, no model): protocol check only"},
+            "weak_scaling": res["weak"], "strong_scaling": res["strong"]}
+    print(json.dumps(line), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# in-graph collective probe (child process, so a hang or a crash cannot take the benchmark down)
+# ------------------------------------------------------------------------------------------------------------------
+def probe_collective_child():
+    """Capture an RCCL all-gather into a hipGraph, replay it on changing inputs, check the result; exit 0 iff it works."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    x = torch.full((32, 3), float(rank), device=dev)
+    out = torch.empty(world * 32, 3, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            dist.all_gather_into_tensor(out, x)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dist.all_gather_into_tensor(out, x)
+    ok = True
+    for it in range(3):
+        x.fill_(float(rank + 10 * it))
+        g.replay()
+        torch.cuda.synchronize()
+        want = torch.arange(world, device=dev, dtype=torch.float32).repeat_interleave(32)[:, None].expand(-1, 3) + 10 * it
+        ok = ok and bool(torch.equal(out, want))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+def probe_collective(timeout=240.0):
+    """Run probe_collective_child with this rank's coordinates on a port of its own.  Called BEFORE this process touches
+    the GPU.  True iff the child exits 0 in time."""
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 17)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-collective"], env=env, timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            print("collective-capture probe failed (rc %d): %s" % (r.returncode, r.stderr[-400:]), file=sys.stderr)
+        return r.returncode == 0
+    except subprocess.TimeoutExpired:
+        print("collective-capture probe timed out", file=sys.stderr)
+        return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# algorithmic work -- what every roofline figure below is computed from
+# ------------------------------------------------------------------------------------------------------------------
 def mha_core_flops(B, L, D, H, dk):
-    """Algorithmic FLOPs of one fused single-query MHA launch:
-    K and V projections 2 * (2*L*D*H*dk) + QK^T and PV 2 * (2*H*dk*L) per sample."""
+    """One fused single-query MHA launch: K and V projections 2*(2*L*D*H*dk) + QK^T and PV 2*(2*H*dk*L) per sample."""
     return B * (4.0 * L * D * H * dk + 4.0 * H * dk * L)
 
 
-def cpu_baseline(cfg, model, inp, pmi, budget_s=20.0):
-    """The CPU oracle (oracle/restatement.py, the pinned restatement of the reference forward) timed on
-    this box's host cores on the SAME synthetic batch.  Checker/baseline only -- never the product."""
+def textgcn_bytes(tok, ngram, D=300):
+    """sum_b [U_b*4D + E_b*12 + 4D]: gathered node rows, (edge id, weight, index) per edge, the output row.
+    U_b = distinct token ids of the document (PAD node included when padded), E_b = n-gram window edges + self loops."""
+    import numpy as np
+    total = 0.0
+    for row in tok:
+        n = int((row != 0).sum())
+        U = len(np.unique(row))
+        i = np.arange(n)
+        E = int((np.minimum(i, ngram) + np.minimum(n - 1 - i, ngram) + 1).sum())
+        total += U * 4.0 * D + E * 12.0 + 4.0 * D
+    return total
+
+
+def sha16(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected live); refused when the kernel
+    source changed since the pass (sha of the .hip file stored with the entry)."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            t = json.load(f).get(kernel_key)
+        if not t:
+            return None, None
+        src = os.path.join(ROOT, t["kernel_source"])
+        if sha16(src) != t["kernel_source_sha16"]:
+            return None, "stale: %s changed since %s" % (t["kernel_source"], t["source"])
+        return t["hbm_bytes"], t["source"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, model, inp, pmi, budget_s=30.0):
+    """The CPU oracle (oracle/restatement.py, the pinned restatement of the reference forward) timed on this box's host
+    cores on the SAME synthetic batch.  Checker/baseline only -- never the product.  Thread sweep on a 64-sample slice,
+    then 3 warm-up + >=5 timed forwards of the full batch at the best thread count, plus a 1-thread figure."""
+    import numpy as np
+    import torch
     from oracle import restatement as R
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ti = {k: torch.as_tensor(v) for k, v in inp.items()}
     lq = model.label_query.detach().cpu()
-    cores = torch.get_num_threads()
-
-    def run():
-        return R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=lq)
-
-    t0 = time.time()
-    ref = run()                                   # warm-up (also the parity reference)
-    first = time.time() - t0
-    times = []
-    while sum(times) + first < budget_s and len(times) < 8:
-        t0 = time.time()
-        run()
-        times.append(time.time() - t0)
-    if not times:
-        times = [first]
     B = ti["text"].shape[0]
-    best = float(np.median(times))
-    return ref, {"value": round(B / best, 2), "unit": "samples/s", "cores": int(cores), "kind": "port",
-                 "sample": "%d timed forwards of the same B=%d synthetic batch through oracle/restatement.py "
-                           "(torch-CPU fp32, %d threads; median %.3f s)" % (len(times), B, cores, best)}
+    ncpu = os.cpu_count() or 1
+    t_begin = time.time()
+
+    def run(t, n):
+        sub = {k: (v[:n] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in t.items()}
+        return R.forward(p, sub, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram, label_query=lq)
+
+    def best_of(n, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            run(ti, n)
+            ts.append(time.time() - t0)
+        return min(ts)
+
+    nsub = min(B, 64)
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu} or {ncpu}):
+        torch.set_num_threads(th)
+        run(ti, nsub)
+        sweep[th] = round(nsub / best_of(nsub, 2), 1)
+    best_th = max(sweep, key=sweep.get)
+    torch.set_num_threads(1)
+    n1 = min(B, 8)
+    one = round(n1 / best_of(n1, 1), 2)
+    torch.set_num_threads(best_th)
+    ref = run(ti, B)                               # warm-up 1 (also the parity reference)
+    per = time.time()
+    run(ti, B)
+    per = time.time() - per                        # warm-up 2 doubles as the cost estimate
+    run(ti, B)
+    left = budget_s - (time.time() - t_begin)
+    reps = int(max(5, min(8, left / max(per, 1e-3))))
+    times = []
+    for _ in range(reps):
+        t0 = time.time()
+        run(ti, B)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return ref, {"value": round(B / med, 2), "unit": "samples/s", "cores": int(best_th), "kind": "port",
+                 "cpu_model": cpu_model(), "host_logical_cpus": ncpu,
+                 "sample": "3 warm-up + %d timed forwards of the same B=%d synthetic batch through oracle/restatement.py "
+                           "(torch-CPU fp32, %d threads = best of the sweep; median %.3f s)" % (len(times), B, best_th, med),
+                 "thread_sweep_samples_per_s": {str(k): v for k, v in sweep.items()},
+                 "thread_sweep_sample": "B=%d slice of the same batch, best of 2 after 1 warm-up" % nsub,
+                 "single_thread_samples_per_s": one}
 
 
+def cpu_baseline_other(names=("mvsa_single_b8", "tumemo_b64")):
+    """configs[0] / configs[1] shapes through the oracle (cfg 1 is the reference's own CPU-runnable case)."""
+    import numpy as np
+    import torch
+    from mgnns_amd import harness, synth
+    from oracle import restatement as R
+    out = {}
+    for name in names:
+        cfg = synth.CONFIGS[name]
+        pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+        A_obj, A_place = harness.synthetic_adjacencies(cfg)
+        inp = synth.make_inputs(cfg, seed=cfg.seed, pmi=pmi)
+        m = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], None)
+        p = {k: v.detach() for k, v in m.state_dict().items()}
+        ti = {k: torch.as_tensor(v) for k, v in inp.items()}
+        f = lambda: R.forward(p, ti, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                              label_query=torch.as_tensor(inp["label_query"]))
+        for _ in range(2):
+            f()
+        ts = []
+        for _ in range(5):
+            t0 = time.time()
+            f()
+            ts.append(time.time() - t0)
+        out[name] = {"samples_per_s": round(cfg.B / float(np.median(ts)), 1), "batch": cfg.B, "timed": 5,
+                     "threads": torch.get_num_threads()}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# extra legs (single GPU only, never part of `value`)
+# ------------------------------------------------------------------------------------------------------------------
 def trunk_leg(dev, batch=128, size=448, iters=3):
     """ResNet-101 (objects) + ResNet-50/365 (places) features of `batch` 448x448 images on the HIP
     implicit-GEMM kernels (seeded weights), eager launches; MFMA utilisation on the algorithmic convolution FLOPs."""
+    import torch
+    from mgnns_amd import synth
     try:
         from mgnns_amd import trunk
         res = {}
@@ -95,46 +463,126 @@ def trunk_leg(dev, batch=128, size=448, iters=3):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
-    ap.add_argument("--config", default="mvsa_multiple_b256")
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
-                    help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
-    ap.add_argument("--attn", default="faithful", choices=["faithful", "folded"],
-                    help="faithful = K/V projected from the memory bank as the reference does (the headline number); "
-                         "folded = the projections folded into the query side (separately reported variant)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra timing of the folded-attention variant")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="with --no-graph: every kernel on one stream (no concurrent kernels) -- the setting the rocprofv3 "
-                         "per-kernel averages under profiles/ are taken in, comparable with roofline.avg_launch_ms")
-    args = ap.parse_args()
+def stress_leg(dev):
+    """BASELINE configs[4] on this GPU: one 10 000-node channel, cache-cold (mgnns_amd/stress.py)."""
+    try:
+        from mgnns_amd import stress
+        return stress.measure(dev)
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
+
+def graphed_variant(model, call, B, steps, warmup, what):
+    import torch
+    from mgnns_amd.graph import GraphedForward
+    gv = GraphedForward(model, call)
+    for _ in range(warmup):
+        vout = gv.replay()
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    for _ in range(steps):
+        vout = gv.replay()
+    torch.cuda.synchronize()
+    dv = (time.perf_counter() - tv) / steps
+    return {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "what": what,
+            "_out": vout[:B].float().cpu()}
+
+
+def roofline_all(timer, cfg, B, P, inp, dtype, model):
+    """Per-kernel achieved fraction of the bounding roofline from the same eager single-stream timing leg as `roofline`
+    (HIP events around each C-ABI call on its launch stream).  Algorithmic bytes / FLOPs per SURVEY 8d."""
+    import numpy as np
+    d = timer.durations_ms()
+    H, dk, D, T = cfg.n_head, cfg.d_kv, cfg.emb_size, cfg.T
+    rows = []
+
+    def add(kernel, key, bound, work, note):
+        v = d.get(key, [])
+        if not v:
+            return
+        us = float(np.mean(v)) * 1e3
+        if bound == "hbm":
+            ach, peak, unit = work / us / 1e3, PEAK_HBM_GBPS, "GB/s"
+        else:
+            ach, peak, unit = work / us / 1e6, PEAK_TFLOPS["f32" if bound == "mfma_f32" else "bf16"], "TFLOP/s"
+        rows.append({"kernel": kernel, "bound": "mfma" if bound.startswith("mfma") else bound, "algorithmic": work,
+                     "algorithmic_unit": "B" if bound == "hbm" else "FLOP", "avg_us": round(us, 2), "launches": len(v),
+                     "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "note": note})
+
+    bf = dtype == "bf16"
+    core = "mgnns_sq_mha_core_bf16_fwd" if bf else "mgnns_sq_mha_core_fwd"
+    mfma = "mfma_bf16" if bf else "mfma_f32"
+    add("sq_mha_core%s (L=%d image bank)" % ("_bf16" if bf else "", P), (core, P, False), mfma,
+        mha_core_flops(B, P, D, H, dk), "K/V projection + QK^T + softmax + PV, all rows valid")
+    add("sq_mha_core%s (L=%d text bank, masked)" % ("_bf16" if bf else "", T), (core, T, True), mfma,
+        mha_core_flops(B, T, D, H, dk), "FLOPs counted over all T rows; masked row tiles are skipped, so this can exceed "
+                                        "the unmasked figure")
+    if bf:
+        add("imgbank_pool_bf16", ("mgnns_imgbank_pool_bf16_fwd",), "hbm", B * (2048.0 * P * 4 + P * D * 2 + 2048 * 4),
+            "fp32 map read once + bf16 bank + pooled row written")
+        add("mha_tail_bf16", ("mgnns_mha_tail_bf16_fwd",), "mfma_bf16",
+            B * 2.0 * (H * dk * D + 2 * D * D) + B * 2.0 * D * H * dk / 2,
+            "fc + FFN per launch; the next layer's w_qs is fused into every other launch (averaged in)")
+    else:
+        add("imgbank_pool (fp32)", ("mgnns_imgbank_pool_fwd",), "mfma_f32", B * 2.0 * P * 2048 * D, "bank projection FLOPs")
+        add("mha_tail (fp32)", ("mgnns_mha_tail_fwd",), "mfma_f32",
+            B * 2.0 * (H * dk * D + 2 * D * D) + B * 2.0 * D * H * dk / 2, "fc + FFN (+ w_qs on every other launch)")
+    add("textgcn", ("mgnns_textgcn_fwd",), "hbm", textgcn_bytes(np.asarray(inp["text"]), cfg.ngram, D),
+        "sum_b U_b*1200 + E_b*12 + 1200 B (SURVEY 8d a1)")
+    lstm_key = ("mgnns_bilstm_bf16_fwd",) if (bf and os.environ.get("MGNNS_LSTM_REC", "bf16") == "bf16") else ("mgnns_bilstm_fwd",)
+    add("bilstm (whole op: pack + 2 input GEMMs + 2 recurrences)", lstm_key, mfma,
+        34.8e6 * B, "34.8 MFLOP/sample; sequential over <=T steps: latency-bound, not an MFMA-roofline kernel")
+    for C, nm in ((cfg.C_obj, "object"), (cfg.C_place, "place")):
+        for F in (1024, 2048):
+            nnz = int((np.asarray(getattr(model, nm + "_A").detach().cpu()) != 0).sum())
+            add("spmm_csr (%s graph, F=%d)" % (nm, F), ("mgnns_spmm_csr_fwd", C, F), "hbm", nnz * 8.0 + 2.0 * C * F * 4,
+                "nnz*8 + 2*C*F*4 B; model-scale graphs are launch-bound (see `stress` for the 10k-node figure)")
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (self-launching) or "
+                         "`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ.get("MGNNS_BENCH_TEST_KILL_RANK") == str(rank):      # tests/test_bench_launch_cpu.py: a rank that never joins
+        raise SystemExit(3)
+    if args.dry_launch:
+        return dry_run(args, rank, world)
+
+    want_dist = world > 1 or os.environ.get("MGNNS_FORCE_DIST") == "1"   # the env switch exercises the RCCL path on one GPU
+    graph_collective = False
+    if want_dist and not args.no_graph and os.environ.get("MGNNS_GRAPH_COLLECTIVE", "1") == "1":
+        graph_collective = probe_collective()          # child process, before this one touches the GPU
+
+    import numpy as np
+    import torch
+    from mgnns_amd import harness, ops, synth
+    from mgnns_amd.graph import GraphedForward
+    from mgnns_amd.sharded import ShardedForward, shard_bounds
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("MGNNS_FORCE_DIST") == "1":   # the env switch exercises the RCCL path on one GPU
+    if want_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ok = torch.tensor([1 if graph_collective else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same path
+        graph_collective = bool(ok.item())
 
     cfg = synth.CONFIGS[args.config]
-    B = args.batch
     pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
     A_obj, A_place = harness.synthetic_adjacencies(cfg)
-    inp = synth.make_inputs(cfg, B=B, seed=cfg.seed + 1000 * rank, pmi=pmi)     # this rank's shard
-    model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
+    label_query = synth.make_inputs(cfg, B=1, seed=cfg.seed, pmi=pmi)["label_query"]
+    model = harness.build_model(cfg, pmi, count, A_obj, A_place, label_query, dev)
     model.set_precision("bf16" if args.dtype == "bf16" else "fp32")
     model.set_attention(args.attn)
     if args.single_stream:
@@ -142,86 +590,95 @@ def main():
     core = "mgnns_sq_mha_core_bf16_fwd" if args.dtype == "bf16" else "mgnns_sq_mha_core_fwd"
     if args.attn == "folded":
         core = "mgnns_sq_mha_folded_fwd"
-    call = harness.call_args(inp, dev)
-    gf = None
-    if args.no_graph:
-        fwd = ShardedForward(lambda *a: model(*a))
-    else:
-        from mgnns_amd.graph import GraphedForward
-        sf = ShardedForward(lambda *a: gf.replay())
-        launch = "hipGraph replay"
-        # opt-in (MGNNS_GRAPH_COLLECTIVE=1): verified here with one rank only -- the multi-rank capture could not be run in
-        # this round's single-GPU boxes, so the default keeps the all-gather behind the replay
-        if dist is not None and os.environ.get("MGNNS_GRAPH_COLLECTIVE", "0") == "1":
-            try:                                  # the logits all-gather as a node of the same graph
-                gf = GraphedForward(model, call, post=sf.gather)
-                fwd = lambda *a: gf.replay()
-                launch = "hipGraph replay (RCCL all-gather captured)"
-            except Exception as e:                # capture of the collective unsupported: gather after the replay
-                print("collective capture failed (%s); gathering after the replay" % type(e).__name__, file=sys.stderr)
-                gf = None
-        if gf is None:
-            gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
-            fwd = sf
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def shard(scaling):
+        """This rank's inputs: weak = its own B-sample draw; strong = its slice of the one global 256-sample batch."""
+        if scaling == "weak":
+            return synth.make_inputs(cfg, B=args.batch, seed=rank_seed(cfg.seed, rank, "weak"), pmi=pmi), args.batch
+        lo, hi = shard_bounds(GLOBAL_BATCH, world, rank)
+        g = synth.make_inputs(cfg, B=GLOBAL_BATCH, seed=rank_seed(cfg.seed, rank, "strong"), pmi=pmi)
+        return {k: (v[lo:hi] if k != "label_query" else v) for k, v in g.items()}, hi - lo
+
+    def measure(scaling):
+        inp, b_local = shard(scaling)
+        if scaling == "strong" and b_local * world != GLOBAL_BATCH:
+            raise SystemExit("strong scaling needs the global batch %d divisible by %d ranks" % (GLOBAL_BATCH, world))
+        call = harness.call_args(inp, dev)
+        launch = "eager"
+        if args.no_graph:
+            fwd = ShardedForward(lambda *a: model(*a))
+        else:
+            sf = ShardedForward(lambda *a: gf.replay())
+            gf, fwd = None, None
+            if dist is not None and graph_collective:
+                try:                                  # the logits all-gather as a node of the same graph
+                    gf = GraphedForward(model, call, post=sf.gather)
+                    fwd = lambda *a: gf.replay()
+                    launch = "hipGraph replay (RCCL all-gather captured)"
+                except Exception as e:                # capture of the collective refused: gather right behind the replay
+                    print("collective capture failed (%s: %s); gathering after the replay" % (type(e).__name__, e), file=sys.stderr)
+                    gf = None
+            if gf is None:
+                gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
+                fwd = sf
+                launch = "hipGraph replay" + (" + RCCL all-gather behind it" if dist is not None else "")
+        out = {}
+
+        def step():
+            out["logits"] = fwd(*call)
+
+        with torch.no_grad():
+            # after the warm-up: RCCL's banner out of every rank's C stdio buffer, long before the JSON line
+            dt = timed_steps(step, args.steps, args.warmup, barrier, flush_c_stdio if dist is not None else None)
+        dt, dts = max_over_ranks(dt, dist, dev)
+        total = world * b_local
+        return {"inp": inp, "call": call, "b_local": b_local, "dt": dt, "dt_ranks": dts, "launch": launch,
+                "value": total / (dt / args.steps), "ms": dt / args.steps * 1e3, "global_batch": total,
+                "logits": out["logits"]}
+
+    weak = measure("weak")
+    strong = measure("strong") if world > 1 else None
+
+    # ---- roofline leg: every C-ABI launch timed with HIP events on the stream it runs on, over eager single-stream
+    #      forwards right after the timed region (events cannot sit inside a graph); rank 0's shard ----
+    B, inp, call = weak["b_local"], weak["inp"], weak["call"]
+    timer = ops.KernelTimer(None)
+    ops.set_timer(timer)
+    model.use_streams = False
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = fwd(*call)
-        if dist is not None:            # RCCL prints its banner at communicator init (first collective, above): get it
-            try:                        # out of every rank's C stdio buffer now, long before rank 0 prints the JSON line
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-            except Exception:
-                pass
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = fwd(*call)
-        barrier()
-        dt = time.perf_counter() - t0
-        # roofline leg: the dominant kernel's launches timed with HIP events on the stream they run on, over
-        # the same number of eager forwards right after the timed region (events cannot sit inside a graph)
-        timer = ops.KernelTimer([core])
-        ops.set_timer(timer)
-        model.use_streams = False
         for _ in range(min(args.steps, 10)):
             model(*call)
-        torch.cuda.synchronize()
-        model.use_streams = not args.single_stream
-        ops.set_timer(None)
-        # separately reported variant (single GPU only): same step with attention='folded', its own graph
-        variant = None
-        if world == 1 and dist is None and args.attn == "faithful" and not args.no_variants and not args.no_graph:
-            model.set_attention("folded")
-            gv = GraphedForward(model, call)
-            for _ in range(args.warmup):
-                vout = gv.replay()
-            torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for _ in range(args.steps):
-                vout = gv.replay()
-            torch.cuda.synchronize()
-            dv = (time.perf_counter() - tv) / args.steps
-            variant = {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4),
-                       "what": "same step, fusion attention with the K/V projections folded into the query "
-                               "(csrc/sq_mha_folded.hip); not the formulation the MFMA target is quoted on",
-                       "_out": vout[:B].float().cpu()}
-            model.set_attention("faithful")
+    torch.cuda.synchronize()
+    model.use_streams = not args.single_stream
+    ops.set_timer(None)
 
-    # row f4 (reported beside the headline, never part of `value`): the two CNN trunks in front of the path
-    trunks = None
-    if world == 1 and dist is None and not args.no_variants:
+    variants = {}
+    trunks = stress = None
+    single = world == 1 and dist is None
+    if single and not args.no_variants and not args.no_graph:
+        with torch.no_grad():
+            if args.attn == "faithful":
+                model.set_attention("folded")
+                variants["attention=folded"] = graphed_variant(
+                    model, call, B, args.steps, args.warmup,
+                    "same step, fusion attention with the K/V projections folded into the query (csrc/sq_mha_folded.hip); "
+                    "not the formulation the MFMA target is quoted on")
+                model.set_attention("faithful")
+            if args.dtype == "bf16":
+                model.set_precision("fp32")
+                variants["dtype=f32 (parity-grade)"] = graphed_variant(
+                    model, call, B, max(5, args.steps // 2), 2,
+                    "same step in fp32 mode: every contraction on the exact-f32 MFMA -- the mode the north-star's 1e-4 "
+                    "logit tolerance is gated on (tests/test_model_gpu.py)")
+                model.set_precision("bf16")
+        stress = stress_leg(dev)
         trunks = trunk_leg(dev)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -240,58 +697,66 @@ def main():
             avg_ms = float(np.mean(durs))
             by = B * P * (320 * 2 if is_bf16 else cfg.emb_size * 4)
             roofline = {"bound": "hbm", "kernel": "mgnns_sq_mha_folded_fwd (3 launches, L=%d, H=%d)" % (P, cfg.n_head),
-                        "achieved": round(by / (avg_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(by / (avg_ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                        "achieved": round(by / (avg_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(by / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs), "bytes_per_launch": by}
     elif durs:
         avg_ms = float(np.mean(durs))
         fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
         ach = fl / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % ("sq_mha_core_bf16_kernel" if args.dtype == "bf16" else
-                                                          "sq_mha_core_kernel", P, cfg.n_head),
+        kname = "sq_mha_core_bf16_kernel" if args.dtype == "bf16" else "sq_mha_core_kernel"
+        roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % (kname, P, cfg.n_head),
                     "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),
                     "flops_per_launch": fl}
-
-    if roofline is not None:
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (cannot be collected live)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                t = json.load(f).get("%s@L%d" % (roofline["kernel"].split(" ")[0], P))
-            if t:
-                roofline["traffic"] = t["hbm_bytes"]
-                roofline["traffic_source"] = t["source"]
-        except (OSError, ValueError):
-            pass
+        if B == GLOBAL_BATCH:
+            tr, src = pmc_traffic("%s@L%d" % (kname, P))
+            roofline["traffic"] = tr
+            if src:
+                roofline["traffic_source"] = src
+    rall = roofline_all(timer, cfg, B, P, inp, args.dtype, model) if args.attn == "faithful" else None
 
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and single:          # N = 1 only (rank 0's host cores)
         ref, cpu = cpu_baseline(cfg, model, inp, pmi)
-        parity = float((out[:B].float().cpu() - ref).abs().max())
-        if variant is not None:
-            variant["max_abs_logit_diff_vs_cpu_oracle"] = float((variant["_out"] - ref).abs().max())
-    if variant is not None:
-        del variant["_out"]
+        parity = float((weak["logits"][:B].float().cpu() - ref).abs().max())
+        for v in variants.values():
+            v["max_abs_logit_diff_vs_cpu_oracle"] = float((v["_out"] - ref).abs().max())
+        if not args.no_variants:
+            try:
+                cpu["other_configs"] = cpu_baseline_other()
+            except Exception as e:
+                cpu["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    for v in variants.values():
+        del v["_out"]
 
-    ms = dt / args.steps * 1e3
+    head = weak if (args.scaling == "weak" or strong is None) else strong
     line = {
         "metric": "forward samples/sec at batch 256 (3-channel GCN + fusion)",
-        "value": round(world * B / (dt / args.steps), 1), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-        "data": "synthetic",
+        "value": round(head["value"], 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(head["ms"], 4),
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: B=%d per GPU, T=%d, V=%d, n_head=%d, stack_num=%d, C=(%d,%d), "
                                "feature maps [B,2048,14,14] fp32 resident in HBM, logits all-gathered"
-                               % (cfg.name, B, cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
-                   "global_batch": world * B, "parallelism": "batch-shard x%d" % world,
-                   "launch": "eager" if args.no_graph else launch},
+                               % (cfg.name, head["b_local"], cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
+                   "global_batch": head["global_batch"], "parallelism": "batch-shard x%d" % world,
+                   "launch": head["launch"], "attention": args.attn},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
-    line["config"]["attention"] = args.attn
-    if variant is not None:
-        line["variants"] = {"attention=folded": variant}
+    if world > 1:
+        for nm, r in (("weak_scaling", weak), ("strong_scaling", strong)):
+            line[nm] = {"value": round(r["value"], 1), "unit": "samples/s", "ms_per_step": round(r["ms"], 4),
+                        "per_gpu_batch": r["b_local"], "global_batch": r["global_batch"], "launch": r["launch"],
+                        "dt_ranks_s": [round(t, 6) for t in r["dt_ranks"]]}
+    if rall:
+        line["roofline_all"] = rall
+    if variants:
+        line["variants"] = variants
+    if stress is not None:
+        line["stress"] = stress
     if trunks is not None:
         line["trunks"] = trunks
     if dist is not None:
@@ -299,13 +764,20 @@ def main():
         dist.destroy_process_group()
     # the JSON line must be the last thing on stdout: push out whatever native libraries (RCCL banner) still hold in
     # the C stdio buffer first
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_c_stdio()
     sys.stdout.flush()
+    assert line["n_gpus"] == args.gpus
     print(json.dumps(line), flush=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.probe_collective:
+        return probe_collective_child()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ engine/Multi_GCN_Multihead_Att_engine.py:825."""
 import torch
 
 from . import synth
-from .model import Multi_GCN_Multihead_Att, Text_model
+from .model import Multi_GCN_Multihead_Att, Text_model_from_parts
 
 
 def make_vocab(V):
@@ -14,7 +14,7 @@ def make_vocab(V):
 def build_model(cfg, pmi, count, A_obj, A_place, label_query, device=None, trunks=False):
     """trunks=True also builds the reference's CNN trunks (MODEL:629-630: ResNet-101 for objects, ResNet-50 with 365
     classes for places) with seeded weights, so the model accepts raw [B,3,448,448] images."""
-    tm = Text_model(make_vocab(cfg.V), pmi, count, cfg.NL, cfg.ngram, 0.5)
+    tm = Text_model_from_parts(make_vocab(cfg.V), pmi, count, cfg.NL, cfg.ngram, 0.5)
     obj = place = None
     if trunks:
         from . import trunk

@@ -191,6 +191,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.register_buffer('label_query', None, persistent=False)
         self._load_label_query(label_glove if label_glove is not None else opt.get('label_glove'))
         self._wt_cache = {}
+        self._lstm_cache = ops.LstmCache()     # derived LSTM weight forms live and die with this module
         self._streams = None
         self.use_streams = bool(opt.get('use_streams', True))
         self.precision = 'fp32'
@@ -200,8 +201,14 @@ class Multi_GCN_Multihead_Att(nn.Module):
 
     def set_precision(self, precision):
         """'fp32': every contraction on the exact-f32 MFMA (the parity path, <=1e-4 on logits).
-        'bf16': the fusion-attention K/V projections use bf16 operands with fp32 accumulation
-        (BASELINE config 3); everything else stays fp32."""
+        'bf16' (BASELINE configs[2]): bf16 operands with fp32 accumulation in the image-bank projection, the fusion
+        attention's K/V projections, the fused layer tail (plain bf16 weights; MGNNS_TAIL_TERMS=3 selects split hi+lo
+        weights) and the BiLSTM's input and recurrent products (MGNNS_LSTM_REC=f32 keeps the exact fp32 recurrence);
+        text GCN, label GCN / attention, scores, softmax, LayerNorms, gates, cell state and residuals stay fp32.
+        Measured |logit - fp32 CPU oracle| at B=256: 1.6e-2 (not inside the 1e-4 gate, which is the fp32 mode's).
+        A feature map whose position count P is not in (104, 200] or not a multiple of 4 uses the fp32 bank kernel
+        for that projection in either mode (the bf16 bank kernel is tiled for 14x14 maps); results then carry fp32
+        accuracy, never less."""
         if precision not in ('fp32', 'bf16'):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
@@ -268,10 +275,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
         if self.precision == 'bf16':
             f32, bf = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
                                  self.hidden_size, self.lstm.num_layers, want_bf16=True,
-                                 recurrence=os.environ.get("MGNNS_LSTM_REC", "bf16"))
+                                 recurrence=os.environ.get("MGNNS_LSTM_REC", "bf16"), cache=self._lstm_cache)
             return MemoryBank(f32=f32, bf16=bf)
         return MemoryBank(f32=ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
-                                         self._lstm_weights(), self.hidden_size, self.lstm.num_layers))
+                                         self._lstm_weights(), self.hidden_size, self.lstm.num_layers,
+                                         cache=self._lstm_cache))
 
     def get_text_memory_bank(self, text, text_lens, return_last_state=True):
         """Embedding gather + packed 2-layer BiLSTM + re-padding to T (MODEL:366-398) as HIP kernels.
@@ -282,7 +290,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         batch_size, max_text_len = list(text.size())
         lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
         memory_bank = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
-                                 self._lstm_weights(), self.hidden_size, self.lstm.num_layers)
+                                 self._lstm_weights(), self.hidden_size, self.lstm.num_layers, cache=self._lstm_cache)
         assert memory_bank.size() == torch.Size([batch_size, max_text_len, self.bi_hidden_size])
         if not return_last_state:
             return memory_bank
@@ -384,6 +392,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
         they are enqueued on separate HIP streams (fork/join with events: no host sync, capturable into one
         hipGraph) and overlap on the GPU instead of running as one serial chain of small launches."""
         main = torch.cuda.current_stream()
+        # input conversions BEFORE any fork: a bool / int mask (the reference documents a bool tensor) launches a cast on
+        # `main`; every side stream and every event below is ordered behind it
+        text_mask = text_mask.float().contiguous()
         s_obj, s_place, s_aux = self._side_streams(text.device) if self.use_streams else (main, main, main)
         for st in (s_obj, s_place):
             st.wait_stream(main)
@@ -404,7 +415,6 @@ class Multi_GCN_Multihead_Att(nn.Module):
         ops.stamp("main: text bank (LSTM) end")
         ev_text_bank = torch.cuda.Event()
         ev_text_bank.record(main)
-        text_mask = text_mask.float().contiguous()
 
         # -- object / place channels ------------------------------------------------------------------------------
         with torch.cuda.stream(s_obj):
@@ -473,20 +483,123 @@ class Multi_GCN_Multihead_Att(nn.Module):
         ]
 
 
-def Text_model(vocab, edges_mappings, count, num_labels, ngram, text_dropout, edges_weights=None):
-    """Text channel factory.  The reference's Text_model (MODEL:598-615) builds the vocabulary and
-    the dense PMI matrices from the training split (utils/pmi.py, out of scope); this one takes the
-    resulting vocabulary, edge map (dense, scipy sparse or PmiCsr) and edge count directly."""
+def Text_model_from_parts(vocab, edges_mappings, count, num_labels, ngram, text_dropout, edges_weights=None):
+    """Text channel from an already built vocabulary, edge map (dense, scipy sparse or PmiCsr) and edge count
+    (what Text_model below derives from the training split)."""
     return Text_GCN_Model(num_labels, hidden_size_node=300, vocab=vocab, n_gram=ngram, drop_out=text_dropout,
                           edges_matrix=edges_mappings, edges_num=count, pmi=edges_weights, cuda=True,
                           trainable_edges=True)
 
 
-def multi_gcn_multihead_att_model(opt, num_labels, object_num_classes, place_num_classes, object_t, place_t,
-                                  text_model, object_model=None, place_model=None,
-                                  object_adj_file=None, place_adj_file=None, in_channel=300, label_glove=None):
-    """Factory mirroring MODEL:619-642 with the text model and the (optional) CNN trunks injected
-    instead of being built from files that only exist on the authors' machine."""
+def get_content(data_root_path):
+    """The `text` field of every line of <data_root>/all_anno_json/train_all_anno.json (utils/pmi.py:17-25)."""
+    import json
+    all_text = []
+    with open(os.path.join(data_root_path, 'all_anno_json', 'train_all_anno.json'), 'r') as f:
+        for line in f:
+            all_text.append(json.loads(line)['text'])
+    return all_text
+
+
+def Text_model(data_root_path, vocab_root_path, text_min_count, window_size,
+               num_labels, ngram, text_dropout, min_cooccurence):
+    """MODEL:598-615 with the reference's signature: vocabulary from <vocab_root>/vocab/vocab-<N>.txt (built from the
+    train split when absent, utils/vocab_new.py:8-15), PMI edge map from the train split (utils/pmi.py:28-105 -- here the
+    sparse builder of mgnns_amd.pmi: same ids, same weights, no dense [V,V] matrices), Text_GCN.Model on top."""
+    from .pmi import build_pmi
+    from .vocab import get_vocab_list
+    vocab = get_vocab_list(data_root_path, vocab_root_path, text_min_count)
+    edges_weights, edges_mappings, count = build_pmi(get_content(data_root_path), vocab, window_size=window_size,
+                                                     min_cooccurence=min_cooccurence)
+    return Text_GCN_Model(num_labels, hidden_size_node=300, vocab=vocab, n_gram=ngram, drop_out=text_dropout,
+                          edges_matrix=edges_mappings, edges_num=count, pmi=torch.from_numpy(edges_weights),
+                          cuda=True, trainable_edges=True)
+
+
+def _weights_dir():
+    return os.environ.get('MGNNS_WEIGHTS_DIR', 'weights')
+
+
+def _trunk_init_random():
+    """MGNNS_TRUNK_INIT=random: build the trunks without a checkpoint (their weights then arrive through
+    load_state_dict, e.g. a resumed MGNNS checkpoint -- ENGINE:399,415).  Default: a missing checkpoint raises."""
+    return os.environ.get('MGNNS_TRUNK_INIT', '') == 'random'
+
+
+def _load_checkpoint(path):
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception:                       # checkpoints pickled with numpy scalars etc. (Places365: 'best_prec1')
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def place_resnet(arch='resnet50'):
+    """MODEL:586-595: the Places365 ResNet from weights/<arch>_places365.pth.tar ('module.' prefixes stripped)."""
+    from . import trunk
+    if arch != 'resnet50':
+        raise ValueError("the HIP trunk implements the bottleneck ResNets the reference uses; got arch=%r" % (arch,))
+    model = trunk.resnet50(num_classes=365)
+    model_file = os.path.join(_weights_dir(), '%s_places365.pth.tar' % arch)
+    if not os.path.exists(model_file):
+        if _trunk_init_random():
+            return model
+        raise FileNotFoundError("%s not found (set MGNNS_WEIGHTS_DIR, or MGNNS_TRUNK_INIT=random to build the trunk "
+                                "uninitialised and load a full model checkpoint afterwards)" % model_file)
+    checkpoint = _load_checkpoint(model_file)
+    state_dict = {str.replace(k, 'module.', ''): v for k, v in checkpoint['state_dict'].items()}
+    model.load_state_dict(state_dict)
+    return model
+
+
+def object_resnet(pretrained=True):
+    """MODEL:629 `models.resnet101(pretrained=pretrained)`.  There is no download here: pretrained=True reads the
+    torchvision checkpoint (resnet101-*.pth) from MGNNS_WEIGHTS_DIR / weights/ or torch's hub cache."""
+    import glob
+    from . import trunk
+    model = trunk.resnet101()
+    if not pretrained:
+        return model
+    hub = os.path.join(os.environ.get('TORCH_HOME', os.path.expanduser('~/.cache/torch')), 'hub', 'checkpoints')
+    found = []
+    for d in (_weights_dir(), hub):
+        found += sorted(glob.glob(os.path.join(d, 'resnet101*.pth')))
+    if not found:
+        if _trunk_init_random():
+            return model
+        raise FileNotFoundError("pretrained=True but no resnet101*.pth under %s or %s (no network to download it; set "
+                                "MGNNS_WEIGHTS_DIR, pass pretrained=False, or MGNNS_TRUNK_INIT=random)" % (_weights_dir(), hub))
+    model.load_state_dict(_load_checkpoint(found[0]))
+    return model
+
+
+def multi_gcn_multihead_att_model(opt,
+                                  num_labels,
+                                  object_num_classes, place_num_classes, object_t, place_t,
+                                  data_root_path, vocab_root_path,
+                                  text_min_count, window_size,
+                                  ngram, min_cooccurence,
+                                  text_dropout=0.5,
+                                  pretrained=True,
+                                  object_adj_file=None, place_adj_file=None, in_channel=300):
+    """MODEL:619-642, same parameters in the same order (the keyword call of Tumblr_Multi_GCN_Multihead_Att.py:144-157
+    works unchanged): ResNet-101 + Places365 ResNet-50 trunks on the HIP convolution kernels, the text channel built
+    from the train split, Multi_GCN_Multihead_Att on top."""
+    object_model = object_resnet(pretrained=pretrained)
+    place_model = place_resnet()
+    text_model = Text_model(data_root_path, vocab_root_path, text_min_count, window_size,
+                            num_labels, ngram, text_dropout, min_cooccurence)
+    return Multi_GCN_Multihead_Att(opt, num_labels, text_model=text_model,
+                                   object_model=object_model, place_model=place_model,
+                                   object_num_classes=object_num_classes, place_num_classes=place_num_classes,
+                                   in_channel=in_channel, object_t=object_t, place_t=place_t,
+                                   object_adj_file=object_adj_file, place_adj_file=place_adj_file)
+
+
+def multi_gcn_multihead_att_model_from_parts(opt, num_labels, object_num_classes, place_num_classes, object_t, place_t,
+                                             text_model, object_model=None, place_model=None,
+                                             object_adj_file=None, place_adj_file=None, in_channel=300, label_glove=None):
+    """The same module with the text model and the (optional) CNN trunks injected instead of being built from the
+    data root (synthetic benchmarks, tests; trunks None = feature-map entry only)."""
     return Multi_GCN_Multihead_Att(opt, num_labels, text_model=text_model, object_model=object_model,
                                    place_model=place_model, object_num_classes=object_num_classes,
                                    place_num_classes=place_num_classes, in_channel=in_channel,

@@ -154,18 +154,23 @@ def dense_to_csr(m):
     return rp, col, val
 
 
-def spmm_csr(csr, x, act=ACT_NONE):
-    """act(adj @ x) with adj in CSR (row_ptr, col, val); x [C, F]."""
+def spmm_csr(csr, x, act=ACT_NONE, out=None):
+    """act(adj @ x) with adj in CSR (row_ptr, col, val); x [C, F].  out: optional preallocated [C, F] result."""
     rp, col, val = csr
     _chk(rp, "row_ptr", torch.int32, 1)
     _chk(col, "col", torch.int32, 1)
     _chk(val, "val", torch.float32, 1)
     _chk(x, "x", ndim=2)
     n = rp.shape[0] - 1
-    y = torch.empty(n, x.shape[1], device=x.device, dtype=torch.float32)
+    if out is None:
+        y = torch.empty(n, x.shape[1], device=x.device, dtype=torch.float32)
+    else:
+        y = _chk(out, "out", ndim=2)
+        if tuple(y.shape) != (n, x.shape[1]) or y.data_ptr() == x.data_ptr():
+            raise ValueError("out must be a [%d, %d] tensor distinct from x" % (n, x.shape[1]))
     L = _lib.lib()
-    _lib.check(L.mgnns_spmm_csr_fwd(_p(rp), _p(col), _p(val), n, _p(x), x.shape[1], _p(y), act, _stream()),
-               "mgnns_spmm_csr_fwd")
+    _launch("mgnns_spmm_csr_fwd", ("mgnns_spmm_csr_fwd", n, x.shape[1]), L.mgnns_spmm_csr_fwd, _p(rp), _p(col), _p(val), n,
+            _p(x), x.shape[1], _p(y), act, _stream())
     return y
 
 
@@ -181,40 +186,43 @@ def embedding(idx, table):
 
 
 # ---- text memory bank: embedding + packed BiLSTM -----------------------------------------------------
-_ws_cache = {}
+class LstmCache:
+    """Derived forms of one nn.LSTM's weights (per-layer [W_ih ; W_ih_reverse], the packed bf16 layouts), owned by the
+    module that owns the weights so their lifetime is the module's (a captured hipGraph bakes these pointers in).
+    An entry keeps strong REFERENCES to the tensors it was derived from, so their storage cannot be freed and handed
+    to another model's weights while the entry lives: a (data_ptr, version) match therefore means the same weights."""
+
+    def __init__(self):
+        self.cat = None        # (sources, versions, value)
+        self.prepack = None
+
+    @staticmethod
+    def _hit(entry, sources):
+        return (entry is not None and len(entry[0]) == len(sources)
+                and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.device == b.device
+                        for a, b in zip(entry[0], sources))
+                and entry[1] == tuple(t._version for t in sources))
 
 
-def _workspace(nbytes, device):
-    key = str(device)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
-
-
-_lstm_cat_cache = {}
-_lstm_prepack_cache = {}
-
-
-def _lstm_cat(weights, num_layers):
+def _lstm_cat(weights, num_layers, cache):
     """Per layer [W_ih ; W_ih_reverse] and [b_ih ; b_ih_reverse], rebuilt when a weight changes (one input-projection
     GEMM per layer instead of two)."""
-    key = tuple((t.data_ptr(), t._version) for tup in weights for t in (tup[0], tup[2]))
-    hit = _lstm_cat_cache.get(key)
-    if hit is None:
-        _lstm_cat_cache.clear()
-        hit = [(torch.cat([weights[2 * l][0], weights[2 * l + 1][0]], 0).contiguous(),
-                torch.cat([weights[2 * l][2], weights[2 * l + 1][2]], 0).contiguous()) for l in range(num_layers)]
-        _lstm_cat_cache[key] = hit
-    return hit
+    src = [t for tup in weights for t in (tup[0], tup[2])]
+    if cache is not None and LstmCache._hit(cache.cat, src):
+        return cache.cat[2]
+    val = [(torch.cat([weights[2 * l][0], weights[2 * l + 1][0]], 0).contiguous(),
+            torch.cat([weights[2 * l][2], weights[2 * l + 1][2]], 0).contiguous()) for l in range(num_layers)]
+    if cache is not None:
+        cache.cat = (src, tuple(t._version for t in src), val)
+    return val
 
 
-def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32"):
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32", cache=None):
     """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
     (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length
     (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16).  recurrence="bf16": W_hh . h of every step on the
-    bf16 MFMA (bf16 operands, fp32 accumulation and state) instead of the exact fp32 GEMV."""
+    bf16 MFMA (bf16 operands, fp32 accumulation and state) instead of the exact fp32 GEMV.
+    cache: an LstmCache owned by the module that owns `weights` (None: derived weight forms are rebuilt per call)."""
     import ctypes
     _chk(tok, "text", torch.int64, 2)
     _chk(lens, "text_lens", torch.int64, 1)
@@ -231,7 +239,7 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
             _chk(t, "lstm weight")
             if tuple(t.shape) != shp:
                 raise ValueError("lstm weight shape %s, expected %s" % (tuple(t.shape), shp))
-    cat = _lstm_cat(weights, num_layers)
+    cat = _lstm_cat(weights, num_layers, cache)
     arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
     c_wih = arr([c[0].data_ptr() for c in cat])
     c_bih = arr([c[1].data_ptr() for c in cat])
@@ -239,7 +247,9 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
     c_bhh = arr([w[3].data_ptr() for w in weights])
     L = _lib.lib()
     nbytes = L.mgnns_bilstm_workspace_bytes(B, T, hidden, num_layers)
-    ws = _workspace(nbytes, tok.device)
+    # per call, on the calling stream: a captured forward keeps it alive in the graph's own pool; nothing is shared
+    # between models, streams or graphs
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=tok.device)
     out = torch.empty(B, T, 2 * hidden, device=tok.device, dtype=torch.float32)
     out_bf = torch.empty(B, T, BANK_LD, device=tok.device, dtype=torch.bfloat16) if want_bf16 else None
     if recurrence not in ("f32", "bf16"):
@@ -250,14 +260,15 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
                 _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _stream())
     else:
         # weight layouts of the bf16 kernels: packed once per weight version, off the per-forward path
-        key = tuple((t.data_ptr(), t._version) for tup in weights for t in (tup[0], tup[1])) + (str(tok.device),)
-        pre = _lstm_prepack_cache.get(key)
-        if pre is None:
-            _lstm_prepack_cache.clear()
+        src = [t for tup in weights for t in (tup[0], tup[1])]
+        if cache is not None and LstmCache._hit(cache.prepack, src):
+            pre = cache.prepack[2]
+        else:
             pre = torch.empty(L.mgnns_bilstm_bf16_prepack_bytes(hidden, num_layers), dtype=torch.uint8, device=tok.device)
             _lib.check(L.mgnns_bilstm_bf16_prepack(c_wih, c_whh, emb_table.shape[1], hidden, num_layers, _p(pre), _stream()),
                        "mgnns_bilstm_bf16_prepack")
-            _lstm_prepack_cache[key] = pre
+            if cache is not None:
+                cache.prepack = (src, tuple(t._version for t in src), pre)
         _launch("mgnns_bilstm_bf16_fwd", ("mgnns_bilstm_bf16_fwd",), L.mgnns_bilstm_bf16_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
                 emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
                 _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _stream())
@@ -549,8 +560,8 @@ def transpose_cast_bf16(x):
     return y
 
 
-def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None):
-    """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 [M, N]."""
+def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None):
+    """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 [M, N] (out: optional preallocated)."""
     _chk(a_bf16, "A", torch.bfloat16, 2)
     _chk(bt_bf16, "Bt", torch.bfloat16, 2)
     M, Kp = a_bf16.shape
@@ -559,7 +570,12 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None):
         raise ValueError("A %s / Bt %s: K rows must match and be a multiple of 64" % (tuple(a_bf16.shape), tuple(bt_bf16.shape)))
     if bias is not None:
         _chk(bias, "bias", ndim=1)
-    c = torch.empty(M, N, device=a_bf16.device, dtype=torch.float32)
+    if out is None:
+        c = torch.empty(M, N, device=a_bf16.device, dtype=torch.float32)
+    else:
+        c = _chk(out, "out", ndim=2)
+        if tuple(c.shape) != (M, N):
+            raise ValueError("out must be [%d, %d]" % (M, N))
     _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), N, act, _stream()),
                "mgnns_gemm_bf16_nt_fwd")
     return c

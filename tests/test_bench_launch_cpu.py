@@ -1,0 +1,95 @@
+"""bench.py's N-rank protocol without a GPU (`--dry-launch`: gloo, no model): the self-launcher starts N ranks before any
+GPU call and fails unless all join, ranks are seeded per scaling mode, the timed region is bracketed by barriers and the
+time is the MAX over ranks, the logits all-gather has the right extent, and stdout carries exactly ONE JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return env
+
+
+def _check_line(out, n, batch, strict=True):
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    if strict:
+        assert len(lines) == 1, "stdout must hold exactly one line, got %r" % lines
+    else:       # under torchrun every rank's stdout is forwarded: gloo's connection banner may precede the line
+        assert sum(ln.startswith("{") for ln in lines) == 1 and lines[-1].startswith("{"), lines
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == n and line["dry_launch"] is True and line["scaling"] == "weak"
+    assert line["steps"] == 5 and line["warmup"] == 1
+    w, s = line["weak_scaling"], line["strong_scaling"]
+    # rank seeding: weak = a different shard per rank, strong = the same global batch on every rank (sliced)
+    assert w["seeds"] == [1237 + 1000 * r for r in range(n)]
+    assert s["seeds"] == [1237] * n
+    # the step of rank r sleeps (r+1) ms: the reported time is the slowest rank's, and every rank left the closing barrier
+    # together (all local times within a step of the maximum)
+    for r in (w, s):
+        assert len(r["dt_ranks"]) == n
+        assert r["ms_per_step"] >= 1.0 * n
+        assert r["ms_per_step"] == pytest.approx(max(r["dt_ranks"]) / 5 * 1e3)
+        assert max(r["dt_ranks"]) - min(r["dt_ranks"]) < 0.05
+    assert w["gathered_rows"] == n * batch and s["gathered_rows"] == 256
+    assert line["value"] == pytest.approx(n * batch / (w["ms_per_step"] * 1e-3), rel=1e-3)
+    assert s["value"] == pytest.approx(256 / (s["ms_per_step"] * 1e-3), rel=1e-3)
+    return line
+
+
+def test_self_launch_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "5", "--warmup", "1", "--batch", "64"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_line(r.stdout, 2, 64)
+
+
+def test_strong_headline_and_single_rank():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "5", "--warmup", "1", "--scaling", "strong"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip())
+    assert line["scaling"] == "strong" and line["value"] == pytest.approx(line["strong_scaling"]["value"], rel=1e-3)
+    r = subprocess.run([sys.executable, BENCH, "--dry-launch", "--steps", "5", "--warmup", "1"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip())
+    assert line["n_gpus"] == 1 and line["weak_scaling"]["gathered_rows"] == 256
+
+
+def test_under_torchrun_two_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--dry-launch", "--steps", "5",
+                        "--warmup", "1", "--batch", "32"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_line(r.stdout, 2, 32, strict=False)
+
+
+def test_world_size_mismatch_fails_loudly():
+    env = _env()
+    env.update({"WORLD_SIZE": "1", "RANK": "0"})
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+
+
+def test_a_dead_rank_fails_the_launch(tmp_path):
+    # rank 1 dies at start-up (bad --config is only read by real runs, so break it through the environment instead)
+    env = _env()
+    env["MGNNS_BENCH_TEST_KILL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0", "--launch-timeout", "60"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "launch failed" in r.stderr

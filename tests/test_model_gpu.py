@@ -190,3 +190,110 @@ def test_full_size_b256_properties():
     # (e) folded attention at full size
     model.set_attention("folded")
     assert H.maxabs(model(*call).cpu()[idx], ref) < TOL
+
+
+def test_bool_and_int_masks_streams_equal_single_stream():
+    """The reference documents text_mask as a bool tensor: the cast to float runs on the main stream BEFORE the side
+    streams fork, so the multi-stream forward (and its hipGraph) equals the single-stream forward bit for bit."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    a = list(call_args(synth.make_inputs(cfg, B=48, seed=5, pmi=pmi), DEV))
+    model.use_streams = False
+    ref = model(*a).clone()
+    for mask in (a[2].bool(), a[2].to(torch.int64), a[2].to(torch.uint8)):
+        b = list(a)
+        b[2] = mask
+        model.use_streams = False
+        assert torch.equal(model(*b), ref)
+        model.use_streams = True
+        for _ in range(3):
+            assert torch.equal(model(*b), ref)
+        assert torch.equal(GraphedForward(model, b).replay(), ref)
+
+
+def test_two_models_in_one_process_do_not_share_derived_lstm_weights():
+    """Derived LSTM weight forms (concatenated W_ih, packed bf16 W_hh) are owned by the module: a second model with
+    DIFFERENT LSTM weights built after the first one was freed must not pick up the first one's packed weights."""
+    cfg = synth.CONFIGS["mvsa_single_b8"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    inp = synth.make_inputs(cfg, B=8, seed=11, pmi=pmi)
+    call = call_args(inp, DEV)
+
+    def bank_of(scale, precision):
+        m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+        with torch.no_grad():
+            for n, p_ in m.lstm.named_parameters():
+                p_.mul_(scale)
+        m.set_precision(precision)
+        out = m._text_bank(call[0], call[1]).f32.clone()
+        ref = R.text_memory_bank({k: v.detach().cpu() for k, v in m.state_dict().items()},
+                                 torch.from_numpy(inp["text"]), torch.from_numpy(inp["text_lens"]))
+        del m
+        torch.cuda.empty_cache()
+        return out.cpu(), ref
+
+    for precision, tol in (("fp32", 1e-5), ("bf16", 1e-2)):
+        o1, r1 = bank_of(1.0, precision)
+        o2, r2 = bank_of(0.5, precision)              # same shapes, same construction path, different values
+        assert H.maxabs(o1, r1) < tol and H.maxabs(o2, r2) < tol
+        assert H.maxabs(r1, r2) > 10 * tol            # the two models really differ
+
+
+def test_tumemo_full_b64_vs_oracle():
+    """BASELINE configs[1] at its full size: B=64, 4 heads, 2 layers, fp32, logits within 1e-4 of the CPU oracle."""
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("full_tumemo_b64.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    inp = synth.make_inputs(cfg, B=64, seed=cfg.seed + 5, pmi=pmi)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    logits = model(*call_args(inp, DEV)).cpu()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in inp.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                    label_query=torch.from_numpy(lq))
+    assert logits.shape == (64, 7) and H.maxabs(logits, ref) < TOL
+
+
+def test_forward_through_the_reference_factory(tmp_path, monkeypatch):
+    """The model built by the reference-signature factory (vocabulary + PMI from a data root, adjacency pickles, label
+    pickle; trunks uninitialised -> feature-map entry) runs the forward and equals the CPU oracle on real token ids."""
+    from mgnns_amd import model as M
+    from mgnns_amd.batching import BatchAssembler
+    from tests.test_factory_cpu import make_data_root, opt_for
+    g, adj = make_data_root(str(tmp_path), with_weights=False)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("MGNNS_TRUNK_INIT", "random")
+    from mgnns_amd.vocab import get_vocab_list
+    vocab = get_vocab_list('data', 'data', 2)
+    model = M.multi_gcn_multihead_att_model(opt=opt_for(len(vocab)), num_labels=7, object_num_classes=80, place_num_classes=365,
+                                            object_t=0.4, place_t=0.3, data_root_path='data', vocab_root_path='data',
+                                            text_min_count=2, window_size=5, ngram=4, min_cooccurence=2, text_dropout=0.5,
+                                            pretrained=True, object_adj_file='data/adj/tumblr_objects_adj.pkl',
+                                            place_adj_file='data/adj/tumblr_resnet50_places_adj.pkl', in_channel=300)
+    # seeded values for everything outside the trunks (the factory leaves torch's default initialisation)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if not k.startswith(("object_features.", "place_features.", "object_A", "place_A")):
+            sd[k] = torch.from_numpy(synth.param_value(k, tuple(v.shape)))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    texts = [t for t in (str(x) for x in g["texts"]) if len(t.split(" ")) <= 60][:12]
+    cfg = synth.Config("factory", B=len(texts), T=60, V=len(vocab), NL=7, n_head=4, stack_num=2, ngram=4, seed=78)
+    asm = BatchAssembler(vocab, max_len=cfg.T, batch_size=len(texts), device=DEV)
+    asm.encode(texts)
+    text, lens, mask = asm.to_device()
+    inp = synth.make_inputs(cfg, B=len(texts), pmi=model.text_features.edges_matrix)
+    inp["text"], inp["text_lens"], inp["text_mask"] = asm.text.numpy().copy(), asm.lens.numpy().copy(), asm.mask.numpy().copy()
+    args = list(call_args(inp, DEV))
+    args[0], args[1], args[2] = text, lens, mask
+    logits = model(*args).cpu()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith(("object_features.", "place_features."))}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in inp.items()}, model.text_features.edges_matrix, 4, 128, 2, 4,
+                    label_query=model.label_query.cpu())
+    assert H.maxabs(logits, ref) < TOL

@@ -3,7 +3,7 @@
 
     python tools/write_profiles.py <run-tag> <profile-prefix>      e.g.  r01e r01_e
 Writes  profiles/<prefix>_{bf16,f32,folded}_kernel_stats.md, <prefix>_pmc_summary.md, <prefix>_bench_{bf16,f32}.json,
-<prefix>_stress_gcn.json and refreshes profiles/r01_pmc_traffic.json (read by bench.py for roofline.traffic)."""
+<prefix>_stress_gcn.json and refreshes profiles/pmc_traffic.json (read by bench.py for roofline.traffic)."""
 import json
 import os
 import shutil
@@ -103,7 +103,9 @@ def main():
             if label.startswith("sq_mha_core_bf16_kernel L=196"):
                 traffic["sq_mha_core_bf16_kernel@L196"] = {
                     "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
-                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre}
+                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre,
+                    "kernel_source": "mgnns_amd/csrc/sq_mha_bf16.hip",
+                    "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/sq_mha_bf16.hip"), "rb").read()).hexdigest()[:16]}
         busy = pmc(dbs["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_mha_core_bf16_kernel")
         with open(os.path.join(PR, "%s_pmc_summary.md" % pre), "w") as f:
             f.write("# rocprofv3 PMC passes, %s (bf16 mode, eager single forwards: `bench.py --steps 3 --warmup 1 --no-cpu-baseline "
@@ -120,7 +122,7 @@ def main():
                         "16 cycles: every issued 16x16x32 MFMA, padding included). Divide by 1024 SIMDs x launch time x clock for the pipe "
                         "occupancy; algorithmic utilisation (61.86 GFLOP / time / 2.5 PF) is what bench.py reports.\n" % hi)
         if traffic:
-            with open(os.path.join(PR, "r01_pmc_traffic.json"), "w") as f:
+            with open(os.path.join(PR, "pmc_traffic.json"), "w") as f:
                 json.dump(traffic, f, indent=1)
     for name in ("bench_bf16", "bench_f32", "stress_gcn"):
         src = os.path.join(GO, "%s_%s.json" % (tag, name))
