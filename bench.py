@@ -274,6 +274,8 @@ def probe_collective(timeout=240.0):
     """Run probe_collective_child with this rank's coordinates on a port of its own.  Called BEFORE this process touches
     the GPU.  True iff the child exits 0 in time."""
     env = dict(os.environ)
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1")):
+        env.setdefault(k, v)                     # a single rank run with MGNNS_FORCE_DIST=1 has no torchrun environment
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 17)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-collective"], env=env, timeout=timeout,

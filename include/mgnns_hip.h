@@ -48,6 +48,9 @@ int mgnns_abi_version(void);
  * tok [B,T] int64 (0 = PAD); node_hidden [V,D] (D <= 320); edge_w [n_edge_w] (seq_edge_w
  * [count,1] flattened); PMI map as CSR over V rows with sorted int32 columns and edge ids
  * (id 0 / absent = "no PMI entry", utils/pmi.py:86-97); out [B,D].
+ * pmi_eid may be NULL: the id of the entry stored at CSR position k is then k + 1 -- the row-major
+ * numbering utils/pmi.py:86-97 hands out -- and the lookup needs one dependent load less.
+ * One 1024-thread workgroup per document; needs min(T,max_length)*(D+2*ngram+4)*4 + ~20 KB <= 160 KB of LDS.
  */
 int mgnns_textgcn_fwd(const int64_t* tok, int B, int T,
                       const float* node_hidden, int V, int D,
@@ -148,7 +151,8 @@ int mgnns_imgbank_pool_fwd(const float* feat, int B, int K, int P,
 /* bf16-operand variant (BASELINE config 3): same reads (the fp32 map crosses HBM once, max-pool exact fp32),
  * W pre-packed by mgnns_imgbank_pack_weights_bf16 into mgnns_imgbank_packed_weight_bytes(K) bytes, the bank is
  * emitted as bf16 [B, P, ld] with ld == 320 (zero padded) -- the layout mgnns_sq_mha_core_bf16_fwd consumes.
- * pooled_work: [B, 2, K] floats of scratch.  104 < P <= 200, P % 4 == 0, N <= 304, K % 128 == 0.
+ * pooled_work: [B, 2, K] floats: the per-half maxima (pooled may be NULL: the caller then consumes these itself,
+ * e.g. mgnns_label_tail_fwd with n_parts = 2).  104 < P <= 200, P % 4 == 0, N <= 304, K % 128 == 0.
  */
 size_t mgnns_imgbank_packed_weight_bytes(int K);
 int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnns_stream_t stream);
@@ -166,6 +170,28 @@ int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld,
  */
 int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
                               int n_heads, int dh, float* x, mgnns_stream_t stream);
+
+/* ---- a5 + a7 (fused): everything of an image channel behind the memory-bank kernel, one launch ----------------
+ * Read-out (MODEL:454-455 max-pool halves + 474 `matmul(feature, x)`), Attention.forward (MODEL:88-133) without its
+ * w_q, then linear_5 and x_linear (MODEL:477-479 / 504-506), optionally the query projection of the fusion stack the
+ * result feeds (submodules.py:63-66):
+ *   x = max_parts(pooled) . G^T                      (or x given: pass g_wp = NULL)
+ *   K = w_k x + b_k, V = w_v x + b_v;  o[b,l] = softmax_d(Q[l] * K[b] / sqrt(dh)) * V[b] per head;
+ *   y[b,l] = Wc o[b,l] + bc  with Wc = linear_5.weight . fc.weight [N5,hid], bc = linear_5.weight . fc.bias +
+ *   linear_5.bias (the two maps have no non-linearity between them; composed by the caller);
+ *   out[b] = x_linear(concat_l y[b,l]);   qh_next[b] = w_qs(out[b]) + b_qs  (wq_next_wp != NULL; needs n_out == hid).
+ * pooled [B,n_parts,K_pool] (n_parts = 2: the memory-bank kernel's per-half maxima), g_wp = mgnns_pack_weight_f32
+ * image of G [C,K_pool]; Q [NLQ,hid] = w_q(label query); wk_wp / wv_wp / wc_wp / xl_wp / wq_next_wp are
+ * mgnns_pack_weight_f32 images of w_k [hid,C], w_v [hid,C], Wc [N5,hid], x_linear.weight [n_out, NLQ*N5],
+ * w_qs.weight [HK_next, hid]; out [B,n_out].  hid = n_heads*dh <= 320, dh <= 64, N5 <= 128, NLQ*N5 >= 512 with G.
+ * One workgroup per 16 samples; every contraction on the exact-f32 MFMA.
+ */
+int mgnns_label_tail_fwd(const float* x, int B, int C, const float* pooled, int n_parts, int K_pool,
+                         const float* g_wp, const float* Q, int NLQ, int n_heads, int dh,
+                         const float* wk_wp, const float* bk, const float* wv_wp, const float* bv,
+                         const float* wc_wp, const float* bc, int N5, const float* xl_wp, const float* bxl,
+                         int n_out, float* out, const float* wq_next_wp, const float* bq_next, int HK_next,
+                         float* qh_next, mgnns_stream_t stream);
 
 /* ---- a8: single-query multi-head attention, K/V projection fused ---------------------------------------
  * MultiHeadAttention.forward + ScaledDotProductAttention.forward (submodules.py:55-119) for len_q == 1,
@@ -296,6 +322,12 @@ int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int Cin, const 
  * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.
  */
 int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream);
+
+/* One thread that spins for `microseconds` of the same counter, then (slots != NULL) stamps slots[idx].  Used once per
+ * process by mgnns_amd.streams to find HIP streams that sit on DIFFERENT hardware queues: a stamp on stream Y that lands
+ * before the end of a spin on stream X proves X and Y do not share an in-order queue.
+ */
+int mgnns_debug_spin(int microseconds, uint64_t* slots, int idx, mgnns_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P = _c.c_void_p
@@ -35,6 +35,8 @@ SIGNATURES = {
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mgnns_label_tail_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P,
+                             _I, _P, _P],
     "mgnns_sq_mha_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "mgnns_sq_mha_pack_weights_bf16": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_cast_pad_bf16": [_P, _L, _I, _I, _P, _P],
@@ -52,6 +54,7 @@ SIGNATURES = {
     "mgnns_maxpool3x3s2_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P],
     "mgnns_conv_bf16_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     "mgnns_debug_stamp": [_P, _I, _P],
+    "mgnns_debug_spin": [_I, _P, _I, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
 }
 

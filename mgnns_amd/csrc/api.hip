@@ -32,11 +32,24 @@ int mg_ensure_dyn_lds(const void* fn, int bytes) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 6; }
+extern "C" int mgnns_abi_version(void) { return 7; }
 
 namespace {
 __global__ void stamp_kernel(unsigned long long* slots, int idx) { slots[idx] = __builtin_amdgcn_s_memrealtime(); }
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* slots, int idx) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (slots) slots[idx] = __builtin_amdgcn_s_memrealtime();
+}
 }  // namespace
+
+extern "C" int mgnns_debug_spin(int microseconds, uint64_t* slots, int idx, mgnns_stream_t stream) {
+    MG_REQUIRE(microseconds >= 0 && microseconds <= 100000 && idx >= 0, "mgnns_debug_spin: bad arguments");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull,
+                       reinterpret_cast<unsigned long long*>(slots), idx);
+    MG_CHECK_LAUNCH("mgnns_debug_spin");
+    return 0;
+}
 
 extern "C" int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream) {
     MG_REQUIRE(slots && idx >= 0, "mgnns_debug_stamp: bad arguments");

@@ -321,7 +321,7 @@ extern "C" int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, voi
 extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,
                                            void* bank_bf16, int ld, float* pooled, float* pooled_work,
                                            mgnns_stream_t stream) {
-    MG_REQUIRE(feat && Wp && bank_bf16 && pooled && pooled_work, "mgnns_imgbank_pool_bf16_fwd: null pointer");
+    MG_REQUIRE(feat && Wp && bank_bf16 && pooled_work, "mgnns_imgbank_pool_bf16_fwd: null pointer");
     MG_REQUIRE(B >= 0 && K > 0 && K % BK == 0, "mgnns_imgbank_pool_bf16_fwd: K=%d must be a positive multiple of %d", K, BK);
     MG_REQUIRE(P % 4 == 0 && P > P_SPLIT && P <= P_SPLIT + (MTH - 1) * 16,
                "mgnns_imgbank_pool_bf16_fwd: P=%d unsupported (multiple of 4 in (%d, %d])", P, P_SPLIT, P_SPLIT + (MTH - 1) * 16);
@@ -336,10 +336,12 @@ extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int 
     hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(nblk), dim3(NTHR), SMEM_BYTES, s, feat, B, K, P,
                        reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
                        pooled_work);
-    const size_t total = (size_t)B * K;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pool_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)pooled_work, B, K, pooled);
+    if (pooled) {                              // pooled == NULL: the caller consumes the two halves in pooled_work itself
+        const size_t total = (size_t)B * K;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(pool_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)pooled_work, B, K, pooled);
+    }
     MG_CHECK_LAUNCH("mgnns_imgbank_pool_bf16_fwd");
     return 0;
 }

@@ -1,0 +1,244 @@
+// The label-attention tail of an image channel in ONE launch (MODEL:88-133 `Attention.forward` minus its w_q, plus
+// MODEL:477-479 / 504-506): from the read-out x = pooled . G^T  [B, C] to the channel feature [B, 300]
+//   K = w_k x + b_k, V = w_v x + b_v                              [B, 300] each
+//   o[b,l,h,:] = softmax_d(Q[l,h,:] * K[b,h,:] / sqrt(dh)) * V[b,h,:]      (element-wise "attention", l < NLQ label rows)
+//   y[b,l,:]  = linear_5(fc(o[b,l,:]))  = Wc o + bc,  Wc = W5 Wfc  [N5, 300]  (no non-linearity between the two maps:
+//                                                          they are composed ONCE per weight version on the host side)
+//   out[b,:]  = x_linear(flatten_l y[b,l,:])                      [B, 300]
+// The reference runs this as 6 GEMMs + ~10 element-wise kernels and a Python loop over the batch (MODEL:114-115); as
+// separate launches here it was 8 small launches that each had to wait for a free CU behind the chip-filling attention
+// and memory-bank kernels of the other streams (200-290 us on the critical path of a 1 ms forward,
+// tools/graph_timeline.py).  One workgroup owns 16 samples through the chain: activations in LDS, weights streamed from
+// L2 in the fragment-major fp32 layout of mgnns_pack_weight_f32, every contraction on the exact-f32 MFMA.
+#include "common.hpp"
+#include "tile_f32.hpp"
+
+namespace {
+
+constexpr int LT_THR = 512;
+constexpr int LT_ROWS = 16;
+constexpr int LT_MAXKQ = 20;                 // hid <= 320: k-quads of the composed map held in registers
+
+__host__ __device__ inline int lt_stride(int k) {          // LDS row stride: >= k rounded to 16, == 2 (mod 32)
+    const int kp = (k + 15) / 16 * 16;
+    return kp + ((34 - (kp % 32)) % 32);
+}
+
+constexpr int LT_KCH = 512;                  // read-out K chunk staged at a time (aliases the flatten buffer)
+
+__global__ __launch_bounds__(LT_THR) void label_tail_kernel(const float* __restrict__ x, int B, int C,
+                                                            const float* __restrict__ pooled, int n_parts, int KP,
+                                                            const float* __restrict__ g_wp,
+                                                            const float* __restrict__ Q, int NLQ, int n_heads, int dh,
+                                                            const float* __restrict__ wk_wp, const float* __restrict__ bk,
+                                                            const float* __restrict__ wv_wp, const float* __restrict__ bv,
+                                                            const float* __restrict__ wc_wp, const float* __restrict__ bc, int N5,
+                                                            const float* __restrict__ xl_wp, const float* __restrict__ bxl, int NO,
+                                                            float* __restrict__ out, const float* __restrict__ wq_wp,
+                                                            const float* __restrict__ bq, int HKn, float* __restrict__ qh_next) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int hid = n_heads * dh;
+    const int sx = lt_stride(C), sh = lt_stride(hid), sf = lt_stride(NLQ * N5);
+    float* s_x = smem;                       // [16][sx]
+    float* s_k = s_x + LT_ROWS * sx;         // [16][sh]
+    float* s_v = s_k + LT_ROWS * sh;
+    float* s_o = s_v + LT_ROWS * sh;
+    float* s_f = s_o + LT_ROWS * sh;         // [16][sf]  flatten_l y[b,l,:]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * LT_ROWS;
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    const int NTh = (hid + 15) / 16, NT5 = (N5 + 15) / 16, NTo = (NO + 15) / 16;
+    const int KQh = (hid + 15) / 16;
+
+    // the composed map's fragments of this wave's column tile stay in registers across the NLQ label rows
+    f32x4 wc[LT_MAXKQ];
+    if (wave < NT5) {
+#pragma unroll
+        for (int kq = 0; kq < LT_MAXKQ; ++kq)
+            wc[kq] = kq < KQh ? reinterpret_cast<const f32x4*>(wc_wp)[((size_t)wave * KQh + kq) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- zero every buffer's padding; x = the read-out, either given or computed here ---------------------------------------
+    for (int i = tid; i < LT_ROWS * sx + 3 * LT_ROWS * sh + LT_ROWS * sf; i += LT_THR) s_x[i] = 0.f;
+    __syncthreads();
+    if (g_wp) {
+        // x = max_parts(pooled) . G^T (MODEL:454-455 + 474): K = 2048 does not fit LDS next to everything else, so it is
+        // walked in chunks of 512 staged into the (still unused) flatten buffer; G streams from L2 in packed form
+        const int NTc = (C + 15) / 16, KQ = (KP + 15) / 16;
+        const int sp = lt_stride(LT_KCH);
+        float* s_p = s_f;
+        for (int t0 = 0; t0 * 8 < NTc; t0 += 3) {
+            f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int k0 = 0; k0 < KP; k0 += LT_KCH) {
+                const int kn = min(LT_KCH, KP - k0);
+                for (int i = tid; i < LT_ROWS * (LT_KCH / 4); i += LT_THR) {
+                    const int r = i / (LT_KCH / 4), c4 = (i - r * (LT_KCH / 4)) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (r0 + r < B && c4 < kn) {            // KP % 4 == 0 (launcher)
+                        const float* src = pooled + ((size_t)(r0 + r) * n_parts) * KP + k0 + c4;
+                        v = *reinterpret_cast<const f32x4*>(src);
+                        for (int pt = 1; pt < n_parts; ++pt) {
+                            const f32x4 u = *reinterpret_cast<const f32x4*>(src + (size_t)pt * KP);
+                            v = f32x4{fmaxf(v.x, u.x), fmaxf(v.y, u.y), fmaxf(v.z, u.z), fmaxf(v.w, u.w)};
+                        }
+                    }
+                    float* d = s_p + r * sp + c4;           // sp is even: 8-byte aligned
+                    *reinterpret_cast<float2*>(d) = float2{v.x, v.y};
+                    *reinterpret_cast<float2*>(d + 2) = float2{v.z, v.w};
+                }
+                __syncthreads();
+                mg_tile_gemm_f32_chunk<3>(acc, s_p, sp, k0 / 16, (k0 + kn + 15) / 16, KQ, g_wp, NTc, wave, lane, t0);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
+                if (nt < NTc && n < C) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_x[(crow + r) * sx + n] = acc[t][r];
+                }
+            }
+        }
+        for (int i = tid; i < LT_ROWS * sf; i += LT_THR) s_f[i] = 0.f;      // the flatten buffer's padding again
+    } else {
+        for (int i = tid; i < LT_ROWS * C; i += LT_THR) {
+            const int r = i / C, c = i - r * C;
+            if (r0 + r < B) s_x[r * sx + c] = x[(size_t)(r0 + r) * C + c];
+        }
+    }
+    __syncthreads();
+
+    // ---- K, V -----------------------------------------------------------------------------------------------------
+    for (int t0 = 0; t0 * 8 < NTh; t0 += 3) {
+        f32x4 ak[3], av[3];
+        mg_tile_gemm_f32<3>(ak, s_x, sx, C, wk_wp, NTh, wave, lane, t0);
+        mg_tile_gemm_f32<3>(av, s_x, sx, C, wv_wp, NTh, wave, lane, t0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
+            if (nt < NTh && n < hid) {
+                const float b0 = bk[n], b1 = bv[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s_k[(crow + r) * sh + n] = ak[t][r] + b0;
+                    s_v[(crow + r) * sh + n] = av[t][r] + b1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per label row l: element-wise attention into s_o, composed map into its slot of s_f --------------------------
+    const float inv_scale = 1.0f / sqrtf((float)dh);
+    for (int l = 0; l < NLQ; ++l) {
+        // wave w owns sample rows 2w, 2w+1; lanes over the dh <= 64 dims of a head
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;
+            for (int h = 0; h < n_heads; ++h) {
+                const bool on = lane < dh;
+                const int c = h * dh + lane;
+                const float e = on ? Q[(size_t)l * hid + c] * s_k[r * sh + c] * inv_scale : -INFINITY;
+                const float m = wave_max(e);
+                const float p = on ? expf(e - m) : 0.f;
+                const float z = wave_sum(p);
+                if (on) s_o[r * sh + c] = (p / z) * s_v[r * sh + c];
+            }
+        }
+        __syncthreads();
+        if (wave < NT5) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* ap = s_o + (lane & 15) * sh + (lane >> 4);
+#pragma unroll
+            for (int kq = 0; kq < LT_MAXKQ; ++kq) {
+                if (kq < KQh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(4 * kq + j) * 4], wc[kq][j], acc, 0, 0, 0);
+                }
+            }
+            const int n = wave * 16 + ccol;
+            if (n < N5) {
+                const float b0 = bc[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_f[(crow + r) * sf + l * N5 + n] = acc[r] + b0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- out = x_linear(flat) ------------------------------------------------------------------------------------------
+    for (int t0 = 0; t0 * 8 < NTo; t0 += 3) {
+        f32x4 acc[3];
+        mg_tile_gemm_f32<3>(acc, s_f, sf, NLQ * N5, xl_wp, NTo, wave, lane, t0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
+            if (nt < NTo && n < NO) {
+                const float b0 = bxl[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = r0 + crow + r;
+                    const float v = acc[t][r] + b0;
+                    if (gr < B) out[(size_t)gr * NO + n] = v;
+                    if (wq_wp) s_o[(crow + r) * sh + n] = v;          // NO == hid when the projection is asked for (launcher)
+                }
+            }
+        }
+    }
+    // ---- the query projection of the fusion stack this feature feeds: qh = w_qs(out) + b (submodules.py:63-66) ----------------
+    if (wq_wp) {
+        __syncthreads();
+        const int NTq = (HKn + 15) / 16;
+        for (int t0 = 0; t0 * 8 < NTq; t0 += 3) {
+            f32x4 acc[3];
+            mg_tile_gemm_f32<3>(acc, s_o, sh, NO, wq_wp, NTq, wave, lane, t0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
+                if (nt < NTq && n < HKn) {
+                    const float b0 = bq ? bq[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = r0 + crow + r;
+                        if (gr < B) qh_next[(size_t)gr * HKn + n] = acc[t][r] + b0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* pooled, int n_parts, int K_pool,
+                                    const float* g_wp, const float* Q, int NLQ, int n_heads, int dh,
+                                    const float* wk_wp, const float* bk, const float* wv_wp, const float* bv,
+                                    const float* wc_wp, const float* bc, int N5, const float* xl_wp, const float* bxl,
+                                    int n_out, float* out, const float* wq_next_wp, const float* bq_next, int HK_next,
+                                    float* qh_next, mgnns_stream_t stream) {
+    MG_REQUIRE(B >= 0 && C > 0 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64 && N5 > 0 && n_out > 0,
+               "mgnns_label_tail_fwd: bad dims B=%d C=%d NLQ=%d heads=%d dh=%d N5=%d out=%d", B, C, NLQ, n_heads, dh, N5, n_out);
+    if (B == 0) return 0;
+    MG_REQUIRE(Q && wk_wp && bk && wv_wp && bv && wc_wp && bc && xl_wp && bxl && out, "mgnns_label_tail_fwd: null pointer");
+    MG_REQUIRE((x != nullptr) != (g_wp != nullptr), "mgnns_label_tail_fwd: pass EITHER the read-out x OR pooled + packed G");
+    if (g_wp) {
+        MG_REQUIRE(pooled && n_parts >= 1 && K_pool > 0 && K_pool % 4 == 0 && mg_aligned16(pooled),
+                   "mgnns_label_tail_fwd: pooled [B,%d,%d] must be 16-byte aligned with K %% 4 == 0", n_parts, K_pool);
+    }
+    const int hid = n_heads * dh;
+    MG_REQUIRE(hid <= 16 * LT_MAXKQ, "mgnns_label_tail_fwd: hidden width %d unsupported (<= %d)", hid, 16 * LT_MAXKQ);
+    MG_REQUIRE(N5 <= 128, "mgnns_label_tail_fwd: linear_5 width %d unsupported (<= 128)", N5);
+    MG_REQUIRE(!wq_next_wp || (qh_next && HK_next > 0 && n_out == hid),
+               "mgnns_label_tail_fwd: the query projection needs qh_next, HK_next and n_out == hidden width");
+    const int sfl = lt_stride(NLQ * N5) > lt_stride(LT_KCH) || !g_wp ? lt_stride(NLQ * N5) : lt_stride(LT_KCH);
+    MG_REQUIRE(!g_wp || lt_stride(NLQ * N5) >= lt_stride(LT_KCH), "mgnns_label_tail_fwd: NLQ*N5=%d too small to stage the read-out (>= %d)",
+               NLQ * N5, LT_KCH);
+    (void)sfl;
+    const size_t lds = (size_t)LT_ROWS * (lt_stride(C) + 3 * lt_stride(hid) + lt_stride(NLQ * N5)) * sizeof(float);
+    MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_fwd: C=%d, NLQ*N5=%d need %zu B of LDS (> 160 KiB)", C, NLQ * N5, lds);
+    MG_DYN_LDS(label_tail_kernel, 160 * 1024);
+    hipLaunchKernelGGL(label_tail_kernel, dim3((B + LT_ROWS - 1) / LT_ROWS), dim3(LT_THR), lds, (hipStream_t)stream, x, B, C,
+                       pooled, n_parts, K_pool, g_wp, Q, NLQ, n_heads, dh, wk_wp, bk, wv_wp, bv, wc_wp, bc, N5, xl_wp, bxl, n_out,
+                       out, wq_next_wp, bq_next, HK_next, qh_next);
+    MG_CHECK_LAUNCH("mgnns_label_tail_fwd");
+    return 0;
+}

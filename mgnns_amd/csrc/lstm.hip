@@ -34,6 +34,7 @@ __global__ __launch_bounds__(1024) void lstm_pack_kernel(const int64_t* __restri
                                                          int32_t* __restrict__ offs, int32_t* __restrict__ order) {
     __shared__ int32_t s_off[1025];
     const int tid = threadIdx.x;
+    if (tid < 8) order[B + tid] = 0;          // chain queues of the persistent recurrence (one per layer x direction)
     if (B <= 1024) {
         // common case, one sample per thread: wave scan (shuffles) + 16 wave totals, lengths in LDS as int4 for the rank count
         __shared__ __attribute__((aligned(16))) int s_l[1024];
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                                                              const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                              const int32_t* __restrict__ order, float* __restrict__ out,
                                                              unsigned short* __restrict__ out_bf16, int ld_bf16, int och,
-                                                             unsigned short* __restrict__ next_x) {
+                                                             unsigned short* __restrict__ next_x, int* __restrict__ queue) {
     __shared__ __attribute__((aligned(16))) unsigned short s_h[2][MH];
+    __shared__ int s_rank;
     extern __shared__ __attribute__((aligned(16))) float s_out[];       // [och][HPAD]: the h rows of a whole chain (och = min(T, 200))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, npair = 2 * B;
@@ -352,25 +354,26 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
     const bool row_on = unit < HID;
     const int row = gate * HID + (row_on ? unit : 0);              // PyTorch row (gate order i, f, g, o)
     const bool is_tanh = gate == 2;
-    // pairs are numbered p = 2 rank + direction; with an even grid the walk below keeps a workgroup on ONE direction, so its
-    // weights are fetched once (a grid that is not even reloads them per sample -- from L2, coalesced)
-    int wdir = -1;
+    // The grid may be SMALLER than the number of chains (and than the chip): a recurrence workgroup is latency bound and
+    // shares its CU with nothing else (its 10 waves plus an attention / memory-bank workgroup do not fit one register
+    // file), so every CU it holds is a CU the chip-filling kernels of the other streams do not get.  Workgroups of even /
+    // odd index serve the forward / reverse direction (weights fetched once) and pull the next chain of the length-sorted
+    // order from a queue: longest first, i.e. LPT scheduling -- the makespan stays max(longest chain, steps / workgroups).
+    const int dir = blockIdx.x & 1;
     s16x4_t w[MKS];
-    float bias = 0.f;
-    for (int r = 0;; ++r) {
-        // even rounds ascend, odd rounds descend (long chains meet short ones); the ^ 1 keeps the pair's parity = direction
-        const int p = r * G + ((r & 1) ? ((G - 1 - (int)blockIdx.x) ^ 1) : (int)blockIdx.x);
-        if (p >= npair) break;                                     // (the next round's index is larger still)
-        const int b = order[p >> 1], dir = p & 1;
-        if (dir != wdir) {
-            wdir = dir;
 #pragma unroll
-            for (int ks = 0; ks < MKS; ++ks) {
-                const uint2 v = packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane];
-                w[ks] = s16x4_t{(short)(v.x & 0xFFFFu), (short)(v.x >> 16), (short)(v.y & 0xFFFFu), (short)(v.y >> 16)};
-            }
-            bias = row_on ? (dir ? bhh_b : bhh_f)[row] : 0.f;
-        }
+    for (int ks = 0; ks < MKS; ++ks) {
+        const uint2 v = packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane];
+        w[ks] = s16x4_t{(short)(v.x & 0xFFFFu), (short)(v.x >> 16), (short)(v.y & 0xFFFFu), (short)(v.y >> 16)};
+    }
+    const float bias = row_on ? (dir ? bhh_b : bhh_f)[row] : 0.f;
+    (void)G; (void)npair;
+    for (;;) {
+        if (tid == 0) s_rank = atomicAdd(&queue[dir], 1);
+        __syncthreads();
+        const int rank = s_rank;
+        if (rank >= B) break;
+        const int b = order[rank];
         long long l = lens[b];
         const int len = (int)(l < 0 ? 0 : (l > T ? T : l));
         const int off = offs[b];
@@ -541,9 +544,15 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
             mgnns_set_error("mgnns_bilstm_bf16_fwd: cannot query the CU count");
             return MGNNS_ERR_LAUNCH;
         }
-        n_cu &= ~1;
-        if (n_cu < 2) n_cu = 2;
-        if (grid_rec > n_cu) grid_rec = n_cu;
+        // default: half of the CUs (LPT over the length-sorted chains keeps the makespan at ~the longest chain as long
+        // as total steps / workgroups stays below it); MGNNS_LSTM_GRID overrides (bench.py decided the default)
+        int cap = n_cu / 2;
+        if (const char* e = getenv("MGNNS_LSTM_GRID")) cap = atoi(e);
+        if (cap > n_cu) cap = n_cu;
+        cap &= ~1;
+        if (cap < 2) cap = 2;
+        if (grid_rec > cap) grid_rec = cap;
+        MG_REQUIRE(2 * num_layers <= 8, "mgnns_bilstm_bf16_fwd: num_layers=%d unsupported (<= 4)", num_layers);
     }
 
     hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
@@ -576,7 +585,8 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
             else hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
             hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), (size_t)och * HPAD * sizeof(float), s, (const float*)Gx,
                                (const int32_t*)offs, lens, B, T, whh, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst,
-                               obf, ld_bf16, och, (layer + 1 < num_layers && 2 * HID <= XKP) ? xb : (unsigned short*)nullptr);
+                               obf, ld_bf16, och, (layer + 1 < num_layers && 2 * HID <= XKP) ? xb : (unsigned short*)nullptr,
+                               order + B + 2 * layer);
         }
         else
             hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,

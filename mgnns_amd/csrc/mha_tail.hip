@@ -9,6 +9,7 @@
 // chain: activations stay in LDS, weights stream from L2 in a pre-packed fragment-major layout (one 16-B load
 // = the B fragments of four k-steps), 8 waves split the output column tiles.  Exact fp32 (v_mfma_f32_16x16x4_f32).
 #include "common.hpp"
+#include "tile_f32.hpp"
 
 namespace {
 
@@ -36,55 +37,6 @@ __global__ __launch_bounds__(256) void pack_w_f32_kernel(const float* __restrict
             if (n < N && k < K) v[j] = W[(size_t)n * K + k];
         }
         reinterpret_cast<f32x4*>(Wp)[i] = v;
-    }
-}
-
-// C[16 x N] tile-GEMM of one wave: acc[t] for column tiles nt = wave + 8t (t < TPW), A from LDS (stride sa), K padded
-// to a multiple of 16 by zero weights (A beyond K must be finite: buffers are zero padded).
-template <int TPW>
-__device__ __forceinline__ void tile_gemm(f32x4 (&acc)[TPW], const float* __restrict__ As, int sa, int K,
-                                          const float* __restrict__ Wp, int NTt, int wave, int lane, int t0) {
-    const int KQ = (K + 15) / 16;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = As + (lane & 15) * sa + (lane >> 4);
-    const f32x4* wp[TPW];
-    bool on[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int nt = wave + 8 * (t0 + t);
-        on[t] = nt < NTt;
-        wp[t] = reinterpret_cast<const f32x4*>(Wp) + ((size_t)(on[t] ? nt : 0) * KQ) * 64 + lane;
-    }
-    // weight fragments run PF k-quads ahead (they come from L2: ~1 us under load, a k-quad of MFMAs is ~0.15 us)
-    constexpr int PF = 4;
-    f32x4 ring[PF][TPW];
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) ring[d][t] = d < KQ ? wp[t][(size_t)d * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kq0 = 0; kq0 < KQ; kq0 += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) {
-            const int kq = kq0 + d;
-            if (kq < KQ) {
-                f32x4 cb[TPW];
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) cb[t] = ring[d][t];
-                if (kq + PF < KQ) {
-#pragma unroll
-                    for (int t = 0; t < TPW; ++t) ring[d][t] = wp[t][(size_t)(kq + PF) * 64];
-                }
-                float a[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = ap[(4 * kq + j) * 4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < TPW; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], cb[t][j], acc[t], 0, 0, 0);
-            }
-        }
     }
 }
 
@@ -224,7 +176,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
 
     f32x4 acc[3];
     // ---- 1. y = LN1(fc(o) + q) --------------------------------------------------------------------------------------
-    tile_gemm<3>(acc, s_o, so, HK, fc_wp, DT, wave, lane, 0);
+    mg_tile_gemm_f32<3>(acc, s_o, so, HK, fc_wp, DT, wave, lane, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -237,7 +189,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     ln_rows_r(s_y, lg1, lb1, eps, wave, lane);
     __syncthreads();
     // ---- 2. h = relu(w_1 y + b_1) ------------------------------------------------------------------------------------
-    tile_gemm<3>(acc, s_y, SD, D, w1_wp, DT, wave, lane, 0);
+    mg_tile_gemm_f32<3>(acc, s_y, SD, D, w1_wp, DT, wave, lane, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -249,7 +201,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
     }
     __syncthreads();
     // ---- 3. out = LN2(w_2 h + b_2 + y) ----------------------------------------------------------------------------------
-    tile_gemm<3>(acc, s_h, SD, D, w2_wp, DT, wave, lane, 0);
+    mg_tile_gemm_f32<3>(acc, s_h, SD, D, w2_wp, DT, wave, lane, 0);
     __syncthreads();                                   // every wave is done reading s_h before it is overwritten
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -272,7 +224,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_kernel(const float* __restrict_
         const int NTq = (HKn + 15) / 16;
         for (int t0 = 0; t0 * 8 < NTq; t0 += 4) {
             f32x4 a4[4];
-            tile_gemm<4>(a4, s_h, SD, D, wq_wp, NTq, wave, lane, t0);
+            mg_tile_gemm_f32<4>(a4, s_h, SD, D, wq_wp, NTq, wave, lane, t0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int nt = wave + 8 * (t0 + t);

@@ -1,41 +1,74 @@
 // Text-level GCN channel: graph construction + PMI edge-weight lookup + max-times aggregation +
-// sum read-out + ReLU in one kernel, one workgroup per document (Text_GCN.py:142-275).
+// sum read-out + ReLU in one kernel, one 16-wave workgroup per document (Text_GCN.py:142-275).
 //
-// Data layout in HBM: tok [B,T] int64; node_hidden [V,D] rows of 1200 B (D=300) read as coalesced
-// 16-B lanes; PMI map as CSR (row_ptr/col/eid int32, columns sorted) searched by bisection.
-// LDS: the document's node rows h[t_i] are staged once (position-major, n <= Tm rows), the
-// (2*ngram+1)-wide band of edge weights, the compacted token list and the same-token chains.
+// Semantics restated: nodes = distinct non-PAD ids of the document; for every position i and every position j within
+// +-ngram of it there is an edge tok[i] -> tok[j] (the window includes i itself, and Text_GCN.py:162-164 adds the self loop
+// once more) with weight seq_edge_w[edges_matrix[tok[i], tok[j]]] -- id 0 ("no PMI entry") is a learned weight like any
+// other; h'_v = max over in-edges of w * h_src; out = relu(sum_v h'_v).
+//
+// Data layout in HBM: tok [B,T] int64; node_hidden [V,D] rows of 1200 B (D=300) gathered as 16-B lanes; PMI map as CSR
+// (row_ptr / col sorted / eid int32; eid == NULL means "id = position + 1", the row-major numbering utils/pmi.py:86-97
+// produces), so a lookup is row_ptr -> a window of <= 9 candidate columns fetched at once -> weight: three dependent
+// loads (rows average 8 entries; longer rows are bisected down to the window first).
+// LDS: the document's node rows staged once (position-major, 16-B lanes), the (2*ngram+1)-wide band of edge weights,
+// the compacted token list, same-token chains, per-chunk partial sums.
+// Work split: the 16 waves share (a) the row gather, (b) one lookup per thread (n*W <= 1024 for the default shapes),
+// (c) the O(n^2) same-token pairing through LDS atomics, and (d) the aggregation as (position chunk x 4-feature group)
+// with 16-B LDS reads and the whole window in flight per destination -- the serial per-feature walk over all positions
+// of the earlier kernel was ~45 of its 88 us on a 100-token document.
 #include "common.hpp"
 
 namespace {
 
-__device__ __forceinline__ int pmi_lookup(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                                          const int32_t* __restrict__ eid, int u, int v) {
-    int lo = row_ptr[u], hi = row_ptr[u + 1];
-    while (lo < hi) {
+constexpr int TG_THREADS = 1024;
+constexpr int TG_MAX_CHUNKS = 16;
+constexpr int TG_WIN = 8;            // candidate window of a lookup: positions lo .. lo+8
+
+__device__ __forceinline__ float pmi_weight(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                            const int32_t* __restrict__ eid, const float* __restrict__ edge_w,
+                                            int n_edge_w, int u, int v) {
+    int lo = row_ptr[u];
+    const int end = row_ptr[u + 1];
+    int hi = end;
+    while (hi - lo > TG_WIN) {                      // lower bound stays inside [lo, hi]
         const int mid = (lo + hi) >> 1;
-        const int c = col[mid];
-        if (c < v) lo = mid + 1; else hi = mid;
+        if (col[mid] < v) lo = mid + 1; else hi = mid;
     }
-    return (lo < row_ptr[u + 1] && col[lo] == v) ? eid[lo] : 0;
+    int pos = -1;
+    const int last = end - 1;
+    if (last >= lo) {
+        int c[TG_WIN + 1];
+#pragma unroll
+        for (int t = 0; t <= TG_WIN; ++t) c[t] = col[min(lo + t, last)];     // all candidates in flight together
+#pragma unroll
+        for (int t = 0; t <= TG_WIN; ++t)
+            if (c[t] == v) pos = min(lo + t, last);
+    }
+    int id = pos < 0 ? 0 : (eid ? eid[pos] : pos + 1);
+    id = (id < 0 || id >= n_edge_w) ? 0 : id;
+    return edge_w[id];
 }
 
-__global__ void textgcn_kernel(const int64_t* __restrict__ tok, int T, int Tm,
+template <int GT>      // compile-time ngram (window fully unrolled), 0 = runtime ngram
+__global__ __launch_bounds__(TG_THREADS) void textgcn_kernel(const int64_t* __restrict__ tok, int T, int Tm,
                                const float* __restrict__ node_hidden, int V, int D,
                                const float* __restrict__ edge_w, int n_edge_w,
                                const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                               const int32_t* __restrict__ eid, int g, float* __restrict__ out, int vec) {
+                               const int32_t* __restrict__ eid, int g_rt, float* __restrict__ out, int vec, int C) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = GT > 0 ? GT : g_rt;
     const int W = 2 * g + 1;
-    float* s_h = smem;                                   // [Tm][D]
-    float* s_w = s_h + (size_t)Tm * D;                   // [Tm][W]
+    const int D4 = (D + 3) >> 2, Dp = D4 << 2;
+    float* s_h = smem;                                   // [Tm][Dp]
+    float* s_part = s_h + (size_t)Tm * Dp;               // [C][Dp]
+    float* s_w = s_part + (size_t)C * Dp;                // [Tm][W]
     int* s_tok = reinterpret_cast<int*>(s_w + (size_t)Tm * W);   // [Tm]
-    int* s_next = s_tok + Tm;                            // [Tm] next position holding the same token, -1 = none
+    int* s_next = s_tok + Tm;                            // [Tm] next position holding the same token, INT_MAX = none
     int* s_first = s_next + Tm;                          // [Tm] 1 if first occurrence of its token
     int* s_n = s_first + Tm;                             // [1]
 
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
 
     // -- 1. compact the non-PAD ids (Text_GCN.py:147-150 drops zeros anywhere), wave 0 ----------
@@ -52,67 +85,114 @@ __global__ void textgcn_kernel(const int64_t* __restrict__ tok, int T, int Tm,
         }
         if (lane == 0) *s_n = n;
     }
+    for (int j = tid; j < Tm; j += TG_THREADS) { s_first[j] = 1; s_next[j] = 0x7fffffff; }
     __syncthreads();
     const int n = *s_n;
 
-    // -- 2a. stage node rows h[t_i] into LDS --------------------------------------------------------
+    // -- 2a. stage node rows h[t_i] into LDS: batches of 4 independent 16-B loads per thread ---------------
     if (vec) {
-        const int D4 = D >> 2;
-        for (int idx = tid; idx < n * D4; idx += nthr) {
-            const int i = idx / D4, c = idx - i * D4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(node_hidden + (size_t)s_tok[i] * D + 4 * c);
-            *reinterpret_cast<f32x4*>(s_h + (size_t)i * D + 4 * c) = v;
+        const int total = n * D4;
+        for (int base = tid; base < total; base += 4 * TG_THREADS) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * TG_THREADS;
+                if (idx < total) {
+                    const int i = idx / D4, c = idx - i * D4;
+                    v[k] = *reinterpret_cast<const f32x4*>(node_hidden + (size_t)s_tok[i] * D + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * TG_THREADS;
+                if (idx < total) *reinterpret_cast<f32x4*>(s_h + (size_t)idx * 4) = v[k];      // [i][c] == idx: Dp = 4*D4
+            }
         }
     } else {
-        for (int idx = tid; idx < n * D; idx += nthr) {
-            const int i = idx / D, c = idx - i * D;
-            s_h[(size_t)i * D + c] = node_hidden[(size_t)s_tok[i] * D + c];
+        for (int idx = tid; idx < n * Dp; idx += TG_THREADS) {
+            const int i = idx / Dp, c = idx - i * Dp;
+            s_h[idx] = c < D ? node_hidden[(size_t)s_tok[i] * D + c] : 0.f;
         }
     }
     // -- 2b. band of edge weights: s_w[j][o] = edge_w[pmi(t_i, t_j)], i = j - g + o (src i -> dst j) ---
-    for (int e = tid; e < n * W; e += nthr) {
+    for (int e = tid; e < n * W; e += TG_THREADS) {
         const int j = e / W, o = e - j * W;
         const int i = j - g + o;
-        float w = 0.f;
-        if (i >= 0 && i < n) {
-            int id = pmi_lookup(row_ptr, col, eid, s_tok[i], s_tok[j]);
-            id = (id < 0 || id >= n_edge_w) ? 0 : id;
-            w = edge_w[id];
-        }
-        s_w[e] = w;
+        s_w[e] = (i >= 0 && i < n) ? pmi_weight(row_ptr, col, eid, edge_w, n_edge_w, s_tok[i], s_tok[j]) : 0.f;
     }
-    // -- 2c. same-token chains: nodes of the graph are the DISTINCT ids (Text_GCN.py:172) ---------------
-    for (int j = tid; j < n; j += nthr) {
-        const int t = s_tok[j];
-        int first = 1;
-        for (int k = 0; k < j; ++k)
-            if (s_tok[k] == t) { first = 0; break; }
-        int nxt = -1;
-        for (int k = j + 1; k < n; ++k)
-            if (s_tok[k] == t) { nxt = k; break; }
-        s_first[j] = first;
-        s_next[j] = nxt;
+    // -- 2c. same-token chains: nodes of the graph are the DISTINCT ids (Text_GCN.py:172).  All pairs k < j. ---------
+    for (int pidx = tid; pidx < n * n; pidx += TG_THREADS) {
+        const int j = pidx / n, k = pidx - j * n;
+        if (k < j && s_tok[k] == s_tok[j]) {
+            s_first[j] = 0;
+            atomicMin(&s_next[k], j);
+        }
     }
     __syncthreads();
 
-    // -- 3. h'_v = max over in-edges (w * h_src); out = relu(sum_v h'_v); thread = feature dim ----------
-    if (tid < D) {
-        float sum = 0.f;
-        for (int j0 = 0; j0 < n; ++j0) {
+    // -- 3. h'_v = max over in-edges (w * h_src); out = relu(sum_v h'_v).  thread = (position chunk c, feature group f):
+    //       chunk c owns the first occurrences j0 = c, c+C, ...; repeated tokens walk their chain -----------------------
+    const int cidx = tid / D4, f = tid - cidx * D4;
+    if (cidx < C) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        const f32x4* h4 = reinterpret_cast<const f32x4*>(s_h);
+        for (int j0 = cidx; j0 < n; j0 += C) {
             if (!s_first[j0]) continue;
-            float mx = -INFINITY;
-            for (int j = j0; j >= 0; j = s_next[j]) {
-                const int lo = max(0, j - g), hi = min(n, j + g + 1);
-                const float* wrow = s_w + (size_t)j * W + (lo - (j - g));
-                for (int i = lo; i < hi; ++i) {
-                    const float m = wrow[i - lo] * s_h[(size_t)i * D + tid];
-                    mx = fmaxf(mx, m);
+            f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int j = j0; j < n; j = s_next[j]) {
+                const float* wrow = s_w + (size_t)j * W;
+                if (GT > 0) {
+                    float w[2 * GT + 1];
+                    f32x4 h[2 * GT + 1];
+#pragma unroll
+                    for (int o = 0; o < 2 * GT + 1; ++o) {
+                        const int i = min(max(j - GT + o, 0), n - 1);
+                        w[o] = wrow[o];
+                        h[o] = h4[(size_t)i * D4 + f];
+                    }
+#pragma unroll
+                    for (int o = 0; o < 2 * GT + 1; ++o) {
+                        const int i = j - GT + o;
+                        if (i >= 0 && i < n) {
+                            mx.x = fmaxf(mx.x, w[o] * h[o].x);
+                            mx.y = fmaxf(mx.y, w[o] * h[o].y);
+                            mx.z = fmaxf(mx.z, w[o] * h[o].z);
+                            mx.w = fmaxf(mx.w, w[o] * h[o].w);
+                        }
+                    }
+                } else {
+                    const int lo = max(0, j - g), hi = min(n, j + g + 1);
+                    for (int i = lo; i < hi; ++i) {
+                        const float w = wrow[i - (j - g)];
+                        const f32x4 h = h4[(size_t)i * D4 + f];
+                        mx.x = fmaxf(mx.x, w * h.x);
+                        mx.y = fmaxf(mx.y, w * h.y);
+                        mx.z = fmaxf(mx.z, w * h.z);
+                        mx.w = fmaxf(mx.w, w * h.w);
+                    }
                 }
             }
             sum += mx;
         }
-        out[(size_t)b * D + tid] = fmaxf(sum, 0.f);
+        *reinterpret_cast<f32x4*>(s_part + (size_t)cidx * Dp + 4 * f) = sum;
     }
+    __syncthreads();
+    if (tid < D) {
+        float total = 0.f;
+        for (int c = 0; c < C; ++c) total += s_part[(size_t)c * Dp + tid];      // fixed order: deterministic
+        out[(size_t)b * D + tid] = fmaxf(total, 0.f);
+    }
+}
+
+template <int GT>
+int launch(const int64_t* tok, int B, int T, int Tm, const float* node_hidden, int V, int D, const float* edge_w, int n_edge_w,
+           const int32_t* rp, const int32_t* col, const int32_t* eid, int ngram, float* out, int vec, int C, size_t lds,
+           hipStream_t st) {
+    MG_DYN_LDS(textgcn_kernel<GT>, 160 * 1024);
+    hipLaunchKernelGGL(textgcn_kernel<GT>, dim3(B), dim3(TG_THREADS), lds, st, tok, T, Tm, node_hidden, V, D, edge_w, n_edge_w,
+                       rp, col, eid, ngram, out, vec, C);
+    MG_CHECK_LAUNCH("mgnns_textgcn_fwd");
+    return 0;
 }
 
 }  // namespace
@@ -121,22 +201,28 @@ extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* 
                                  const float* edge_w, int n_edge_w, const int32_t* pmi_row_ptr,
                                  const int32_t* pmi_col, const int32_t* pmi_eid, int ngram, int max_length,
                                  float* out, mgnns_stream_t stream) {
-    MG_REQUIRE(tok && node_hidden && edge_w && pmi_row_ptr && pmi_col && pmi_eid && out,
-               "mgnns_textgcn_fwd: null pointer");
     MG_REQUIRE(B >= 0 && T > 0 && V > 0 && n_edge_w > 0, "mgnns_textgcn_fwd: bad dims B=%d T=%d V=%d", B, T, V);
+    if (B == 0) return 0;                       // empty batch: tok / out may be null
+    MG_REQUIRE(tok && node_hidden && edge_w && pmi_row_ptr && pmi_col && out, "mgnns_textgcn_fwd: null pointer");
     MG_REQUIRE(D > 0 && D <= 320, "mgnns_textgcn_fwd: D=%d unsupported (1..320)", D);
     MG_REQUIRE(ngram >= 0 && ngram <= 15, "mgnns_textgcn_fwd: ngram=%d unsupported (0..15)", ngram);
     MG_REQUIRE(max_length > 0, "mgnns_textgcn_fwd: max_length=%d", max_length);
-    if (B == 0) return 0;
     const int Tm = T < max_length ? T : max_length;
     const int W = 2 * ngram + 1;
-    const size_t lds = ((size_t)Tm * D + (size_t)Tm * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
+    const int D4 = (D + 3) / 4, Dp = 4 * D4;
+    int C = TG_THREADS / D4;
+    C = C > TG_MAX_CHUNKS ? TG_MAX_CHUNKS : C;
+    const size_t lds = ((size_t)Tm * Dp + (size_t)C * Dp + (size_t)Tm * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_textgcn_fwd: min(T,max_length)=%d needs %zu B of LDS (> 160 KiB)", Tm, lds);
     const int vec = (D % 4 == 0) && mg_aligned16(node_hidden);
-    const int threads = ((D + 63) / 64) * 64;
-    MG_DYN_LDS(textgcn_kernel, 160 * 1024);
-    hipLaunchKernelGGL(textgcn_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, tok, T, Tm, node_hidden, V, D,
-                       edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec);
-    MG_CHECK_LAUNCH("mgnns_textgcn_fwd");
-    return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define TG_ARGS tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec, C, lds, st
+    switch (ngram) {
+        case 1: return launch<1>(TG_ARGS);
+        case 2: return launch<2>(TG_ARGS);
+        case 3: return launch<3>(TG_ARGS);
+        case 4: return launch<4>(TG_ARGS);
+        default: return launch<0>(TG_ARGS);
+    }
+#undef TG_ARGS
 }

@@ -232,10 +232,17 @@ def _wq_pack(layer):
     return hit[1]
 
 
-def run_stack(layers, q, bank, mask=None):
+def first_query_pack(layers):
+    """(packed fp32 w_qs, bias, H*dk) of a stack's first layer: what a producer kernel needs to emit the stack's first
+    projected query itself (ops.label_tail next_q=...), so the stack starts with its attention core."""
+    return _wq_pack(list(layers)[0])
+
+
+def run_stack(layers, q, bank, mask=None, qh=None):
     """A stack of MyMultiHeadAttention layers sharing one memory bank (MODEL:509-546): per layer TWO launches --
     the fused attention core and the fused tail (which also emits the next layer's projected query) -- instead
-    of the reference's ~12 small kernels.  Numerically the same chain as calling the layers one by one."""
+    of the reference's ~12 small kernels.  Numerically the same chain as calling the layers one by one.
+    qh: the first layer's projected query w_qs(q) + b when the producer of q already computed it."""
     layers = list(layers)
     if not layers:
         return q
@@ -251,7 +258,8 @@ def run_stack(layers, q, bank, mask=None):
     q = q.reshape(B, -1).contiguous()
     m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
     a0 = layers[0].slf_attn
-    qh = ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
+    if qh is None:
+        qh = ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
     for i, layer in enumerate(layers):
         a = layer.slf_attn
         if a.attention == 'folded':

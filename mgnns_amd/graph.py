@@ -1,23 +1,43 @@
-"""Whole-forward hipGraph: capture one forward (all streams, ~130 kernel launches) once, replay it per batch.
+"""Whole-forward hipGraphs: capture one forward once, replay it per batch.
 
 The eval forward is static for a given batch shape -- no host-side decisions, no device-to-host syncs (the
 reference's Text_GCN forward syncs and loops in Python per document, Text_GCN.py:232-234) -- so it is captured
 with PyTorch's HIP-graph support: kernels launched through the C ABI go to the capturing stream like any other
 launch.  Inputs live in static device buffers that the caller (or `copy_inputs`) fills before each replay.
+
+Two capture modes:
+
+* ``mode="segments"`` (default): the model's forward_plan() -- 11 segments, each a LINEAR chain of launches on one of
+  four streams -- is captured as one linear hipGraph per segment; a replay launches them on the model's four streams
+  with the plan's event waits in between.  Who runs concurrently with whom is then decided by four in-order HIP
+  streams, exactly as in eager execution, at ~11 graph launches per forward instead of ~130 kernel launches.
+* ``mode="single"``: the whole multi-stream forward as ONE graph with four parallel branches.  The graph runtime maps
+  branches onto its own internal streams; on this stack it ran at most three of the four fusion-stack chains at a
+  time (tools/graph_timeline.py: the fourth started when a sibling had finished, ~200 us late) and the result moved
+  170-252 k samples/s with GPU_MAX_HW_QUEUES.  Kept for comparison.
 """
+import os
+
 import torch
 
 
 class GraphedForward:
-    def __init__(self, model, example_args, warmup=3, post=None):
+    def __init__(self, model, example_args, warmup=3, post=None, mode=None):
         """example_args: the 7 forward arguments on the GPU (text_lens included, int64 on the device).
         post: optional callable applied to the logits INSIDE the capture (e.g. ShardedForward.gather: the RCCL
-        all-gather becomes a node of the same graph)."""
+        all-gather becomes a node of the last graph)."""
         self.model = model
+        self.mode = mode or os.environ.get("MGNNS_GRAPH_MODE", "auto")
+        if self.mode not in ("segments", "single", "auto"):
+            raise ValueError("mode must be 'segments', 'single' or 'auto'")
+        if not getattr(model, "use_streams", True):
+            self.mode = "single"                    # one stream: the forward is one linear chain anyway
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         for a in self.static_in:
             if torch.is_tensor(a) and not a.is_cuda:
                 raise RuntimeError("GraphedForward needs every tensor argument on the GPU (text_lens too)")
+        if getattr(model, "use_streams", True):
+            model._side_streams(self.static_in[0].device)   # bound to hardware queues other than the CALLER's stream's
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -27,11 +47,78 @@ class GraphedForward:
                     self.static_out = post(self.static_out)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.static_out = model(*self.static_in)
-            if post is not None:
-                self.static_out = post(self.static_out)
+        if self.mode in ("single", "auto"):
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph), torch.no_grad():
+                    self._single_out = model(*self.static_in)
+                    if post is not None:
+                        self._single_out = post(self._single_out)
+                self.static_out = self._single_out
+            except Exception:
+                if self.mode == "single":
+                    raise
+                self.graph, self.mode = None, "segments"          # the runtime refused this topology as one graph
+                torch.cuda.synchronize()
+        if self.mode in ("segments", "auto"):
+            self._capture_segments(post)
+        if self.mode == "auto":
+            # Both forms compute the same thing; which is faster depends on the batch (11 graph launches per forward cost
+            # more than they gain below ~100 samples): time a few replays of each, keep the faster, drop the other.
+            # With a collective inside (post) every rank must take the same branch: no timing, segments.
+            self.mode = "segments" if post is not None else self._pick_mode()
+            if self.mode == "single":
+                self._segs, self._ctx = None, None
+                self.static_out = self._single_out
+            else:
+                self.graph = None
+
+    def _pick_mode(self, reps=6):
+        import time
+        best = {}
+        for m in ("single", "segments"):
+            self.mode = m
+            for _ in range(2):
+                self.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.replay()
+            torch.cuda.synchronize()
+            best[m] = time.perf_counter() - t0
+        return min(best, key=best.get)
+
+    # ---- one linear graph per plan segment ------------------------------------------------------------------------
+    def _capture_segments(self, post):
+        model = self.model
+        dev = self.static_in[0].device
+        s_obj, s_place, s_aux = model._side_streams(dev)
+        self._side = {"s1": s_obj, "s2": s_place, "s3": s_aux}
+        plan, ctx = model.forward_plan(*self.static_in)
+        self._ctx = ctx                             # keeps every cross-segment tensor (graph outputs) alive
+        needed = {d for _, _, deps, _ in plan for d in deps}
+        self._segs = []
+        # a dedicated capture stream per plan stream: per-stream workspaces (ops._gemm_workspace) are keyed by the
+        # launch stream, and segments that replay concurrently must not share one
+        self._cap = {k: torch.cuda.Stream(device=dev) for k in ("main", "s1", "s2", "s3")}
+        from . import ops
+        for st in self._cap.values():               # their workspaces exist BEFORE any capture (ordinary memory)
+            with torch.cuda.stream(st):
+                ops._gemm_workspace(dev)
+        with torch.no_grad():
+            for i, (name, skey, deps, fn) in enumerate(plan):
+                g = torch.cuda.CUDAGraph()
+                last = i == len(plan) - 1
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=self._cap[skey]):
+                    fn()
+                    if last and post is not None:
+                        ctx['logits'] = post(ctx['logits'])
+                ev = torch.cuda.Event() if name in needed else None
+                self._segs.append((name, skey, deps, g, ev))
+        torch.cuda.synchronize()
+        self._seg_out = self.static_out = ctx['logits']
+        self._fork = torch.cuda.Event()
 
     def copy_inputs(self, *args):
         for dst, src in zip(self.static_in, args):
@@ -40,8 +127,28 @@ class GraphedForward:
 
     def replay(self):
         """Run the captured forward on the static inputs; returns the static logits tensor."""
-        self.graph.replay()
-        return self.static_out
+        if self.mode == "single":
+            self.graph.replay()
+            return self._single_out
+        main = torch.cuda.current_stream()
+        streams = dict(self._side, main=main)
+        self._fork.record(main)                     # inputs (copy_inputs) and the previous replay's readers are on `main`
+        for st in self._side.values():
+            st.wait_event(self._fork)
+        done = {}
+        for name, skey, deps, g, ev in self._segs:
+            st = streams[skey]
+            for d in deps:
+                if done[d][1] is not st:
+                    st.wait_event(done[d][0])
+            with torch.cuda.stream(st):
+                g.replay()
+                if ev is not None:
+                    ev.record(st)
+                    done[name] = (ev, st)
+        for st in self._side.values():
+            main.wait_stream(st)
+        return self._seg_out
 
     def __call__(self, *args):
         self.copy_inputs(*args)

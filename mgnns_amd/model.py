@@ -17,7 +17,8 @@ from torch.nn import Parameter
 
 from . import ops
 from .adjacency import gen_A, gen_adj_csr
-from .fusion import MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, run_stack
+from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query_pack,
+                     run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
@@ -194,6 +195,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self._lstm_cache = ops.LstmCache()     # derived LSTM weight forms live and die with this module
         self._streams = None
         self.use_streams = bool(opt.get('use_streams', True))
+        self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'channels'))
+        self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
+        self.fused_label_tail_min_batch = 96
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
         self.attention = 'faithful'
@@ -342,23 +346,59 @@ class Multi_GCN_Multihead_Att(nn.Module):
         return ops.imgbank_pool(f3, self._wt(self.liner_img_place), self.liner_img_place.bias.detach(),
                                 self.liner_img_place.out_features, want_pool=False)[0]
 
-    def _channel(self, feats, lin, A, inp, attention, linear_5, x_linear):
-        """One image channel (MODEL:450-479 / 482-506): bank, pooled read-out through the label GCN,
-        label attention, 300->100->700->300 tail."""
-        # the label GCN does not depend on the image: enqueue it first so it overlaps the other streams' head
+    def _label_gcn(self, A, inp):
+        """MODEL:460-473 / 489-499: gen_adj + GraphConvolution x2 over the label graph -> G [C, 2048] (batch independent)."""
         _, csr = gen_adj_csr(A)
         x = self.gc1(inp[0].float().contiguous(), csr, act=ops.ACT_LRELU2)
-        G = self.gc2(x, csr)                                     # [C, 2048]
+        G = self.gc2(x, csr)
         ops.stamp("  label GCN end")
-        bank, pooled = self._img_bank_and_pool(feats, lin)
-        ops.stamp("  image bank end")
-        ev_bank = torch.cuda.Event()
-        ev_bank.record(torch.cuda.current_stream())              # the bank alone: all a text->image stack needs of the channel
-        x = ops.linear(pooled, G)                                # pooled @ G^T -> [B, C]
+        return G
+
+    def _tail_pack(self, attention, linear_5, x_linear):
+        """Packed weights of one channel's fused label-attention tail, rebuilt when any of them changes:
+        w_k / w_v / x_linear in the fragment-major fp32 layout, fc and linear_5 composed into one map (no non-linearity
+        between them, MODEL:131 -> 477): Wc = W5 . Wfc, bc = W5 . b_fc + b5."""
+        ps = (attention.w_k.weight, attention.w_k.bias, attention.w_v.weight, attention.w_v.bias, attention.fc.weight,
+              attention.fc.bias, linear_5.weight, linear_5.bias, x_linear.weight, x_linear.bias)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (str(ps[0].device),)
+        hit = self._wt_cache.get((id(attention), 'tail'))
+        if hit is None or hit[0] != key:
+            w5 = linear_5.weight.detach()
+            wc = ops.matmul(w5.contiguous(), attention.fc.weight.detach().contiguous())               # [N5, hid]
+            bc = ops.linear(attention.fc.bias.detach()[None, :].contiguous(), w5, linear_5.bias.detach())[0]
+            d = {"wk": ops.pack_weight_f32(attention.w_k.weight.detach()), "bk": attention.w_k.bias.detach(),
+                 "wv": ops.pack_weight_f32(attention.w_v.weight.detach()), "bv": attention.w_v.bias.detach(),
+                 "wc": ops.pack_weight_f32(wc), "bc": bc.contiguous(), "n5": linear_5.out_features,
+                 "xl": ops.pack_weight_f32(x_linear.weight.detach()), "bxl": x_linear.bias.detach(),
+                 "n_out": x_linear.out_features, "C": attention.w_k.in_features, "_src": ps}
+            hit = (key, d)
+            self._wt_cache[(id(attention), 'tail')] = hit
+        return hit[1]
+
+    def _label_q(self, attention):
+        """w_q(label query) [NLQ, hid] (MODEL:97): batch independent, computed next to the label GCN."""
+        return ops.linear(self.label_query.float().contiguous(), attention.w_q.weight.detach(), attention.w_q.bias.detach())
+
+    def _channel_tail(self, pooled, G, Q, attention, linear_5, x_linear, next_stack=None):
+        """Second half of an image channel (MODEL:474-479 / 500-506): read-out through the label GCN, then label attention
+        + 300->100->700->300 + the projected query of the fusion stack the feature feeds as ONE fused launch
+        (csrc/label_tail.hip) -- for batches of at least fused_label_tail_min_batch samples: the fused kernel runs on
+        B/16 CUs, which wins when the small launches it replaces would each queue for a CU behind the chip-filling
+        kernels (B=256: 0.955 vs 0.993 ms per forward) and loses on an idle chip (B=32: 0.61 vs 0.54 ms).  Below the
+        threshold, or with MGNNS_FUSED_LABEL_TAIL=0: the chain of module-level operators.  -> (att [B,300], qh or None)"""
+        B = pooled.shape[0]
+        if (self.fused_label_tail and B >= self.fused_label_tail_min_batch
+                and x_linear.in_features == Q.shape[0] * linear_5.out_features):
+            pk = self._tail_pack(attention, linear_5, x_linear)
+            nq = first_query_pack(next_stack) if next_stack is not None and len(next_stack) else None
+            # the read-out stays a launch of its own: 2*B*2048*C FLOPs on the exact-f32 MFMA want many CUs, the fused
+            # kernel runs on B/16 of them (measured with the read-out inside: 0.99 vs 0.955 ms per B=256 forward)
+            r = ops.label_tail(ops.linear(pooled.contiguous(), G), Q, attention.n_heads, pk, next_q=nq)
+            return r if nq is not None else (r, None)
+        x = ops.linear(pooled.contiguous(), G)                   # pooled @ G^T -> [B, C]
         att = attention(query=self.label_query, key=x, value=x)  # [B, NLQ, 300]
-        att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(feats.shape[0], -1)
-        att = ops.linear(att, x_linear.weight.detach(), x_linear.bias.detach())
-        return bank, att, ev_bank
+        att = ops.linear(att, linear_5.weight.detach(), linear_5.bias.detach()).view(pooled.shape[0], -1)
+        return ops.linear(att, x_linear.weight.detach(), x_linear.bias.detach()), None
 
     def _features(self, trunk, x):
         if x.dim() == 4 and x.shape[1] == 2048:
@@ -382,89 +422,170 @@ class Multi_GCN_Multihead_Att(nn.Module):
                                          object_inp, place_inp)
 
     def _side_streams(self, device):
-        key = str(device)
+        """Three side streams on hardware queues of their own (mgnns_amd.streams measures the binding once)."""
+        key = str(device)      # probed against the stream that is current at FIRST use (never inside a graph capture)
         if self._streams is None or self._streams[0] != key:
-            self._streams = (key, [torch.cuda.Stream(device=device) for _ in range(3)])
+            from .streams import independent_streams
+            chosen, distinct = independent_streams(device, 3)
+            self._streams = (key, chosen, distinct)
         return self._streams[1]
 
-    def _forward_streams(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp):
-        """The three channels and then the four fusion stacks are independent of each other (MODEL:444-546), so
-        they are enqueued on separate HIP streams (fork/join with events: no host sync, capturable into one
-        hipGraph) and overlap on the GPU instead of running as one serial chain of small launches."""
-        main = torch.cuda.current_stream()
-        # input conversions BEFORE any fork: a bool / int mask (the reference documents a bool tensor) launches a cast on
-        # `main`; every side stream and every event below is ordered behind it
-        text_mask = text_mask.float().contiguous()
-        s_obj, s_place, s_aux = self._side_streams(text.device) if self.use_streams else (main, main, main)
-        for st in (s_obj, s_place):
-            st.wait_stream(main)
+    # data dependencies between the forward's segments (MODEL:444-567)
+    SEGMENT_DEPS = {
+        "text_gcn": (), "text_bank": (), "lgcn_obj": (), "lgcn_place": (), "bank_obj": (), "bank_place": (),
+        "tail_obj": ("lgcn_obj", "bank_obj"), "tail_place": ("lgcn_place", "bank_place"),
+        "tio": ("bank_obj", "text_gcn"), "tip": ("bank_place", "text_gcn"),
+        "iot": ("text_bank", "tail_obj"), "ipt": ("text_bank", "tail_place"),
+        "head": ("tio", "tip", "iot", "ipt"),
+    }
+    # schedules: enqueue order and stream of every segment ('main' = the caller's stream, 's1'..'s3' side streams;
+    # 's3' is created with high priority).  Decided by bench.py measurements (DESIGN.md section 6).
+    SCHEDULES = {
+        # one stream per channel, stacks where their producer ran (the round-1 schedule)
+        "channels": [("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
+                     ("text_bank", "main"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+                     ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # the same, but a text->image stack also waits for its channel's label-attention tail: the tail's two small
+        # launches then run BEFORE the chip-filling attention cores start instead of queueing for CUs behind them
+        "tails_first": [("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
+                        ("text_bank", "main"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"),
+                        ("tip+tail_place", "s3"), ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # chip-filling kernels in two chains, every small launch on a stream of its own:
+        #   main: BiLSTM -> head;  s1: both image banks, then the two masked stacks;  s2: the two text->image stacks;
+        #   s3: text GCN, label GCNs, label-attention tails
+        "bigsmall": [("text_gcn", "s3"), ("bank_obj", "s1"), ("text_bank", "main"), ("lgcn_obj", "s3"), ("bank_place", "s1"),
+                     ("lgcn_place", "s3"), ("tio", "s2"), ("tail_obj", "s3"), ("tail_place", "s3"), ("tip", "s2"),
+                     ("iot", "s1"), ("ipt", "s1"), ("head", "main")],
+    }
 
-        for st in (s_aux,):
-            st.wait_stream(main)
-        # -- text channel: the text-level GCN (aux stream) and the BiLSTM memory bank (main stream) ---------------
-        ops.stamp("main: start")
-        with torch.cuda.stream(s_aux):
-            ops.stamp("aux: text GCN start")
-            text_feature = self.text_features(text)
-            ops.stamp("aux: text GCN end")
-            ev_text_feature = torch.cuda.Event()
-            ev_text_feature.record(s_aux)
+    def forward_plan(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp, schedule=None):
+        """The forward as SEGMENTS: a list of (name, stream key, names of the segments on OTHER streams it waits for,
+        callable) in enqueue order.  The channels and the four fusion stacks are independent of each other
+        (MODEL:444-546); each segment is a linear chain of launches on one stream and every cross-stream dependency is
+        a wait on the event recorded right behind the producing segment -- never on a whole stream, which would also
+        wait for whatever is queued behind the producer.  Eager execution (_forward_streams) and hipGraph capture
+        (mgnns_amd.graph.GraphedForward: one linear graph per segment) both run this list; results go into the returned
+        context dict (ctx['logits'] at the end)."""
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
-        text_memory_bank = self._text_bank(text, text_lens)
-        ops.stamp("main: text bank (LSTM) end")
-        ev_text_bank = torch.cuda.Event()
-        ev_text_bank.record(main)
+        ctx = {}
 
-        # -- object / place channels ------------------------------------------------------------------------------
-        with torch.cuda.stream(s_obj):
-            ops.stamp("obj: channel start")
-            self.object_feature = self._features(self.object_features, object_feature)
-            bank_obj, att_obj, ev_bank_obj = self._channel(self.object_feature, self.liner_img_object, self.object_A, object_inp,
-                                              self.object_attention, self.object_linear_5, self.object_x_linear)
-            ops.stamp("obj: channel end")
-        with torch.cuda.stream(s_place):
-            ops.stamp("place: channel start")
-            self.place_feature = self._features(self.place_features, place_feature)
-            bank_place, att_place, ev_bank_place = self._channel(self.place_feature, self.liner_img_place, self.place_A, place_inp,
-                                                  self.place_attention, self.place_linear_5, self.place_x_linear)
-            ops.stamp("place: channel end")
+        def text_gcn():
+            ops.stamp("text GCN start")
+            tf = ctx['text_feature'] = self.text_features(text)
+            # first projected queries of the two text->image stacks: here, early, instead of in front of their cores
+            for nm, layers in (('tio', self.text_img_object_multi_head_att), ('tip', self.text_img_place_multi_head_att)):
+                if len(layers):
+                    a0 = layers[0].slf_attn
+                    ctx['qh_' + nm] = ops.linear(tf, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
+            ops.stamp("text GCN end")
 
-        # -- four fusion stacks: image->text on the channel streams, text->image on main / aux.  Every wait is on an EVENT
-        #    recorded right behind the producer: waiting on a whole stream would also wait for the stack queued behind
-        #    the producer on that stream (tools/graph_timeline.py showed tio idling until iot had finished).
-        s_obj.wait_event(ev_text_bank)
-        with torch.cuda.stream(s_obj):
-            ops.stamp("obj: iot stack start")
-            iot = run_stack(self.img_object_text_multi_head_att, att_obj, text_memory_bank, text_mask)
-            ops.stamp("obj: iot stack end")
-        main.wait_event(ev_bank_obj)             # the object bank only -- not the label-attention tail of the channel, nor the iot stack
-        main.wait_event(ev_text_feature)         # text_feature was produced on the aux stream
-        ops.stamp("main: tio stack start")
-        tio = run_stack(self.text_img_object_multi_head_att, text_feature, bank_obj)
-        ops.stamp("main: tio stack end")
-        s_place.wait_event(ev_text_bank)
-        with torch.cuda.stream(s_place):
-            ops.stamp("place: ipt stack start")
-            ipt = run_stack(self.img_place_text_multi_head_att, att_place, text_memory_bank, text_mask)
-            ops.stamp("place: ipt stack end")
-        # (the hipGraph runtime still runs this fourth branch after its sibling ipt -- both hang off the place channel;
-        #  see DESIGN.md section 6)
-        s_aux.wait_event(ev_bank_place)          # the place bank only
-        with torch.cuda.stream(s_aux):
-            ops.stamp("aux: tip stack start")
-            tip = run_stack(self.text_img_place_multi_head_att, text_feature, bank_place)
-            ops.stamp("aux: tip stack end")
+        def text_bank():
+            ops.stamp("main: start")
+            # input conversion first: a bool / int mask (the reference documents a bool tensor) is cast HERE, in the
+            # segment both masked stacks wait for
+            ctx['text_mask'] = text_mask.float().contiguous()
+            ctx['text_bank'] = self._text_bank(text, text_lens)
+            ops.stamp("text bank (LSTM) end")
 
-        main.wait_stream(s_obj)
-        main.wait_stream(s_place)
-        main.wait_stream(s_aux)
-        multi_feature = torch.cat([tio, tip, iot, ipt], dim=1)
-        multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
-                                   self.multi_linear_1.bias.detach())
-        logits = ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
-        ops.stamp("main: logits")
-        return logits
+        def lgcn(tag, A, inp, attention):
+            def run():
+                ctx['Q_' + tag] = self._label_q(attention)       # batch independent: off the critical path, with the GCN
+                ctx['G_' + tag] = self._label_gcn(A, inp)
+            return run
+
+        def bank(tag, trunk, feature, lin):
+            def run():
+                ops.stamp("%s: bank start" % tag)
+                feats = self._features(trunk, feature)
+                setattr(self, 'object_feature' if tag == 'obj' else 'place_feature', feats)      # MODEL:450,482 keep them
+                ctx['bank_' + tag], ctx['pooled_' + tag] = self._img_bank_and_pool(feats, lin)
+                ops.stamp("%s: bank end" % tag)
+            return run
+
+        def tail(tag, attention, linear_5, x_linear, next_stack, next_name):
+            def run():
+                ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
+                    ctx['pooled_' + tag], ctx['G_' + tag], ctx['Q_' + tag], attention, linear_5, x_linear, next_stack)
+                ops.stamp("%s: label-attention tail end" % tag)
+            return run
+
+        def stack(name, layers, q_key, bank_key, masked):
+            def run():
+                ops.stamp("%s stack start" % name)
+                ctx[name] = run_stack(layers, ctx[q_key], ctx[bank_key], ctx['text_mask'] if masked else None,
+                                      qh=ctx.get('qh_' + name))
+                ops.stamp("%s stack end" % name)
+            return run
+
+        def head():
+            multi_feature = torch.cat([ctx['tio'], ctx['tip'], ctx['iot'], ctx['ipt']], dim=1)
+            multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
+                                       self.multi_linear_1.bias.detach())
+            ctx['logits'] = ops.linear(multi_feature, self.multi_linear_2.weight.detach(), self.multi_linear_2.bias.detach())
+            ops.stamp("logits")
+
+        fns = {
+            "text_gcn": text_gcn, "text_bank": text_bank,
+            "lgcn_obj": lgcn('obj', self.object_A, object_inp, self.object_attention),
+            "lgcn_place": lgcn('place', self.place_A, place_inp, self.place_attention),
+            "bank_obj": bank('obj', self.object_features, object_feature, self.liner_img_object),
+            "bank_place": bank('place', self.place_features, place_feature, self.liner_img_place),
+            "tail_obj": tail('obj', self.object_attention, self.object_linear_5, self.object_x_linear,
+                             self.img_object_text_multi_head_att, 'iot'),
+            "tail_place": tail('place', self.place_attention, self.place_linear_5, self.place_x_linear,
+                               self.img_place_text_multi_head_att, 'ipt'),
+            # text->image stacks need the image bank alone (not the channel's label-attention tail) and the text GCN
+            "tio": stack("tio", self.text_img_object_multi_head_att, 'text_feature', 'bank_obj', False),
+            "tip": stack("tip", self.text_img_place_multi_head_att, 'text_feature', 'bank_place', False),
+            # image->text stacks need the text bank (and the mask cast next to it) and the channel's tail
+            "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj', 'text_bank', True),
+            "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place', 'text_bank', True),
+            "head": head,
+        }
+        sched = self.SCHEDULES[schedule or self.schedule]
+        where, plan = {}, []
+        for entry, skey in sched:
+            name, *extra = entry.split("+")          # "seg+other": also wait for `other` (ordering only, no data)
+            deps = tuple(self.SEGMENT_DEPS[name]) + tuple(extra)
+            for d in deps:
+                if d not in where:
+                    raise ValueError("schedule runs %s before %s" % (name, d))
+            plan.append((name, skey, tuple(d for d in deps if where[d] != skey), fns[name]))
+            where[name] = skey
+        if set(where) != set(self.SEGMENT_DEPS):
+            raise ValueError("schedule must run every segment exactly once")
+        return plan, ctx
+
+    def _forward_streams(self, *args):
+        """Eager execution of forward_plan on four HIP streams (fork / join with events, no host sync)."""
+        main = torch.cuda.current_stream()
+        if self.use_streams:
+            s_obj, s_place, s_aux = self._side_streams(args[0].device)
+        else:
+            s_obj = s_place = s_aux = main
+        streams = {"main": main, "s1": s_obj, "s2": s_place, "s3": s_aux}
+        for st in (s_obj, s_place, s_aux):
+            if st is not main:
+                st.wait_stream(main)                 # the caller produced the inputs on `main`
+        plan, ctx = self.forward_plan(*args)
+        needed = {d for _, _, deps, _ in plan for d in deps}
+        done = {}
+        for name, skey, deps, fn in plan:
+            st = streams[skey]
+            for d in deps:
+                if done[d][1] is not st:
+                    st.wait_event(done[d][0])
+            with torch.cuda.stream(st):
+                fn()
+                if name in needed:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done[name] = (ev, st)
+        for st in (s_obj, s_place, s_aux):
+            if st is not main:
+                main.wait_stream(st)                 # also orders every side-stream allocation before the caller's reuse
+        return ctx['logits']
 
     def get_config_optim(self, lr, lrp):
         return [

@@ -284,7 +284,10 @@ def textgcn(tok, node_hidden, edge_w, pmi_dev, ngram, max_length=100):
     rp, col, eid = pmi_dev
     _chk(rp, "pmi row_ptr", torch.int32, 1)
     _chk(col, "pmi col", torch.int32, 1)
-    _chk(eid, "pmi eid", torch.int32, 1)
+    if eid is not None:                    # None: ids are positional (eid[k] == k + 1), the kernel derives them
+        _chk(eid, "pmi eid", torch.int32, 1)
+        if eid.shape != col.shape:
+            raise ValueError("pmi eid and col must have the same length")
     B, T = tok.shape
     V, D = node_hidden.shape
     if rp.shape[0] != V + 1:
@@ -336,8 +339,9 @@ def pack_imgbank_weights_bf16(w):
     return buf
 
 
-def imgbank_pool_bf16(feat, wp, bias, n_out):
-    """feat [B,K,P] fp32 -> (bank bf16 [B,P,320], pooled fp32 [B,K])."""
+def imgbank_pool_bf16(feat, wp, bias, n_out, combine=True):
+    """feat [B,K,P] fp32 -> (bank bf16 [B,P,320], pooled fp32 [B,K]); combine=False: pooled stays as the kernel's two
+    per-half maxima [B,2,K] (label_tail takes the max itself: one launch less on the channel's critical chain)."""
     _chk(feat, "feature map", ndim=3)
     _chk(wp, "packed weight", torch.uint8, 1)
     B, K, P = feat.shape
@@ -348,8 +352,8 @@ def imgbank_pool_bf16(feat, wp, bias, n_out):
     work = torch.empty(B, 2, K, device=feat.device, dtype=torch.float32)
     L = _lib.lib()
     _launch("mgnns_imgbank_pool_bf16_fwd", ("mgnns_imgbank_pool_bf16_fwd",), L.mgnns_imgbank_pool_bf16_fwd, _p(feat),
-            B, K, P, _p(wp), _p(bias), n_out, _p(bank), BANK_LD, _p(pooled), _p(work), _stream())
-    return bank, pooled
+            B, K, P, _p(wp), _p(bias), n_out, _p(bank), BANK_LD, _p(pooled) if combine else None, _p(work), _stream())
+    return bank, (pooled if combine else work)
 
 
 # ---- label attention core ---------------------------------------------------------------------------
@@ -366,6 +370,44 @@ def label_attn_core(Q, K, V, n_heads):
     _lib.check(L.mgnns_label_attn_core_fwd(_p(Q), _p(K), _p(V), B, NLQ, n_heads, hid // n_heads, _p(x), _stream()),
                "mgnns_label_attn_core_fwd")
     return x
+
+
+def label_tail(x, Q, n_heads, packed, pooled=None, g_wp=None, next_q=None):
+    """Fused label-attention tail (mgnns_label_tail_fwd).  Either x [B,C] (the read-out) or pooled [B,parts,K] +
+    g_wp = pack_weight_f32(G [C,K]) (read-out computed in the kernel); Q [NLQ,hid] = w_q(label query); packed =
+    dict(wk, bk, wv, bv, wc, bc, n5, xl, bxl, n_out, C) with wk/wv/wc/xl = pack_weight_f32 images; next_q = (wq_wp, bq,
+    HK) adds qh = w_qs(out) + b.  -> out [B, n_out]  (or (out, qh) with next_q)."""
+    _chk(Q, "Q", ndim=2)
+    NLQ, hid = Q.shape
+    if hid % n_heads:
+        raise ValueError("hidden width %d is not a multiple of %d heads" % (hid, n_heads))
+    if (x is None) == (g_wp is None):
+        raise ValueError("pass either x or (pooled, g_wp)")
+    parts = kp = 0
+    if x is not None:
+        _chk(x, "x", ndim=2)
+        B, C = x.shape
+    else:
+        _chk(pooled, "pooled", ndim=3)
+        _chk(g_wp, "packed G", ndim=1)
+        B, parts, kp = pooled.shape
+        C = packed["C"]
+    if C != packed["C"]:
+        raise ValueError("read-out width %d does not match the packed w_k / w_v (%d)" % (C, packed["C"]))
+    for k in ("wk", "wv", "wc", "xl", "bk", "bv", "bc", "bxl"):
+        _chk(packed[k], k, ndim=1)
+    out = torch.empty(B, packed["n_out"], device=Q.device, dtype=torch.float32)
+    wq = bq = qh = None
+    hkn = 0
+    if next_q is not None:
+        wq, bq, hkn = next_q
+        qh = torch.empty(B, hkn, device=Q.device, dtype=torch.float32)
+    L = _lib.lib()
+    _launch("mgnns_label_tail_fwd", ("mgnns_label_tail_fwd", C), L.mgnns_label_tail_fwd, _p(x), B, C, _p(pooled), parts, kp,
+            _p(g_wp), _p(Q), NLQ, n_heads, hid // n_heads, _p(packed["wk"]), _p(packed["bk"]), _p(packed["wv"]),
+            _p(packed["bv"]), _p(packed["wc"]), _p(packed["bc"]), packed["n5"], _p(packed["xl"]), _p(packed["bxl"]),
+            packed["n_out"], _p(out), _p(wq), _p(bq), hkn, _p(qh), _stream())
+    return out if next_q is None else (out, qh)
 
 
 # ---- single-query MHA core -------------------------------------------------------------------------------

@@ -82,13 +82,21 @@ class PmiCsr:
         return int(self.eid.max()) if self.eid.size else 0
 
     # -- device residency ---------------------------------------------------
+    def eid_is_positional(self):
+        """True when eid[k] == k + 1 for every stored entry -- the row-major numbering utils/pmi.py:86-97 hands out
+        (and build_pmi reproduces).  The kernel then derives the id from the position and never reads `eid`."""
+        return bool(np.array_equal(self.eid, np.arange(1, self.eid.shape[0] + 1, dtype=np.int32)))
+
     def device_arrays(self, device):
-        """(row_ptr, col, eid) int32 tensors on `device`, cached per device."""
+        """(row_ptr, col, eid) int32 tensors on `device`, cached per device; eid is None when ids are positional."""
         import torch
         key = str(device)
         if key not in self._dev:
-            self._dev[key] = tuple(
-                torch.from_numpy(a).to(device) for a in (self.row_ptr, self.col, self.eid))
+            rp, col = (torch.from_numpy(a).to(device) for a in (self.row_ptr, self.col))
+            if col.numel() == 0:
+                col = torch.zeros(1, dtype=torch.int32, device=device)
+            eid = None if self.eid_is_positional() else torch.from_numpy(self.eid).to(device)
+            self._dev[key] = (rp, col, eid)
         return self._dev[key]
 
 

@@ -132,6 +132,53 @@ def test_label_attention_against_goldens():
         assert H.maxabs(z.cpu(), g[tag + "_z"]) < 1e-5
 
 
+def test_fused_label_tail_against_goldens_and_ragged_batches():
+    """csrc/label_tail.hip (read-out + K/V projection + element-wise attention + fc.linear_5 composed + x_linear + the next
+    stack's query projection in one launch) vs the reference's golden `z` (Attention -> linear_5 -> x_linear on the
+    unmodified reference classes), then batches that are not a multiple of the 16-sample tile vs the oracle, with the
+    read-out given (x) and computed in the kernel from the two max-pool halves and the packed label-GCN matrix."""
+    g = H.load_golden("label_attention.npz")
+    lq = dev(g["label_query"])
+    for tag, C in (("object", 80), ("place", 365)):
+        pc = H.params_for(H.label_attention_shapes(tag, C))
+        p = dparams(pc)
+        a = tag + "_attention."
+        Q = ops.linear(lq, p[a + "w_q.weight"], p[a + "w_q.bias"])
+        wc = ops.matmul(p[tag + "_linear_5.weight"], p[a + "fc.weight"])
+        bc = ops.linear(p[a + "fc.bias"][None, :].contiguous(), p[tag + "_linear_5.weight"], p[tag + "_linear_5.bias"])[0].contiguous()
+        packed = {"wk": ops.pack_weight_f32(p[a + "w_k.weight"]), "bk": p[a + "w_k.bias"],
+                  "wv": ops.pack_weight_f32(p[a + "w_v.weight"]), "bv": p[a + "w_v.bias"],
+                  "wc": ops.pack_weight_f32(wc), "bc": bc, "n5": 100, "C": C,
+                  "xl": ops.pack_weight_f32(p[tag + "_x_linear.weight"]), "bxl": p[tag + "_x_linear.bias"], "n_out": 300}
+        key = dev(GI.label_attention_key(tag))
+        z = ops.label_tail(key, Q, 5, packed)
+        assert H.maxabs(z.cpu(), g[tag + "_z"]) < 1e-5
+        rs = np.random.RandomState(C)
+        G = (0.05 * rs.standard_normal((C, 2048))).astype(np.float32)
+        wq = (0.05 * rs.standard_normal((512, 300))).astype(np.float32)
+        bq = (0.05 * rs.standard_normal(512)).astype(np.float32)
+        nq = (ops.pack_weight_f32(dev(wq)), dev(bq), 512)
+        Gp = ops.pack_weight_f32(dev(G))
+        for B in (1, 15, 17, 50):
+            x = torch.from_numpy(rs.standard_normal((B, C)).astype(np.float32))
+            ref = R.label_attention_tail(pc, tag, R.label_attention(pc, tag + "_attention", torch.from_numpy(g["label_query"]), x))
+            z = ops.label_tail(dev(x.numpy()), Q, 5, packed)
+            assert tuple(z.shape) == (B, 300) and H.maxabs(z.cpu(), ref) < 2e-5, (tag, B)
+            # read-out inside: pooled = max of two halves, x = pooled . G^T
+            halves = np.maximum(rs.standard_normal((B, 2, 2048)), 0).astype(np.float32)
+            pooled = halves.max(axis=1)
+            xr = torch.from_numpy(pooled) @ torch.from_numpy(G).t()
+            ref = R.label_attention_tail(pc, tag, R.label_attention(pc, tag + "_attention", torch.from_numpy(g["label_query"]), xr))
+            z2, qh = ops.label_tail(None, Q, 5, packed, pooled=dev(halves), g_wp=Gp, next_q=nq)
+            scale = float(ref.abs().max())
+            assert H.maxabs(z2.cpu(), ref) < 2e-5 * max(1.0, scale), (tag, B)
+            ref_q = ref @ torch.from_numpy(wq).t() + torch.from_numpy(bq)
+            assert H.maxabs(qh.cpu(), ref_q) < 5e-5 * max(1.0, float(ref_q.abs().max())), (tag, B)
+            z3 = ops.label_tail(None, Q, 5, packed, pooled=dev(pooled[:, None, :].copy()), g_wp=Gp)     # one part
+            assert torch.equal(z3, z2)
+        assert tuple(ops.label_tail(key[:0].contiguous(), Q, 5, packed).shape) == (0, 300)
+
+
 def test_layernorm_against_golden():
     g = H.load_golden("layernorm.npz")
     p = dparams(H.params_for({"ln.gamma": (300,), "ln.beta": (300,)}))
@@ -249,6 +296,44 @@ def test_textgcn_vs_oracle_full_length_and_edge_cases():
         y = ops.textgcn(dev(tok), dev(p["text_features.node_hidden.weight"]),
                         dev(p["text_features.seq_edge_w.weight"]), pmi.device_arrays(DEV), ngram)
         assert H.relerr(y.cpu(), ref) < 1e-5
+
+
+def test_textgcn_explicit_ids_long_rows_and_odd_width():
+    """(a) a PMI map whose ids are NOT positional (shuffled ids: the kernel must read `eid`), (b) rows far longer than the
+    lookup's 9-candidate window (bisection first), hit and miss, first / last column, (c) hidden width not a multiple of 4
+    (scalar gather, padded LDS rows), (d) B = 0."""
+    from mgnns_amd.pmi import PmiCsr
+    V, T, B = 400, 64, 9
+    rs = np.random.RandomState(21)
+    rows, cols = [], []
+    for u in range(2, V):
+        k = 120 if u % 7 == 0 else rs.randint(0, 12)              # long rows for every 7th word
+        c = np.sort(rs.choice(np.arange(2, V), size=k, replace=False))
+        rows += [u] * k
+        cols += list(c)
+    nnz = len(rows)
+    eids = rs.permutation(np.arange(1, nnz + 1))                  # explicit, non-positional ids
+    pmi = PmiCsr.from_coo(rows, cols, eids, V)
+    assert not pmi.eid_is_positional() and pmi.device_arrays(DEV)[2] is not None
+    pos = PmiCsr(pmi.row_ptr, pmi.col, np.arange(1, nnz + 1), V)
+    assert pos.eid_is_positional() and pos.device_arrays(DEV)[2] is None
+    count = nnz + 1
+    tok = rs.randint(2, V, size=(B, T)).astype(np.int64)
+    tok[0, :] = 7 * (1 + rs.randint(0, 50, size=T))               # sources with long rows
+    tok[1, 10:] = 0
+    tok[2, :] = 0                                                  # empty document -> zeros
+    for D in (300, 150, 7):
+        p = H.params_for({"text_features.node_hidden.weight": (V, D), "text_features.seq_edge_w.weight": (count, 1)})
+        for m in (pmi, pos):
+            for ngram in (4, 6):
+                ref = R.text_gcn(tok, p["text_features.node_hidden.weight"], p["text_features.seq_edge_w.weight"], m, ngram)
+                y = ops.textgcn(dev(tok), dev(p["text_features.node_hidden.weight"]),
+                                dev(p["text_features.seq_edge_w.weight"]), m.device_arrays(DEV), ngram)
+                assert H.relerr(y.cpu(), ref) < 1e-5, (D, ngram)
+                assert float(y[2].abs().max()) == 0.0
+    y0 = ops.textgcn(dev(tok[:0]), dev(p["text_features.node_hidden.weight"]), dev(p["text_features.seq_edge_w.weight"]),
+                     pos.device_arrays(DEV), 4)
+    assert tuple(y0.shape) == (0, 7)
 
 
 @pytest.mark.parametrize("B", [1, 3])
