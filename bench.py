@@ -474,6 +474,20 @@ def stress_leg(dev):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def text_pipeline_leg(dev):
+    """real texts -> ids -> pinned buffers -> H2D -> captured forward, serial vs two-deep pipelined
+    (tools/bench_text_pipeline.py); reported beside the headline, never part of `value`."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_text_pipeline
+        r = bench_text_pipeline.measure(str(dev), n_batches=40)
+        r["what"] = ("end-to-end samples/s with the text side coming from the HOST per batch (302 real val-split texts, cycled): "
+                     "word2id + padding into pinned buffers + async H2D + hipGraph replay; feature maps resident")
+        return r
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def graphed_variant(model, call, B, steps, warmup, what):
     import torch
     from mgnns_amd.graph import GraphedForward
@@ -660,7 +674,7 @@ def run_rank(args):
     ops.set_timer(None)
 
     variants = {}
-    trunks = stress = None
+    trunks = stress = textpipe = None
     single = world == 1 and dist is None
     if single and not args.no_variants and not args.no_graph:
         with torch.no_grad():
@@ -679,6 +693,7 @@ def run_rank(args):
                     "logit tolerance is gated on (tests/test_model_gpu.py)")
                 model.set_precision("bf16")
         stress = stress_leg(dev)
+        textpipe = text_pipeline_leg(dev)
         trunks = trunk_leg(dev)
 
     if rank != 0:
@@ -759,6 +774,8 @@ def run_rank(args):
         line["variants"] = variants
     if stress is not None:
         line["stress"] = stress
+    if textpipe is not None:
+        line["text_pipeline"] = textpipe
     if trunks is not None:
         line["trunks"] = trunks
     if dist is not None:

@@ -82,3 +82,25 @@ def test_metric_scores_from_confusion_match_sklearn():
                    "macro_f1": f1_score(y, p, average="macro"), "weighted_f1": f1_score(y, p, average="weighted")}
             for k, v in ref.items():
                 assert abs(s[k] - v) < 1e-12, (NL, trial, k)
+
+
+def test_token_cache_and_encode_ids_equal_string_path():
+    """Tokenise-once path (TokenCache rows -> BatchAssembler.encode_ids, vectorised padding) == the per-batch string path
+    == the reference's padding golden."""
+    from mgnns_amd.batching import TokenCache
+    g = _g()
+    vocab = [str(w) for w in g["vocab"]]
+    texts = [str(t) for t in g["pad_texts"]]
+    T = g["pad_ids"].shape[1]
+    a = BatchAssembler(vocab, max_len=T, batch_size=len(texts) + 3)
+    b = BatchAssembler(vocab, max_len=T, batch_size=len(texts) + 3)
+    a.encode(texts)
+    tc = TokenCache(vocab, texts)
+    text, lens, mask = b.encode_ids(tc.batch(0, len(texts)))
+    assert torch.equal(a.text, b.text) and torch.equal(a.lens, b.lens) and torch.equal(a.mask, b.mask)
+    assert np.array_equal(text.numpy(), g["pad_ids"]) and np.array_equal(lens.numpy(), g["pad_lens"])
+    b.encode_ids(tc.batch(0, 2))                      # a shorter batch leaves the tail rows PAD / 0
+    assert int(b.text[2:].abs().sum()) == 0 and int(b.lens[2:].sum()) == 0 and float(b.mask[2:].sum()) == 0.0
+    import pytest
+    with pytest.raises(ValueError, match="max_len"):
+        b.encode_ids([np.arange(1, T + 2)])

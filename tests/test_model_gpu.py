@@ -297,3 +297,44 @@ def test_forward_through_the_reference_factory(tmp_path, monkeypatch):
     ref = R.forward(p, {k: torch.from_numpy(v) for k, v in inp.items()}, model.text_features.edges_matrix, 4, 128, 2, 4,
                     label_query=model.label_query.cpu())
     assert H.maxabs(logits, ref) < TOL
+
+
+def test_pipelined_text_batches_equal_serial():
+    """Row f3: two-deep pipeline (assemble i+1 and H2D it while the GPU replays i) == the serial order, batch by batch,
+    from strings and from tokenise-once ids; the last partial-free batch is checked against the CPU oracle."""
+    from mgnns_amd.batching import PipelinedForward, TokenCache
+    from mgnns_amd.graph import GraphedForward
+    from mgnns_amd.pmi import build_pmi
+    g = H.load_golden("hostside.npz")
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    texts = [t for t in (str(x) for x in g["texts"]) if len(t.split(" ")) <= 60]
+    vocab = [str(w) for w in g["vocab"]]
+    weights, pmi, count = build_pmi(texts, vocab, window_size=5, min_cooccurence=2)
+    B, nb = 16, 7
+    cfg = synth.Config("realtext", B=B, T=60, V=len(vocab), NL=7, n_head=4, stack_num=2, ngram=4, seed=77)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    inp = synth.make_inputs(cfg, B=B, pmi=pmi)
+    gf = GraphedForward(model, call_args(inp, DEV))
+    corpus = (texts * 3)[:B * nb]
+    cache = TokenCache(vocab, corpus)
+    pipe = PipelinedForward(gf, vocab, cfg.T, B, DEV)
+    got = {}
+    for name, fn, ids in (("serial", pipe.run_serial, False), ("pipe", pipe.run, False), ("pipe_ids", pipe.run, True)):
+        outs = []
+        src = (cache.batch(i * B, (i + 1) * B) for i in range(nb)) if ids else (corpus[i * B:(i + 1) * B] for i in range(nb))
+        n = fn(src, from_ids=ids, on_logits=lambda i, o: outs.append(o.clone()))
+        torch.cuda.synchronize()
+        assert n == nb
+        got[name] = torch.stack(outs).cpu()
+    assert torch.equal(got["serial"], got["pipe"]) and torch.equal(got["serial"], got["pipe_ids"])
+    assert float((got["serial"][0] - got["serial"][1]).abs().max()) > 1e-3           # the batches really differ
+    # the last batch against the oracle
+    from mgnns_amd.batching import BatchAssembler
+    asm = BatchAssembler(vocab, cfg.T, B)
+    asm.encode(corpus[(nb - 1) * B:])
+    inp["text"], inp["text_lens"], inp["text_mask"] = asm.text.numpy().copy(), asm.lens.numpy().copy(), asm.mask.numpy().copy()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in inp.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                    label_query=torch.from_numpy(lq))
+    assert H.maxabs(got["pipe"][-1], ref) < TOL
