@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgnns_hip.so")
+LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
 ABI_VERSION = 7
 
 _c = ctypes

@@ -12,6 +12,7 @@
 // (300 outputs) 3,3,3,2,2,2,2,2; the B operand (W) comes straight from L2 in a pre-packed fragment-major layout.
 // v_mfma_f32_16x16x32_bf16, fp32 accumulation; epilogue transposes through LDS so bank rows leave as 16-B lanes.
 #include "common.hpp"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -64,180 +65,248 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
     }
 }
 
-// NTN = column tiles of this wave (3 for waves 0-2, 2 for waves 3-7): compile-time so the MFMA stream is branch-free.
-// Every wave runs the same number of barriers; the two instantiations only differ in the tile count.
+// ---- roles ------------------------------------------------------------------------------------------------------------
+// Waves 4-7 are PRODUCERS: they own the HBM stream.  Each keeps THREE k-slices of its share of the map in flight in
+// registers (a quarter of the 128 feature rows x its 28 region quads: 16 x 16 B per lane and slice), takes the max-pool,
+// converts to bf16 and transposes into the LDS double buffer.  With the loads issued by the same waves that also ran the
+// MFMAs (round 1) only one slice could be in flight per CU and the memory pipe idled through every conversion:
+// ~56 KB in flight per CU at ~4 us per slice = 3.5 TB/s.
+// Waves 0-3 are CONSUMERS: MFMA only (7 row tiles x 5 | 5 | 5 | 4 column tiles), A fragments from LDS through a 3-deep
+// register ring, B fragments (W, L2 resident) of the NEXT slice requested as soon as the current slice's MFMAs are issued,
+// so they fly across the slice barrier.  One LDS-only barrier per slice orders the two groups.
+struct ImgGeom {
+    int b, mh, p0, p_store_end, K, P, KS, nchunk;
+};
+
+constexpr int PMS = 36;                 // row stride (floats) of a producer wave's partial-maxima tile [32 rows][28 -> 36]
+
+__device__ __forceinline__ void imgbank_producer(uint4* __restrict__ Fs, float* __restrict__ s_pm_all, const float* __restrict__ feat,
+                                                 const ImgGeom& gm, float* __restrict__ pooled_part, int pw, int lane) {
+    float* s_pm = s_pm_all + pw * 32 * PMS;
+    const int pq = lane & 31, hw = lane >> 5;
+    const int kc0 = 4 * pw + 2 * hw;                                    // this half-wave's two 8-row groups: kc0, kc0 + 1
+    const int npq = gm.mh ? (gm.P - P_SPLIT + 3) / 4 : ROWS / 4;        // 23 | 28 quads carry data
+    const bool st_on = pq < ROWS / 4;                                   // lanes that own LDS rows (28 per half-wave)
+    const bool ld_on = st_on && pq < npq && (gm.p0 + 4 * pq + 3 < gm.P);
+    // The map is read through a buffer resource: ONE per-lane byte offset (a single VGPR for all 48 loads in flight) plus
+    // a wave-uniform row offset in an SGPR.  With flat 64-bit per-load addresses the compiler recycled address registers
+    // between the sets and put s_waitcnt vmcnt(31..39) in front of every refill, i.e. a refill waited for the NEXT set.
+    // lanes without data (pq >= npq) load what lane npq - 1 loads and ignore it: the loads must be UNCONDITIONAL -- behind a
+    // branch the compiler no longer knows how many are outstanding and every wait becomes vmcnt(0)
+    const int pqc = pq < npq ? pq : npq - 1;
+    const int loff = (int)((16 * hw * gm.P + gm.p0 + 4 * pqc) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(feat + (size_t)gm.b * gm.K * gm.P), 0, gm.K * gm.P * (int)sizeof(float), 0x00027000);
+    const int urow0 = 32 * pw;                                           // first feature row of this wave inside a slice
+    const int P = gm.P, nchunk = gm.nchunk;
+
+    f32x4 st[3][16];
+    auto gload = [&](f32x4 (&s)[16], int c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            // streamed once: non-temporal (aux bit 1), so the map does not evict the W fragments every workgroup re-reads from L2
+            s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, loff, (c * BK + urow0 + i) * P * (int)sizeof(float), 2));
+        }
+    };
+    // slice (in registers) -> max-pool of its 16 feature rows + bf16 transpose-write into LDS buffer `buf`
+    auto emit = [&](f32x4 (&s)[16], int c, int buf) {
+#ifdef MG_IMG_NO_EMIT
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) asm volatile("" ::"v"(s[gi]));
+        return;
+#endif
+        // max-pool (exact fp32): in-lane over the lane's 4 regions, then across the half-wave's 28 lanes THROUGH LDS -- the
+        // wave writes its 32 x 32 partial maxima, 32 of its lanes read a feature row each (7 x 16 B) and finish it.  (The
+        // cross-lane form -- 4 DPP steps + 4 v_readlane per row -- was most of the ~5 k cycles per slice a producer spent here,
+        // and a producer that computes is a producer that does not refill the memory pipe.)
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi)
+            s_pm[(16 * hw + gi) * PMS + pq] = ld_on ? fmaxf(fmaxf(s[gi][0], s[gi][1]), fmaxf(s[gi][2], s[gi][3])) : -INFINITY;
+        if (st_on) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // lanes past the half's last region quad hold a copy of the last quad: their LDS rows are never stored
+                    uint4 pk;
+                    pk.x = pack2(s[8 * g + 0][j], s[8 * g + 1][j]);
+                    pk.y = pack2(s[8 * g + 2][j], s[8 * g + 3][j]);
+                    pk.z = pack2(s[8 * g + 4][j], s[8 * g + 5][j]);
+                    pk.w = pack2(s[8 * g + 6][j], s[8 * g + 7][j]);
+                    Fs[(buf * ROWS + 4 * pq + j) * FSTR + ((kc0 + g) ^ (pq & 7))] = pk;
+                }
+        }
+        if (lane < 32) {                                       // same wave wrote s_pm: LDS operations of a wave complete in order
+            const f32x4* r4 = reinterpret_cast<const f32x4*>(s_pm + lane * PMS);
+            f32x4 m = r4[0];
+#pragma unroll
+            for (int q = 1; q < 7; ++q) {
+                const f32x4 v = r4[q];
+                m = f32x4{fmaxf(m[0], v[0]), fmaxf(m[1], v[1]), fmaxf(m[2], v[2]), fmaxf(m[3], v[3])};
+            }
+            pooled_part[((size_t)gm.b * 2 + gm.mh) * gm.K + c * BK + 32 * pw + lane] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+        }
+    };
+    gload(st[0], 0);
+    if (nchunk > 1) gload(st[1], 1);
+    if (nchunk > 2) gload(st[2], 2);
+    emit(st[0], 0, 0);
+    if (nchunk > 3) gload(st[0], 3);
+    mg_lds_barrier();
+    // iteration c: slice c + 1 leaves its registers (set (c+1) % 3), which take slice c + 4 at once.  The steady-state
+    // loop is branch-free: with a conditional load in it the compiler's wait for "the loads of this set" has to assume
+    // the fewest newer loads any path issued, i.e. it waits for the NEXT set too and the third slice in flight is lost.
+#ifdef MG_IMG_TRACE
+    unsigned long long t_emit = 0, t_issue = 0, t_bar = 0, t_first = 0;
+#define MG_TT(v) const unsigned long long v = IMG_T(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define MG_TT(v)
+#endif
+#define MG_PFULL(S, c)                                                      \
+    do {                                                                    \
+        MG_TT(ta_);                                                         \
+        asm volatile("" ::"v"(st[S][0]));   /* wait for the set's FIRST row only */ \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MG_TT(tb_);                                                         \
+        emit(st[S], (c) + 1, ((c) + 1) & 1);                                \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MG_TT(tc_);                                                         \
+        gload(st[S], (c) + 4);                                              \
+        __builtin_amdgcn_sched_barrier(0); /* nothing of the NEXT emit is hoisted between / above these loads: it would wait for the next set */ \
+        MG_TT(td_);                                                         \
+        mg_lds_barrier();                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MG_TT(te_);                                                         \
+        MG_TACC();                                                          \
+    } while (0)
+#define MG_PSTEP(S, c)                                                      \
+    do {                                                                    \
+        if ((c) < nchunk) {                                                 \
+            if ((c) + 1 < nchunk) {                                         \
+                emit(st[S], (c) + 1, ((c) + 1) & 1);                        \
+                if ((c) + 4 < nchunk) gload(st[S], (c) + 4);                \
+            }                                                               \
+            mg_lds_barrier();                                               \
+        }                                                                   \
+    } while (0)
+#ifdef MG_IMG_TRACE
+#define MG_TACC() do { t_first += tb_ - ta_; t_emit += tc_ - tb_; t_issue += td_ - tc_; t_bar += te_ - td_; } while (0)
+#else
+#define MG_TACC() do { } while (0)
+#endif
+    int c = 0;
+    for (; c + 6 < nchunk; c += 3) {
+        MG_PFULL(1, c);
+        MG_PFULL(2, c + 1);
+        MG_PFULL(0, c + 2);
+    }
+    for (; c < nchunk; c += 3) {
+        MG_PSTEP(1, c);
+        MG_PSTEP(2, c + 1);
+        MG_PSTEP(0, c + 2);
+    }
+#undef MG_PFULL
+#ifdef MG_IMG_TRACE
+    if (lane == 0 && pw == 0 && (blockIdx.x == 0 || blockIdx.x == 301)) {
+        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + 1];
+        g[0] = t_first; g[1] = t_emit; g[2] = t_issue; g[3] = t_bar;
+    }
+#endif
+#undef MG_PSTEP
+}
+
 template <int NTN>
-__device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* __restrict__ feat, int Bn, int K, int P,
-                                             const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
-                                             unsigned short* __restrict__ bank, float* __restrict__ pooled_part) {
-    uint4* Fs = reinterpret_cast<uint4*>(smem);                            // [2][ROWS][FSTR] chunks
-    uint4* Os = Fs + 2 * ROWS * FSTR;                                      // [ROWS][OCH] chunks (epilogue)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the two halves of a sample share the 128-B lines at their seam and the same W stream: keep the pair on ONE
-    // XCD (workgroup id % 8 is the XCD in practice) so those lines are served by one L2; any mapping is correct
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    const int b_raw = (jq >> 1) * 8 + xcd, mh = jq & 1;
-    if (b_raw >= Bn) return;                   // tail when B % 8 != 0 (whole workgroup exits together)
-    const int b = b_raw;
-    const int p0 = mh ? P_SPLIT : 0;
-    const int p_store_end = mh ? P : P_SPLIT;                              // rows [p0, p_store_end) are ours
-    const int nt0 = wave < 3 ? 3 * wave : 9 + 2 * (wave - 3);
-    const int KS = K / 32;
-
-    // staging role: half-wave = 8-row group kc (0..15) of the 128-row slice, lane&31 = region quad pq
-    const int pq = lane & 31, kc = 2 * wave + (lane >> 5);
-    const int npq = mh ? (P - P_SPLIT + 3) / 4 : ROWS / 4;                 // 23 | 28 quads carry data
-    const bool st_on = pq < ROWS / 4;                                      // lanes that own LDS rows (28 per half-wave)
-    const bool ld_on = st_on && pq < npq && (p0 + 4 * pq + 3 < P);
-    const float* fsrc = feat + ((size_t)b * K + 8 * kc) * P + p0 + 4 * pq;
-
+__device__ __forceinline__ void imgbank_consumer(unsigned char* smem, const ImgGeom& gm, const unsigned short* __restrict__ Wp,
+                                                 const float* __restrict__ bias, int N, int wave, int lane) {
+    const uint4* Fs = reinterpret_cast<const uint4*>(smem);
+    uint4* Os = reinterpret_cast<uint4*>(smem) + 2 * ROWS * FSTR;
+    const int nt0 = 5 * wave, KS = gm.KS, nchunk = gm.nchunk;
     f32x4 acc[MTH][NTN];
 #pragma unroll
     for (int i = 0; i < MTH; ++i)
 #pragma unroll
         for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    f32x4 st[8];
-    auto gload = [&](int c) {
+    const uint4* wu = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64;      // wave-uniform: SGPR base + lane*16
+    // B fragments: a ring of THREE k-steps (the four of a slice at once do not fit beside 140 accumulators); k-step g of
+    // the whole K (= 4 c + kk) lives in ring[g % 3] and is requested when k-step g - 3 has issued its MFMAs, i.e. two
+    // k-steps (70 MFMAs, ~0.5 us) ahead, across slice barriers too.  A consumer wave is alone on its SIMD's MFMA pipe, so what
+    // the ring does not cover of the L2 latency is exposed -- the consumers have slack for it: a slice is ~1 us of MFMAs
+    // against >= 3 us of HBM time.  (With a 2-deep ring they did not: 5.3 us per slice, 171 us per launch.)
+    constexpr int RD = 3;
+    uint4 bq[RD][NTN];
+    const int nks = nchunk * (BK / 32);
+    // A fragment of (k-step kk, row tile i): row = 16 i + (lane & 15), chunk = (4 kk + (lane >> 4)) ^ ((row >> 2) & 7).
+    // (row >> 2) & 7 = (lane & 15) >> 2 for even i, + 4 for odd i, so the address is ONE per-lane base plus a
+    // compile-time offset per (kk, i): no per-fragment address registers.
+    const int abase_l = (lane & 15) * FSTR + ((lane >> 4) ^ ((lane & 15) >> 2));
+    auto afrag = [&](const uint4* fb, int kk, int i) { return fb[abase_l + i * 16 * FSTR + ((4 * kk) ^ (4 * (i & 1)))]; };
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // streamed once: non-temporal, so the map does not evict the W fragments every workgroup re-reads from L2
-            if (ld_on) st[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(fsrc + ((size_t)c * BK + i) * P));
-        }
-    };
-    // A slice goes global -> st (fp32) -> pk (max-pool taken, packed bf16, half the registers) -> LDS.  Converting at
-    // the TOP of an iteration frees st for the next slice's loads before the MFMAs start, so those loads have the
-    // whole iteration (MFMAs + LDS write + barrier) to land and the memory pipe idles only during the conversion.
-    uint4 pk[4];
-    auto convert = [&](int c) {
-        // max-pool of the 8 feature rows this wave just loaded (exact fp32): each half-wave = two DPP rows holds one
-        // 8-row group: lanes 0/16 and 32/48 carry the row maxima; lane i keeps the result of feature row i of the
-        // wave's 16, so they leave as ONE 64-byte store per wave
-        float mine = -INFINITY;
+    for (int d = 0; d < RD; ++d)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float m = ld_on ? fmaxf(fmaxf(st[i][0], st[i][1]), fmaxf(st[i][2], st[i][3])) : -INFINITY;
-            m = row16_max(m);
-            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
-            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
-            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
-            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
-            if (lane == i) mine = fmaxf(a0, a1);
-            if (lane == 8 + i) mine = fmaxf(b0, b1);
-        }
-        if (lane < 16) pooled_part[((size_t)b * 2 + mh) * K + c * BK + 16 * wave + lane] = mine;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pk[j].x = pack2(st[0][j], st[1][j]);
-            pk[j].y = pack2(st[2][j], st[3][j]);
-            pk[j].z = pack2(st[4][j], st[5][j]);
-            pk[j].w = pack2(st[6][j], st[7][j]);
-        }
-    };
-    auto lstore = [&](int buf) {          // transpose-write of the packed slice
-        if (st_on) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Fs[(buf * ROWS + 4 * pq + j) * FSTR + (kc ^ (pq & 7))] = pk[j];
-        }
-    };
-
-    const uint4* wb = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64 + lane;
-    const int nchunk = K / BK;
-    // B fragments (L2) of ALL four k-steps of a slice are requested at the top of its iteration, BEFORE the next map
-    // slice is requested: vector-memory results return in order, so a W fragment requested after the map loads
-    // would not be usable until those (HBM latency) have landed -- that stall, once per slice, used to be ~60 % of
-    // the MFMA phase
-    uint4 bq[BK / 32][NTN];
-    constexpr int HA = 4, HB = MTH - HA;
-    uint4 ga[HA], gb[HB];
-    auto afrag_a = [&](const uint4* fb, int kk) {
-#pragma unroll
-        for (int i = 0; i < HA; ++i) {
-            const int row = i * 16 + (lane & 15);
-            ga[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
-        }
-    };
-    auto afrag_b = [&](const uint4* fb, int kk) {
-#pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int row = (HA + i) * 16 + (lane & 15);
-            gb[i] = fb[row * FSTR + ((4 * kk + (lane >> 4)) ^ ((row >> 2) & 7))];
-        }
-    };
-    gload(0);
-    convert(0);
-    lstore(0);
-    if (nchunk > 1) gload(1);
-    __syncthreads();
+        for (int j = 0; j < NTN; ++j) bq[d][j] = (wu + ((size_t)j * KS + min(d, nks - 1)) * 64)[lane];
+    mg_lds_barrier();
+    // 12 k-steps (three slices) per trip so that ring slots are compile-time: K / 32 is a multiple of 4, the trip handles
+    // slices c, c+1, c+2 with slot = (4 (c % 3) + kk) % 3
 #ifdef MG_IMG_TRACE
-    unsigned long long tc = 0, tm = 0, tb = 0, t_start = IMG_T();
+    unsigned long long t_work = 0, t_cbar = 0;
 #endif
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-#ifdef MG_IMG_TRACE
-        const unsigned long long t0 = IMG_T();
-#endif
-        const uint4* fb = Fs + (size_t)buf * ROWS * FSTR;
+    auto slice = [&](int c, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
+        MG_TT(ta_);
+        const uint4* fb = Fs + (size_t)(c & 1) * ROWS * FSTR;
+        constexpr int AD = 6;                                    // A ring depth: fragments AD - 1 (k-step, row tile) pairs ahead
+        uint4 ar[AD];
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk)
-#pragma unroll
-            for (int j = 0; j < NTN; ++j) bq[kk][j] = wb[((size_t)j * KS + c * (BK / 32) + kk) * 64];
-        afrag_a(fb, 0);                           // first k-step's fragments fly under the conversion below
-        afrag_b(fb, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunk) {
-            convert(c + 1);                       // waits for slice c+1 (requested one iteration ago)
-            if (c + 2 < nchunk) gload(c + 2);     // ... and its registers take slice c+2 at once
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MG_IMG_TRACE
-        const unsigned long long t1 = IMG_T();
-#endif
-        // MFMAs of the slice, software pipelined in two half-groups of row tiles: while one half's MFMAs run, the
-        // other half's A fragments (ds_read_b128) for the same / next k-step are in flight, so an LDS round trip is
-        // exposed once per slice (and that one overlaps the conversion above) instead of once per k-step
+        for (int d = 0; d < AD - 1; ++d) ar[d] = afrag(fb, d / MTH, d % MTH);
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            __builtin_amdgcn_sched_barrier(0);
+            constexpr int dummy = 0;
+            (void)dummy;
 #pragma unroll
-            for (int i = 0; i < HA; ++i) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, ga[i]);
+            for (int i = 0; i < MTH; ++i) {
+                const int sidx = kk * MTH + i;                       // A ring over the (k-step, row tile) pairs: a consumer wave is
+                // alone on its SIMD, nothing else hides an LDS round trip (~130 cycles idle, more behind the producers' writes)
+                if (sidx + AD - 1 < (BK / 32) * MTH)
+                    ar[(sidx + AD - 1) % AD] = afrag(fb, (sidx + AD - 1) / MTH, (sidx + AD - 1) % MTH);
+                const bf16x8 av = __builtin_bit_cast(bf16x8, ar[sidx % AD]);
+#ifndef MG_IMG_NO_MFMA
 #pragma unroll
                 for (int j = 0; j < NTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[kk][j]), av,
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[(S0 + kk) % RD][j]), av,
                                                                        acc[i][j], 0, 0, 0);
+#else
+                asm volatile("" ::"v"(av));
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (kk + 1 < BK / 32) afrag_a(fb, kk + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            // unconditional (the last RD requests re-read the last k-step and are never used): behind a branch the
+            // compiler cannot count the outstanding loads and every wait for a ring slot becomes vmcnt(0)
+            const int gk = min(c * (BK / 32) + kk + RD, nks - 1);
+#ifndef MG_IMG_NO_W
 #pragma unroll
-            for (int i = 0; i < HB; ++i) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, gb[i]);
-#pragma unroll
-                for (int j = 0; j < NTN; ++j)
-                    acc[HA + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[kk][j]), av,
-                                                                            acc[HA + i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < NTN; ++j) bq[(S0 + kk) % RD][j] = (wu + ((size_t)j * KS + gk) * 64)[lane];
+#else
+            (void)gk;
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            if (kk + 1 < BK / 32) afrag_b(fb, kk + 1);
         }
-#ifdef MG_IMG_TRACE
+        MG_TT(tb_);
+        mg_lds_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t2 = IMG_T();
-#endif
-        if (c + 1 < nchunk) lstore(buf ^ 1);
-        mg_lds_barrier();        // NOT __syncthreads(): its vmcnt(0) would wait for the map slice requested above
+        MG_TT(tc_);
 #ifdef MG_IMG_TRACE
-        const unsigned long long t3 = IMG_T();
-        tc += t1 - t0; tm += t2 - t1; tb += t3 - t2;
+        t_work += tb_ - ta_; t_cbar += tc_ - tb_;
 #endif
+    };
+    for (int c = 0; c < nchunk; c += 3) {
+        slice(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nchunk) slice(c + 1, std::integral_constant<int, (BK / 32) % RD>{});
+        if (c + 2 < nchunk) slice(c + 2, std::integral_constant<int, (2 * (BK / 32)) % RD>{});
     }
 #ifdef MG_IMG_TRACE
-    if ((lane == 0) && (wave == 0 || wave == 7) && (blockIdx.x == 0 || blockIdx.x == 301)) {
-        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + (wave ? 1 : 0)];
-        g[0] = tc; g[1] = tm; g[2] = tb; g[3] = IMG_T() - t_start;
+    if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 301)) {
+        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0)];
+        g[0] = t_work; g[1] = t_cbar;
     }
 #endif
 
@@ -263,16 +332,6 @@ __device__ __forceinline__ void imgbank_body(unsigned char* smem, const float* _
             *reinterpret_cast<uint2*>(osb + (size_t)row * OSTR + n * 2) = o;
         }
     }
-    // zero the pad columns 304..319 (two chunks per row)
-    for (int q = tid; q < ROWS * 2; q += NTHR)
-        *reinterpret_cast<uint4*>(osb + (size_t)(q >> 1) * OSTR + (NT * 2 + (q & 1)) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)b * P * OCH;
-    const int nrows = p_store_end - p0;
-    for (int q = tid; q < nrows * OCH; q += NTHR) {
-        const int row = q / OCH, ch = q - row * OCH;
-        ob[(size_t)(p0 + row) * OCH + ch] = *reinterpret_cast<const uint4*>(osb + (size_t)row * OSTR + ch * 16);
-    }
 }
 
 __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __restrict__ feat, int Bn, int K, int P,
@@ -281,10 +340,36 @@ __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __
                                                                  unsigned short* __restrict__ bank,
                                                                  float* __restrict__ pooled_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 3 * 64)
-        imgbank_body<3>(smem, feat, Bn, K, P, Wp, bias, N, bank, pooled_part);
-    else
-        imgbank_body<2>(smem, feat, Bn, K, P, Wp, bias, N, bank, pooled_part);
+    uint4* Fs = reinterpret_cast<uint4*>(smem);                            // [2][ROWS][FSTR] chunks
+    unsigned char* osb = smem + (size_t)2 * ROWS * FSTR * 16;              // [ROWS][OSTR] bytes (epilogue)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the two halves of a sample share the 128-B lines at their seam and the same W stream: keep the pair on ONE
+    // XCD (workgroup id % 8 is the XCD in practice) so those lines are served by one L2; any mapping is correct
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    ImgGeom gm;
+    gm.b = (jq >> 1) * 8 + xcd;
+    gm.mh = jq & 1;
+    if (gm.b >= Bn) return;                    // tail when B % 8 != 0 (whole workgroup exits together)
+    gm.p0 = gm.mh ? P_SPLIT : 0;
+    gm.p_store_end = gm.mh ? P : P_SPLIT;      // rows [p0, p_store_end) are ours
+    gm.K = K; gm.P = P; gm.KS = K / 32; gm.nchunk = K / BK;
+
+    float* s_pm_all = reinterpret_cast<float*>(osb + (size_t)ROWS * OSTR);      // [4][32][PMS]
+    if (wave >= 4) imgbank_producer(Fs, s_pm_all, feat, gm, pooled_part, wave - 4, lane);
+    else if (wave == 3) imgbank_consumer<4>(smem, gm, Wp, bias, N, wave, lane);
+    else imgbank_consumer<5>(smem, gm, Wp, bias, N, wave, lane);
+
+    // zero the pad columns 304..319 (two chunks per row), then the rows leave as 16-B lanes (all eight waves)
+    for (int q = tid; q < ROWS * 2; q += NTHR)
+        *reinterpret_cast<uint4*>(osb + (size_t)(q >> 1) * OSTR + (NT * 2 + (q & 1)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)gm.b * P * OCH;
+    const int nrows = gm.p_store_end - gm.p0;
+    for (int q = tid; q < nrows * OCH; q += NTHR) {
+        const int row = q / OCH, ch = q - row * OCH;
+        ob[(size_t)(gm.p0 + row) * OCH + ch] = *reinterpret_cast<const uint4*>(osb + (size_t)row * OSTR + ch * 16);
+    }
 }
 
 // pooled[b,k] = max(part[b,0,k], part[b,1,k])
@@ -296,7 +381,8 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
     }
 }
 
-constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR) * 16 + (size_t)ROWS * OSTR;
+constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR) * 16 + (size_t)ROWS * OSTR + (size_t)4 * 32 * PMS * sizeof(float);
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 
 }  // namespace
 

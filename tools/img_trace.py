@@ -24,6 +24,10 @@ buf = (ctypes.c_ulonglong * 32)()
 fn = _lib.lib().mgnns_debug_img_trace
 fn.argtypes = [ctypes.c_void_p]
 assert fn(ctypes.addressof(buf)) == 0
-for i, name in enumerate(["wg0 wave0", "wg0 wave7", "wg301 wave0", "wg301 wave7"]):
+for i, name in enumerate(["wg0 consumer0", "wg0 producer0", "wg301 consumer0", "wg301 producer0"]):
     t = buf[i * 8:(i + 1) * 8]
-    print("%s: wait+convert %d  mfma %d  lds write+barrier %d  loop total %d" % (name, t[0], t[1], t[2], t[3]))
+    if i % 2 == 0:
+        print("%s: work (A reads + MFMAs + W requests) %d  barrier wait %d   [s_memtime ticks, 16 slices]" % (name, t[0], t[1]))
+    else:
+        print("%s: wait for the set's first row %d  emit (rest of the waits + pool + cvt + LDS write) %d  refill issue %d  barrier wait %d"
+              % (name, t[0], t[1], t[2], t[3]))
