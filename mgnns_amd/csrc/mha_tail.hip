@@ -326,30 +326,47 @@ __global__ __launch_bounds__(256) void pack_w_split_kernel(const float* __restri
     }
 }
 
+// Weight fragments of a GEMM's first PF k-steps, requested AHEAD of the phase that consumes them: every GEMM of the chain
+// used to start cold (request, wait an L2 round trip of ~1 us, compute), four times per layer; the weights do not depend on
+// the activations, so the next GEMM's first fragments fly through the LayerNorm / conversion / barrier in front of it.
 template <int TPW, int TERMS>
-__device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* __restrict__ Ahi, const uint4* __restrict__ Alo,
-                                               int sa, int KS, const unsigned short* __restrict__ Whi,
-                                               const unsigned short* __restrict__ Wlo, int NTt, int wave, int lane, int t0) {
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int aoff = (lane & 15) * sa + (lane >> 4);
+struct WRing {
+    static constexpr int PF = TERMS == 1 ? 10 : 3;     // k-steps in flight (L2 latency ~1-2 us, a k-step of MFMAs ~50 ns)
+    uint4 rh[PF][TPW], rl[TERMS == 3 ? PF : 1][TPW];
     size_t woff[TPW];
+};
+
+template <int TPW, int TERMS>
+__device__ __forceinline__ void ring_prime(WRing<TPW, TERMS>& r, int KS, const unsigned short* __restrict__ Whi,
+                                           const unsigned short* __restrict__ Wlo, int NTt, int wave, int lane, int t0) {
+    constexpr int PF = WRing<TPW, TERMS>::PF;
+    const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
+    const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int nt = wave + 8 * (t0 + t);
-        woff[t] = ((size_t)(nt < NTt ? nt : 0) * KS) * 64 + lane;
+        r.woff[t] = ((size_t)(nt < NTt ? nt : 0) * KS) * 64 + lane;
     }
-    const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
-    const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
-    constexpr int PF = TERMS == 1 ? 10 : 3;     // k-steps of weight fragments in flight (L2 latency ~1-2 us, a k-step of MFMAs ~50 ns)
-    uint4 rh[PF][TPW], rl[PF][TPW];
 #pragma unroll
     for (int d = 0; d < PF; ++d)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            rh[d][t] = d < KS ? Wh[woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
-            if (TERMS == 3) rl[d][t] = d < KS ? Wl[woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
+            r.rh[d][t] = d < KS ? Wh[r.woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
+            if (TERMS == 3) r.rl[d][t] = d < KS ? Wl[r.woff[t] + (size_t)d * 64] : make_uint4(0u, 0u, 0u, 0u);
         }
+}
+
+// acc = A[16 x K] . W^T for this wave's TPW column tiles; `r` must have been primed for the same (W, t0).
+template <int TPW, int TERMS>
+__device__ __forceinline__ void ring_gemm(f32x4 (&acc)[TPW], WRing<TPW, TERMS>& r, const uint4* __restrict__ Ahi,
+                                          const uint4* __restrict__ Alo, int sa, int KS, const unsigned short* __restrict__ Whi,
+                                          const unsigned short* __restrict__ Wlo, int lane) {
+    constexpr int PF = WRing<TPW, TERMS>::PF;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int aoff = (lane & 15) * sa + (lane >> 4);
+    const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
+    const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
     for (int ks0 = 0; ks0 < KS; ks0 += PF) {
         // the chunk's A fragments (activations in LDS) all at once: read one k-step at a time right before its MFMAs,
         // every k-step exposed an LDS round trip (3 MFMAs per wave and k-step hide nothing)
@@ -367,14 +384,14 @@ __device__ __forceinline__ void tile_gemm_bf16(f32x4 (&acc)[TPW], const uint4* _
                 uint4 ch[TPW], cl[TPW];
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
-                    ch[t] = rh[d][t];
-                    if (TERMS == 3) cl[t] = rl[d][t];
+                    ch[t] = r.rh[d][t];
+                    if (TERMS == 3) cl[t] = r.rl[d][t];
                 }
                 if (ks + PF < KS) {
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
-                        rh[d][t] = Wh[woff[t] + (size_t)(ks + PF) * 64];
-                        if (TERMS == 3) rl[d][t] = Wl[woff[t] + (size_t)(ks + PF) * 64];
+                        r.rh[d][t] = Wh[r.woff[t] + (size_t)(ks + PF) * 64];
+                        if (TERMS == 3) r.rl[d][t] = Wl[r.woff[t] + (size_t)(ks + PF) * 64];
                     }
                 }
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, ahq[d]);
@@ -432,6 +449,9 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
         lg2[i] = c < D ? w.g2[c] : 0.f;
         lb2[i] = c < D ? w.be2[c] : 0.f;
     }
+    // the first GEMM's weights fly through the staging of o
+    WRing<3, TERMS> ring;
+    ring_prime<3, TERMS>(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
     // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
     // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
     // item by item: ~30 % of the kernel), converted afterwards
@@ -489,7 +509,8 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
             }
         }
     }
-    tile_gemm_bf16<3, TERMS>(acc, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+    ring_gemm<3, TERMS>(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
+    ring_prime<3, TERMS>(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -507,7 +528,8 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     }
     __syncthreads();
     // ---- 2. h = relu(w_1 y + b_1) ----------------------------------------------------------------------------------------
-    tile_gemm_bf16<3, TERMS>(acc, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);
+    ring_gemm<3, TERMS>(acc, ring, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, lane);
+    ring_prime<3, TERMS>(ring, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);          // w_2 flies through the ReLU / barrier
     __syncthreads();                                   // all A reads of y done before h overwrites the buffer
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -520,7 +542,14 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     }
     __syncthreads();
     // ---- 3. out = LN2(w_2 h + b_2 + y) --------------------------------------------------------------------------------------
-    tile_gemm_bf16<3, TERMS>(acc, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);
+    ring_gemm<3, TERMS>(acc, ring, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, lane);
+    // the projection's first column-tile pair flies through LayerNorm 2
+    const int NTq = (HKn + 15) / 16;
+    const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
+    const int per = (slots + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_lo = (int)blockIdx.y * per, s_hi = min(slots, s_lo + per);
+    WRing<2, TERMS> ringq;
+    if (w.wq_h) ring_prime<2, TERMS>(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -536,26 +565,29 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     for (int i = tid; i < ROWS * D; i += NTHR) {
         const int r = i / D, c = i - r * D;
         const float v = s_t[r * SD + c];
-        if (r0 + r < B) out[(size_t)(r0 + r) * D + c] = v;
+        if (r0 + r < B && blockIdx.y == 0) out[(size_t)(r0 + r) * D + c] = v;
         if (w.wq_h) split_store(ah16, al16, r * SCD * 8 + c, v);
     }
     // ---- 4. next layer's query projection -------------------------------------------------------------------------------------
+    // gridDim.y workgroups share a 16-sample tile: each recomputes steps 1-3 (identical results; rank 0 stores `out`) and
+    // takes 1 / gridDim.y of the projection's column tiles.  The projection is 40 % of the weight bytes a workgroup streams
+    // at the per-CU L2 rate, and the only part of the chain whose columns are independent.
     if (w.wq_h) {
         __syncthreads();
-        const int NTq = (HKn + 15) / 16;
-        for (int t0 = 0; t0 * 8 < NTq; t0 += 4) {
-            f32x4 a4[4];
-            tile_gemm_bf16<4, TERMS>(a4, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+        for (int t0 = s_lo; t0 < s_hi; t0 += 2) {
+            f32x4 a2[2];
+            if (t0 != s_lo) ring_prime<2, TERMS>(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+            ring_gemm<2, TERMS>(a2, ringq, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, lane);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 const int nt = wave + 8 * (t0 + t);
                 const int n = nt * 16 + ccol;
-                if (nt < NTq && n < HKn) {
+                if (t0 + t < s_hi && nt < NTq && n < HKn) {
                     const float bv = w.bq ? w.bq[n] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gr = r0 + crow + r;
-                        if (gr < B) qh_next[(size_t)gr * HKn + n] = a4[t][r] + bv;
+                        if (gr < B) qh_next[(size_t)gr * HKn + n] = a2[t][r] + bv;
                     }
                 }
             }
@@ -604,7 +636,12 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_bf16_fwd: needs %zu B of LDS", lds);
     MG_DYN_LDS(mha_tail_bf16_kernel<1>, 160 * 1024);
     MG_DYN_LDS(mha_tail_bf16_kernel<3>, 160 * 1024);
-    dim3 grid((B + ROWS - 1) / ROWS);
+    // with a next-layer projection: four workgroups per 16-sample tile (MGNNS_TAIL_CLUSTER overrides: 1 = none)
+    int cl = packed[6] ? 4 : 1;
+    if (const char* e = getenv("MGNNS_TAIL_CLUSTER")) cl = packed[6] ? atoi(e) : 1;
+    if (cl < 1) cl = 1;
+    if (cl > 8) cl = 8;
+    dim3 grid((B + ROWS - 1) / ROWS, cl);
     if (terms == 3)
         hipLaunchKernelGGL(mha_tail_bf16_kernel<3>, grid, dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w, eps, out, HK_next, qh_next);
     else

@@ -92,15 +92,14 @@ class GraphedForward:
     def _capture_segments(self, post):
         model = self.model
         dev = self.static_in[0].device
-        s_obj, s_place, s_aux = model._side_streams(dev)
-        self._side = {"s1": s_obj, "s2": s_place, "s3": s_aux}
+        self._side = dict(model._side_streams(dev))
         plan, ctx = model.forward_plan(*self.static_in)
         self._ctx = ctx                             # keeps every cross-segment tensor (graph outputs) alive
         needed = {d for _, _, deps, _ in plan for d in deps}
         self._segs = []
         # a dedicated capture stream per plan stream: per-stream workspaces (ops._gemm_workspace) are keyed by the
         # launch stream, and segments that replay concurrently must not share one
-        self._cap = {k: torch.cuda.Stream(device=dev) for k in ("main", "s1", "s2", "s3")}
+        self._cap = {k: torch.cuda.Stream(device=dev) for k in ["main"] + list(self._side)}
         from . import ops
         for st in self._cap.values():               # their workspaces exist BEFORE any capture (ordinary memory)
             with torch.cuda.stream(st):

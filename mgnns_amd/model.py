@@ -422,12 +422,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
                                          object_inp, place_inp)
 
     def _side_streams(self, device):
-        """Three side streams on hardware queues of their own (mgnns_amd.streams measures the binding once)."""
+        """The side streams of the forward's schedule by key ('s1'..'s3'), each on a hardware queue of its own
+        (mgnns_amd.streams measures the binding once)."""
         key = str(device)      # probed against the stream that is current at FIRST use (never inside a graph capture)
         if self._streams is None or self._streams[0] != key:
             from .streams import independent_streams
             chosen, distinct = independent_streams(device, 3)
-            self._streams = (key, chosen, distinct)
+            self._streams = (key, {"s1": chosen[0], "s2": chosen[1], "s3": chosen[2]}, distinct)
         return self._streams[1]
 
     # data dependencies between the forward's segments (MODEL:444-567)
@@ -560,14 +561,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
     def _forward_streams(self, *args):
         """Eager execution of forward_plan on four HIP streams (fork / join with events, no host sync)."""
         main = torch.cuda.current_stream()
-        if self.use_streams:
-            s_obj, s_place, s_aux = self._side_streams(args[0].device)
-        else:
-            s_obj = s_place = s_aux = main
-        streams = {"main": main, "s1": s_obj, "s2": s_place, "s3": s_aux}
-        for st in (s_obj, s_place, s_aux):
-            if st is not main:
-                st.wait_stream(main)                 # the caller produced the inputs on `main`
+        side = self._side_streams(args[0].device) if self.use_streams else {}
+        streams = dict(side, main=main)
+        for k in {k for _, k in self.SCHEDULES[self.schedule]}:
+            streams.setdefault(k, main)              # use_streams = False: everything on the caller's stream
+        for st in side.values():
+            st.wait_stream(main)                     # the caller produced the inputs on `main`
         plan, ctx = self.forward_plan(*args)
         needed = {d for _, _, deps, _ in plan for d in deps}
         done = {}
@@ -582,9 +581,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(st)
                     done[name] = (ev, st)
-        for st in (s_obj, s_place, s_aux):
-            if st is not main:
-                main.wait_stream(st)                 # also orders every side-stream allocation before the caller's reuse
+        for st in side.values():
+            main.wait_stream(st)                     # also orders every side-stream allocation before the caller's reuse
         return ctx['logits']
 
     def get_config_optim(self, lr, lrp):

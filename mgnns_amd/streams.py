@@ -57,3 +57,4 @@ def independent_streams(device, n=3, candidates=16):
             chosen.append(c)
     _cache[key] = (chosen, distinct)
     return _cache[key]
+
