@@ -574,8 +574,14 @@ def run_rank(args):
         return dry_run(args, rank, world)
 
     want_dist = world > 1 or os.environ.get("MGNNS_FORCE_DIST") == "1"   # the env switch exercises the RCCL path on one GPU
+    # test hooks for a ONE-GPU box (tools/r2_check.sh): MGNNS_BENCH_BACKEND=gloo + MGNNS_BENCH_SAME_GPU=1 run every rank of
+    # a multi-rank launch on cuda:0 with the gloo backend (RCCL refuses two ranks on one device), which exercises the whole
+    # N-rank code path -- shards, both scalings, MAX-reduced timing, the JSON line -- except RCCL itself
+    backend = os.environ.get("MGNNS_BENCH_BACKEND", "nccl")
+    if os.environ.get("MGNNS_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     graph_collective = False
-    if want_dist and not args.no_graph and os.environ.get("MGNNS_GRAPH_COLLECTIVE", "1") == "1":
+    if want_dist and backend == "nccl" and not args.no_graph and os.environ.get("MGNNS_GRAPH_COLLECTIVE", "1") == "1":
         graph_collective = probe_collective()          # child process, before this one touches the GPU
 
     import numpy as np
@@ -589,7 +595,10 @@ def run_rank(args):
     dist = None
     if want_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         ok = torch.tensor([1 if graph_collective else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same path
         graph_collective = bool(ok.item())
@@ -657,8 +666,12 @@ def run_rank(args):
                 "value": total / (dt / args.steps), "ms": dt / args.steps * 1e3, "global_batch": total,
                 "logits": out["logits"]}
 
-    weak = measure("weak")
-    strong = measure("strong") if world > 1 else None
+    if os.environ.get("MGNNS_BENCH_ORDER") == "strong_first" and world > 1:      # test hook: order effects
+        strong = measure("strong")
+        weak = measure("weak")
+    else:
+        weak = measure("weak")
+        strong = measure("strong") if (world > 1 or os.environ.get("MGNNS_BENCH_FORCE_STRONG") == "1") else None
 
     # ---- roofline leg: every C-ABI launch timed with HIP events on the stream it runs on, over eager single-stream
     #      forwards right after the timed region (events cannot sit inside a graph); rank 0's shard ----
@@ -763,7 +776,7 @@ def run_rank(args):
                    "launch": head["launch"], "attention": args.attn},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
-    if world > 1:
+    if strong is not None:
         for nm, r in (("weak_scaling", weak), ("strong_scaling", strong)):
             line[nm] = {"value": round(r["value"], 1), "unit": "samples/s", "ms_per_step": round(r["ms"], 4),
                         "per_gpu_batch": r["b_local"], "global_batch": r["global_batch"], "launch": r["launch"],

@@ -30,6 +30,8 @@ class GraphedForward:
         self.mode = mode or os.environ.get("MGNNS_GRAPH_MODE", "auto")
         if self.mode not in ("segments", "single", "auto"):
             raise ValueError("mode must be 'segments', 'single' or 'auto'")
+        if self.mode == "auto" and post is not None:
+            self.mode = "segments"                  # a collective inside: every rank must capture the same thing, once
         if not getattr(model, "use_streams", True):
             self.mode = "single"                    # one stream: the forward is one linear chain anyway
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
@@ -65,8 +67,7 @@ class GraphedForward:
         if self.mode == "auto":
             # Both forms compute the same thing; which is faster depends on the batch (11 graph launches per forward cost
             # more than they gain below ~100 samples): time a few replays of each, keep the faster, drop the other.
-            # With a collective inside (post) every rank must take the same branch: no timing, segments.
-            self.mode = "segments" if post is not None else self._pick_mode()
+            self.mode = self._pick_mode()
             if self.mode == "single":
                 self._segs, self._ctx = None, None
                 self.static_out = self._single_out
