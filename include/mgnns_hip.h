@@ -193,6 +193,17 @@ int mgnns_label_tail_fwd(const float* x, int B, int C, const float* pooled, int 
                          int n_out, float* out, const float* wq_next_wp, const float* bq_next, int HK_next,
                          float* qh_next, mgnns_stream_t stream);
 
+/* bf16 precision mode of the same chain, read-out always inside, every contraction on the bf16 MFMA (fp32 accumulation;
+ * softmax, biases, attention products fp32).  terms = 1: plain bf16 operands; terms = 3: split-bf16 (hi + lo operands, three
+ * MFMAs per product, fp32-class accuracy).  packed[12] = the (hi, lo) buffer pairs of mgnns_pack_weight_bf16_split for
+ * G [C,K_pool], w_k, w_v [hid,C], Wc [N5,hid], x_linear.weight [n_out, NLQ*N5], w_qs.weight [HK_next, hid] (last pair may
+ * be NULL; lo buffers are not read with terms = 1).  C <= 384, K_pool % 64 == 0, hid <= 320, N5 <= 128, n_out <= 384.
+ */
+int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts, int K_pool, int C, int terms,
+                              const void* const* packed, const float* Q, int NLQ, int n_heads, int dh, const float* bk,
+                              const float* bv, const float* bc, int N5, const float* bxl, int n_out, float* out,
+                              const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
+
 /* ---- a8: single-query multi-head attention, K/V projection fused ---------------------------------------
  * MultiHeadAttention.forward + ScaledDotProductAttention.forward (submodules.py:55-119) for len_q == 1,
  * up to (not including) fc:  per (b,h)

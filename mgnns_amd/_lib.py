@@ -35,6 +35,7 @@ SIGNATURES = {
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mgnns_label_tail_bf16_fwd": [_P, _I, _I, _I, _I, _I, _PP, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P],
     "mgnns_label_tail_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P,
                              _I, _P, _P],
     "mgnns_sq_mha_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],

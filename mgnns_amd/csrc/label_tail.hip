@@ -242,3 +242,269 @@ extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* p
     MG_CHECK_LAUNCH("mgnns_label_tail_fwd");
     return 0;
 }
+
+// =====================================================================================================================
+// bf16 precision mode: the WHOLE channel tail behind the memory-bank kernel in one launch, read-out included --
+//   x = max_parts(pooled) . G^T,  K/V,  element-wise attention,  Wc,  x_linear,  the next stack's w_qs
+// -- every contraction on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulation; softmax, biases and the attention
+// products in fp32).  On the exact-f32 MFMA the read-out alone is 40 us of matrix pipe on the 16 CUs a 256-sample batch
+// gives this kernel (which is why the fp32 mode keeps it as a separate, chip-wide GEMM launch); in bf16 it is 2 us and the
+// kernel is bound by streaming ~3 MB of packed weights per workgroup from L2.  One launch instead of three matters because
+// every launch of this chain waits for a free CU behind the chip-filling attention cores of the other streams
+// (tools/graph_timeline.py: 200-270 us for the three launches, on the critical path of the two image->text stacks).
+// =====================================================================================================================
+#include "tile_bf16.hpp"
+
+namespace {
+
+constexpr int LB_MAXKS = 10;                 // hid <= 320: k-steps of the composed map held in registers
+
+struct LabelW {             // packed hi / lo buffers (lo unused with TERMS == 1) + fp32 vectors
+    const unsigned short *g_h, *g_l, *wk_h, *wk_l, *wv_h, *wv_l, *wc_h, *wc_l, *xl_h, *xl_l, *wq_h, *wq_l;
+    const float *bk, *bv, *bc, *bxl, *bq;
+};
+
+__device__ __forceinline__ unsigned pk2(float a, float b) { return f2bf_t(a) | (unsigned)f2bf_t(b) << 16; }
+
+// TERMS = 1: plain bf16 operands (+1e-2 on the logits of the B=256 batch: the label-attention feature is the QUERY of two
+// fusion stacks, every bf16 stage of this chain costs ~1e-2 there).  TERMS = 3 (default): split-bf16 operands, three MFMAs
+// per product, fp32-class accuracy at twice the weight bytes -- still one launch.
+template <int TERMS>
+__global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __restrict__ pooled, int B, int n_parts, int KP, int C,
+                                                                 const float* __restrict__ Q, int NLQ, int n_heads, int dh,
+                                                                 LabelW w, int N5, int NO, float* __restrict__ out, int HKn,
+                                                                 float* __restrict__ qh_next) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    constexpr int NH = TERMS == 3 ? 2 : 1;                              // passes over the read-out's K (LDS holds K / NH of pooled)
+    constexpr int LO = TERMS == 3 ? 1 : 0;
+    const int hid = n_heads * dh;
+    const int KSp = KP / 32, KSpp = KSp / NH, KSx = (C + 31) / 32, KSh = (hid + 31) / 32, KSf = (NLQ * N5 + 31) / 32;
+    const int sp = 4 * KSpp + 2, sxc = 4 * KSx + 2, shc = 4 * KSh + 2, sfc = 4 * KSf + 2;     // chunk strides, == 2 (mod 4)
+    const int shf = lt_stride(hid);                                                             // fp32 stride of K / V
+    const int spf = sp > sfc ? sp : sfc;
+    uint4* s_ph = reinterpret_cast<uint4*>(smem_b);                  // [16][sp]   pooled K-part hi; later the flatten buffer hi
+    uint4* s_pl = s_ph + LT_ROWS * spf;                              //            ... lo (TERMS == 3)
+    uint4* s_xh = s_pl + LO * LT_ROWS * spf;                         // [16][sxc]  read-out
+    uint4* s_xl = s_xh + LT_ROWS * sxc;
+    uint4* s_oh = s_xl + LO * LT_ROWS * sxc;                         // [16][shc]  attention output of one label row / out
+    uint4* s_ol = s_oh + LT_ROWS * shc;
+    float* s_k = reinterpret_cast<float*>(s_ol + LO * LT_ROWS * shc);   // [16][shf]  fp32
+    float* s_v = s_k + LT_ROWS * shf;
+    uint4* s_fh = s_ph;
+    uint4* s_fl = s_pl;
+    if (!LO) { s_pl = s_ph; s_xl = s_xh; s_ol = s_oh; s_fl = s_fh; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * LT_ROWS;
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    const int NTc = (C + 15) / 16, NTh = (hid + 15) / 16, NT5 = (N5 + 15) / 16, NTo = (NO + 15) / 16;
+    unsigned short* xh16 = reinterpret_cast<unsigned short*>(s_xh);
+    unsigned short* xl16 = reinterpret_cast<unsigned short*>(s_xl);
+    unsigned short* oh16 = reinterpret_cast<unsigned short*>(s_oh);
+    unsigned short* ol16 = reinterpret_cast<unsigned short*>(s_ol);
+    unsigned short* fh16 = reinterpret_cast<unsigned short*>(s_fh);
+    unsigned short* fl16 = reinterpret_cast<unsigned short*>(s_fl);
+    auto put = [&](unsigned short* h, unsigned short* l, int idx, float v) {
+        if (LO) split_store(h, l, idx, v); else h[idx] = f2bf_t(v);
+    };
+
+    WRing<3, TERMS> ring;
+    ring_prime<3, TERMS>(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, 0);     // G flies through the staging of pooled
+    for (int i = tid; i < (1 + LO) * LT_ROWS * (sxc + shc); i += LT_THR) s_xh[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * LT_ROWS * shf; i += LT_THR) s_k[i] = 0.f;
+
+    // ---- x = max_parts(pooled) . G^T (MODEL:454-455 + 474), K walked in NH parts ----------------------------------------------
+    f32x4 acc[3];
+    for (int hpart = 0; hpart < NH; ++hpart) {
+        const int kq8 = KP / NH / 8;
+        for (int i = tid; i < LT_ROWS * kq8; i += LT_THR) {
+            const int r = i / kq8, c8 = i - r * kq8;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+            if (r0 + r < B) {
+                const float* src = pooled + ((size_t)(r0 + r) * n_parts) * KP + hpart * (KP / NH) + 8 * c8;
+                a = *reinterpret_cast<const f32x4*>(src);
+                b = *reinterpret_cast<const f32x4*>(src + 4);
+                for (int pt = 1; pt < n_parts; ++pt) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(src + (size_t)pt * KP);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pt * KP + 4);
+                    a = f32x4{fmaxf(a.x, u.x), fmaxf(a.y, u.y), fmaxf(a.z, u.z), fmaxf(a.w, u.w)};
+                    b = f32x4{fmaxf(b.x, v.x), fmaxf(b.y, v.y), fmaxf(b.z, v.z), fmaxf(b.w, v.w)};
+                }
+            }
+            s_ph[r * sp + c8] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+            if (LO) {
+                auto lo = [](float x) { return x - bf2f_t(f2bf_t(x)); };
+                s_pl[r * sp + c8] = make_uint4(pk2(lo(a.x), lo(a.y)), pk2(lo(a.z), lo(a.w)), pk2(lo(b.x), lo(b.y)), pk2(lo(b.z), lo(b.w)));
+            }
+        }
+        __syncthreads();
+        if (hpart) ring_prime<3, TERMS>(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, hpart * KSpp);
+        ring_gemm<3, TERMS>(acc, ring, s_ph, s_pl, sp, KSpp, w.g_h, w.g_l, lane, hpart != 0);
+        __syncthreads();                               // every wave is done reading this part of pooled
+    }
+    ring_prime<3, TERMS>(ring, KSx, w.wk_h, w.wk_l, NTh, wave, lane, 0);           // w_k flies through the conversion of x
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int nt = wave + 8 * t, n = nt * 16 + ccol;
+        if (nt < NTc && n < C) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put(xh16, xl16, (crow + r) * sxc * 8 + n, acc[t][r]);
+        }
+    }
+    for (int i = tid; i < (1 + LO) * LT_ROWS * spf; i += LT_THR) s_ph[i] = make_uint4(0u, 0u, 0u, 0u);   // -> flatten buffer, zero padded
+    __syncthreads();
+    // ---- K, V ----------------------------------------------------------------------------------------------------------------
+    ring_gemm<3, TERMS>(acc, ring, s_xh, s_xl, sxc, KSx, w.wk_h, w.wk_l, lane);
+    ring_prime<3, TERMS>(ring, KSx, w.wv_h, w.wv_l, NTh, wave, lane, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int nt = wave + 8 * t, n = nt * 16 + ccol;
+        if (nt < NTh && n < hid) {
+            const float b0 = w.bk[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_k[(crow + r) * shf + n] = acc[t][r] + b0;
+        }
+    }
+    ring_gemm<3, TERMS>(acc, ring, s_xh, s_xl, sxc, KSx, w.wv_h, w.wv_l, lane);
+    ring_prime<3, TERMS>(ring, KSf, w.xl_h, w.xl_l, NTo, wave, lane, 0);            // x_linear's first k-steps fly through the label loop
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int nt = wave + 8 * t, n = nt * 16 + ccol;
+        if (nt < NTh && n < hid) {
+            const float b0 = w.bv[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_v[(crow + r) * shf + n] = acc[t][r] + b0;
+        }
+    }
+    // the composed map's fragments of this wave's column tile stay in registers across the NLQ label rows
+    uint4 wch[LB_MAXKS], wcl[LO ? LB_MAXKS : 1];
+    if (wave < NT5) {
+#pragma unroll
+        for (int ks = 0; ks < LB_MAXKS; ++ks) {
+            const size_t off = ((size_t)wave * KSh + (ks < KSh ? ks : 0)) * 64 + lane;
+            wch[ks] = reinterpret_cast<const uint4*>(w.wc_h)[off];
+            if (LO) wcl[ks] = reinterpret_cast<const uint4*>(w.wc_l)[off];
+        }
+    }
+    __syncthreads();
+
+    // ---- per label row l: element-wise attention (fp32) into s_o, composed map into its slot of the flatten buffer -----------
+    const float inv_scale = 1.0f / sqrtf((float)dh);
+    for (int l = 0; l < NLQ; ++l) {
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;
+            for (int h = 0; h < n_heads; ++h) {
+                const bool on = lane < dh;
+                const int c = h * dh + lane;
+                const float e = on ? Q[(size_t)l * hid + c] * s_k[r * shf + c] * inv_scale : -INFINITY;
+                const float m = wave_max(e);
+                const float p = on ? expf(e - m) : 0.f;
+                const float z = wave_sum(p);
+                if (on) put(oh16, ol16, r * shc * 8 + c, (p / z) * s_v[r * shf + c]);
+            }
+        }
+        __syncthreads();
+        if (wave < NT5) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const int aoff = (lane & 15) * shc + (lane >> 4);
+#pragma unroll
+            for (int ks = 0; ks < LB_MAXKS; ++ks)
+                if (ks < KSh) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, s_oh[aoff + ks * 4]);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, wch[ks]), a, 0, 0, 0);
+                    if (LO) {
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, wcl[ks]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s_ol[aoff + ks * 4]),
+                                                                    __builtin_bit_cast(bf16x8, wch[ks]), a, 0, 0, 0);
+                    }
+                }
+            const int n = wave * 16 + ccol;
+            if (n < N5) {
+                const float b0 = w.bc[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(fh16, fl16, (crow + r) * sfc * 8 + l * N5 + n, a[r] + b0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- out = x_linear(flat) -------------------------------------------------------------------------------------------------
+    ring_gemm<3, TERMS>(acc, ring, s_fh, s_fl, sfc, KSf, w.xl_h, w.xl_l, lane);
+    if (w.wq_h) ring_prime<3, TERMS>(ring, KSh, w.wq_h, w.wq_l, (HKn + 15) / 16, wave, lane, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int nt = wave + 8 * t, n = nt * 16 + ccol;
+        if (nt < NTo && n < NO) {
+            const float b0 = w.bxl[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = r0 + crow + r;
+                const float v = acc[t][r] + b0;
+                if (gr < B) out[(size_t)gr * NO + n] = v;
+                if (w.wq_h) put(oh16, ol16, (crow + r) * shc * 8 + n, v);          // NO == hid (launcher)
+            }
+        }
+    }
+    // ---- qh = w_qs(out) + b -----------------------------------------------------------------------------------------------------
+    if (w.wq_h) {
+        __syncthreads();
+        const int NTq = (HKn + 15) / 16;
+        for (int t0 = 0; t0 * 8 < NTq; t0 += 3) {
+            if (t0) ring_prime<3, TERMS>(ring, KSh, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+            ring_gemm<3, TERMS>(acc, ring, s_oh, s_ol, shc, KSh, w.wq_h, w.wq_l, lane);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
+                if (nt < NTq && n < HKn) {
+                    const float b0 = w.bq ? w.bq[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = r0 + crow + r;
+                        if (gr < B) qh_next[(size_t)gr * HKn + n] = acc[t][r] + b0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts, int K_pool, int C, int terms,
+                                         const void* const* packed /* g, wk, wv, wc, xl, wq_next: (hi, lo) pairs */,
+                                         const float* Q, int NLQ, int n_heads, int dh, const float* bk, const float* bv,
+                                         const float* bc, int N5, const float* bxl, int n_out, float* out,
+                                         const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream) {
+    MG_REQUIRE(B >= 0 && C > 0 && C <= 384 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64 && N5 > 0 && N5 <= 128 && n_out > 0,
+               "mgnns_label_tail_bf16_fwd: bad dims B=%d C=%d (<= 384) NLQ=%d heads=%d dh=%d N5=%d out=%d", B, C, NLQ, n_heads, dh, N5, n_out);
+    MG_REQUIRE(terms == 1 || terms == 3, "mgnns_label_tail_bf16_fwd: terms must be 1 (bf16) or 3 (split-bf16)");
+    if (B == 0) return 0;
+    MG_REQUIRE(pooled && packed && Q && bk && bv && bc && bxl && out, "mgnns_label_tail_bf16_fwd: null pointer");
+    for (int i = 0; i < 10; ++i) MG_REQUIRE(packed[i], "mgnns_label_tail_bf16_fwd: packed weight %d missing", i);
+    MG_REQUIRE(n_parts >= 1 && K_pool > 0 && K_pool % 64 == 0 && mg_aligned16(pooled),
+               "mgnns_label_tail_bf16_fwd: pooled [B,%d,%d] must be 16-byte aligned with K %% 64 == 0", n_parts, K_pool);
+    const int hid = n_heads * dh;
+    MG_REQUIRE(hid <= 32 * LB_MAXKS && n_out <= 384, "mgnns_label_tail_bf16_fwd: hidden width %d / output width %d unsupported", hid, n_out);
+    MG_REQUIRE(!packed[10] || (packed[11] && qh_next && HK_next > 0 && n_out == hid),
+               "mgnns_label_tail_bf16_fwd: the query projection needs both packed buffers, qh_next, HK_next and n_out == hidden width");
+    LabelW w;
+    const unsigned short* const* pk = reinterpret_cast<const unsigned short* const*>(packed);
+    w.g_h = pk[0]; w.g_l = pk[1]; w.wk_h = pk[2]; w.wk_l = pk[3]; w.wv_h = pk[4]; w.wv_l = pk[5]; w.wc_h = pk[6]; w.wc_l = pk[7];
+    w.xl_h = pk[8]; w.xl_l = pk[9]; w.wq_h = pk[10]; w.wq_l = pk[11];
+    w.bk = bk; w.bv = bv; w.bc = bc; w.bxl = bxl; w.bq = bq_next;
+    const int nh = terms == 3 ? 2 : 1, lo = terms == 3 ? 1 : 0;
+    const int sp = 4 * (K_pool / 32 / nh) + 2, sxc = 4 * ((C + 31) / 32) + 2, shc = 4 * ((hid + 31) / 32) + 2, sfc = 4 * ((NLQ * N5 + 31) / 32) + 2;
+    const size_t lds = (size_t)(1 + lo) * LT_ROWS * ((sp > sfc ? sp : sfc) + sxc + shc) * 16 + (size_t)2 * LT_ROWS * lt_stride(hid) * sizeof(float);
+    MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_bf16_fwd: K_pool=%d, C=%d need %zu B of LDS (> 160 KiB)", K_pool, C, lds);
+    MG_DYN_LDS(label_tail_bf16_kernel<1>, 160 * 1024);
+    MG_DYN_LDS(label_tail_bf16_kernel<3>, 160 * 1024);
+    const dim3 grid((B + LT_ROWS - 1) / LT_ROWS), blk(LT_THR);
+    if (terms == 3)
+        hipLaunchKernelGGL(label_tail_bf16_kernel<3>, grid, blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
+                           w, N5, n_out, out, HK_next, qh_next);
+    else
+        hipLaunchKernelGGL(label_tail_bf16_kernel<1>, grid, blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
+                           w, N5, n_out, out, HK_next, qh_next);
+    MG_CHECK_LAUNCH("mgnns_label_tail_bf16_fwd");
+    return 0;
+}

@@ -238,6 +238,11 @@ def first_query_pack(layers):
     return _wq_pack(list(layers)[0])
 
 
+def first_query_pack_bf16(layers):
+    """The same with the split-bf16 (hi, lo) packed weight, for the bf16-mode producer (ops.label_tail_bf16)."""
+    return _wq_pack_bf16(list(layers)[0])
+
+
 def run_stack(layers, q, bank, mask=None, qh=None):
     """A stack of MyMultiHeadAttention layers sharing one memory bank (MODEL:509-546): per layer TWO launches --
     the fused attention core and the fused tail (which also emits the next layer's projected query) -- instead

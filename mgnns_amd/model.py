@@ -18,9 +18,10 @@ from torch.nn import Parameter
 from . import ops
 from .adjacency import gen_A, gen_adj_csr
 from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query_pack,
-                     run_stack)
+                     first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
+_EXP = os.environ.get("MGNNS_EXP_NO_TAIL_DEP") == "1"
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
 
 
@@ -198,6 +199,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'channels'))
         self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
         self.fused_label_tail_min_batch = 96
+        self.fused_label_tail_bf16 = os.environ.get('MGNNS_FUSED_LABEL_TAIL_BF16', '1') == '1'
+        self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
         self.attention = 'faithful'
@@ -330,7 +333,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         B = feats.shape[0]
         f3 = feats.float().contiguous().view(B, feats.shape[1], -1)
         if self.precision == 'bf16' and 104 < f3.shape[2] <= 200 and f3.shape[2] % 4 == 0:
-            bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features)
+            keep_halves = (self.fused_label_tail and self.fused_label_tail_bf16 and B >= self.fused_label_tail_min_batch)
+            bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features, combine=not keep_halves)
             return MemoryBank(bf16=bank), pooled
         bank, pooled = ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
         return MemoryBank(f32=bank), pooled
@@ -375,11 +379,31 @@ class Multi_GCN_Multihead_Att(nn.Module):
             self._wt_cache[(id(attention), 'tail')] = hit
         return hit[1]
 
+    def _tail_pack_bf16(self, attention, linear_5, x_linear):
+        """The same weights as split-bf16 fragment-major (hi, lo) buffers for the bf16-mode fused tail."""
+        ps = (attention.w_k.weight, attention.w_k.bias, attention.w_v.weight, attention.w_v.bias, attention.fc.weight,
+              attention.fc.bias, linear_5.weight, linear_5.bias, x_linear.weight, x_linear.bias)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (str(ps[0].device),)
+        hit = self._wt_cache.get((id(attention), 'tail_bf16'))
+        if hit is None or hit[0] != key:
+            w5 = linear_5.weight.detach()
+            wc = ops.matmul(w5.contiguous(), attention.fc.weight.detach().contiguous())
+            bc = ops.linear(attention.fc.bias.detach()[None, :].contiguous(), w5, linear_5.bias.detach())[0]
+            sp = lambda w: ops.pack_weight_bf16_split(w.contiguous())
+            d = {"wk": sp(attention.w_k.weight.detach()), "bk": attention.w_k.bias.detach(),
+                 "wv": sp(attention.w_v.weight.detach()), "bv": attention.w_v.bias.detach(),
+                 "wc": sp(wc), "bc": bc.contiguous(), "n5": linear_5.out_features,
+                 "xl": sp(x_linear.weight.detach()), "bxl": x_linear.bias.detach(),
+                 "n_out": x_linear.out_features, "C": attention.w_k.in_features, "_src": ps}
+            hit = (key, d)
+            self._wt_cache[(id(attention), 'tail_bf16')] = hit
+        return hit[1]
+
     def _label_q(self, attention):
         """w_q(label query) [NLQ, hid] (MODEL:97): batch independent, computed next to the label GCN."""
         return ops.linear(self.label_query.float().contiguous(), attention.w_q.weight.detach(), attention.w_q.bias.detach())
 
-    def _channel_tail(self, pooled, G, Q, attention, linear_5, x_linear, next_stack=None):
+    def _channel_tail(self, pooled, G, Gp, Q, attention, linear_5, x_linear, next_stack=None):
         """Second half of an image channel (MODEL:474-479 / 500-506): read-out through the label GCN, then label attention
         + 300->100->700->300 + the projected query of the fusion stack the feature feeds as ONE fused launch
         (csrc/label_tail.hip) -- for batches of at least fused_label_tail_min_batch samples: the fused kernel runs on
@@ -387,6 +411,17 @@ class Multi_GCN_Multihead_Att(nn.Module):
         kernels (B=256: 0.955 vs 0.993 ms per forward) and loses on an idle chip (B=32: 0.61 vs 0.54 ms).  Below the
         threshold, or with MGNNS_FUSED_LABEL_TAIL=0: the chain of module-level operators.  -> (att [B,300], qh or None)"""
         B = pooled.shape[0]
+        ok = (self.fused_label_tail and B >= self.fused_label_tail_min_batch
+              and x_linear.in_features == Q.shape[0] * linear_5.out_features)
+        if ok and Gp is not None:
+            # bf16 precision mode: the whole chain, read-out included, as ONE launch on the bf16 MFMA
+            pk = self._tail_pack_bf16(attention, linear_5, x_linear)
+            nq = first_query_pack_bf16(next_stack) if next_stack is not None and len(next_stack) else None
+            parts = pooled if pooled.dim() == 3 else pooled.unsqueeze(1)
+            r = ops.label_tail_bf16(parts.contiguous(), Gp, Q, attention.n_heads, pk, next_q=nq, terms=self.label_tail_terms)
+            return r if nq is not None else (r, None)
+        if pooled.dim() == 3:
+            pooled = pooled.amax(dim=1) if pooled.shape[1] > 1 else pooled[:, 0].contiguous()
         if (self.fused_label_tail and B >= self.fused_label_tail_min_batch
                 and x_linear.in_features == Q.shape[0] * linear_5.out_features):
             pk = self._tail_pack(attention, linear_5, x_linear)
@@ -443,14 +478,25 @@ class Multi_GCN_Multihead_Att(nn.Module):
     # 's3' is created with high priority).  Decided by bench.py measurements.
     SCHEDULES = {
         # one stream per channel, stacks where their producer ran (the round-1 schedule)
-        "channels": [("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
-                     ("text_bank", "main"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+        # (the BiLSTM chain is the longest of the forward: it is enqueued FIRST -- at B=32 the single-graph runtime started
+        #  it 199 us into a 587-us replay when it was captured sixth)
+        "channels": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                     ("bank_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                      ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
         # the same, but a text->image stack also waits for its channel's label-attention tail: the tail's two small
         # launches then run BEFORE the chip-filling attention cores start instead of queueing for CUs behind them
-        "tails_first": [("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
-                        ("text_bank", "main"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"),
+        "tails_first": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
+                        ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"),
                         ("tip+tail_place", "s3"), ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        "exp_stacks_before_tails": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                     ("bank_place", "s2"), ("tio", "main"), ("tip", "s3"), ("iot", "s1"), ("ipt", "s2"),
+                     ("tail_obj", "s1"), ("tail_place", "s2"), ("head+tail_obj+tail_place", "main")],
+        "tails_first_obj": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                            ("bank_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"), ("tip", "s3"),
+                            ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        "tails_first_place": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                              ("bank_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip+tail_place", "s3"),
+                              ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
         # chip-filling kernels in two chains, every small launch on a stream of its own:
         #   main: BiLSTM -> head;  s1: both image banks, then the two masked stacks;  s2: the two text->image stacks;
         #   s3: text GCN, label GCNs, label-attention tails
@@ -470,6 +516,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
         ctx = {}
+        fused_bf16 = (self.precision == 'bf16' and self.fused_label_tail and text.shape[0] >= self.fused_label_tail_min_batch
+                      and self.fused_label_tail_bf16)
 
         def text_gcn():
             ops.stamp("text GCN start")
@@ -493,6 +541,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
             def run():
                 ctx['Q_' + tag] = self._label_q(attention)       # batch independent: off the critical path, with the GCN
                 ctx['G_' + tag] = self._label_gcn(A, inp)
+                if fused_bf16:                                   # its fragment-major bf16 image for the fused tail's read-out
+                    ctx['Gp_' + tag] = ops.pack_weight_bf16_split(ctx['G_' + tag])
             return run
 
         def bank(tag, trunk, feature, lin):
@@ -507,7 +557,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         def tail(tag, attention, linear_5, x_linear, next_stack, next_name):
             def run():
                 ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
-                    ctx['pooled_' + tag], ctx['G_' + tag], ctx['Q_' + tag], attention, linear_5, x_linear, next_stack)
+                    ctx['pooled_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag), ctx['Q_' + tag], attention, linear_5, x_linear,
+                    next_stack)
                 ops.stamp("%s: label-attention tail end" % tag)
             return run
 
@@ -540,15 +591,19 @@ class Multi_GCN_Multihead_Att(nn.Module):
             "tio": stack("tio", self.text_img_object_multi_head_att, 'text_feature', 'bank_obj', False),
             "tip": stack("tip", self.text_img_place_multi_head_att, 'text_feature', 'bank_place', False),
             # image->text stacks need the text bank (and the mask cast next to it) and the channel's tail
-            "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj', 'text_bank', True),
-            "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place', 'text_bank', True),
+            "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj' if not _EXP else 'text_feature', 'text_bank', True),
+            "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place' if not _EXP else 'text_feature', 'text_bank', True),
             "head": head,
         }
         sched = self.SCHEDULES[schedule or self.schedule]
+        if _EXP:
+            sched = [(e, k) for e, k in sched]
         where, plan = {}, []
         for entry, skey in sched:
             name, *extra = entry.split("+")          # "seg+other": also wait for `other` (ordering only, no data)
             deps = tuple(self.SEGMENT_DEPS[name]) + tuple(extra)
+            if _EXP and name in ("iot", "ipt"):
+                deps = ("text_bank", "text_gcn")          # TIMING EXPERIMENT ONLY: wrong query, no wait for the channel tail
             for d in deps:
                 if d not in where:
                     raise ValueError("schedule runs %s before %s" % (name, d))

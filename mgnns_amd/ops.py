@@ -410,6 +410,41 @@ def label_tail(x, Q, n_heads, packed, pooled=None, g_wp=None, next_q=None):
     return out if next_q is None else (out, qh)
 
 
+def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3):
+    """bf16-mode fused channel tail (mgnns_label_tail_bf16_fwd): pooled [B,parts,K] fp32, g_pair = pack_weight_bf16_split(G
+    [C,K]); packed = dict(wk, wv, wc, xl = (hi, lo) pairs of pack_weight_bf16_split, bk, bv, bc, bxl, n5, n_out, C);
+    next_q = ((hi, lo), bq, HK).  terms = 1 plain bf16 | 3 split-bf16.  -> out [B,n_out] (or (out, qh))."""
+    import ctypes
+    _chk(pooled, "pooled", ndim=3)
+    _chk(Q, "Q", ndim=2)
+    B, parts, kp = pooled.shape
+    NLQ, hid = Q.shape
+    if hid % n_heads:
+        raise ValueError("hidden width %d is not a multiple of %d heads" % (hid, n_heads))
+    pairs = [g_pair, packed["wk"], packed["wv"], packed["wc"], packed["xl"]]
+    for k in ("bk", "bv", "bc", "bxl"):
+        _chk(packed[k], k, ndim=1)
+    out = torch.empty(B, packed["n_out"], device=Q.device, dtype=torch.float32)
+    bq = qh = None
+    hkn = 0
+    if next_q is not None:
+        wqp, bq, hkn = next_q
+        pairs.append(wqp)
+        qh = torch.empty(B, hkn, device=Q.device, dtype=torch.float32)
+    ptrs = []
+    for h, l in pairs:
+        _chk(h, "packed hi", torch.uint8, 1)
+        _chk(l, "packed lo", torch.uint8, 1)
+        ptrs += [h.data_ptr(), l.data_ptr()]
+    ptrs += [None] * (12 - len(ptrs))
+    arr = (ctypes.c_void_p * 12)(*ptrs)
+    L = _lib.lib()
+    _launch("mgnns_label_tail_bf16_fwd", ("mgnns_label_tail_bf16_fwd", packed["C"]), L.mgnns_label_tail_bf16_fwd, _p(pooled), B,
+            parts, kp, packed["C"], int(terms), arr, _p(Q), NLQ, n_heads, hid // n_heads, _p(packed["bk"]), _p(packed["bv"]),
+            _p(packed["bc"]), packed["n5"], _p(packed["bxl"]), packed["n_out"], _p(out), _p(bq), hkn, _p(qh), _stream())
+    return out if next_q is None else (out, qh)
+
+
 # ---- single-query MHA core -------------------------------------------------------------------------------
 def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
     _chk(qh, "qh", ndim=2)

@@ -179,6 +179,44 @@ def test_fused_label_tail_against_goldens_and_ragged_batches():
         assert tuple(ops.label_tail(key[:0].contiguous(), Q, 5, packed).shape) == (0, 300)
 
 
+def test_fused_label_tail_bf16_vs_oracle():
+    """bf16-mode fused channel tail (read-out + attention + maps + next query on the bf16 MFMA) vs the fp32 oracle.
+    terms = 1 (plain bf16 operands, ~3 significant digits): gate 2e-2 of the output scale (measured ~3e-3);
+    terms = 3 (split-bf16, fp32-class): gate 1e-4 of the output scale."""
+    g = H.load_golden("label_attention.npz")
+    lq = dev(g["label_query"])
+    for tag, C in (("object", 80), ("place", 365)):
+        pc = H.params_for(H.label_attention_shapes(tag, C))
+        p = dparams(pc)
+        a = tag + "_attention."
+        Q = ops.linear(lq, p[a + "w_q.weight"], p[a + "w_q.bias"])
+        wc = ops.matmul(p[tag + "_linear_5.weight"], p[a + "fc.weight"])
+        bc = ops.linear(p[a + "fc.bias"][None, :].contiguous(), p[tag + "_linear_5.weight"], p[tag + "_linear_5.bias"])[0].contiguous()
+        sp = lambda w: ops.pack_weight_bf16_split(w.contiguous())
+        packed = {"wk": sp(p[a + "w_k.weight"]), "bk": p[a + "w_k.bias"], "wv": sp(p[a + "w_v.weight"]), "bv": p[a + "w_v.bias"],
+                  "wc": sp(wc), "bc": bc, "n5": 100, "C": C, "xl": sp(p[tag + "_x_linear.weight"]), "bxl": p[tag + "_x_linear.bias"],
+                  "n_out": 300}
+        rs = np.random.RandomState(C + 1)
+        G = (0.05 * rs.standard_normal((C, 2048))).astype(np.float32)
+        wq = (0.05 * rs.standard_normal((1024, 300))).astype(np.float32)
+        bq = (0.05 * rs.standard_normal(1024)).astype(np.float32)
+        nq = (sp(dev(wq)), dev(bq), 1024)
+        Gp = sp(dev(G))
+        for B in (1, 17, 64):
+            halves = np.maximum(rs.standard_normal((B, 2, 2048)), 0).astype(np.float32)
+            xr = torch.from_numpy(halves.max(axis=1)) @ torch.from_numpy(G).t()
+            ref = R.label_attention_tail(pc, tag, R.label_attention(pc, tag + "_attention", torch.from_numpy(g["label_query"]), xr))
+            ref_q = ref @ torch.from_numpy(wq).t() + torch.from_numpy(bq)
+            for terms, gate in ((1, 2e-2), (3, 1e-4)):
+                z, qh = ops.label_tail_bf16(dev(halves), Gp, Q, 5, packed, next_q=nq, terms=terms)
+                ez = H.maxabs(z.cpu(), ref) / float(ref.abs().max())
+                eq = H.maxabs(qh.cpu(), ref_q) / float(ref_q.abs().max())
+                print("label_tail_bf16 %s B=%d terms=%d: rel err out %.2e, qh %.2e" % (tag, B, terms, ez, eq))
+                assert ez < gate and eq < gate, (tag, B, terms, ez, eq)
+                z1 = ops.label_tail_bf16(dev(halves.max(axis=1)[:, None, :].copy()), Gp, Q, 5, packed, terms=terms)
+                assert torch.equal(z1, z)
+
+
 def test_layernorm_against_golden():
     g = H.load_golden("layernorm.npz")
     p = dparams(H.params_for({"ln.gamma": (300,), "ln.beta": (300,)}))
