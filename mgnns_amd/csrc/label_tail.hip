@@ -18,6 +18,7 @@ namespace {
 constexpr int LT_THR = 512;
 constexpr int LT_ROWS = 16;
 constexpr int LT_MAXKQ = 20;                 // hid <= 320: k-quads of the composed map held in registers
+constexpr int LT_MAXH = 8;                   // heads of the label attention (the reference hard-codes 5, MODEL:312-313)
 
 __host__ __device__ inline int lt_stride(int k) {          // LDS row stride: >= k rounded to 16, == 2 (mod 32)
     const int kp = (k + 15) / 16 * 16;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_kernel(const float* __restr
     float* s_v = s_k + LT_ROWS * sh;
     float* s_o = s_v + LT_ROWS * sh;
     float* s_f = s_o + LT_ROWS * sh;         // [16][sf]  flatten_l y[b,l,:]
+    float* s_q = s_f + LT_ROWS * sf;         // [NLQ][hid] the projected label query (read 70 x per wave in the label loop)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * LT_ROWS;
     const int crow = (lane >> 4) * 4, ccol = lane & 15;
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_kernel(const float* __restr
     }
     // ---- zero every buffer's padding; x = the read-out, either given or computed here ---------------------------------------
     for (int i = tid; i < LT_ROWS * sx + 3 * LT_ROWS * sh + LT_ROWS * sf; i += LT_THR) s_x[i] = 0.f;
+    for (int i = tid; i < NLQ * hid; i += LT_THR) s_q[i] = Q[i];
     __syncthreads();
     if (g_wp) {
         // x = max_parts(pooled) . G^T (MODEL:454-455 + 474): K = 2048 does not fit LDS next to everything else, so it is
@@ -130,18 +133,26 @@ __global__ __launch_bounds__(LT_THR) void label_tail_kernel(const float* __restr
     // ---- per label row l: element-wise attention into s_o, composed map into its slot of s_f --------------------------
     const float inv_scale = 1.0f / sqrtf((float)dh);
     for (int l = 0; l < NLQ; ++l) {
-        // wave w owns sample rows 2w, 2w+1; lanes over the dh <= 64 dims of a head
+        // wave w owns sample rows 2w, 2w+1; a lane holds dim `lane` of EVERY head (the independent reductions interleave)
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * wave + rr;
-            for (int h = 0; h < n_heads; ++h) {
-                const bool on = lane < dh;
-                const int c = h * dh + lane;
-                const float e = on ? Q[(size_t)l * hid + c] * s_k[r * sh + c] * inv_scale : -INFINITY;
-                const float m = wave_max(e);
-                const float p = on ? expf(e - m) : 0.f;
-                const float z = wave_sum(p);
-                if (on) s_o[r * sh + c] = (p / z) * s_v[r * sh + c];
+            const bool on = lane < dh;
+            float e[LT_MAXH], vv[LT_MAXH];
+#pragma unroll
+            for (int h = 0; h < LT_MAXH; ++h) {
+                const int c = (h < n_heads ? h : 0) * dh + (on ? lane : 0);
+                e[h] = (on && h < n_heads) ? s_q[l * hid + c] * s_k[r * sh + c] * inv_scale : -INFINITY;
+                vv[h] = s_v[r * sh + c];
+            }
+#pragma unroll
+            for (int h = 0; h < LT_MAXH; ++h) {
+                if (h < n_heads) {                                  // wave-uniform
+                    const float m = wave_max_dpp(e[h]);
+                    const float p = on ? expf(e[h] - m) : 0.f;
+                    const float z = wave_sum_dpp(p);
+                    if (on) s_o[r * sh + h * dh + lane] = (p / z) * vv[h];
+                }
             }
         }
         __syncthreads();
@@ -225,7 +236,8 @@ extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* p
                    "mgnns_label_tail_fwd: pooled [B,%d,%d] must be 16-byte aligned with K %% 4 == 0", n_parts, K_pool);
     }
     const int hid = n_heads * dh;
-    MG_REQUIRE(hid <= 16 * LT_MAXKQ, "mgnns_label_tail_fwd: hidden width %d unsupported (<= %d)", hid, 16 * LT_MAXKQ);
+    MG_REQUIRE(hid <= 16 * LT_MAXKQ && n_heads <= LT_MAXH, "mgnns_label_tail_fwd: hidden width %d / %d heads unsupported (<= %d, <= %d)",
+               hid, n_heads, 16 * LT_MAXKQ, LT_MAXH);
     MG_REQUIRE(N5 <= 128, "mgnns_label_tail_fwd: linear_5 width %d unsupported (<= 128)", N5);
     MG_REQUIRE(!wq_next_wp || (qh_next && HK_next > 0 && n_out == hid),
                "mgnns_label_tail_fwd: the query projection needs qh_next, HK_next and n_out == hidden width");
@@ -233,7 +245,7 @@ extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* p
     MG_REQUIRE(!g_wp || lt_stride(NLQ * N5) >= lt_stride(LT_KCH), "mgnns_label_tail_fwd: NLQ*N5=%d too small to stage the read-out (>= %d)",
                NLQ * N5, LT_KCH);
     (void)sfl;
-    const size_t lds = (size_t)LT_ROWS * (lt_stride(C) + 3 * lt_stride(hid) + lt_stride(NLQ * N5)) * sizeof(float);
+    const size_t lds = ((size_t)LT_ROWS * (lt_stride(C) + 3 * lt_stride(hid) + lt_stride(NLQ * N5)) + (size_t)NLQ * hid) * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_fwd: C=%d, NLQ*N5=%d need %zu B of LDS (> 160 KiB)", C, NLQ * N5, lds);
     MG_DYN_LDS(label_tail_kernel, 160 * 1024);
     hipLaunchKernelGGL(label_tail_kernel, dim3((B + LT_ROWS - 1) / LT_ROWS), dim3(LT_THR), lds, (hipStream_t)stream, x, B, C,
@@ -255,6 +267,16 @@ extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* p
 // =====================================================================================================================
 #include "tile_bf16.hpp"
 
+#ifdef MG_LT_TRACE
+__device__ unsigned long long g_lt_trace[16];
+#define LT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_lt_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mgnns_debug_lt_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#else
+#define LT_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int LB_MAXKS = 10;                 // hid <= 320: k-steps of the composed map held in registers
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
                                                                  LabelW w, int N5, int NO, float* __restrict__ out, int HKn,
                                                                  float* __restrict__ qh_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    constexpr int NH = TERMS == 3 ? 2 : 1;                              // passes over the read-out's K (LDS holds K / NH of pooled)
+    constexpr int NH = TERMS == 3 ? 4 : 1;                              // passes over the read-out's K (LDS holds K / NH of pooled)
     constexpr int LO = TERMS == 3 ? 1 : 0;
     const int hid = n_heads * dh;
     const int KSp = KP / 32, KSpp = KSp / NH, KSx = (C + 31) / 32, KSh = (hid + 31) / 32, KSf = (NLQ * N5 + 31) / 32;
@@ -290,6 +312,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     uint4* s_ol = s_oh + LT_ROWS * shc;
     float* s_k = reinterpret_cast<float*>(s_ol + LO * LT_ROWS * shc);   // [16][shf]  fp32
     float* s_v = s_k + LT_ROWS * shf;
+    float* s_q = s_v + LT_ROWS * shf;                                   // [NLQ][hid] the projected label query (read 70 x per wave)
     uint4* s_fh = s_ph;
     uint4* s_fl = s_pl;
     if (!LO) { s_pl = s_ph; s_xl = s_xh; s_ol = s_oh; s_fl = s_fh; }
@@ -307,13 +330,18 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
         if (LO) split_store(h, l, idx, v); else h[idx] = f2bf_t(v);
     };
 
-    WRing<3, TERMS> ring;
-    ring_prime<3, TERMS>(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, 0);     // G flies through the staging of pooled
+    // split-bf16 streams twice the bytes per k-step: six k-steps in flight instead of the tail kernel's three (this kernel has
+    // the registers: its accumulators are 12 VGPRs)
+    LT_STAMP(0);
+    WRing<3, TERMS, (TERMS == 3 ? 4 : 10)> ring;
+    ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, 0);     // G flies through the staging of pooled
     for (int i = tid; i < (1 + LO) * LT_ROWS * (sxc + shc); i += LT_THR) s_xh[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * LT_ROWS * shf; i += LT_THR) s_k[i] = 0.f;
+    for (int i = tid; i < NLQ * hid; i += LT_THR) s_q[i] = Q[i];
 
     // ---- x = max_parts(pooled) . G^T (MODEL:454-455 + 474), K walked in NH parts ----------------------------------------------
     f32x4 acc[3];
+    LT_STAMP(1);
     for (int hpart = 0; hpart < NH; ++hpart) {
         const int kq8 = KP / NH / 8;
         for (int i = tid; i < LT_ROWS * kq8; i += LT_THR) {
@@ -337,11 +365,12 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             }
         }
         __syncthreads();
-        if (hpart) ring_prime<3, TERMS>(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, hpart * KSpp);
-        ring_gemm<3, TERMS>(acc, ring, s_ph, s_pl, sp, KSpp, w.g_h, w.g_l, lane, hpart != 0);
+        if (hpart) ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, hpart * KSpp);
+        ring_gemm(acc, ring, s_ph, s_pl, sp, KSpp, w.g_h, w.g_l, lane, hpart != 0);
         __syncthreads();                               // every wave is done reading this part of pooled
     }
-    ring_prime<3, TERMS>(ring, KSx, w.wk_h, w.wk_l, NTh, wave, lane, 0);           // w_k flies through the conversion of x
+    LT_STAMP(2);
+    ring_prime(ring, KSx, w.wk_h, w.wk_l, NTh, wave, lane, 0);           // w_k flies through the conversion of x
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -353,8 +382,9 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     for (int i = tid; i < (1 + LO) * LT_ROWS * spf; i += LT_THR) s_ph[i] = make_uint4(0u, 0u, 0u, 0u);   // -> flatten buffer, zero padded
     __syncthreads();
     // ---- K, V ----------------------------------------------------------------------------------------------------------------
-    ring_gemm<3, TERMS>(acc, ring, s_xh, s_xl, sxc, KSx, w.wk_h, w.wk_l, lane);
-    ring_prime<3, TERMS>(ring, KSx, w.wv_h, w.wv_l, NTh, wave, lane, 0);
+    LT_STAMP(3);
+    ring_gemm(acc, ring, s_xh, s_xl, sxc, KSx, w.wk_h, w.wk_l, lane);
+    ring_prime(ring, KSx, w.wv_h, w.wv_l, NTh, wave, lane, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -364,8 +394,8 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             for (int r = 0; r < 4; ++r) s_k[(crow + r) * shf + n] = acc[t][r] + b0;
         }
     }
-    ring_gemm<3, TERMS>(acc, ring, s_xh, s_xl, sxc, KSx, w.wv_h, w.wv_l, lane);
-    ring_prime<3, TERMS>(ring, KSf, w.xl_h, w.xl_l, NTo, wave, lane, 0);            // x_linear's first k-steps fly through the label loop
+    ring_gemm(acc, ring, s_xh, s_xl, sxc, KSx, w.wv_h, w.wv_l, lane);
+    ring_prime(ring, KSf, w.xl_h, w.xl_l, NTo, wave, lane, 0);            // x_linear's first k-steps fly through the label loop
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -389,18 +419,29 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
 
     // ---- per label row l: element-wise attention (fp32) into s_o, composed map into its slot of the flatten buffer -----------
     const float inv_scale = 1.0f / sqrtf((float)dh);
+    LT_STAMP(4);
     for (int l = 0; l < NLQ; ++l) {
+        // wave w owns sample rows 2w, 2w+1; a lane holds dim `lane` of EVERY head (independent reductions interleave:
+        // one head at a time was a ~400-cycle dependent chain per (row, head), 70 of them per wave)
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * wave + rr;
-            for (int h = 0; h < n_heads; ++h) {
-                const bool on = lane < dh;
-                const int c = h * dh + lane;
-                const float e = on ? Q[(size_t)l * hid + c] * s_k[r * shf + c] * inv_scale : -INFINITY;
-                const float m = wave_max(e);
-                const float p = on ? expf(e - m) : 0.f;
-                const float z = wave_sum(p);
-                if (on) put(oh16, ol16, r * shc * 8 + c, (p / z) * s_v[r * shf + c]);
+            const bool on = lane < dh;
+            float e[LT_MAXH], vv[LT_MAXH];
+#pragma unroll
+            for (int h = 0; h < LT_MAXH; ++h) {
+                const int c = (h < n_heads ? h : 0) * dh + (on ? lane : 0);
+                e[h] = (on && h < n_heads) ? s_q[l * hid + c] * s_k[r * shf + c] * inv_scale : -INFINITY;
+                vv[h] = s_v[r * shf + c];
+            }
+#pragma unroll
+            for (int h = 0; h < LT_MAXH; ++h) {
+                if (h < n_heads) {                                  // wave-uniform
+                    const float m = wave_max_dpp(e[h]);
+                    const float p = on ? __expf(e[h] - m) : 0.f;
+                    const float z = wave_sum_dpp(p);
+                    if (on) put(oh16, ol16, r * shc * 8 + h * dh + lane, (p / z) * vv[h]);
+                }
             }
         }
         __syncthreads();
@@ -429,8 +470,10 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     }
 
     // ---- out = x_linear(flat) -------------------------------------------------------------------------------------------------
-    ring_gemm<3, TERMS>(acc, ring, s_fh, s_fl, sfc, KSf, w.xl_h, w.xl_l, lane);
-    if (w.wq_h) ring_prime<3, TERMS>(ring, KSh, w.wq_h, w.wq_l, (HKn + 15) / 16, wave, lane, 0);
+    LT_STAMP(5);
+    ring_gemm(acc, ring, s_fh, s_fl, sfc, KSf, w.xl_h, w.xl_l, lane);
+    LT_STAMP(6);
+    if (w.wq_h) ring_prime(ring, KSh, w.wq_h, w.wq_l, (HKn + 15) / 16, wave, lane, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -450,8 +493,8 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
         __syncthreads();
         const int NTq = (HKn + 15) / 16;
         for (int t0 = 0; t0 * 8 < NTq; t0 += 3) {
-            if (t0) ring_prime<3, TERMS>(ring, KSh, w.wq_h, w.wq_l, NTq, wave, lane, t0);
-            ring_gemm<3, TERMS>(acc, ring, s_oh, s_ol, shc, KSh, w.wq_h, w.wq_l, lane);
+            if (t0) ring_prime(ring, KSh, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+            ring_gemm(acc, ring, s_oh, s_ol, shc, KSh, w.wq_h, w.wq_l, lane);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
@@ -466,6 +509,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             }
         }
     }
+    LT_STAMP(7);
 }
 
 }  // namespace
@@ -481,10 +525,11 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
     if (B == 0) return 0;
     MG_REQUIRE(pooled && packed && Q && bk && bv && bc && bxl && out, "mgnns_label_tail_bf16_fwd: null pointer");
     for (int i = 0; i < 10; ++i) MG_REQUIRE(packed[i], "mgnns_label_tail_bf16_fwd: packed weight %d missing", i);
-    MG_REQUIRE(n_parts >= 1 && K_pool > 0 && K_pool % 64 == 0 && mg_aligned16(pooled),
-               "mgnns_label_tail_bf16_fwd: pooled [B,%d,%d] must be 16-byte aligned with K %% 64 == 0", n_parts, K_pool);
+    MG_REQUIRE(n_parts >= 1 && K_pool > 0 && K_pool % 128 == 0 && mg_aligned16(pooled),
+               "mgnns_label_tail_bf16_fwd: pooled [B,%d,%d] must be 16-byte aligned with K %% 128 == 0", n_parts, K_pool);
     const int hid = n_heads * dh;
-    MG_REQUIRE(hid <= 32 * LB_MAXKS && n_out <= 384, "mgnns_label_tail_bf16_fwd: hidden width %d / output width %d unsupported", hid, n_out);
+    MG_REQUIRE(hid <= 32 * LB_MAXKS && n_out <= 384 && n_heads <= LT_MAXH,
+               "mgnns_label_tail_bf16_fwd: hidden width %d / output width %d / %d heads unsupported", hid, n_out, n_heads);
     MG_REQUIRE(!packed[10] || (packed[11] && qh_next && HK_next > 0 && n_out == hid),
                "mgnns_label_tail_bf16_fwd: the query projection needs both packed buffers, qh_next, HK_next and n_out == hidden width");
     LabelW w;
@@ -492,9 +537,10 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
     w.g_h = pk[0]; w.g_l = pk[1]; w.wk_h = pk[2]; w.wk_l = pk[3]; w.wv_h = pk[4]; w.wv_l = pk[5]; w.wc_h = pk[6]; w.wc_l = pk[7];
     w.xl_h = pk[8]; w.xl_l = pk[9]; w.wq_h = pk[10]; w.wq_l = pk[11];
     w.bk = bk; w.bv = bv; w.bc = bc; w.bxl = bxl; w.bq = bq_next;
-    const int nh = terms == 3 ? 2 : 1, lo = terms == 3 ? 1 : 0;
+    const int nh = terms == 3 ? 4 : 1, lo = terms == 3 ? 1 : 0;
     const int sp = 4 * (K_pool / 32 / nh) + 2, sxc = 4 * ((C + 31) / 32) + 2, shc = 4 * ((hid + 31) / 32) + 2, sfc = 4 * ((NLQ * N5 + 31) / 32) + 2;
-    const size_t lds = (size_t)(1 + lo) * LT_ROWS * ((sp > sfc ? sp : sfc) + sxc + shc) * 16 + (size_t)2 * LT_ROWS * lt_stride(hid) * sizeof(float);
+    const size_t lds = (size_t)(1 + lo) * LT_ROWS * ((sp > sfc ? sp : sfc) + sxc + shc) * 16 +
+                       ((size_t)2 * LT_ROWS * lt_stride(hid) + (size_t)NLQ * hid) * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_bf16_fwd: K_pool=%d, C=%d need %zu B of LDS (> 160 KiB)", K_pool, C, lds);
     MG_DYN_LDS(label_tail_bf16_kernel<1>, 160 * 1024);
     MG_DYN_LDS(label_tail_bf16_kernel<3>, 160 * 1024);

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     }
     // the first GEMM's weights fly through the staging of o
     WRing<3, TERMS> ring;
-    ring_prime<3, TERMS>(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+    ring_prime(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
     // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
     // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
     // item by item: ~30 % of the kernel), converted afterwards
@@ -412,8 +412,8 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
             }
         }
     }
-    ring_gemm<3, TERMS>(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
-    ring_prime<3, TERMS>(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
+    ring_gemm(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
+    ring_prime(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     }
     __syncthreads();
     // ---- 2. h = relu(w_1 y + b_1) ----------------------------------------------------------------------------------------
-    ring_gemm<3, TERMS>(acc, ring, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, lane);
-    ring_prime<3, TERMS>(ring, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);          // w_2 flies through the ReLU / barrier
+    ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, lane);
+    ring_prime(ring, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);          // w_2 flies through the ReLU / barrier
     __syncthreads();                                   // all A reads of y done before h overwrites the buffer
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -445,14 +445,14 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     }
     __syncthreads();
     // ---- 3. out = LN2(w_2 h + b_2 + y) --------------------------------------------------------------------------------------
-    ring_gemm<3, TERMS>(acc, ring, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, lane);
+    ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, lane);
     // the projection's first column-tile pair flies through LayerNorm 2
     const int NTq = (HKn + 15) / 16;
     const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
     const int per = (slots + (int)gridDim.y - 1) / (int)gridDim.y;
     const int s_lo = (int)blockIdx.y * per, s_hi = min(slots, s_lo + per);
     WRing<2, TERMS> ringq;
-    if (w.wq_h) ring_prime<2, TERMS>(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
+    if (w.wq_h) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
         __syncthreads();
         for (int t0 = s_lo; t0 < s_hi; t0 += 2) {
             f32x4 a2[2];
-            if (t0 != s_lo) ring_prime<2, TERMS>(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
-            ring_gemm<2, TERMS>(a2, ringq, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, lane);
+            if (t0 != s_lo) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+            ring_gemm(a2, ringq, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, lane);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int nt = wave + 8 * (t0 + t);

@@ -24,21 +24,21 @@ __device__ __forceinline__ void split_store(unsigned short* hi, unsigned short* 
 // Weight fragments of a GEMM's first PF k-steps, requested AHEAD of the phase that consumes them: every GEMM of the chain
 // used to start cold (request, wait an L2 round trip of ~1 us, compute), four times per layer; the weights do not depend on
 // the activations, so the next GEMM's first fragments fly through the LayerNorm / conversion / barrier in front of it.
-template <int TPW, int TERMS>
+template <int TPW, int TERMS, int PFX = 0>
 struct WRing {
-    static constexpr int PF = TERMS == 1 ? 10 : 3;     // k-steps in flight (L2 latency ~1-2 us, a k-step of MFMAs ~50 ns)
+    static constexpr int PF = PFX ? PFX : (TERMS == 1 ? 10 : 3);     // k-steps in flight (L2 latency ~1-2 us, a k-step of MFMAs ~50 ns)
     uint4 rh[PF][TPW], rl[TERMS == 3 ? PF : 1][TPW];
     size_t woff[TPW];
 };
 
-template <int TPW, int TERMS>
-__device__ __forceinline__ void ring_prime(WRing<TPW, TERMS>& r, int KS, const unsigned short* __restrict__ Whi,
+template <int TPW, int TERMS, int PFX>
+__device__ __forceinline__ void ring_prime(WRing<TPW, TERMS, PFX>& r, int KS, const unsigned short* __restrict__ Whi,
                                            const unsigned short* __restrict__ Wlo, int NTt, int wave, int lane, int t0,
                                            int KSW = 0, int ks_off = 0) {
     // KS: k-steps this GEMM pass walks; KSW: k-steps per column tile in the packed weight (0: = KS); ks_off: first k-step of
     // the pass inside the weight (a K walked in several passes because the activations do not fit LDS at once)
     if (KSW == 0) KSW = KS;
-    constexpr int PF = WRing<TPW, TERMS>::PF;
+    constexpr int PF = WRing<TPW, TERMS, PFX>::PF;
     const uint4* Wh = reinterpret_cast<const uint4*>(Whi);
     const uint4* Wl = reinterpret_cast<const uint4*>(Wlo);
 #pragma unroll
@@ -56,11 +56,11 @@ __device__ __forceinline__ void ring_prime(WRing<TPW, TERMS>& r, int KS, const u
 }
 
 // acc = A[16 x K] . W^T for this wave's TPW column tiles; `r` must have been primed for the same (W, t0).
-template <int TPW, int TERMS>
-__device__ __forceinline__ void ring_gemm(f32x4 (&acc)[TPW], WRing<TPW, TERMS>& r, const uint4* __restrict__ Ahi,
+template <int TPW, int TERMS, int PFX>
+__device__ __forceinline__ void ring_gemm(f32x4 (&acc)[TPW], WRing<TPW, TERMS, PFX>& r, const uint4* __restrict__ Ahi,
                                           const uint4* __restrict__ Alo, int sa, int KS, const unsigned short* __restrict__ Whi,
                                           const unsigned short* __restrict__ Wlo, int lane, bool accumulate = false) {
-    constexpr int PF = WRing<TPW, TERMS>::PF;
+    constexpr int PF = WRing<TPW, TERMS, PFX>::PF;
     if (!accumulate) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};

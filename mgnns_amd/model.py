@@ -198,7 +198,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.use_streams = bool(opt.get('use_streams', True))
         self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'channels'))
         self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
-        self.fused_label_tail_min_batch = 96
+        self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))
         self.fused_label_tail_bf16 = os.environ.get('MGNNS_FUSED_LABEL_TAIL_BF16', '1') == '1'
         self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
@@ -488,6 +488,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "tails_first": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"), ("bank_place", "s2"),
                         ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"),
                         ("tip+tail_place", "s3"), ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # memory banks first on their streams (they start at ~20 us instead of behind their label GCN); both label GCNs on
+        # the text-GCN stream, which is otherwise idle until the place bank is done
+        "banks_first": [("text_bank", "main"), ("bank_obj", "s1"), ("bank_place", "s2"), ("text_gcn", "s3"), ("lgcn_obj", "s3"),
+                        ("lgcn_place", "s3"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+                        ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
         "exp_stacks_before_tails": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                      ("bank_place", "s2"), ("tio", "main"), ("tip", "s3"), ("iot", "s1"), ("ipt", "s2"),
                      ("tail_obj", "s1"), ("tail_place", "s2"), ("head+tail_obj+tail_place", "main")],
