@@ -493,6 +493,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "banks_first": [("text_bank", "main"), ("bank_obj", "s1"), ("bank_place", "s2"), ("text_gcn", "s3"), ("lgcn_obj", "s3"),
                         ("lgcn_place", "s3"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                         ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # 'channels' with the two HBM-bound memory-bank kernels one after the other instead of side by side: together they
+        # take as long either way, but the first one -- and the stack and the label tail behind it -- is done in half the time
+        "banks_serial": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                         ("bank_place+bank_obj", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+                         ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
         "exp_stacks_before_tails": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                      ("bank_place", "s2"), ("tio", "main"), ("tip", "s3"), ("iot", "s1"), ("ipt", "s2"),
                      ("tail_obj", "s1"), ("tail_place", "s2"), ("head+tail_obj+tail_place", "main")],
