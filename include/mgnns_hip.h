@@ -328,6 +328,21 @@ int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int Cin, const 
                              int KH, int KW, int stride, int pad, const void* residual, int relu, int out_nchw_f32,
                              void* y, mgnns_stream_t stream);
 
+/* ---- a8 (fused layer, bf16 mode): attention core + the rest of the layer in ONE launch ------------------------------
+ * mgnns_sq_mha_core_bf16_fwd followed by mgnns_mha_tail_bf16_fwd(terms = 1) for every 16-sample tile, the tail run by the
+ * tile's LAST attention-core workgroup to finish (system-scope write-through stores of o, one relaxed agent-scope atomic per
+ * workgroup on tile_counters[tile], no fences, nobody spins).  Results are bit-identical to the two separate launches.
+ * o_scratch [B, H*dk] fp32 (the cores' output, not needed afterwards); q_in [B, d_model] the layer input (residual);
+ * packed[8] as in mgnns_mha_tail_bf16_fwd; tile_counters: ceil(B/16) int32, ZERO before the first launch (the kernel
+ * leaves them zero), one array per concurrently running launch.
+ */
+int mgnns_sq_mha_layer_bf16_fwd(const float* qh, const void* bank_bf16, const float* mask, int B, int L, int ld, int H, int dk,
+                                const void* Wp, const float* bk, const float* bv, float* o_scratch, const float* q_in,
+                                int d_model, const void* const* packed, const float* fc_b, const float* ln1_gamma,
+                                const float* ln1_beta, const float* b1, const float* b2, const float* ln2_gamma,
+                                const float* ln2_beta, float eps, float* out, const float* bq_next, int HK_next,
+                                float* qh_next, int* tile_counters, mgnns_stream_t stream);
+
 /* ---- measurement aid: a one-thread kernel that writes the GPU's constant-rate real-time counter (s_memrealtime,
  * 100 MHz) into slots[idx] when the stream reaches it.  Captured into the forward's hipGraph it gives the REAL
  * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.

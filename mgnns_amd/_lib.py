@@ -42,6 +42,8 @@ SIGNATURES = {
     "mgnns_sq_mha_pack_weights_bf16": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_cast_pad_bf16": [_P, _L, _I, _I, _P, _P],
     "mgnns_sq_mha_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_sq_mha_layer_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
+                                    _I, _P, _P, _P],
     "mgnns_sq_mha_folded_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _P],
     "mgnns_pack_weight_f32": [_P, _I, _I, _P, _P],
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],

@@ -11,14 +11,18 @@
 #include "common.hpp"
 #include "tile_f32.hpp"
 #include "tile_bf16.hpp"
+#include "mha_tail_body.hpp"
 
 namespace {
 
-constexpr int NTHR = 512;
-constexpr int ROWS = 16;
-constexpr int D = 300;                       // d_model (host checks)
-constexpr int DT = 19;                       // column tiles of a 300-wide output
-constexpr int SD = 322;                      // LDS row stride for 300-wide activations (322 % 32 == 2: conflict-free A frags)
+using mg_tail::NTHR;
+using mg_tail::ROWS;
+using mg_tail::D;
+using mg_tail::DT;
+using mg_tail::SD;
+using mg_tail::SCD;
+using mg_tail::TailW;
+using mg_tail::ln_rows_r;
 
 // Wp[nt][kq][lane][4]: B fragments of k-steps 4kq..4kq+3 for column tile nt:
 //   Wp[...][j] = W[nt*16 + (lane&15)][(4*kq + j)*4 + (lane>>4)]     (0 outside [N, K])
@@ -68,38 +72,6 @@ __device__ __forceinline__ void ln_rows(float* __restrict__ buf, const float* __
         for (int i = 0; i < 5; ++i) {
             const int c = lane + 64 * i;
             if (c < D) row[c] = gamma[c] * (v[i] - mean) * inv + beta[c];
-        }
-    }
-}
-
-// the same with gamma / beta of this lane's five columns already in registers (loaded at kernel start: inside the
-// LayerNorm they are a global round trip right behind the reduction)
-__device__ __forceinline__ void ln_rows_r(float* __restrict__ buf, const float (&gamma)[5], const float (&beta)[5], float eps,
-                                          int wave, int lane) {
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        float* row = buf + (2 * wave + rr) * SD;
-        float v[5];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < D ? row[c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum_dpp(s) / (float)D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = lane + 64 * i;
-            const float d = c < D ? v[i] - mean : 0.f;
-            q += d * d;
-        }
-        const float inv = 1.0f / (sqrtf(wave_sum_dpp(q) / (float)(D - 1)) + eps);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) row[c] = gamma[i] * (v[i] - mean) * inv + beta[i];
         }
     }
 }
@@ -291,8 +263,6 @@ extern "C" int mgnns_mha_tail_fwd(const float* o, int HK, const float* q, int B,
 // =====================================================================================================================
 namespace {
 
-constexpr int SCD = 42;                      // LDS stride (16-B chunks) of 300(->320)-wide bf16 activations
-
 // Wp{hi,lo}[nt][ks][lane][8] = split(W[nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j])   (0 outside [N,K])
 __global__ __launch_bounds__(256) void pack_w_split_kernel(const float* __restrict__ W, int N, int K,
                                                            unsigned short* __restrict__ Whi, unsigned short* __restrict__ Wlo) {
@@ -313,189 +283,12 @@ __global__ __launch_bounds__(256) void pack_w_split_kernel(const float* __restri
     }
 }
 
-struct TailW {            // packed hi/lo pairs + fp32 vectors of one layer
-    const unsigned short *fc_h, *fc_l, *w1_h, *w1_l, *w2_h, *w2_l, *wq_h, *wq_l;
-    const float *fc_b, *g1, *be1, *b1, *b2, *g2, *be2, *bq;
-};
-
 template <int TERMS>
 __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __restrict__ o, int HK, const float* __restrict__ q, int B,
                                                              TailW w, float eps, float* __restrict__ out, int HKn,
                                                              float* __restrict__ qh_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int so = (HK >> 3) + 2;                                   // chunk stride of the o tile: == 2 (mod 4)
-    uint4* s_oh = reinterpret_cast<uint4*>(smem_b);                 // [16][so]
-    uint4* s_ol = s_oh + ROWS * so;
-    uint4* s_ah = s_ol + ROWS * so;                                 // [16][SCD] activation hi (y, h, out in turn)
-    uint4* s_al = s_ah + ROWS * SCD;
-    float* s_y = reinterpret_cast<float*>(s_al + ROWS * SCD);       // [16][SD] fp32 y (residual of the FFN)
-    float* s_t = s_y + ROWS * SD;                                   // [16][SD] fp32 pre-LayerNorm scratch / out
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * ROWS;
-    const int KSo = (HK + 31) / 32, KSd = (D + 31) / 32;
-
-    // per-lane parameter vectors first: b_1 / b_2 of this lane's output columns, gamma / beta of its LayerNorm columns
-    const int ccol0 = lane & 15;
-    float pb1[3], pb2[3], lg1[5], lb1[5], lg2[5], lb2[5];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int n = (wave + 8 * t) * 16 + ccol0;
-        const bool ok = wave + 8 * t < DT && n < D;
-        pb1[t] = ok ? w.b1[n] : 0.f;
-        pb2[t] = ok ? w.b2[n] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int c = lane + 64 * i;
-        lg1[i] = c < D ? w.g1[c] : 0.f;
-        lb1[i] = c < D ? w.be1[c] : 0.f;
-        lg2[i] = c < D ? w.g2[c] : 0.f;
-        lb2[i] = c < D ? w.be2[c] : 0.f;
-    }
-    // the first GEMM's weights fly through the staging of o
-    WRing<3, TERMS> ring;
-    ring_prime(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
-    // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
-    // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
-    // item by item: ~30 % of the kernel), converted afterwards
-    {
-        constexpr int MAXIT = (ROWS * (2048 / 8 + 2) + NTHR - 1) / NTHR;      // HK <= 2048
-        f32x4 v[MAXIT][2];
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const int i = tid + it * NTHR;
-            const int r = i / so, c = i - r * so;
-            v[it][0] = v[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < ROWS * so && r0 + r < B && c * 8 < HK) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(o + (size_t)(r0 + r) * HK + c * 8);
-                v[it][0] = src[0];
-                v[it][1] = src[1];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < ROWS * so) {
-                unsigned short h[8], l[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = v[it][j >> 2][j & 3];
-                    h[j] = f2bf_t(x);
-                    l[j] = TERMS == 3 ? f2bf_t(x - bf2f_t(h[j])) : (unsigned short)0;
-                }
-                s_oh[i] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
-                if (TERMS == 3)
-                    s_ol[i] = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
-            }
-        }
-    }
-    for (int i = tid; i < 2 * ROWS * SCD; i += NTHR) s_ah[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-
-    unsigned short* ah16 = reinterpret_cast<unsigned short*>(s_ah);
-    unsigned short* al16 = reinterpret_cast<unsigned short*>(s_al);
-    const int crow = (lane >> 4) * 4, ccol = lane & 15;
-    f32x4 acc[3];
-    // ---- 1. y = LN1(fc(o) + q) ----------------------------------------------------------------------------------------
-    // residual + bias of this lane's 12 outputs requested BEFORE the GEMM (they used to be a global round trip after it)
-    f32x4 qb[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int n = (wave + 8 * t) * 16 + ccol;
-        qb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wave + 8 * t < DT && n < D) {
-            const float bv = w.fc_b[n];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = r0 + crow + r;
-                qb[t][r] = bv + (gr < B ? q[(size_t)gr * D + n] : 0.f);
-            }
-        }
-    }
-    ring_gemm(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
-    ring_prime(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int n = (wave + 8 * t) * 16 + ccol;
-        if (wave + 8 * t < DT && n < D) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_y[(crow + r) * SD + n] = acc[t][r] + qb[t][r];
-        }
-    }
-    __syncthreads();
-    ln_rows_r(s_y, lg1, lb1, eps, wave, lane);
-    __syncthreads();
-    for (int i = tid; i < ROWS * D; i += NTHR) {
-        const int r = i / D, c = i - r * D;
-        split_store(ah16, al16, r * SCD * 8 + c, s_y[r * SD + c]);
-    }
-    __syncthreads();
-    // ---- 2. h = relu(w_1 y + b_1) ----------------------------------------------------------------------------------------
-    ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, lane);
-    ring_prime(ring, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);          // w_2 flies through the ReLU / barrier
-    __syncthreads();                                   // all A reads of y done before h overwrites the buffer
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int n = (wave + 8 * t) * 16 + ccol;
-        if (wave + 8 * t < DT && n < D) {
-            const float bv = pb1[t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) split_store(ah16, al16, (crow + r) * SCD * 8 + n, fmaxf(acc[t][r] + bv, 0.f));
-        }
-    }
-    __syncthreads();
-    // ---- 3. out = LN2(w_2 h + b_2 + y) --------------------------------------------------------------------------------------
-    ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, lane);
-    // the projection's first column-tile pair flies through LayerNorm 2
-    const int NTq = (HKn + 15) / 16;
-    const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
-    const int per = (slots + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int s_lo = (int)blockIdx.y * per, s_hi = min(slots, s_lo + per);
-    WRing<2, TERMS> ringq;
-    if (w.wq_h) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int n = (wave + 8 * t) * 16 + ccol;
-        if (wave + 8 * t < DT && n < D) {
-            const float bv = pb2[t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_t[(crow + r) * SD + n] = acc[t][r] + bv + s_y[(crow + r) * SD + n];
-        }
-    }
-    __syncthreads();
-    ln_rows_r(s_t, lg2, lb2, eps, wave, lane);
-    __syncthreads();
-    for (int i = tid; i < ROWS * D; i += NTHR) {
-        const int r = i / D, c = i - r * D;
-        const float v = s_t[r * SD + c];
-        if (r0 + r < B && blockIdx.y == 0) out[(size_t)(r0 + r) * D + c] = v;
-        if (w.wq_h) split_store(ah16, al16, r * SCD * 8 + c, v);
-    }
-    // ---- 4. next layer's query projection -------------------------------------------------------------------------------------
-    // gridDim.y workgroups share a 16-sample tile: each recomputes steps 1-3 (identical results; rank 0 stores `out`) and
-    // takes 1 / gridDim.y of the projection's column tiles.  The projection is 40 % of the weight bytes a workgroup streams
-    // at the per-CU L2 rate, and the only part of the chain whose columns are independent.
-    if (w.wq_h) {
-        __syncthreads();
-        for (int t0 = s_lo; t0 < s_hi; t0 += 2) {
-            f32x4 a2[2];
-            if (t0 != s_lo) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
-            ring_gemm(a2, ringq, s_ah, s_al, SCD, KSd, w.wq_h, w.wq_l, lane);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int nt = wave + 8 * (t0 + t);
-                const int n = nt * 16 + ccol;
-                if (t0 + t < s_hi && nt < NTq && n < HKn) {
-                    const float bv = w.bq ? w.bq[n] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gr = r0 + crow + r;
-                        if (gr < B) qh_next[(size_t)gr * HKn + n] = a2[t][r] + bv;
-                    }
-                }
-            }
-        }
-    }
+    mg_tail::tail_bf16_body<TERMS, false>(smem_b, o, HK, q, B, w, eps, out, HKn, qh_next, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 }  // namespace

@@ -11,8 +11,7 @@
 // carries X.  Per head pair: phase 0 = K tiles -> scores -> softmax, phase 1 = V tiles -> weighted sum.
 // Row tiles behind the last unmasked position are skipped (their probability is exactly 0).
 #include "common.hpp"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#include "mha_tail_body.hpp"      // (defines bf16x8)
 
 #ifdef MG_MHA_TRACE
 // profiling aid (off by default): s_memtime stamps of wave 0 / wave 4 of two workgroups at every phase boundary
@@ -210,7 +209,9 @@ __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, cons
 }
 
 // everything after the bank is staged: all head pairs of this workgroup, for a compile-time tile-count class
-template <int NMT>
+// COH: `o` is stored with system-scope write-through stores (aux sc0 | sc1) because ANOTHER workgroup of this launch reads it
+// (the fused layer kernel below); otherwise ordinary stores
+template <int NMT, bool COH>
 __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __restrict__ qh, const float* __restrict__ mask,
                                          int B, int L, int H, const unsigned short* __restrict__ Wp,
                                          const float* __restrict__ bk, const float* __restrict__ bv, float temp,
@@ -354,8 +355,8 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { t0[r] += vb0[r]; t1[r] += vb1[r]; }
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t0), o_rsrc, dbase * 4, hoff, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t0), o_rsrc, dbase * 4, hoff, COH ? 17 : 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, COH ? 17 : 0);
                     }
                 }
                 __syncthreads();      // s_p / s_part are rewritten by the next head pair
@@ -366,13 +367,13 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     (void)n_mt;
 }
 
-__global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __restrict__ qh,
+template <bool COH>
+__device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* __restrict__ qh,
                                                                 const unsigned short* __restrict__ bank,   // [B,L,KP] bf16
                                                                 const float* __restrict__ mask, int B, int L, int H,
                                                                 const unsigned short* __restrict__ Wp,
                                                                 const float* __restrict__ bk, const float* __restrict__ bv,
                                                                 float temp, float* __restrict__ o, float* __restrict__ attn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* Xs = reinterpret_cast<uint4*>(smem);                                   // [LMAX][LSTR] chunks
     int* s_lvalid = reinterpret_cast<int*>(smem + (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float));
     const int tid = threadIdx.x;
@@ -423,12 +424,55 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __r
     }
 
     switch (n_sel) {
-        case 1: mha_body<1>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 2: mha_body<2>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 4: mha_body<4>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 7: mha_body<7>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        default: mha_body<MT>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 1: mha_body<1, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 2: mha_body<2, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 4: mha_body<4, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 7: mha_body<7, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        default: mha_body<MT, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
     }
+}
+
+
+__global__ __launch_bounds__(NTHR) void sq_mha_core_bf16_kernel(const float* __restrict__ qh, const unsigned short* __restrict__ bank,
+                                                                const float* __restrict__ mask, int B, int L, int H,
+                                                                const unsigned short* __restrict__ Wp, const float* __restrict__ bk,
+                                                                const float* __restrict__ bv, float temp, float* __restrict__ o,
+                                                                float* __restrict__ attn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mha_core_part<false>(smem, qh, bank, mask, B, L, H, Wp, bk, bv, temp, o, attn);
+}
+
+// One MyMultiHeadAttention layer in ONE launch (moudles.py:207-230): the attention core above for every sample, and the rest
+// of the layer (fc, residual, LN, FFN, residual, LN, the next layer's w_qs: mha_tail_body.hpp) for a 16-sample tile run by
+// whichever of the tile's core workgroups FINISHES LAST.  As a launch of its own the tail (16 workgroups that each need a
+// whole CU) queued for CUs behind the chip-filling cores of the other stacks: 40-90 us on every link of the four stack
+// chains (tools/trace_timeline.py).  Hand-over without agent-scope fences (a __threadfence() per workgroup doubles this
+// kernel: 62.7 -> 125 us, the L2 write-back / invalidate walks are that slow): `o` leaves through system-scope
+// write-through stores (sc0 | sc1), every thread waits for its own acknowledgements (vmcnt(0)), ONE relaxed agent-scope
+// atomic per workgroup counts the tile's arrivals, and the last arriver reads `o` with loads that bypass the non-coherent
+// caches.  Nobody spins: the last arriver does the work, the others exit.
+__global__ __launch_bounds__(NTHR) void sq_mha_layer_bf16_kernel(const float* __restrict__ qh, const unsigned short* __restrict__ bank,
+                                                                 const float* __restrict__ mask, int B, int L, int H,
+                                                                 const unsigned short* __restrict__ Wp, const float* __restrict__ bk,
+                                                                 const float* __restrict__ bv, float temp, float* __restrict__ o,
+                                                                 const float* __restrict__ q_in, mg_tail::TailW w, float eps,
+                                                                 float* __restrict__ out, int HKn, float* __restrict__ qh_next,
+                                                                 int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_last;
+    mha_core_part<true>(smem, qh, bank, mask, B, L, H, Wp, bk, bv, temp, o, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores of `o` are acknowledged
+    __syncthreads();
+    const int tile = (int)blockIdx.x / mg_tail::ROWS;
+    if (threadIdx.x == 0) {
+        const int rows = B - tile * mg_tail::ROWS < mg_tail::ROWS ? B - tile * mg_tail::ROWS : mg_tail::ROWS;
+        const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == rows * (int)gridDim.y - 1;
+        if (s_last) __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    mg_tail::tail_bf16_body<1, true>(smem, o, H * DK, q_in, B, w, eps, out, HKn, qh_next, tile, 0, 1);
 }
 
 constexpr size_t SMEM_BYTES = (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float) + 16 + QMAX * sizeof(float);
@@ -490,5 +534,45 @@ extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16
                        reinterpret_cast<const unsigned short*>(bank_bf16), mask, B, L, H,
                        reinterpret_cast<const unsigned short*>(Wp), bk, bv, temp, o, attn);
     MG_CHECK_LAUNCH("mgnns_sq_mha_core_bf16_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_sq_mha_layer_bf16_fwd(const float* qh, const void* bank_bf16, const float* mask, int B, int L, int ld, int H, int dk,
+                                           const void* Wp, const float* bk, const float* bv, float* o_scratch, const float* q_in,
+                                           int d_model, const void* const* packed /* fc, w1, w2, wq_next: (hi, lo) pairs */,
+                                           const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
+                                           const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                                           const float* bq_next, int HK_next, float* qh_next, int* tile_counters,
+                                           mgnns_stream_t stream) {
+    MG_REQUIRE(qh && bank_bf16 && Wp && o_scratch && q_in && packed && fc_b && ln1_gamma && ln1_beta && b1 && b2 && ln2_gamma &&
+               ln2_beta && out && tile_counters, "mgnns_sq_mha_layer_bf16_fwd: null pointer");
+    MG_REQUIRE(dk == DK, "mgnns_sq_mha_layer_bf16_fwd: d_kv=%d unsupported (128 only)", dk);
+    MG_REQUIRE(d_model == mg_tail::D, "mgnns_sq_mha_layer_bf16_fwd: d_model=%d unsupported (300 only)", d_model);
+    MG_REQUIRE(ld == KP, "mgnns_sq_mha_layer_bf16_fwd: bank row length %d must be %d (bf16, zero padded)", ld, KP);
+    MG_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= LMAX, "mgnns_sq_mha_layer_bf16_fwd: L=%d unsupported (1..%d)", L, LMAX);
+    MG_REQUIRE(H * DK <= QMAX && (H * DK) % 32 == 0, "mgnns_sq_mha_layer_bf16_fwd: n_head=%d unsupported", H);
+    MG_REQUIRE(mg_aligned16(bank_bf16) && mg_aligned16(Wp) && mg_aligned16(o_scratch), "mgnns_sq_mha_layer_bf16_fwd: bank/Wp/o must be 16-byte aligned");
+    for (int i = 0; i < 6; ++i) MG_REQUIRE(packed[i], "mgnns_sq_mha_layer_bf16_fwd: packed weight %d missing", i);
+    MG_REQUIRE(!packed[6] || (qh_next && HK_next > 0), "mgnns_sq_mha_layer_bf16_fwd: next-layer projection incomplete");
+    if (B == 0) return 0;
+    mg_tail::TailW w;
+    w.fc_h = (const unsigned short*)packed[0]; w.fc_l = (const unsigned short*)packed[1];
+    w.w1_h = (const unsigned short*)packed[2]; w.w1_l = (const unsigned short*)packed[3];
+    w.w2_h = (const unsigned short*)packed[4]; w.w2_l = (const unsigned short*)packed[5];
+    w.wq_h = (const unsigned short*)packed[6]; w.wq_l = (const unsigned short*)packed[7];
+    w.fc_b = fc_b; w.g1 = ln1_gamma; w.be1 = ln1_beta; w.b1 = b1; w.b2 = b2; w.g2 = ln2_gamma; w.be2 = ln2_beta; w.bq = bq_next;
+    const int so = ((H * DK) >> 3) + 2;
+    const size_t tail_lds = (size_t)(2 * mg_tail::ROWS * so + 2 * mg_tail::ROWS * mg_tail::SCD) * 16 + 2 * (size_t)mg_tail::ROWS * mg_tail::SD * sizeof(float);
+    MG_REQUIRE(tail_lds <= SMEM_BYTES, "mgnns_sq_mha_layer_bf16_fwd: the tail needs %zu B of LDS, the core has %zu", tail_lds, SMEM_BYTES);
+    MG_DYN_LDS(sq_mha_layer_bf16_kernel, SMEM_BYTES);
+    const int pairs = (H + 1) / 2;
+    int gy = 1;
+    while (gy < pairs && B * gy < 256) gy *= 2;
+    if (gy > pairs) gy = pairs;
+    const float temp = (float)sqrt((double)dk);
+    hipLaunchKernelGGL(sq_mha_layer_bf16_kernel, dim3(B, gy), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, qh,
+                       reinterpret_cast<const unsigned short*>(bank_bf16), mask, B, L, H, reinterpret_cast<const unsigned short*>(Wp), bk,
+                       bv, temp, o_scratch, q_in, w, eps, out, HK_next, qh_next, tile_counters);
+    MG_CHECK_LAUNCH("mgnns_sq_mha_layer_bf16_fwd");
     return 0;
 }

@@ -19,6 +19,10 @@ from . import ops
 import os as _os
 
 TAIL_TERMS = int(_os.environ.get('MGNNS_TAIL_TERMS', '1'))   # bf16-mode tail: 3 = split-bf16 (hi/lo), 1 = plain bf16
+# bf16 mode, 1-term tail: attention core + tail as ONE launch (the tile's last core workgroup runs its tail).  Correct and
+# bit-identical (tests), but OFF by default: 100 us per L=196 layer stand-alone against 91 us for the two launches (the in-kernel
+# tail has no 4-workgroup cluster for the next projection) and 0.99 against 0.91 ms per forward -- DESIGN.md section 6
+FUSED_LAYER = _os.environ.get('MGNNS_FUSED_LAYER', '0') == '1'
 
 
 def _require_eval(mod):
@@ -222,6 +226,16 @@ def _wq_pack_bf16(layer):
     return hit[1]
 
 
+def _tile_counters(layer, B, device):
+    """int32 zeros [ceil(B/16)] owned by the layer: arrival counters of the fused layer kernel (it leaves them zero)."""
+    n = (B + 15) // 16
+    c = getattr(layer, "_tile_counters", None)
+    if c is None or c.shape[0] < n or c.device != device:
+        c = torch.zeros(max(n, 64), dtype=torch.int32, device=device)
+        layer._tile_counters = c
+    return c
+
+
 def _wq_pack(layer):
     a = layer.slf_attn
     key = _versions(a.w_qs.weight, a.w_qs.bias)
@@ -269,6 +283,13 @@ def run_stack(layers, q, bank, mask=None, qh=None):
         a = layer.slf_attn
         if a.attention == 'folded':
             o, _ = a._folded(qh, bank, m2, False)
+        elif a.precision == 'bf16' and FUSED_LAYER and TAIL_TERMS == 1 and a.n_head * a.d_v % 32 == 0:
+            # the whole layer in one launch: the tile's last attention-core workgroup runs the tile's tail
+            nxt = _wq_pack_bf16(layers[i + 1]) if i + 1 < len(layers) else None
+            q, qh = ops.sq_mha_layer_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
+                                          a.w_vs.bias.detach(), q, _tail_pack_bf16(layer), a.layer_norm.eps,
+                                          _tile_counters(layer, B, q.device), nxt)
+            continue
         elif a.precision == 'bf16':
             o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
                                         a.w_vs.bias.detach(), want_attn=False)

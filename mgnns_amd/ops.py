@@ -510,6 +510,44 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     return o, attn
 
 
+def sq_mha_layer_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, q, packed, eps, counters, next_packed=None):
+    """One fusion layer in one launch (mgnns_sq_mha_layer_bf16_fwd): attention core + fused tail (plain bf16 operands).
+    q: the layer input [B,300]; packed / next_packed as for mha_tail_bf16; counters: int32 zeros [ceil(B/16)] owned by the
+    layer (left zero by the kernel).  -> (out [B,300], qh_next or None)"""
+    import ctypes
+    _chk(qh, "qh", ndim=2)
+    _chk(bank_bf16, "memory bank (bf16)", torch.bfloat16, 3)
+    _chk(wp, "packed K/V weights", torch.uint8, 1)
+    _chk(q, "q", ndim=2)
+    _chk(counters, "tile counters", torch.int32, 1)
+    B, L_, ld = bank_bf16.shape
+    if qh.shape != (B, n_head * d_kv) or q.shape != (B, 300):
+        raise ValueError("qh %s / q %s do not match batch %d" % (tuple(qh.shape), tuple(q.shape), B))
+    if counters.shape[0] < (B + 15) // 16:
+        raise ValueError("need %d tile counters" % ((B + 15) // 16))
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
+    out = torch.empty(B, 300, device=qh.device, dtype=torch.float32)
+    ptrs = [packed["fc"][0].data_ptr(), packed["fc"][1].data_ptr(), packed["w1"][0].data_ptr(), packed["w1"][1].data_ptr(),
+            packed["w2"][0].data_ptr(), packed["w2"][1].data_ptr(), None, None]
+    bq = qhn = None
+    hkn = 0
+    if next_packed is not None:
+        (wh, wl), bq, hkn = next_packed
+        ptrs[6], ptrs[7] = wh.data_ptr(), wl.data_ptr()
+        qhn = torch.empty(B, hkn, device=qh.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * 8)(*ptrs)
+    L = _lib.lib()
+    _launch("mgnns_sq_mha_layer_bf16_fwd", ("mgnns_sq_mha_layer_bf16_fwd", L_, mask is not None), L.mgnns_sq_mha_layer_bf16_fwd,
+            _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk), _p(bv), _p(o), _p(q), 300, arr,
+            _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]), _p(packed["g2"]),
+            _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qhn), _p(counters), _stream())
+    return out, qhn
+
+
 def sq_mha_folded(qh, bank, mask, n_head, d_kv, wk, wv, bv, want_attn=True):
     """Folded single-query attention (mgnns_sq_mha_folded_fwd): same result as sq_mha_core, K and V never formed.
     bank: fp32 [B, L, D] or bf16 [B, L, ld] (zero padded).  b_k is not needed (it drops out of the softmax)."""

@@ -578,6 +578,47 @@ def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
     assert 1e-4 < e1 < 5e-2
 
 
+@pytest.mark.parametrize("Hn,L,masked", [(8, 196, False), (8, 100, True), (4, 196, False), (1, 50, True)])
+def test_fused_layer_bf16_equals_core_plus_tail(Hn, L, masked):
+    """mgnns_sq_mha_layer_bf16_fwd (attention core + the tile's tail run by its last-finishing core workgroup, hand-over of
+    `o` through system-scope stores and one relaxed atomic per workgroup) == the two separate launches, BIT FOR BIT, for
+    batches that fill the chip (one workgroup per sample), smaller ones (head pairs split over workgroups), batches that are
+    not a multiple of the 16-sample tile, repeated launches on the same counters, with and without a next-layer projection."""
+    name = "h%d_img" % Hn
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    a, f = name + ".slf_attn.", name + ".pos_ffn."
+    w1 = p[f + "w_1.weight"].squeeze(-1).contiguous()
+    w2 = p[f + "w_2.weight"].squeeze(-1).contiguous()
+    pk = {"fc_b": p[a + "fc.bias"], "g1": p[a + "layer_norm.gamma"], "be1": p[a + "layer_norm.beta"], "b1": p[f + "w_1.bias"],
+          "b2": p[f + "w_2.bias"], "g2": p[f + "layer_norm.gamma"], "be2": p[f + "layer_norm.beta"],
+          "fc": ops.pack_weight_bf16_split(p[a + "fc.weight"]), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
+    nx = (ops.pack_weight_bf16_split(p[a + "w_qs.weight"]), p[a + "w_qs.bias"], Hn * 128)
+    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128)
+    counters = torch.zeros(64, dtype=torch.int32, device=DEV)
+    rs = np.random.RandomState(Hn + L)
+    for B in (256, 37, 16, 1, 300):
+        bank = ops.cast_pad_bf16(dev(rs.standard_normal((B, L, 300)).astype(np.float32)))
+        qh = dev(rs.standard_normal((B, Hn * 128)).astype(np.float32))
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        mask = None
+        if masked:
+            m = np.ones((B, L), np.float32)
+            for b in range(B):
+                m[b, rs.randint(1, L + 1):] = 0.0
+            mask = dev(m)
+        o, _ = ops.sq_mha_core_bf16(qh, bank, mask, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"], want_attn=False)
+        for nxt in (nx, None):
+            ref_out, ref_qh = ops.mha_tail_bf16(o, q, pk, 1e-6, nxt, terms=1)
+            for rep in range(3):
+                out, qhn = ops.sq_mha_layer_bf16(qh, bank, mask, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"], q, pk, 1e-6,
+                                                 counters, nxt)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref_out), (B, rep, float((out - ref_out).abs().max()))
+                assert (qhn is None) == (nxt is None) and (nxt is None or torch.equal(qhn, ref_qh)), (B, rep)
+                assert int(counters.abs().sum()) == 0                 # every tile was handed over exactly once
+
+
 def test_metrics_tail_softmax_argmax_confusion():
     """The evaluation tail on the device (ENGINE:828-838): softmax == torch.softmax, pred == argmax(softmax) incl. ties
     (first maximum), confusion matrix accumulated over batches, scores == sklearn's on the concatenated predictions."""
