@@ -635,6 +635,18 @@ def run_rank(args):
         g = synth.make_inputs(cfg, B=GLOBAL_BATCH, seed=rank_seed(cfg.seed, rank, "strong"), pmi=pmi)
         return {k: (v[lo:hi] if k != "label_query" else v) for k, v in g.items()}, hi - lo
 
+    comm = None
+    if dist is not None and backend == "nccl" and os.environ.get("MGNNS_COLLECTIVE", "torch") == "abi":
+        try:          # the all-gather through the C ABI (mgnns_allgather_logits); torch.distributed is only the rendezvous
+            from mgnns_amd.comm import AbiComm
+            comm = AbiComm.from_torch_distributed(device=dev)
+        except Exception as e:
+            print("C-ABI communicator unavailable (%s: %s); using torch.distributed" % (type(e).__name__, e), file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok.item()):
+            comm = None
+
     def measure(scaling):
         inp, b_local = shard(scaling)
         if scaling == "strong" and b_local * world != GLOBAL_BATCH:
@@ -642,9 +654,9 @@ def run_rank(args):
         call = harness.call_args(inp, dev)
         launch = "eager"
         if args.no_graph:
-            fwd = ShardedForward(lambda *a: model(*a))
+            fwd = ShardedForward(lambda *a: model(*a), comm=comm)
         else:
-            sf = ShardedForward(lambda *a: gf.replay())
+            sf = ShardedForward(lambda *a: gf.replay(), comm=comm)
             gf, fwd = None, None
             if dist is not None and graph_collective:
                 try:                                  # the logits all-gather as a node of the same graph
@@ -779,7 +791,9 @@ def run_rank(args):
                                "feature maps [B,2048,14,14] fp32 resident in HBM, logits all-gathered"
                                % (cfg.name, head["b_local"], cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
                    "global_batch": head["global_batch"], "parallelism": "batch-shard x%d" % world,
-                   "launch": head["launch"], "attention": args.attn},
+                   "launch": head["launch"], "attention": args.attn,
+                   "collective": (None if dist is None else "RCCL all-gather via the C ABI (mgnns_allgather_logits)" if comm is not None
+                                  else "RCCL all-gather via torch.distributed" if backend == "nccl" else backend)},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     if strong is not None:

@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 typedef void* mgnns_stream_t;
+typedef struct mgnns_comm_s* mgnns_comm_t;      /* an RCCL communicator (one per rank / per device) */
 
 /* activation codes for mgnns_linear_fwd / mgnns_matmul_fwd */
 #define MGNNS_ACT_NONE   0
@@ -198,11 +199,16 @@ int mgnns_label_tail_fwd(const float* x, int B, int C, const float* pooled, int 
  * MFMAs per product, fp32-class accuracy).  packed[12] = the (hi, lo) buffer pairs of mgnns_pack_weight_bf16_split for
  * G [C,K_pool], w_k, w_v [hid,C], Wc [N5,hid], x_linear.weight [n_out, NLQ*N5], w_qs.weight [HK_next, hid] (last pair may
  * be NULL; lo buffers are not read with terms = 1).  C <= 384, K_pool % 64 == 0, hid <= 320, N5 <= 128, n_out <= 384.
+ * cluster_scratch / cluster_counters (both or neither; terms = 3 only): with them FOUR workgroups share each 16-sample
+ * tile (read-out K and next-query columns divided, partial read-outs exchanged through the scratch):
+ * scratch >= ceil(B/16) * 4 * 24576 B, 16-byte aligned; counters = 2 * ceil(B/16) ints, ZERO before the first launch
+ * (every launch leaves them zero).  One (scratch, counters) pair must not be shared by launches that may run concurrently.
  */
 int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts, int K_pool, int C, int terms,
                               const void* const* packed, const float* Q, int NLQ, int n_heads, int dh, const float* bk,
                               const float* bv, const float* bc, int N5, const float* bxl, int n_out, float* out,
-                              const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
+                              const float* bq_next, int HK_next, float* qh_next, float* cluster_scratch,
+                              int* cluster_counters, mgnns_stream_t stream);
 
 /* ---- a8: single-query multi-head attention, K/V projection fused ---------------------------------------
  * MultiHeadAttention.forward + ScaledDotProductAttention.forward (submodules.py:55-119) for len_q == 1,
@@ -280,6 +286,14 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
                             const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
                             const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
 
+/* ---- a9: classifier over the four fusion features (Multi_GCN_Multihead_att.py:560-566, eval: dropout is the identity) --
+ * logits[b,:] = W [f0[b]; f1[b]; f2[b]; f3[b]] + bias without materialising the concatenation.  f_p [B,D]; W [NL, 4*D];
+ * bias [NL]; logits [B,NL].  The host passes W = multi_linear_2.weight . multi_linear_1.weight (no non-linearity between
+ * them in eval) or any single [NL, 4D] map.
+ */
+int mgnns_classifier_head_fwd(const float* f0, const float* f1, const float* f2, const float* f3, int B, int D,
+                              const float* W, const float* bias, int NL, float* logits, mgnns_stream_t stream);
+
 /* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
  * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.
  */
@@ -354,6 +368,27 @@ int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream);
  * before the end of a spin on stream X proves X and Y do not share an in-order queue.
  */
 int mgnns_debug_spin(int microseconds, uint64_t* slots, int idx, mgnns_stream_t stream);
+
+/* ---- e: the forward's one collective -------------------------------------------------------------------------
+ * The reference runs on one GPU (hard-coded cuda:0, Multi_GCN_Multihead_att.py:85,465,493; the DataParallel line at
+ * engine/Multi_GCN_Multihead_Att_engine.py:365 is commented out).  Its eval forward has no cross-sample reduction, so the
+ * batch shards over ranks with replicated weights and ONE all-gather of the [rows_local, num_labels] logits restores the
+ * single-process result exactly.  RCCL (over xGMI inside a node) is bound at run time -- the instance the process already
+ * carries (torch's) or the system librccl.so.1; MGNNS_ERR_UNSUPP if neither loads.
+ *   one process per GPU:  rank 0 calls mgnns_comm_unique_id and ships the 128 bytes to the other ranks by any host channel
+ *                         (a torch.distributed store, MPI, a file); every rank, with its device current, calls
+ *                         mgnns_comm_init_rank (collective: returns when all ranks have joined);
+ *   one process, n GPUs:  mgnns_comm_init_all(n, devices or NULL for 0..n-1, comms[n]).
+ * mgnns_allgather_logits enqueues on `stream` (no host sync; capturable into a hipGraph); `all` is
+ * [world * rows_local, num_labels] in rank order; every rank passes the same rows_local.
+ */
+int mgnns_comm_unique_id(void* id, size_t bytes /* >= 128 */);
+int mgnns_comm_init_rank(int world, int rank, const void* id, size_t bytes, mgnns_comm_t* comm);
+int mgnns_comm_init_all(int ndev, const int* devices, mgnns_comm_t* comms);
+int mgnns_comm_info(mgnns_comm_t comm, int* world, int* rank);
+int mgnns_allgather_logits(mgnns_comm_t comm, const float* local, int rows_local, int num_labels, float* all,
+                           mgnns_stream_t stream);
+int mgnns_comm_destroy(mgnns_comm_t comm);
 
 #ifdef __cplusplus
 }

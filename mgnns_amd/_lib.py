@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c = ctypes
 _P = _c.c_void_p
@@ -35,7 +35,8 @@ SIGNATURES = {
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "mgnns_label_tail_bf16_fwd": [_P, _I, _I, _I, _I, _I, _PP, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P],
+    "mgnns_classifier_head_fwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P],
+    "mgnns_label_tail_bf16_fwd": [_P, _I, _I, _I, _I, _I, _PP, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "mgnns_label_tail_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P,
                              _I, _P, _P],
     "mgnns_sq_mha_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -59,6 +60,12 @@ SIGNATURES = {
     "mgnns_debug_stamp": [_P, _I, _P],
     "mgnns_debug_spin": [_I, _P, _I, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],
+    "mgnns_comm_unique_id": [_P, _SZ],
+    "mgnns_comm_init_rank": [_I, _I, _P, _SZ, _PP],
+    "mgnns_comm_init_all": [_I, _P, _PP],
+    "mgnns_comm_info": [_P, _c.POINTER(_I), _c.POINTER(_I)],
+    "mgnns_allgather_logits": [_P, _P, _I, _I, _P, _P],
+    "mgnns_comm_destroy": [_P],
 }
 
 # size_t-returning helpers (buffer sizes the caller allocates)

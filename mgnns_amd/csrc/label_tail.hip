@@ -286,16 +286,26 @@ struct LabelW {             // packed hi / lo buffers (lo unused with TERMS == 1
     const float *bk, *bv, *bc, *bxl, *bq;
 };
 
+typedef int lt_i32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ unsigned pk2(float a, float b) { return f2bf_t(a) | (unsigned)f2bf_t(b) << 16; }
 
 // TERMS = 1: plain bf16 operands (+1e-2 on the logits of the B=256 batch: the label-attention feature is the QUERY of two
 // fusion stacks, every bf16 stage of this chain costs ~1e-2 there).  TERMS = 3 (default): split-bf16 operands, three MFMAs
 // per product, fp32-class accuracy at twice the weight bytes -- still one launch.
-template <int TERMS>
+//
+// CL = 4 (split-bf16 only): a CLUSTER of four workgroups shares a 16-sample tile.  The two wide phases are divided --
+// rank r contracts the r-th quarter of the read-out's K and takes a quarter of the next query's column tiles -- and the
+// narrow middle (K/V, label loop, x_linear: 44 % of the single-workgroup time) is recomputed by every rank.  The read-out
+// partials cross through global memory without fences: system-scope write-through stores, vmcnt(0), ONE relaxed agent-scope
+// arrival count per workgroup, cache-bypassing loads; every rank adds the four partials in the same order, so the ranks hold
+// identical x.  A departure count lets the last rank to finish reading re-arm both counters for the next launch.
+template <int TERMS, int CL>
 __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __restrict__ pooled, int B, int n_parts, int KP, int C,
                                                                  const float* __restrict__ Q, int NLQ, int n_heads, int dh,
                                                                  LabelW w, int N5, int NO, float* __restrict__ out, int HKn,
-                                                                 float* __restrict__ qh_next) {
+                                                                 float* __restrict__ qh_next, float* __restrict__ xpart,
+                                                                 int* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     constexpr int NH = TERMS == 3 ? 4 : 1;                              // passes over the read-out's K (LDS holds K / NH of pooled)
     constexpr int LO = TERMS == 3 ? 1 : 0;
@@ -317,7 +327,8 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     uint4* s_fl = s_pl;
     if (!LO) { s_pl = s_ph; s_xl = s_xh; s_ol = s_oh; s_fl = s_fh; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * LT_ROWS;
+    const int tile = (int)blockIdx.x / CL, crank = (int)blockIdx.x % CL;      // a tile's ranks are adjacent in dispatch order
+    const int r0 = tile * LT_ROWS;
     const int crow = (lane >> 4) * 4, ccol = lane & 15;
     const int NTc = (C + 15) / 16, NTh = (hid + 15) / 16, NT5 = (N5 + 15) / 16, NTo = (NO + 15) / 16;
     unsigned short* xh16 = reinterpret_cast<unsigned short*>(s_xh);
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     // the registers: its accumulators are 12 VGPRs)
     LT_STAMP(0);
     WRing<3, TERMS, (TERMS == 3 ? 4 : 10)> ring;
-    ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, 0);     // G flies through the staging of pooled
+    ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, CL > 1 ? crank * KSpp : 0);     // G flies through the staging of pooled
     for (int i = tid; i < (1 + LO) * LT_ROWS * (sxc + shc); i += LT_THR) s_xh[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * LT_ROWS * shf; i += LT_THR) s_k[i] = 0.f;
     for (int i = tid; i < NLQ * hid; i += LT_THR) s_q[i] = Q[i];
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     // ---- x = max_parts(pooled) . G^T (MODEL:454-455 + 474), K walked in NH parts ----------------------------------------------
     f32x4 acc[3];
     LT_STAMP(1);
-    for (int hpart = 0; hpart < NH; ++hpart) {
+    static_assert(CL == 1 || CL == NH, "a cluster rank owns one K part of the read-out");
+    for (int hpart = CL > 1 ? crank : 0; hpart < (CL > 1 ? crank + 1 : NH); ++hpart) {
         const int kq8 = KP / NH / 8;
         for (int i = tid; i < LT_ROWS * kq8; i += LT_THR) {
             const int r = i / kq8, c8 = i - r * kq8;
@@ -365,12 +377,41 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             }
         }
         __syncthreads();
-        if (hpart) ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, hpart * KSpp);
-        ring_gemm(acc, ring, s_ph, s_pl, sp, KSpp, w.g_h, w.g_l, lane, hpart != 0);
+        if (CL == 1 && hpart) ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, hpart * KSpp);
+        ring_gemm(acc, ring, s_ph, s_pl, sp, KSpp, w.g_h, w.g_l, lane, CL == 1 && hpart != 0);
         __syncthreads();                               // every wave is done reading this part of pooled
     }
     LT_STAMP(2);
-    ring_prime(ring, KSx, w.wk_h, w.wk_l, NTh, wave, lane, 0);           // w_k flies through the conversion of x
+    ring_prime(ring, KSx, w.wk_h, w.wk_l, NTh, wave, lane, 0);           // w_k flies through the conversion / exchange of x
+    if (CL > 1) {
+        // partial [tile][rank][wave][t][lane] x 16 B: a lane writes and reads exactly the accumulator slots it owns
+        const __amdgpu_buffer_rsrc_t xp = __builtin_amdgcn_make_buffer_rsrc(xpart + (size_t)tile * CL * (8 * 3 * 64 * 4), 0,
+                                                                            CL * 8 * 3 * 64 * 16, 0x00027000);
+        const int slot = (wave * 3 * 64 + lane) * 16;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (wave + 8 * t < NTc)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lt_i32x4, acc[t]), xp, slot + t * 64 * 16, crank * (8 * 3 * 64 * 16), 17);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&counters[2 * tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(&counters[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CL) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f32x4 pr[CL];
+#pragma unroll
+            for (int rk = 0; rk < CL; ++rk)
+                pr[rk] = wave + 8 * t < NTc ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xp, slot + t * 64 * 16, rk * (8 * 3 * 64 * 16), 17))
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[t] = pr[0];
+#pragma unroll
+            for (int rk = 1; rk < CL; ++rk) acc[t] += pr[rk];
+        }
+        // (the loads above are complete once acc is consumed below; the departure count follows the conversion barrier)
+    }
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -381,6 +422,13 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     }
     for (int i = tid; i < (1 + LO) * LT_ROWS * spf; i += LT_THR) s_ph[i] = make_uint4(0u, 0u, 0u, 0u);   // -> flatten buffer, zero padded
     __syncthreads();
+    if (CL > 1 && tid == 0) {      // every thread of this rank has consumed the partials: the last rank to get here re-arms the counters
+        const int old = __hip_atomic_fetch_add(&counters[2 * tile + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == CL - 1) {
+            __hip_atomic_store(&counters[2 * tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&counters[2 * tile + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // ---- K, V ----------------------------------------------------------------------------------------------------------------
     LT_STAMP(3);
     ring_gemm(acc, ring, s_xh, s_xl, sxc, KSx, w.wk_h, w.wk_l, lane);
@@ -473,7 +521,10 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     LT_STAMP(5);
     ring_gemm(acc, ring, s_fh, s_fl, sfc, KSf, w.xl_h, w.xl_l, lane);
     LT_STAMP(6);
-    if (w.wq_h) ring_prime(ring, KSh, w.wq_h, w.wq_l, (HKn + 15) / 16, wave, lane, 0);
+    // the next query's column-tile slots (8 tiles each) are divided over the cluster ranks
+    const int q_slots = ((HKn + 15) / 16 + 7) / 8, q_per = (q_slots + CL - 1) / CL;
+    const int q_lo = crank * q_per, q_hi = q_lo + q_per < q_slots ? q_lo + q_per : q_slots;
+    if (w.wq_h) ring_prime(ring, KSh, w.wq_h, w.wq_l, (HKn + 15) / 16, wave, lane, q_lo);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt = wave + 8 * t, n = nt * 16 + ccol;
@@ -483,7 +534,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             for (int r = 0; r < 4; ++r) {
                 const int gr = r0 + crow + r;
                 const float v = acc[t][r] + b0;
-                if (gr < B) out[(size_t)gr * NO + n] = v;
+                if (gr < B && crank == 0) out[(size_t)gr * NO + n] = v;
                 if (w.wq_h) put(oh16, ol16, (crow + r) * shc * 8 + n, v);          // NO == hid (launcher)
             }
         }
@@ -492,13 +543,13 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     if (w.wq_h) {
         __syncthreads();
         const int NTq = (HKn + 15) / 16;
-        for (int t0 = 0; t0 * 8 < NTq; t0 += 3) {
-            if (t0) ring_prime(ring, KSh, w.wq_h, w.wq_l, NTq, wave, lane, t0);
+        for (int t0 = q_lo; t0 < q_hi; t0 += 3) {
+            if (t0 != q_lo) ring_prime(ring, KSh, w.wq_h, w.wq_l, NTq, wave, lane, t0);
             ring_gemm(acc, ring, s_oh, s_ol, shc, KSh, w.wq_h, w.wq_l, lane);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt = wave + 8 * (t0 + t), n = nt * 16 + ccol;
-                if (nt < NTq && n < HKn) {
+                if (t0 + t < q_hi && nt < NTq && n < HKn) {
                     const float b0 = w.bq ? w.bq[n] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -518,7 +569,8 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
                                          const void* const* packed /* g, wk, wv, wc, xl, wq_next: (hi, lo) pairs */,
                                          const float* Q, int NLQ, int n_heads, int dh, const float* bk, const float* bv,
                                          const float* bc, int N5, const float* bxl, int n_out, float* out,
-                                         const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream) {
+                                         const float* bq_next, int HK_next, float* qh_next, float* cluster_scratch,
+                                         int* cluster_counters, mgnns_stream_t stream) {
     MG_REQUIRE(B >= 0 && C > 0 && C <= 384 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64 && N5 > 0 && N5 <= 128 && n_out > 0,
                "mgnns_label_tail_bf16_fwd: bad dims B=%d C=%d (<= 384) NLQ=%d heads=%d dh=%d N5=%d out=%d", B, C, NLQ, n_heads, dh, N5, n_out);
     MG_REQUIRE(terms == 1 || terms == 3, "mgnns_label_tail_bf16_fwd: terms must be 1 (bf16) or 3 (split-bf16)");
@@ -542,15 +594,22 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
     const size_t lds = (size_t)(1 + lo) * LT_ROWS * ((sp > sfc ? sp : sfc) + sxc + shc) * 16 +
                        ((size_t)2 * LT_ROWS * lt_stride(hid) + (size_t)NLQ * hid) * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_bf16_fwd: K_pool=%d, C=%d need %zu B of LDS (> 160 KiB)", K_pool, C, lds);
-    MG_DYN_LDS(label_tail_bf16_kernel<1>, 160 * 1024);
-    MG_DYN_LDS(label_tail_bf16_kernel<3>, 160 * 1024);
-    const dim3 grid((B + LT_ROWS - 1) / LT_ROWS), blk(LT_THR);
-    if (terms == 3)
-        hipLaunchKernelGGL(label_tail_bf16_kernel<3>, grid, blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
-                           w, N5, n_out, out, HK_next, qh_next);
+    MG_REQUIRE((cluster_scratch != nullptr) == (cluster_counters != nullptr), "mgnns_label_tail_bf16_fwd: cluster scratch and counters go together");
+    MG_REQUIRE(!cluster_scratch || mg_aligned16(cluster_scratch), "mgnns_label_tail_bf16_fwd: cluster scratch must be 16-byte aligned");
+    MG_DYN_LDS((label_tail_bf16_kernel<1, 1>), 160 * 1024);
+    MG_DYN_LDS((label_tail_bf16_kernel<3, 1>), 160 * 1024);
+    MG_DYN_LDS((label_tail_bf16_kernel<3, 4>), 160 * 1024);
+    const int tiles = (B + LT_ROWS - 1) / LT_ROWS;
+    const dim3 blk(LT_THR);
+    if (terms == 3 && cluster_scratch)
+        hipLaunchKernelGGL((label_tail_bf16_kernel<3, 4>), dim3(tiles * 4), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ,
+                           n_heads, dh, w, N5, n_out, out, HK_next, qh_next, cluster_scratch, cluster_counters);
+    else if (terms == 3)
+        hipLaunchKernelGGL((label_tail_bf16_kernel<3, 1>), dim3(tiles), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
+                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr);
     else
-        hipLaunchKernelGGL(label_tail_bf16_kernel<1>, grid, blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
-                           w, N5, n_out, out, HK_next, qh_next);
+        hipLaunchKernelGGL((label_tail_bf16_kernel<1, 1>), dim3(tiles), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
+                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr);
     MG_CHECK_LAUNCH("mgnns_label_tail_bf16_fwd");
     return 0;
 }

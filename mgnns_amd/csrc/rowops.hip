@@ -102,7 +102,39 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
+// logits[b, n] = bias[n] + sum_p f_p[b, :] . W[n, p*D : (p+1)*D]: the classifier over the four fusion features WITHOUT
+// materialising their concatenation (MODEL:560-566); one wave per sample, lane-strided partial sums + DPP reduction
+__global__ __launch_bounds__(256) void classifier_head_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                              const float* __restrict__ f2, const float* __restrict__ f3, int B,
+                                                              int D, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              int NL, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* f[4] = {f0 + (size_t)b * D, f1 + (size_t)b * D, f2 + (size_t)b * D, f3 + (size_t)b * D};
+    for (int n = 0; n < NL; ++n) {
+        const float* w = W + (size_t)n * 4 * D;
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            for (int c = lane; c < D; c += 64) s = fmaf(f[p][c], w[p * D + c], s);
+        s = wave_sum(s);
+        if (lane == 0) logits[(size_t)b * NL + n] = s + bias[n];
+    }
+}
+
 }  // namespace
+
+extern "C" int mgnns_classifier_head_fwd(const float* f0, const float* f1, const float* f2, const float* f3, int B, int D,
+                                         const float* W, const float* bias, int NL, float* logits, mgnns_stream_t stream) {
+    MG_REQUIRE(B >= 0 && D > 0 && NL > 0, "mgnns_classifier_head_fwd: bad dims B=%d D=%d NL=%d", B, D, NL);
+    if (B == 0) return 0;
+    MG_REQUIRE(f0 && f1 && f2 && f3 && W && bias && logits, "mgnns_classifier_head_fwd: null pointer");
+    hipLaunchKernelGGL(classifier_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, f0, f1, f2, f3, B, D, W, bias,
+                       NL, logits);
+    MG_CHECK_LAUNCH("mgnns_classifier_head_fwd");
+    return 0;
+}
 
 extern "C" int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V, int D,
                                    float* out, mgnns_stream_t stream) {

@@ -22,6 +22,7 @@ from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention
 from .text_gcn import Model as Text_GCN_Model
 
 _EXP = os.environ.get("MGNNS_EXP_NO_TAIL_DEP") == "1"
+_EXP_LGCN = os.environ.get("MGNNS_EXP_CACHE_LGCN") == "1"
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
 
 
@@ -200,6 +201,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
         self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))
         self.fused_label_tail_bf16 = os.environ.get('MGNNS_FUSED_LABEL_TAIL_BF16', '1') == '1'
+        self.fused_head = os.environ.get('MGNNS_FUSED_HEAD', '1') == '1'      # classifier as one launch (composed maps)
         self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
@@ -379,6 +381,20 @@ class Multi_GCN_Multihead_Att(nn.Module):
             self._wt_cache[(id(attention), 'tail')] = hit
         return hit[1]
 
+    def _head_pack(self):
+        """multi_linear_2 . multi_linear_1 as one [num_labels, 1200] map (MODEL:563-566: only dropout between them, the
+        identity in eval), rebuilt when either changes: Wc = W2 . W1, bc = W2 . b1 + b2."""
+        l1, l2 = self.multi_linear_1, self.multi_linear_2
+        ps = (l1.weight, l1.bias, l2.weight, l2.bias)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (str(ps[0].device),)
+        hit = self._wt_cache.get('head')
+        if hit is None or hit[0] != key:
+            wc = ops.matmul(l2.weight.detach().contiguous(), l1.weight.detach().contiguous())                # [NL, 1200]
+            bc = ops.linear(l1.bias.detach()[None, :].contiguous(), l2.weight.detach(), l2.bias.detach())[0]
+            hit = (key, (wc.contiguous(), bc.contiguous(), ps))
+            self._wt_cache['head'] = hit
+        return hit[1][0], hit[1][1]
+
     def _tail_pack_bf16(self, attention, linear_5, x_linear):
         """The same weights as split-bf16 fragment-major (hi, lo) buffers for the bf16-mode fused tail."""
         ps = (attention.w_k.weight, attention.w_k.bias, attention.w_v.weight, attention.w_v.bias, attention.fc.weight,
@@ -549,10 +565,21 @@ class Multi_GCN_Multihead_Att(nn.Module):
 
         def lgcn(tag, A, inp, attention):
             def run():
+                if _EXP_LGCN:        # timing experiment only: what the forward costs with the label GCN off the schedule
+                    hit = getattr(self, '_exp_lgcn', {}).get(tag)
+                    if hit is not None:
+                        ctx['Q_' + tag], ctx['G_' + tag] = hit[0], hit[1]
+                        if fused_bf16:
+                            ctx['Gp_' + tag] = hit[2]
+                        return
                 ctx['Q_' + tag] = self._label_q(attention)       # batch independent: off the critical path, with the GCN
                 ctx['G_' + tag] = self._label_gcn(A, inp)
                 if fused_bf16:                                   # its fragment-major bf16 image for the fused tail's read-out
                     ctx['Gp_' + tag] = ops.pack_weight_bf16_split(ctx['G_' + tag])
+                if _EXP_LGCN:
+                    if not hasattr(self, '_exp_lgcn'):
+                        self._exp_lgcn = {}
+                    self._exp_lgcn[tag] = (ctx['Q_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag))
             return run
 
         def bank(tag, trunk, feature, lin):
@@ -581,6 +608,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
             return run
 
         def head():
+            if self.fused_head:      # one launch: multi_linear_2 . multi_linear_1 composed (eval: nothing between them)
+                wc, bc = self._head_pack()
+                ctx['logits'] = ops.classifier_head([ctx['tio'], ctx['tip'], ctx['iot'], ctx['ipt']], wc, bc)
+                ops.stamp("logits")
+                return
             multi_feature = torch.cat([ctx['tio'], ctx['tip'], ctx['iot'], ctx['ipt']], dim=1)
             multi_feature = ops.linear(multi_feature, self.multi_linear_1.weight.detach(),
                                        self.multi_linear_1.bias.detach())

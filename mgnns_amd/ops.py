@@ -3,6 +3,8 @@ libmgnns_hip.so on the caller's current stream.  Shape / dtype / device / contig
 validated here (the reference's convention is Python exceptions); nothing in this file
 computes.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -106,6 +108,27 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None):
     _lib.check(L.mgnns_linear_fwd(_p(x2), x2.shape[0], K, _p(weight), _p(bias), N, _p(residual), _p(y), act,
                                   _p(ws), ws.numel(), _stream()), "mgnns_linear_fwd")
     return y.view(*x.shape[:-1], N)
+
+
+def classifier_head(feats, weight, bias):
+    """logits = cat(feats, dim=1) @ weight.T + bias for the four fusion features [B, D] (MODEL:560-566), one launch, no cat."""
+    if len(feats) != 4:
+        raise ValueError("classifier_head takes the four fusion features")
+    B, D = feats[0].shape
+    for i, f in enumerate(feats):
+        _chk(f, "feature %d" % i, ndim=2)
+        if tuple(f.shape) != (B, D):
+            raise ValueError("feature %d shape %s, expected %s" % (i, tuple(f.shape), (B, D)))
+    _chk(weight, "weight", ndim=2)
+    _chk(bias, "bias", ndim=1)
+    NL = weight.shape[0]
+    if weight.shape[1] != 4 * D or bias.shape[0] != NL:
+        raise ValueError("weight %s / bias %s do not match four [B,%d] features" % (tuple(weight.shape), tuple(bias.shape), D))
+    out = torch.empty(B, NL, device=weight.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.mgnns_classifier_head_fwd(_p(feats[0]), _p(feats[1]), _p(feats[2]), _p(feats[3]), B, D, _p(weight), _p(bias), NL,
+                                           _p(out), _stream()), "mgnns_classifier_head_fwd")
+    return out
 
 
 def matmul(x, w, act=ACT_NONE):
@@ -410,10 +433,15 @@ def label_tail(x, Q, n_heads, packed, pooled=None, g_wp=None, next_q=None):
     return out if next_q is None else (out, qh)
 
 
-def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3):
+LABEL_TAIL_CLUSTER = os.environ.get("MGNNS_LABEL_TAIL_CLUSTER", "1") != "0"
+
+
+def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3, cluster=None):
     """bf16-mode fused channel tail (mgnns_label_tail_bf16_fwd): pooled [B,parts,K] fp32, g_pair = pack_weight_bf16_split(G
     [C,K]); packed = dict(wk, wv, wc, xl = (hi, lo) pairs of pack_weight_bf16_split, bk, bv, bc, bxl, n5, n_out, C);
-    next_q = ((hi, lo), bq, HK).  terms = 1 plain bf16 | 3 split-bf16.  -> out [B,n_out] (or (out, qh))."""
+    next_q = ((hi, lo), bq, HK).  terms = 1 plain bf16 | 3 split-bf16.  cluster: four workgroups per 16-sample tile
+    (terms = 3; default on, MGNNS_LABEL_TAIL_CLUSTER=0 turns it off); the exchange scratch lives in `packed`, one per
+    channel, so the two channels' launches never share one.  -> out [B,n_out] (or (out, qh))."""
     import ctypes
     _chk(pooled, "pooled", ndim=3)
     _chk(Q, "Q", ndim=2)
@@ -438,10 +466,22 @@ def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3):
         ptrs += [h.data_ptr(), l.data_ptr()]
     ptrs += [None] * (12 - len(ptrs))
     arr = (ctypes.c_void_p * 12)(*ptrs)
+    if cluster is None:
+        cluster = LABEL_TAIL_CLUSTER
+    scratch = counters = None
+    if cluster and int(terms) == 3 and B > 0:
+        tiles = (B + 15) // 16
+        ws = packed.get("_cluster_ws")
+        if ws is None or ws[0] < tiles or ws[1].device != Q.device:
+            ws = (tiles, torch.empty(tiles * 4 * 6144, device=Q.device, dtype=torch.float32),
+                  torch.zeros(2 * tiles, device=Q.device, dtype=torch.int32))
+            packed["_cluster_ws"] = ws
+        scratch, counters = ws[1], ws[2]
     L = _lib.lib()
     _launch("mgnns_label_tail_bf16_fwd", ("mgnns_label_tail_bf16_fwd", packed["C"]), L.mgnns_label_tail_bf16_fwd, _p(pooled), B,
             parts, kp, packed["C"], int(terms), arr, _p(Q), NLQ, n_heads, hid // n_heads, _p(packed["bk"]), _p(packed["bv"]),
-            _p(packed["bc"]), packed["n5"], _p(packed["bxl"]), packed["n_out"], _p(out), _p(bq), hkn, _p(qh), _stream())
+            _p(packed["bc"]), packed["n5"], _p(packed["bxl"]), packed["n_out"], _p(out), _p(bq), hkn, _p(qh), _p(scratch),
+            _p(counters), _stream())
     return out if next_q is None else (out, qh)
 
 

@@ -18,10 +18,13 @@ def shard_bounds(n, world, rank):
 class ShardedForward:
     """Wraps a forward callable; gathers logits of all ranks in rank order."""
 
-    def __init__(self, forward_fn, group=None):
+    def __init__(self, forward_fn, group=None, comm=None):
+        """comm: an mgnns_amd.comm.AbiComm -- the all-gather then goes through the C ABI (mgnns_allgather_logits) instead
+        of torch.distributed; same RCCL underneath, same result."""
         self.forward_fn = forward_fn
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = comm
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self._out = None
 
     def __call__(self, *local_args):
@@ -30,6 +33,8 @@ class ShardedForward:
     def gather(self, logits):
         """The collective alone (also usable as GraphedForward's `post` hook: RCCL collectives capture into the
         forward's hipGraph, so a step is one graph launch including the all-gather)."""
+        if self.comm is not None:
+            return self.comm.all_gather(logits)
         if self.world == 1 and not dist.is_initialized():
             return logits
         shape = (self.world * logits.shape[0],) + tuple(logits.shape[1:])

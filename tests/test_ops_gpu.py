@@ -41,6 +41,27 @@ def test_linear_and_matmul(M, K, N):
     assert H.relerr(y, ref - torch.from_numpy(b).double()) < 2e-6
 
 
+@pytest.mark.parametrize("B", [1, 5, 256])
+def test_classifier_head_equals_cat_linear_linear(B):
+    """MODEL:560-566 in eval: cat -> multi_linear_1 -> (dropout = identity) -> multi_linear_2, as one launch over the composed map."""
+    rs = np.random.RandomState(B)
+    feats = [rs.standard_normal((B, 300)).astype(np.float32) for _ in range(4)]
+    w1 = (rs.standard_normal((600, 1200)) / np.sqrt(1200)).astype(np.float32)
+    b1 = rs.standard_normal(600).astype(np.float32)
+    w2 = (rs.standard_normal((3, 600)) / np.sqrt(600)).astype(np.float32)
+    b2 = rs.standard_normal(3).astype(np.float32)
+    cat = torch.from_numpy(np.concatenate(feats, axis=1)).double()
+    ref = (cat @ torch.from_numpy(w1).double().t() + torch.from_numpy(b1).double()) @ torch.from_numpy(w2).double().t() + torch.from_numpy(b2).double()
+    wc = ops.matmul(dev(w2), dev(w1))
+    bc = ops.linear(dev(b1)[None, :].contiguous(), dev(w2), dev(b2))[0].contiguous()
+    y = ops.classifier_head([dev(f) for f in feats], wc, bc).cpu()
+    assert H.relerr(y, ref) < 2e-6
+    two = ops.linear(ops.linear(dev(np.concatenate(feats, axis=1)), dev(w1), dev(b1)), dev(w2), dev(b2)).cpu()
+    assert H.maxabs(y, two) < 1e-5 * max(1.0, float(two.abs().max()))
+    with pytest.raises(ValueError):
+        ops.classifier_head([dev(f) for f in feats[:3]], wc, bc)
+
+
 def test_embedding_gather():
     rs = np.random.RandomState(1)
     table = rs.standard_normal((1000, 300)).astype(np.float32)
@@ -215,6 +236,21 @@ def test_fused_label_tail_bf16_vs_oracle():
                 assert ez < gate and eq < gate, (tag, B, terms, ez, eq)
                 z1 = ops.label_tail_bf16(dev(halves.max(axis=1)[:, None, :].copy()), Gp, Q, 5, packed, terms=terms)
                 assert torch.equal(z1, z)
+                if terms == 3:     # one workgroup per tile (no cluster): same result up to the order of the four K-part sums
+                    z0, q0 = ops.label_tail_bf16(dev(halves), Gp, Q, 5, packed, next_q=nq, terms=3, cluster=False)
+                    assert H.maxabs(z0.cpu(), z.cpu()) < 1e-5 * float(ref.abs().max())
+                    assert H.maxabs(q0.cpu(), qh.cpu()) < 1e-5 * float(ref_q.abs().max())
+        # the cluster exchange: deterministic over repeated launches at a chip-filling size, ragged last tile, counters re-armed
+        for B in (256, 300):
+            halves = dev(np.maximum(rs.standard_normal((B, 2, 2048)), 0).astype(np.float32))
+            z, qh = ops.label_tail_bf16(halves, Gp, Q, 5, packed, next_q=nq, terms=3)
+            for _ in range(5):
+                z2, qh2 = ops.label_tail_bf16(halves, Gp, Q, 5, packed, next_q=nq, terms=3)
+                assert torch.equal(z2, z) and torch.equal(qh2, qh)
+            assert int(packed["_cluster_ws"][2].abs().sum()) == 0
+            z0, q0 = ops.label_tail_bf16(halves, Gp, Q, 5, packed, next_q=nq, terms=3, cluster=False)
+            assert H.maxabs(z0.cpu(), z.cpu()) < 1e-5 * float(z0.abs().max())
+            assert H.maxabs(q0.cpu(), qh.cpu()) < 1e-5 * float(q0.abs().max())
 
 
 def test_layernorm_against_golden():

@@ -17,8 +17,10 @@ for C in (80, 365):
               "xl": sp(rn(300, 700)), "bxl": rn(300), "n_out": 300}
     Gp = sp(rn(C, 2048)); nq = (sp(rn(1024, 300)), rn(1024), 1024)
     for terms in (1, 3):
-        print("C=%d terms=%d: %.1f us (+qh)  %.1f us (no qh)" % (C, terms, t(lambda: ops.label_tail_bf16(pooled, Gp, Q, 5, packed, next_q=nq, terms=terms)),
-                                                                   t(lambda: ops.label_tail_bf16(pooled, Gp, Q, 5, packed, terms=terms))))
+        print("C=%d terms=%d: %.1f us (+qh)  %.1f us (no qh)  | one workgroup per tile: %.1f us (+qh)" % (
+            C, terms, t(lambda: ops.label_tail_bf16(pooled, Gp, Q, 5, packed, next_q=nq, terms=terms)),
+            t(lambda: ops.label_tail_bf16(pooled, Gp, Q, 5, packed, terms=terms)),
+            t(lambda: ops.label_tail_bf16(pooled, Gp, Q, 5, packed, next_q=nq, terms=terms, cluster=False))))
 
 import ctypes, os
 from mgnns_amd import _lib
