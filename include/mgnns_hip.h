@@ -286,6 +286,27 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
                             const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
                             const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
 
+/* ---- a3 + a4 (+ a7's w_q): one image channel's label GCN as ONE persistent launch ---------------------------------
+ * gen_adj (utils/util.py:421-426) + GraphConvolution x 2 with LeakyReLU(0.2) between them
+ * (Multi_GCN_Multihead_att.py:460-473 / 489-499, 42-58) + optionally w_q(label_query) (MODEL:97):
+ *   adj = D^-1/2 A^T D^-1/2;  X1 = lrelu(adj @ (inp @ W1));  G = adj @ (X1 @ W2);  Q = label_query @ wq^T + bq
+ * as a grid of `grid` (0: default 64, capped at the CU count) co-resident workgroups with grid barriers between the phases
+ * instead of 11-12 dependent launches.  split = 0: exact-fp32 MFMA, w1a / w2a = mgnns_pack_weight_f32 of W1^T [N1,K0] /
+ * W2^T [N2,N1] (bit-equal to mgnns_gen_adj + mgnns_matmul_fwd + mgnns_spmm_csr_fwd); split = 1: split-bf16 operands
+ * (fp32-class), (w1a, w1b) / (w2a, w2b) = the (hi, lo) buffers of mgnns_pack_weight_bf16_split.
+ * A [C,C]; inp [C,K0]; G [C,N2]; Gp_hi / Gp_lo (both or neither): the mgnns_pack_weight_bf16_split image of G the fused
+ * channel tail reads; Q [NLQ,HQ] or NULL.  C <= 512, K0 % 4 == 0, N1, N2 % 256 == 0, N1 <= 1024.
+ * scratch: mgnns_label_gcn_scratch_bytes(C, N1, N2) bytes, 256-byte aligned, its first 256 bytes ZERO before the first
+ * launch (every launch leaves them zero); one scratch must not be shared by launches that may run concurrently.
+ * The launch must not be queued behind work that needs ITS completion to free CUs (it spins at the barriers until all
+ * of its workgroups are resident); other kernels may run beside it.
+ */
+size_t mgnns_label_gcn_scratch_bytes(int C, int N1, int N2);
+int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int K0, int split, const void* w1a, const void* w1b, int N1,
+                        const void* w2a, const void* w2b, int N2, float* G, void* Gp_hi, void* Gp_lo,
+                        const float* label_query, int NLQ, const float* wq, const float* bq, int HQ, float* Q,
+                        void* scratch, size_t scratch_bytes, int grid, mgnns_stream_t stream);
+
 /* ---- a9: classifier over the four fusion features (Multi_GCN_Multihead_att.py:560-566, eval: dropout is the identity) --
  * logits[b,:] = W [f0[b]; f1[b]; f2[b]; f3[b]] + bias without materialising the concatenation.  f_p [B,D]; W [NL, 4*D];
  * bias [NL]; logits [B,NL].  The host passes W = multi_linear_2.weight . multi_linear_1.weight (no non-linearity between

@@ -35,6 +35,7 @@ SIGNATURES = {
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mgnns_label_gcn_fwd": [_P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _I, _P],
     "mgnns_classifier_head_fwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P],
     "mgnns_label_tail_bf16_fwd": [_P, _I, _I, _I, _I, _I, _PP, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "mgnns_label_tail_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P,
@@ -78,6 +79,7 @@ SIZE_GETTERS = {
     "mgnns_sq_mha_folded_workspace_bytes": [_I, _I, _I],
     "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
     "mgnns_bilstm_bf16_prepack_bytes": [_I, _I],
+    "mgnns_label_gcn_scratch_bytes": [_I, _I, _I],
 }
 
 _lib = None

@@ -202,6 +202,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))
         self.fused_label_tail_bf16 = os.environ.get('MGNNS_FUSED_LABEL_TAIL_BF16', '1') == '1'
         self.fused_head = os.environ.get('MGNNS_FUSED_HEAD', '1') == '1'      # classifier as one launch (composed maps)
+        self.fused_label_gcn = os.environ.get('MGNNS_FUSED_LABEL_GCN', '1') == '1'      # label GCN as one persistent launch
         self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
         self.set_precision(opt.get('precision', 'fp32'))
@@ -379,6 +380,21 @@ class Multi_GCN_Multihead_Att(nn.Module):
                  "n_out": x_linear.out_features, "C": attention.w_k.in_features, "_src": ps}
             hit = (key, d)
             self._wt_cache[(id(attention), 'tail')] = hit
+        return hit[1]
+
+    def _lgcn_pack(self, tag):
+        """Packed GraphConvolution weights of one channel for the persistent label-GCN launch (exact fp32 fragments in fp32
+        mode, split-bf16 pairs in bf16 mode), rebuilt when a weight or the precision changes; carries the launch's scratch."""
+        gc1, gc2 = (self.gc1, self.gc2)
+        ps = (gc1.weight, gc2.weight)
+        split = self.precision == 'bf16'
+        key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (str(ps[0].device), split)
+        hit = self._wt_cache.get(('lgcn', tag))
+        if hit is None or hit[0] != key:
+            d = ops.label_gcn_pack(gc1.weight.detach(), gc2.weight.detach(), split)
+            d["_src"] = ps
+            hit = (key, d)
+            self._wt_cache[('lgcn', tag)] = hit
         return hit[1]
 
     def _head_pack(self):
@@ -564,6 +580,20 @@ class Multi_GCN_Multihead_Att(nn.Module):
             ops.stamp("text bank (LSTM) end")
 
         def lgcn(tag, A, inp, attention):
+            def run_fused():
+                # gen_adj + both GraphConvolutions + the packed image of G + w_q(label query): ONE persistent launch
+                pk = self._lgcn_pack(tag)
+                G, Gp, Q = ops.label_gcn(A.detach(), inp[0].float().contiguous(), pk, want_packed_g=fused_bf16,
+                                         query=(self.label_query.float().contiguous(), attention.w_q.weight.detach(),
+                                                attention.w_q.bias.detach()))
+                ctx['Q_' + tag], ctx['G_' + tag] = Q, G
+                if fused_bf16:
+                    ctx['Gp_' + tag] = Gp
+                ops.stamp("  label GCN end")
+
+            if self.fused_label_gcn and not _EXP_LGCN:
+                return run_fused
+
             def run():
                 if _EXP_LGCN:        # timing experiment only: what the forward costs with the label GCN off the schedule
                     hit = getattr(self, '_exp_lgcn', {}).get(tag)

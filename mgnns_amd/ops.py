@@ -164,6 +164,67 @@ def gen_adj(A, want_csr=False):
     return (adj, (rp, col, val)) if want_csr else adj
 
 
+def label_gcn_pack(w1, w2, split):
+    """GraphConvolution weights W1 [K0,N1], W2 [N1,N2] ([in,out] layout) -> the packed dict label_gcn() takes:
+    split = False: exact-fp32 fragment-major buffers; True: (hi, lo) split-bf16 pairs."""
+    _chk(w1, "gc1.weight", ndim=2)
+    _chk(w2, "gc2.weight", ndim=2)
+    if w1.shape[1] != w2.shape[0]:
+        raise ValueError("gc1.weight %s / gc2.weight %s do not chain" % (tuple(w1.shape), tuple(w2.shape)))
+    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()               # [N, K]: the layout the pack kernels take
+    if split:
+        a, b = pack_weight_bf16_split(w1t), pack_weight_bf16_split(w2t)
+        d = {"w1": a, "w2": b}
+    else:
+        d = {"w1": (pack_weight_f32(w1t), None), "w2": (pack_weight_f32(w2t), None)}
+    d.update(split=bool(split), K0=w1.shape[0], N1=w1.shape[1], N2=w2.shape[1])
+    return d
+
+
+LABEL_GCN_GRID = int(os.environ.get("MGNNS_LGCN_GRID", "0"))
+
+
+def label_gcn(A, inp, packed, want_packed_g=False, query=None, grid=0):
+    """One channel's whole label GCN in one persistent launch (mgnns_label_gcn_fwd): gen_adj + GraphConvolution x 2 (+ the
+    label query projection).  A [C,C]; inp [C,K0]; packed = label_gcn_pack(...) (also carries this channel's scratch);
+    query = (label_query [NLQ,K0], w_q.weight [HQ,K0], w_q.bias or None).  -> (G [C,N2], (Gp_hi, Gp_lo) or None, Q or None)."""
+    _chk(A, "A", ndim=2)
+    _chk(inp, "inp", ndim=2)
+    C = A.shape[0]
+    if A.shape[1] != C or inp.shape[0] != C or inp.shape[1] != packed["K0"]:
+        raise ValueError("A %s / inp %s do not match a [C,C] adjacency and [C,%d] label embeddings" %
+                         (tuple(A.shape), tuple(inp.shape), packed["K0"]))
+    N1, N2 = packed["N1"], packed["N2"]
+    L = _lib.lib()
+    need = L.mgnns_label_gcn_scratch_bytes(C, N1, N2)
+    ws = packed.get("_scratch")
+    if ws is None or ws.numel() < need or ws.device != A.device:
+        ws = torch.zeros(need, dtype=torch.uint8, device=A.device)        # counters (first 256 B) start at zero
+        packed["_scratch"] = ws
+    G = torch.empty(C, N2, device=A.device, dtype=torch.float32)
+    gh = gl = None
+    if want_packed_g:
+        n = L.mgnns_packed_bf16_weight_bytes(C, N2)
+        gh = torch.empty(n, dtype=torch.uint8, device=A.device)
+        gl = torch.empty(n, dtype=torch.uint8, device=A.device)
+    lq = wq = bq = Q = None
+    nlq = hq = 0
+    if query is not None:
+        lq, wq, bq = query
+        _chk(lq, "label_query", ndim=2)
+        _chk(wq, "w_q.weight", ndim=2)
+        if lq.shape[1] != packed["K0"] or wq.shape[1] != packed["K0"]:
+            raise ValueError("label_query %s / w_q.weight %s must be [*, %d]" % (tuple(lq.shape), tuple(wq.shape), packed["K0"]))
+        if bq is not None:
+            _chk(bq, "w_q.bias", ndim=1)
+        nlq, hq = lq.shape[0], wq.shape[0]
+        Q = torch.empty(nlq, hq, device=A.device, dtype=torch.float32)
+    _launch("mgnns_label_gcn_fwd", ("mgnns_label_gcn_fwd", C, packed["split"]), L.mgnns_label_gcn_fwd, _p(A), C, _p(inp), packed["K0"],
+            1 if packed["split"] else 0, _p(packed["w1"][0]), _p(packed["w1"][1]), N1, _p(packed["w2"][0]), _p(packed["w2"][1]), N2,
+            _p(G), _p(gh), _p(gl), _p(lq), nlq, _p(wq), _p(bq), hq, _p(Q), _p(ws), ws.numel(), int(grid) or LABEL_GCN_GRID, _stream())
+    return G, ((gh, gl) if want_packed_g else None), Q
+
+
 def dense_to_csr(m):
     _chk(m, "adj", ndim=2)
     C = m.shape[0]

@@ -135,6 +135,52 @@ def test_image_gcn_chain_against_goldens():
         assert H.relerr(x.cpu(), g[tag + "_x"]) < 1e-5
 
 
+def test_persistent_label_gcn_against_goldens_and_the_separate_operators():
+    """csrc/label_gcn.hip: gen_adj + GraphConvolution x 2 (+ w_q(label query), + the split-bf16 image of G) as ONE launch.
+    Exact mode: the reference's golden G / read-out (1e-5) and the separate operators to fp32 rounding (their GEMM walks K in
+    a different order); split-bf16 mode: fp32-class (2e-5 of the output scale).  Repeated launches, grids of 1..256 workgroups, a dense adjacency (every ELL slot
+    full) and a single-class graph."""
+    g = H.load_golden("image_gcn.npz")
+    adjg = H.load_golden("adjacency.npz")
+    p = dparams(H.params_for({"gc1.weight": (300, 1024), "gc2.weight": (1024, 2048)}))
+    proj = torch.from_numpy(GI.gcn_projection())
+    rs = np.random.RandomState(3)
+    lq, wq, bq = dev(rs.standard_normal((7, 300)).astype(np.float32)), dev((0.05 * rs.standard_normal((300, 300))).astype(np.float32)), dev(rs.standard_normal(300).astype(np.float32))
+    exact = ops.label_gcn_pack(p["gc1.weight"], p["gc2.weight"], split=False)
+    split = ops.label_gcn_pack(p["gc1.weight"], p["gc2.weight"], split=True)
+    for tag, key in (("object", "object_t04"), ("place", "place_t03")):
+        X, pooled = GI.image_gcn_case(tag)
+        A = dev(adjg[key + "_A"])
+        _, csr = ops.gen_adj(A, want_csr=True)
+        G_sep = ops.spmm_csr(csr, ops.matmul(ops.spmm_csr(csr, ops.matmul(dev(X), p["gc1.weight"]), act=ops.ACT_LRELU2), p["gc2.weight"]))
+        for grid in (0, 1, 7, 256):
+            G, Gp, Q = ops.label_gcn(A, dev(X), exact, want_packed_g=True, query=(lq, wq, bq), grid=grid)
+            assert H.maxabs(G.cpu(), G_sep.cpu()) < 2e-6 * float(G_sep.abs().max()), (tag, grid)
+            if grid:
+                assert torch.equal(G, G0), (tag, grid)              # the grid size does not change a single bit
+            G0 = G
+            assert H.relerr(G.cpu() @ proj, g[tag + "_Gproj"]) < 1e-5
+            assert H.relerr(ops.linear(dev(pooled), G).cpu(), g[tag + "_x"]) < 1e-5
+            ref_p = ops.pack_weight_bf16_split(G)
+            assert torch.equal(Gp[0], ref_p[0]) and torch.equal(Gp[1], ref_p[1])
+            assert H.maxabs(Q.cpu(), ops.linear(lq, wq, bq).cpu()) < 1e-5
+            assert int(exact["_scratch"][:256].view(torch.int32).abs().sum()) == 0          # counters re-armed
+        for _ in range(3):
+            G2, Gp2, _ = ops.label_gcn(A, dev(X), split, want_packed_g=True)
+            assert H.maxabs(G2.cpu(), G_sep.cpu()) < 2e-5 * float(G_sep.abs().max()), tag
+            assert torch.equal(Gp2[0], ops.pack_weight_bf16_split(G2)[0])
+    # dense adjacency (all C entries of every ELL row) and C = 1
+    for C in (37, 1):
+        A = dev((rs.rand(C, C) + 0.1).astype(np.float32))
+        X = dev(rs.standard_normal((C, 300)).astype(np.float32))
+        _, csr = ops.gen_adj(A, want_csr=True)
+        G_sep = ops.spmm_csr(csr, ops.matmul(ops.spmm_csr(csr, ops.matmul(X, p["gc1.weight"]), act=ops.ACT_LRELU2), p["gc2.weight"]))
+        G, _, _ = ops.label_gcn(A, X, exact)
+        assert H.maxabs(G.cpu(), G_sep.cpu()) < 2e-6 * float(G_sep.abs().max()), C
+    with pytest.raises(ValueError):
+        ops.label_gcn(dev(np.eye(5, dtype=np.float32)), dev(np.zeros((4, 300), np.float32)), exact)
+
+
 def test_label_attention_against_goldens():
     g = H.load_golden("label_attention.npz")
     lq = dev(g["label_query"])
