@@ -104,6 +104,9 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 
 // logits[b, n] = bias[n] + sum_p f_p[b, :] . W[n, p*D : (p+1)*D]: the classifier over the four fusion features WITHOUT
 // materialising their concatenation (MODEL:560-566); one wave per sample, lane-strided partial sums + DPP reduction
+// NI = ceil(D / 64): the sample's four feature rows are requested up front (4 * NI independent loads per lane), every weight
+// row likewise -- as a plain loop this kernel was a chain of ~60 dependent global round trips (21 us on an idle chip)
+template <int NI>
 __global__ __launch_bounds__(256) void classifier_head_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                               const float* __restrict__ f2, const float* __restrict__ f3, int B,
                                                               int D, const float* __restrict__ W, const float* __restrict__ bias,
@@ -112,12 +115,23 @@ __global__ __launch_bounds__(256) void classifier_head_kernel(const float* __res
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const float* f[4] = {f0 + (size_t)b * D, f1 + (size_t)b * D, f2 + (size_t)b * D, f3 + (size_t)b * D};
+    float x[4][NI];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) x[p][i] = lane + 64 * i < D ? f[p][lane + 64 * i] : 0.f;
     for (int n = 0; n < NL; ++n) {
         const float* w = W + (size_t)n * 4 * D;
+        float wv[4][NI];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wv[p][i] = lane + 64 * i < D ? w[p * D + lane + 64 * i] : 0.f;
         float s = 0.f;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            for (int c = lane; c < D; c += 64) s = fmaf(f[p][c], w[p * D + c], s);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) s = fmaf(x[p][i], wv[p][i], s);
         s = wave_sum(s);
         if (lane == 0) logits[(size_t)b * NL + n] = s + bias[n];
     }
@@ -130,8 +144,12 @@ extern "C" int mgnns_classifier_head_fwd(const float* f0, const float* f1, const
     MG_REQUIRE(B >= 0 && D > 0 && NL > 0, "mgnns_classifier_head_fwd: bad dims B=%d D=%d NL=%d", B, D, NL);
     if (B == 0) return 0;
     MG_REQUIRE(f0 && f1 && f2 && f3 && W && bias && logits, "mgnns_classifier_head_fwd: null pointer");
-    hipLaunchKernelGGL(classifier_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, f0, f1, f2, f3, B, D, W, bias,
-                       NL, logits);
+    MG_REQUIRE(D <= 1024, "mgnns_classifier_head_fwd: feature width %d unsupported (<= 1024)", D);
+    const dim3 grid((B + 3) / 4), blk(256);
+    if (D <= 320)
+        hipLaunchKernelGGL(classifier_head_kernel<5>, grid, blk, 0, (hipStream_t)stream, f0, f1, f2, f3, B, D, W, bias, NL, logits);
+    else
+        hipLaunchKernelGGL(classifier_head_kernel<16>, grid, blk, 0, (hipStream_t)stream, f0, f1, f2, f3, B, D, W, bias, NL, logits);
     MG_CHECK_LAUNCH("mgnns_classifier_head_fwd");
     return 0;
 }
