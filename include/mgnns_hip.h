@@ -290,7 +290,8 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
  * gen_adj (utils/util.py:421-426) + GraphConvolution x 2 with LeakyReLU(0.2) between them
  * (Multi_GCN_Multihead_att.py:460-473 / 489-499, 42-58) + optionally w_q(label_query) (MODEL:97):
  *   adj = D^-1/2 A^T D^-1/2;  X1 = lrelu(adj @ (inp @ W1));  G = adj @ (X1 @ W2);  Q = label_query @ wq^T + bq
- * as a grid of `grid` (0: default 64, capped at the CU count) co-resident workgroups with grid barriers between the phases
+ * as a grid of `grid` (0 or more than a quarter of the CUs: a quarter of the CUs, 64 on an MI355X -- two channels' launches
+ * run side by side and must both fit) co-resident workgroups with grid barriers between the phases
  * instead of 11-12 dependent launches.  split = 0: exact-fp32 MFMA, w1a / w2a = mgnns_pack_weight_f32 of W1^T [N1,K0] /
  * W2^T [N2,N1] (bit-equal to mgnns_gen_adj + mgnns_matmul_fwd + mgnns_spmm_csr_fwd); split = 1: split-bf16 operands
  * (fp32-class), (w1a, w1b) / (w2a, w2b) = the (hi, lo) buffers of mgnns_pack_weight_bf16_split.

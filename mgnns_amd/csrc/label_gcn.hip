@@ -322,16 +322,18 @@ extern "C" int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int 
     const size_t tile = split ? (size_t)2 * 16 * lg_sc(kmax) * 16 : (size_t)16 * lg_sa(kmax) * 4;
     const size_t lds = tile + (size_t)8 * LG_MAXC * 8;
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_gcn_fwd: %zu B of LDS needed", lds);
-    // the grid barrier needs every workgroup resident at once: never more workgroups than CUs (one 512-thread workgroup with
-    // this LDS footprint per CU); default 64 -- the phases' work items (23 x 4, 23 x 8 tiles at C = 365) divide evenly enough
-    // and the launch leaves three quarters of the chip to the memory-bank kernels that start beside it
+    // The grid barrier needs every workgroup resident at once (one 512-thread workgroup with this LDS footprint per CU), and
+    // the forward runs TWO of these launches side by side (object and scene channel): two grids that each wait for more than
+    // half of the CUs dead-lock each other (measured: grid 256 on both channels hangs).  Hence at most a QUARTER of the CUs
+    // per launch -- 64 on an MI355X, which is also the default: the phases' work items (23 x 4, 23 x 8 tiles at C = 365)
+    // divide evenly enough and the launch leaves the rest of the chip to the memory-bank kernels that start beside it.
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
         mgnns_set_error("mgnns_label_gcn_fwd: cannot query the CU count");
         return MGNNS_ERR_LAUNCH;
     }
-    if (grid <= 0) grid = 64;
-    if (grid > n_cu) grid = n_cu;
+    const int cap = n_cu / 4 > 0 ? n_cu / 4 : 1;
+    if (grid <= 0 || grid > cap) grid = cap;
     if (split) {
         MG_DYN_LDS(label_gcn_kernel<true>, 160 * 1024);
         hipLaunchKernelGGL(label_gcn_kernel<true>, dim3(grid), dim3(LG_THR), lds, (hipStream_t)stream, a);

@@ -34,6 +34,12 @@ class GraphedForward:
             self.mode = "segments"                  # a collective inside: every rank must capture the same thing, once
         if not getattr(model, "use_streams", True):
             self.mode = "single"                    # one stream: the forward is one linear chain anyway
+        elif self.mode == "auto" and hasattr(model, "resolve_schedule") and \
+                model.resolve_schedule(example_args[0].shape[0]) != "channels":
+            # hipStreamEndCapture SEGFAULTS inside the runtime (ROCm 7.0 / 7.2) on the single-graph form of every schedule
+            # but 'channels' (lgcn_side, banks_first, channels2: python -X faulthandler points at capture_end) -- not an
+            # exception this process could survive, so the one-graph attempt is only made for the topology known to work
+            self.mode = "segments"
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         for a in self.static_in:
             if torch.is_tensor(a) and not a.is_cuda:

@@ -197,9 +197,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self._lstm_cache = ops.LstmCache()     # derived LSTM weight forms live and die with this module
         self._streams = None
         self.use_streams = bool(opt.get('use_streams', True))
-        self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'channels'))
+        # 'auto': 'channels' for batches of at least 128 samples, 'channels2' below (resolve_schedule)
+        self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'auto'))
         self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
-        self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))
+        self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))      # fp32 fused tail (16 CUs per 256 samples)
+        # the bf16 fused tail runs as 4-workgroup clusters: it wins at every batch size (B=32: 0.471 -> 0.431 ms, B=16: 0.438 -> 0.419)
+        self.fused_label_tail_bf16_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_BF16_MIN_BATCH', '1'))
         self.fused_label_tail_bf16 = os.environ.get('MGNNS_FUSED_LABEL_TAIL_BF16', '1') == '1'
         self.fused_head = os.environ.get('MGNNS_FUSED_HEAD', '1') == '1'      # classifier as one launch (composed maps)
         self.fused_label_gcn = os.environ.get('MGNNS_FUSED_LABEL_GCN', '1') == '1'      # label GCN as one persistent launch
@@ -336,7 +339,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         B = feats.shape[0]
         f3 = feats.float().contiguous().view(B, feats.shape[1], -1)
         if self.precision == 'bf16' and 104 < f3.shape[2] <= 200 and f3.shape[2] % 4 == 0:
-            keep_halves = (self.fused_label_tail and self.fused_label_tail_bf16 and B >= self.fused_label_tail_min_batch)
+            keep_halves = (self.fused_label_tail and self.fused_label_tail_bf16 and B >= self.fused_label_tail_bf16_min_batch)
             bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features, combine=not keep_halves)
             return MemoryBank(bf16=bank), pooled
         bank, pooled = ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
@@ -438,14 +441,16 @@ class Multi_GCN_Multihead_Att(nn.Module):
     def _channel_tail(self, pooled, G, Gp, Q, attention, linear_5, x_linear, next_stack=None):
         """Second half of an image channel (MODEL:474-479 / 500-506): read-out through the label GCN, then label attention
         + 300->100->700->300 + the projected query of the fusion stack the feature feeds as ONE fused launch
-        (csrc/label_tail.hip) -- for batches of at least fused_label_tail_min_batch samples: the fused kernel runs on
-        B/16 CUs, which wins when the small launches it replaces would each queue for a CU behind the chip-filling
-        kernels (B=256: 0.955 vs 0.993 ms per forward) and loses on an idle chip (B=32: 0.61 vs 0.54 ms).  Below the
-        threshold, or with MGNNS_FUSED_LABEL_TAIL=0: the chain of module-level operators.  -> (att [B,300], qh or None)"""
+        (csrc/label_tail.hip).  bf16 mode: always (four-workgroup clusters per 16 samples).  fp32 mode: for batches of at
+        least fused_label_tail_min_batch samples -- that kernel runs on B/16 CUs, which wins when the small launches it
+        replaces would each queue for a CU behind the chip-filling kernels (B=256: 0.955 vs 0.993 ms per forward) and loses
+        on an idle chip (B=32: 0.61 vs 0.54 ms).  Below the threshold, or with MGNNS_FUSED_LABEL_TAIL=0: the chain of
+        module-level operators.  -> (att [B,300], qh or None)"""
         B = pooled.shape[0]
         ok = (self.fused_label_tail and B >= self.fused_label_tail_min_batch
               and x_linear.in_features == Q.shape[0] * linear_5.out_features)
-        if ok and Gp is not None:
+        if (Gp is not None and self.fused_label_tail and B >= self.fused_label_tail_bf16_min_batch
+                and x_linear.in_features == Q.shape[0] * linear_5.out_features):
             # bf16 precision mode: the whole chain, read-out included, as ONE launch on the bf16 MFMA
             pk = self._tail_pack_bf16(attention, linear_5, x_linear)
             nq = first_query_pack_bf16(next_stack) if next_stack is not None and len(next_stack) else None
@@ -525,6 +530,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "banks_first": [("text_bank", "main"), ("bank_obj", "s1"), ("bank_place", "s2"), ("text_gcn", "s3"), ("lgcn_obj", "s3"),
                         ("lgcn_place", "s3"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                         ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # 'channels' with the object-side stacks re-homed: the text->object stack right behind the object bank (not behind the
+        # BiLSTM chain on the caller's stream, which ends later than the bank at small batches), the image->text stack behind the
+        # BiLSTM it needs, the object tail on the text-GCN stream
+        "channels2": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                      ("bank_place", "s2"), ("tio", "s1"), ("tail_obj", "s3"), ("tail_place", "s2"), ("tip", "s3"),
+                      ("iot", "main"), ("ipt", "s2"), ("head", "main")],
         # 'channels' with the two HBM-bound memory-bank kernels one after the other instead of side by side: together they
         # take as long either way, but the first one -- and the stack and the label tail behind it -- is done in half the time
         "banks_serial": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
@@ -547,6 +558,17 @@ class Multi_GCN_Multihead_Att(nn.Module):
                      ("iot", "s1"), ("ipt", "s1"), ("head", "main")],
     }
 
+    def resolve_schedule(self, batch, schedule=None):
+        """Name of the schedule a forward of `batch` samples runs.  'auto': at 128 samples and more the chip-filling kernels
+        decide and 'channels' is best; below, the BiLSTM chain on the caller's stream is the longest segment and 'channels2'
+        (no text->image stack queued behind it) wins: 0.424 vs 0.437 ms at B=32, 0.457 vs 0.481 at B=64, equal at B=256."""
+        name = schedule or self.schedule
+        if name == 'auto':
+            name = 'channels' if batch >= 128 else 'channels2'
+        if name not in self.SCHEDULES:
+            raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
+        return name
+
     def forward_plan(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp, schedule=None):
         """The forward as SEGMENTS: a list of (name, stream key, names of the segments on OTHER streams it waits for,
         callable) in enqueue order.  The channels and the four fusion stacks are independent of each other
@@ -558,8 +580,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
         ctx = {}
-        fused_bf16 = (self.precision == 'bf16' and self.fused_label_tail and text.shape[0] >= self.fused_label_tail_min_batch
-                      and self.fused_label_tail_bf16)
+        fused_bf16 = (self.precision == 'bf16' and self.fused_label_tail and self.fused_label_tail_bf16
+                      and text.shape[0] >= self.fused_label_tail_bf16_min_batch)
 
         def text_gcn():
             ops.stamp("text GCN start")
@@ -667,7 +689,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place' if not _EXP else 'text_feature', 'text_bank', True),
             "head": head,
         }
-        sched = self.SCHEDULES[schedule or self.schedule]
+        sched = self.SCHEDULES[self.resolve_schedule(text.shape[0], schedule)]
         if _EXP:
             sched = [(e, k) for e, k in sched]
         where, plan = {}, []
@@ -690,7 +712,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_streams(args[0].device) if self.use_streams else {}
         streams = dict(side, main=main)
-        for k in {k for _, k in self.SCHEDULES[self.schedule]}:
+        for k in {k for _, k in self.SCHEDULES[self.resolve_schedule(args[0].shape[0])]}:
             streams.setdefault(k, main)              # use_streams = False: everything on the caller's stream
         for st in side.values():
             st.wait_stream(main)                     # the caller produced the inputs on `main`

@@ -199,6 +199,8 @@ def label_gcn(A, inp, packed, want_packed_g=False, query=None, grid=0):
     need = L.mgnns_label_gcn_scratch_bytes(C, N1, N2)
     ws = packed.get("_scratch")
     if ws is None or ws.numel() < need or ws.device != A.device:
+        if ws is not None:
+            packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
         ws = torch.zeros(need, dtype=torch.uint8, device=A.device)        # counters (first 256 B) start at zero
         packed["_scratch"] = ws
     G = torch.empty(C, N2, device=A.device, dtype=torch.float32)
@@ -534,6 +536,8 @@ def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3, cl
         tiles = (B + 15) // 16
         ws = packed.get("_cluster_ws")
         if ws is None or ws[0] < tiles or ws[1].device != Q.device:
+            if ws is not None:
+                packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(tiles * 4 * 6144, device=Q.device, dtype=torch.float32),
                   torch.zeros(2 * tiles, device=Q.device, dtype=torch.int32))
             packed["_cluster_ws"] = ws

@@ -126,6 +126,34 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
         assert torch.equal(gf(*a1), ref1)
 
 
+def test_every_schedule_gives_the_same_logits_eager_and_graphed():
+    """The schedules only place the forward's segments on streams: same kernels, same operands -> bit-equal logits, eager and
+    as per-segment hipGraphs; 'auto' resolves by batch size; the one-graph form is only attempted for 'channels'."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    model.set_precision("bf16")
+    a = call_args(synth.make_inputs(cfg, B=24, seed=4, pmi=pmi), DEV)
+    assert model.resolve_schedule(24) == "channels2" and model.resolve_schedule(256) == "channels"
+    model.use_streams = False
+    ref = model(*a).clone()
+    model.use_streams = True
+    for name in sorted(model.SCHEDULES):
+        if name.startswith("exp_"):
+            continue
+        model.schedule = name
+        assert torch.equal(model(*a), ref), name
+        gf = GraphedForward(model, a)
+        assert gf.mode == "segments" or name == "channels", (name, gf.mode)
+        assert torch.equal(gf.replay(), ref), name
+    model.schedule = "nope"
+    with pytest.raises(ValueError):
+        model(*a)
+
+
 def test_real_text_pipeline_vocab_pmi_batching_forward():
     """Rows f2+f3 feeding the path: vocabulary + sparse PMI edge map built from real (val-split) texts, batch
     assembled in pinned buffers, copied to the device, forward == CPU oracle on the same ids."""

@@ -138,7 +138,7 @@ def test_image_gcn_chain_against_goldens():
 def test_persistent_label_gcn_against_goldens_and_the_separate_operators():
     """csrc/label_gcn.hip: gen_adj + GraphConvolution x 2 (+ w_q(label query), + the split-bf16 image of G) as ONE launch.
     Exact mode: the reference's golden G / read-out (1e-5) and the separate operators to fp32 rounding (their GEMM walks K in
-    a different order); split-bf16 mode: fp32-class (2e-5 of the output scale).  Repeated launches, grids of 1..256 workgroups, a dense adjacency (every ELL slot
+    a different order); split-bf16 mode: fp32-class (2e-5 of the output scale).  Repeated launches, grids of 1..64 workgroups (256 is clamped to a quarter of the CUs), a dense adjacency (every ELL slot
     full) and a single-class graph."""
     g = H.load_golden("image_gcn.npz")
     adjg = H.load_golden("adjacency.npz")
