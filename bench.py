@@ -555,10 +555,21 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
     add("bilstm (whole op: pack + 2 input GEMMs + 2 recurrences)", lstm_key, mfma,
         34.8e6 * B, "34.8 MFLOP/sample; sequential over <=T steps: latency-bound, not an MFMA-roofline kernel")
     for C, nm in ((cfg.C_obj, "object"), (cfg.C_place, "place")):
+        add("label_gcn (%s graph, C=%d): gen_adj + 2 GraphConvolutions + w_q, one persistent launch" % (nm, C),
+            ("mgnns_label_gcn_fwd", C, bf), mfma, 2.0 * C * (D * 1024 + 1024 * 2048) + 2.0 * 7 * D * D,
+            "64 workgroups, three grid barriers: a latency chain (DESIGN.md section 4), not an MFMA-roofline kernel; "
+            "split-bf16 operands in bf16 mode (3 MFMAs per product, not counted)")
+        if bf:
+            add("label_tail_bf16 (%s channel, C=%d): read-out + label attention + maps + next query, one launch" % (nm, C),
+                ("mgnns_label_tail_bf16_fwd", C), "mfma_bf16",
+                B * 2.0 * (2048 * C + 2 * C * D + 7 * D * 100 + 700 * D + D * H * dk),
+                "4-workgroup clusters per 16 samples, split-bf16 operands (3 MFMAs per product, not counted); bound by "
+                "streaming the packed weights from L2, not by the matrix pipe")
         for F in (1024, 2048):
             nnz = int((np.asarray(getattr(model, nm + "_A").detach().cpu()) != 0).sum())
             add("spmm_csr (%s graph, F=%d)" % (nm, F), ("mgnns_spmm_csr_fwd", C, F), "hbm", nnz * 8.0 + 2.0 * C * F * 4,
-                "nnz*8 + 2*C*F*4 B; model-scale graphs are launch-bound (see `stress` for the 10k-node figure)")
+                "nnz*8 + 2*C*F*4 B; the separate operator, timed beside the forward (the forward runs the label GCN as one "
+                "persistent launch); model-scale graphs are launch-bound (see `stress` for the 10k-node figure)")
     return rows
 
 
@@ -670,6 +681,7 @@ def run_rank(args):
                 gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
                 fwd = sf
                 launch = "hipGraph replay" + (" + RCCL all-gather behind it" if dist is not None else "")
+            launch += " [%s%s]" % (gf.mode, "; auto timed %s ms" % gf.pick_ms if gf.pick_ms else "")
         out = {}
 
         def step():
@@ -700,6 +712,9 @@ def run_rank(args):
     with torch.no_grad():
         for _ in range(min(args.steps, 10)):
             model(*call)
+        for _ in range(3):          # the label GCN as separate operators (gen_adj / GEMM / CSR SpMM): their own roofline rows
+            model._label_gcn(model.object_A, call[5])
+            model._label_gcn(model.place_A, call[6])
     torch.cuda.synchronize()
     model.use_streams = not args.single_stream
     ops.set_timer(None)
