@@ -400,7 +400,8 @@ int mgnns_debug_spin(int microseconds, uint64_t* slots, int idx, mgnns_stream_t 
  *   one process per GPU:  rank 0 calls mgnns_comm_unique_id and ships the 128 bytes to the other ranks by any host channel
  *                         (a torch.distributed store, MPI, a file); every rank, with its device current, calls
  *                         mgnns_comm_init_rank (collective: returns when all ranks have joined);
- *   one process, n GPUs:  mgnns_comm_init_all(n, devices or NULL for 0..n-1, comms[n]).
+ *   one process, n GPUs:  mgnns_comm_init_all(n, devices or NULL for 0..n-1, comms[n]); a single thread that issues the
+ *                         all-gathers of several devices brackets them with mgnns_comm_group_start / _end.
  * mgnns_allgather_logits enqueues on `stream` (no host sync; capturable into a hipGraph); `all` is
  * [world * rows_local, num_labels] in rank order; every rank passes the same rows_local.
  */
@@ -410,6 +411,8 @@ int mgnns_comm_init_all(int ndev, const int* devices, mgnns_comm_t* comms);
 int mgnns_comm_info(mgnns_comm_t comm, int* world, int* rank);
 int mgnns_allgather_logits(mgnns_comm_t comm, const float* local, int rows_local, int num_labels, float* all,
                            mgnns_stream_t stream);
+int mgnns_comm_group_start(void);   /* one thread driving several communicators brackets its per-device all-gathers with these */
+int mgnns_comm_group_end(void);
 int mgnns_comm_destroy(mgnns_comm_t comm);
 
 #ifdef __cplusplus

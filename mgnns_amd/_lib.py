@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c = ctypes
 _P = _c.c_void_p
@@ -66,6 +66,8 @@ SIGNATURES = {
     "mgnns_comm_init_all": [_I, _P, _PP],
     "mgnns_comm_info": [_P, _c.POINTER(_I), _c.POINTER(_I)],
     "mgnns_allgather_logits": [_P, _P, _I, _I, _P, _P],
+    "mgnns_comm_group_start": [],
+    "mgnns_comm_group_end": [],
     "mgnns_comm_destroy": [_P],
 }
 

@@ -24,6 +24,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char why[256] = "";
 };
@@ -60,6 +62,8 @@ Rccl* rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         if (!ok) r.handle = nullptr;
         if (!r.handle) g_rccl_why = r.why;
@@ -137,6 +141,21 @@ extern "C" int mgnns_allgather_logits(mgnns_comm_t comm, const float* local, int
     MG_RCCL(R->AllGather(local, all, (size_t)rows_local * num_labels, ncclFloat32, reinterpret_cast<ncclComm_t>(comm),
                          (hipStream_t)stream),
             "ncclAllGather");
+    return 0;
+}
+
+// One thread driving several communicators (mgnns_comm_init_all) brackets its per-device all-gathers with these, as RCCL
+// requires for multi-device calls from a single thread; one process per GPU does not need them.
+extern "C" int mgnns_comm_group_start(void) {
+    Rccl* R = rccl();
+    if (!R) { mgnns_set_error("mgnns_comm_group_start: %s", rccl_why()); return MGNNS_ERR_UNSUPP; }
+    MG_RCCL(R->GroupStart(), "ncclGroupStart");
+    return 0;
+}
+extern "C" int mgnns_comm_group_end(void) {
+    Rccl* R = rccl();
+    if (!R) { mgnns_set_error("mgnns_comm_group_end: %s", rccl_why()); return MGNNS_ERR_UNSUPP; }
+    MG_RCCL(R->GroupEnd(), "ncclGroupEnd");
     return 0;
 }
 

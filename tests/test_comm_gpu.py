@@ -57,8 +57,10 @@ def test_init_all_single_process_form_and_argument_errors():
     assert (w.value, r.value) == (1, 0)
     x = torch.arange(12, device=DEV, dtype=torch.float32).view(4, 3)
     y = torch.empty_like(x)
+    _lib.check(L.mgnns_comm_group_start(), "mgnns_comm_group_start")          # the single-thread multi-device form
     _lib.check(L.mgnns_allgather_logits(h[0], x.data_ptr(), 4, 3, y.data_ptr(), torch.cuda.current_stream().cuda_stream),
                "mgnns_allgather_logits")
+    _lib.check(L.mgnns_comm_group_end(), "mgnns_comm_group_end")
     torch.cuda.synchronize()
     assert torch.equal(x, y)
     assert L.mgnns_allgather_logits(None, x.data_ptr(), 4, 3, y.data_ptr(), None) == -1
