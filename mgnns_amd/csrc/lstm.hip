@@ -320,6 +320,89 @@ __global__ __launch_bounds__(256) void lstm_gather_cast_kernel(const float* __re
         uint4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
 }
 
+// bf16 mode, B <= 1024: pack + fill + gather as ONE launch.  lstm_pack_kernel is a single workgroup that every other
+// launch of the text bank waits for (9 us alone, 16-18 us inside a replay), then lstm_fill and lstm_gather_cast follow as two
+// more dependent launches -- at the head of the chain that decides the forward below 128 samples.  Here workgroup b derives ITS
+// offset (sum of the lengths in front of it), ITS rank in the longest-first order and the total straight from the length
+// vector (B * 8 bytes, L2 resident after the first workgroup), then writes its rows of pack_tok / pack_pos and gathers + casts
+// its embedding rows (the layer-0 projection's bf16 A operand).  Same results as the three kernels, bit for bit.
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+constexpr int PREP_THR = 256;
+constexpr int PREP_MAXT = 1024;
+__global__ __launch_bounds__(PREP_THR) void lstm_prep_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ lens, int B,
+                                                            int T, int V, const float* __restrict__ X, int K,
+                                                            int32_t* __restrict__ offs, int32_t* __restrict__ order,
+                                                            int32_t* __restrict__ pack_tok, int32_t* __restrict__ pack_pos,
+                                                            unsigned short* __restrict__ Xb) {
+    __shared__ int s_len[1024];
+    __shared__ int s_tok[PREP_MAXT];
+    __shared__ int s_red[3][PREP_THR / 64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int i = tid; i < B; i += PREP_THR) {
+        const long long l = lens[i];
+        s_len[i] = (int)(l < 0 ? 0 : (l > T ? T : l));
+    }
+    __syncthreads();
+    const int len = s_len[b];
+    int off = 0, rank = 0, total = 0;
+    for (int i = tid; i < B; i += PREP_THR) {
+        const int li = s_len[i];
+        total += li;
+        off += i < b ? li : 0;
+        rank += (li > len) || (li == len && i < b);
+    }
+    off = wave_sum_i(off); rank = wave_sum_i(rank); total = wave_sum_i(total);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = off; s_red[1][tid >> 6] = rank; s_red[2][tid >> 6] = total; }
+    for (int t = tid; t < len; t += PREP_THR) {                     // this sample's token ids (clamped like lstm_fill)
+        long long id = tok[(size_t)b * T + t];
+        s_tok[t] = (int)(id < 0 ? 0 : (id >= V ? V - 1 : id));
+    }
+    __syncthreads();
+    off = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    rank = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    total = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+    if (tid == 0) {
+        offs[b] = off;
+        order[rank] = b;
+        if (b == 0) offs[B] = total;
+    }
+    if (b == 0 && tid < 8) order[B + tid] = 0;                      // chain queues of the persistent recurrence
+    for (int t = tid; t < len; t += PREP_THR) {
+        pack_tok[off + t] = s_tok[t];
+        pack_pos[off + t] = b * T + t;
+    }
+    // gather + cast: (row, 8-column chunk) items, four in flight per thread
+    constexpr int per = XKP / 8;
+    const int items = len * per;
+    for (int i0 = tid; i0 < items; i0 += 4 * PREP_THR) {
+        f32x4 q[4][2];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PREP_THR;
+            const int ic = i < items ? i : items - 1;                // clamped: the loads stay unconditional
+            rr[u] = ic / per;
+            cc[u] = (ic - rr[u] * per) * 8;
+            const float* src = X + (size_t)s_tok[rr[u]] * K + cc[u];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                q[u][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cc[u] + 4 * h + 4 <= K) q[u][h] = *reinterpret_cast<const f32x4*>(src + 4 * h);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * PREP_THR < items)
+                *reinterpret_cast<uint4*>(Xb + (size_t)(off + rr[u]) * XKP + cc[u]) =
+                    uint4{pack2_bf16(q[u][0][0], q[u][0][1]), pack2_bf16(q[u][0][2], q[u][0][3]), pack2_bf16(q[u][1][0], q[u][1][1]),
+                          pack2_bf16(q[u][1][2], q[u][1][3])};
+    }
+}
+
 // W_hh of both directions in the register layout of the kernel below: packed[((dir * MW + wave) * MKS + ks) * 64 + lane] =
 // the four bf16 weights W'[64 wave + lane][4 ks .. 4 ks + 3] (gate rows permuted to n' = 4 unit + gate), so a workgroup
 // fetches its 194 KB with 38 coalesced 8-byte loads per lane instead of 152 strided scalar ones.
@@ -555,8 +638,15 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
         MG_REQUIRE(2 * num_layers <= 8, "mgnns_bilstm_bf16_fwd: num_layers=%d unsupported (<= 4)", num_layers);
     }
 
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
-    hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
+    // bf16 mode, up to 1024 samples of up to 1024 tokens: pack + fill + the layer-0 gather as one launch
+    const bool prep_fused = bf16_rec && B <= 1024 && T <= PREP_MAXT && emb_dim % 4 == 0 && emb_dim <= XKP;
+    if (prep_fused) {
+        hipLaunchKernelGGL(lstm_prep_kernel, dim3(B), dim3(PREP_THR), 0, s, tok, lens, B, T, V, emb_table, emb_dim, offs, order, pack_tok,
+                           pack_pos, xb);
+    } else {
+        hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
+        hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
+    }
     for (int layer = 0; layer < num_layers; ++layer) {
         const float* X = layer == 0 ? emb_table : mid;
         const int K = layer == 0 ? emb_dim : 2 * HID;
@@ -568,7 +658,7 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
         if (bf16_rec && K % 4 == 0 && K <= XKP) {
             // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42.
             // Layer 0 gathers + casts the embedding rows; the later layers find their operand written by the recurrence below.
-            if (layer == 0)
+            if (layer == 0 && !prep_fused)
                 hipLaunchKernelGGL(lstm_gather_cast_kernel, dim3((unsigned)((rows * (XKP / 8) + 255) / 256)), dim3(256), 0, s, X, K, gidx,
                                    (const int32_t*)(offs + B), (int)rows, xb);
             const void* wih = wb;

@@ -21,8 +21,6 @@ from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention
                      first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
-_EXP = os.environ.get("MGNNS_EXP_NO_TAIL_DEP") == "1"
-_EXP_LGCN = os.environ.get("MGNNS_EXP_CACHE_LGCN") == "1"
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
 
 
@@ -541,9 +539,6 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "banks_serial": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                          ("bank_place+bank_obj", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                          ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
-        "exp_stacks_before_tails": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
-                     ("bank_place", "s2"), ("tio", "main"), ("tip", "s3"), ("iot", "s1"), ("ipt", "s2"),
-                     ("tail_obj", "s1"), ("tail_place", "s2"), ("head+tail_obj+tail_place", "main")],
         "tails_first_obj": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                             ("bank_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"), ("tip", "s3"),
                             ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
@@ -613,25 +608,14 @@ class Multi_GCN_Multihead_Att(nn.Module):
                     ctx['Gp_' + tag] = Gp
                 ops.stamp("  label GCN end")
 
-            if self.fused_label_gcn and not _EXP_LGCN:
+            if self.fused_label_gcn:
                 return run_fused
 
             def run():
-                if _EXP_LGCN:        # timing experiment only: what the forward costs with the label GCN off the schedule
-                    hit = getattr(self, '_exp_lgcn', {}).get(tag)
-                    if hit is not None:
-                        ctx['Q_' + tag], ctx['G_' + tag] = hit[0], hit[1]
-                        if fused_bf16:
-                            ctx['Gp_' + tag] = hit[2]
-                        return
                 ctx['Q_' + tag] = self._label_q(attention)       # batch independent: off the critical path, with the GCN
                 ctx['G_' + tag] = self._label_gcn(A, inp)
                 if fused_bf16:                                   # its fragment-major bf16 image for the fused tail's read-out
                     ctx['Gp_' + tag] = ops.pack_weight_bf16_split(ctx['G_' + tag])
-                if _EXP_LGCN:
-                    if not hasattr(self, '_exp_lgcn'):
-                        self._exp_lgcn = {}
-                    self._exp_lgcn[tag] = (ctx['Q_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag))
             return run
 
         def bank(tag, trunk, feature, lin):
@@ -685,19 +669,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
             "tio": stack("tio", self.text_img_object_multi_head_att, 'text_feature', 'bank_obj', False),
             "tip": stack("tip", self.text_img_place_multi_head_att, 'text_feature', 'bank_place', False),
             # image->text stacks need the text bank (and the mask cast next to it) and the channel's tail
-            "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj' if not _EXP else 'text_feature', 'text_bank', True),
-            "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place' if not _EXP else 'text_feature', 'text_bank', True),
+            "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj', 'text_bank', True),
+            "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place', 'text_bank', True),
             "head": head,
         }
         sched = self.SCHEDULES[self.resolve_schedule(text.shape[0], schedule)]
-        if _EXP:
-            sched = [(e, k) for e, k in sched]
         where, plan = {}, []
         for entry, skey in sched:
             name, *extra = entry.split("+")          # "seg+other": also wait for `other` (ordering only, no data)
             deps = tuple(self.SEGMENT_DEPS[name]) + tuple(extra)
-            if _EXP and name in ("iot", "ipt"):
-                deps = ("text_bank", "text_gcn")          # TIMING EXPERIMENT ONLY: wrong query, no wait for the channel tail
             for d in deps:
                 if d not in where:
                     raise ValueError("schedule runs %s before %s" % (name, d))
