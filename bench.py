@@ -680,7 +680,7 @@ def run_rank(args):
             if gf is None:
                 gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
                 fwd = sf
-                launch = "hipGraph replay" + (" + RCCL all-gather behind it" if dist is not None else "")
+                launch = "hipGraph replay" + ((" + %s all-gather behind it" % ("RCCL" if backend == "nccl" else backend)) if dist is not None else "")
             launch += " [%s%s]" % (gf.mode, "; auto timed %s ms" % gf.pick_ms if gf.pick_ms else "")
         out = {}
 

@@ -1,10 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-one() { python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', l['value'], l['ms_per_step'], l.get('max_abs_logit_diff_vs_cpu_oracle'))"; }
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -k "lstm or forward or graph or pipeline" > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -4
-for i in 1 2; do
-for b in 32 64 256; do
-timeout 300 python bench.py --batch $b --no-variants --no-cpu-baseline --steps 50 --warmup 10 2>gpurun_out/s.err | one B$b
-done
-done
-timeout 200 python tools/bench_kernels.py lstm 2>&1 | tail -6
+MGNNS_FORCE_DIST=1 timeout 600 python bench.py --no-variants --no-cpu-baseline > gpurun_out/d1.json 2> gpurun_out/d1.err; echo "dist1 rc=$?"; tail -c 300 gpurun_out/d1.err; cut -c1-700 gpurun_out/d1.json
+MGNNS_BENCH_BACKEND=gloo MGNNS_BENCH_SAME_GPU=1 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/two.json 2> gpurun_out/two.err; echo "two-rank rc=$?"; tail -c 300 gpurun_out/two.err; python -c "
+import json; l=json.loads(open('gpurun_out/two.json').read().strip().splitlines()[-1]); print(l['n_gpus'], l['value'], l['ms_per_step'], l['config']['launch'], l.get('weak_scaling',{}).get('ms_per_step'), l.get('strong_scaling',{}).get('ms_per_step'), l.get('strong_scaling',{}).get('per_gpu_batch'))"
