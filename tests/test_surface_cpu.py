@@ -69,3 +69,34 @@ def test_pmi_csr_matches_dense_lookup():
     import scipy.sparse as sp
     m2 = PmiCsr.coerce(sp.csr_matrix(dense))
     assert np.array_equal(m2.col, m.col) and np.array_equal(m2.eid, m.eid)
+
+
+def test_every_schedule_is_a_valid_plan_without_a_gpu():
+    """forward_plan only builds closures: every schedule must run each of the 13 segments exactly once, after the segments
+    it depends on, on one of the four stream keys; cross-stream dependencies are exactly the data dependencies that live
+    on another stream; 'auto' resolves by batch size; unknown names raise."""
+    cfg = synth.CONFIGS["mvsa_single_b8"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    adj = H.load_golden("adjacency.npz")
+    m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], np.zeros((7, 300), np.float32))
+    inp = synth.make_inputs(cfg, B=2, pmi=pmi)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    args = (t["text"], t["text_lens"], t["text_mask"], t["object_feature"], t["place_feature"], t["object_inp"], t["place_inp"])
+    assert m.schedule == "auto" and m.resolve_schedule(2) == "channels2" and m.resolve_schedule(128) == "channels"
+    for name, sched in m.SCHEDULES.items():
+        plan, ctx = m.forward_plan(*args, schedule=name)
+        assert ctx == {}                                              # nothing ran
+        seen = {}
+        for seg, skey, cross, fn in plan:
+            assert callable(fn) and skey in ("main", "s1", "s2", "s3"), (name, seg, skey)
+            base = seg.split("+")[0]
+            assert base == seg and base not in seen, (name, seg)
+            for d in m.SEGMENT_DEPS[base]:
+                assert d in seen, (name, seg, d)
+            want = {d for d in m.SEGMENT_DEPS[base] if seen[d] != skey}
+            assert want <= set(cross) and all(seen[d] != skey for d in cross), (name, seg, cross)
+            seen[base] = skey
+        assert set(seen) == set(m.SEGMENT_DEPS), name
+        assert plan[-1][0] == "head" and plan[-1][1] == "main", name
+    with pytest.raises(ValueError):
+        m.forward_plan(*args, schedule="no-such-schedule")
