@@ -181,11 +181,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
 // Large graphs (X = [n_rows, F] well beyond one XCD's 4-MiB L2): the same product walked in feature SLABS of 64
 // floats.  A slab of X is n_rows x 256 B (2.5 MB at 10 000 nodes) and stays resident in the L2 of the XCD that works
 // on it, so every gather after the first touch of a row segment is an L2 hit and X crosses the fabric once instead of
-// once per non-zero.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx & 7 = XCD), slab s belongs to
-// XCD s & 7.  A wave handles four rows at a time (16 lanes x 16 B = one 256-B row segment each), up to four
+// once per non-zero.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx & 7 = XCD), XCD x owns the adjacent
+// slabs [x * spx, (x + 1) * spx).  A wave handles four rows at a time (16 lanes x 16 B = one 256-B row segment each), up to four
 // gathers per lane in flight, non-zeros in ascending order exactly like spmm_csr_kernel.
-// LPR lanes x 16 B = one row segment (slab width 4 * LPR floats); a pass walks NS slabs (s, s + 8, ...) of the XCD at
-// once with ONE fetch of the row's col / val for all of them; RU independent rows per lane group.
+// LPR lanes x 16 B = one row segment (slab width 4 * LPR floats); a pass walks NS adjacent slabs of the XCD at once with
+// ONE fetch of the row's col / val for all of them; RU independent rows per lane group.
+// What bounds it cache-cold (tools/dev/spmm_exp2.py, N = 10 000, F = 1024, a copy of the same bytes: 17.4 us = 4.70 TB/s):
+// the identity graph 16.8 us, a random permutation (one random gather per row) 17.7 us -- the kernel streams at copy speed
+// and random first touches cost nothing extra; four gathers per row inside a band (re-reads hit the CU's L1) 19.8 us; four
+// RANDOM gathers per row 24.8 us, the 4e-4 random graph (Poisson row lengths) 27.3 us: the loss is the ~3 re-reads of every
+// X row, which are L2 / Infinity-Cache hits, not free ones (X = 41 MB does not fit the 32 MB of L2 on the chip).
 template <int LPR, int NS, int RU>
 __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
@@ -198,13 +203,18 @@ __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __res
     const int lane = threadIdx.x & 63, g = lane / LPR, l = lane % LPR;
     const int wave = bj * 4 + (threadIdx.x >> 6), nwaves = nb * 4;
     const int nslabs = (F + SW - 1) / SW;
-    for (int slab0 = xcd; slab0 < nslabs; slab0 += 8 * NS) {
+    const int spx = (nslabs + 7) / 8;           // slabs per XCD
+    // XCD x owns the ADJACENT slabs [x * spx, (x + 1) * spx): the NS slabs of a pass are one contiguous NS * 256-B piece of
+    // every gathered row.  (Round 1 gave slab s to XCD s & 7, i.e. pieces 2 KB apart: 29.1 / 55.9 us cache-cold at N = 10 000,
+    // F = 1024 / 2048 against 27.3 / 50.9 us with adjacent slabs, two per pass and 384 workgroups per XCD.)
+    for (int slab0 = xcd * spx; slab0 < (xcd + 1) * spx && slab0 < nslabs; slab0 += NS) {
         int f[NS];
         bool fon[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            f[q] = (slab0 + 8 * q) * SW + l * 4;
-            fon[q] = slab0 + 8 * q < nslabs && f[q] < F;
+            const int sl = slab0 + q;
+            f[q] = sl * SW + l * 4;
+            fon[q] = sl < nslabs && sl < (xcd + 1) * spx && f[q] < F;
         }
         for (int r0 = wave * GPW * RU; r0 < n_rows; r0 += nwaves * GPW * RU) {
             int p[RU], hi[RU], row[RU];
@@ -318,14 +328,15 @@ extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, co
         // slabs per XCD walked in ONE pass share a single fetch of the row's col / val (measured at 10 000 nodes: two slabs
         // per pass 20.1 us vs 24.2 us one at a time at F = 1024; four per pass 46.9 us vs 48.9 us at F = 2048)
         const int spx = ((F + 63) / 64 + 7) / 8;
-        const dim3 grid(8 * 192), blk(256);
+        // two adjacent slabs per pass (512 contiguous bytes of every gathered row), 384 workgroups per XCD (12 per CU: the
+        // gathers are latency bound, occupancy is what keeps bytes in flight); four slabs per pass or two rows per lane
+        // group were slower cache-cold (F = 2048: 53.1 / 57.9 us against 50.9)
+        const dim3 blk(256);
         hipStream_t st = (hipStream_t)stream;
-        if (spx >= 4)
-            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 4, 1>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
-        else if (spx >= 2)
-            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 2, 1>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+        if (spx >= 2)
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 2, 1>), dim3(8 * 384), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
         else
-            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 1, 2>), grid, blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 1, 2>), dim3(8 * 192), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
         MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
         return 0;
     }

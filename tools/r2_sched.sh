@@ -1,5 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out
-MGNNS_FORCE_DIST=1 timeout 600 python bench.py --no-variants --no-cpu-baseline > gpurun_out/d1.json 2> gpurun_out/d1.err; echo "dist1 rc=$?"; tail -c 300 gpurun_out/d1.err; cut -c1-700 gpurun_out/d1.json
-MGNNS_BENCH_BACKEND=gloo MGNNS_BENCH_SAME_GPU=1 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/two.json 2> gpurun_out/two.err; echo "two-rank rc=$?"; tail -c 300 gpurun_out/two.err; python -c "
-import json; l=json.loads(open('gpurun_out/two.json').read().strip().splitlines()[-1]); print(l['n_gpus'], l['value'], l['ms_per_step'], l['config']['launch'], l.get('weak_scaling',{}).get('ms_per_step'), l.get('strong_scaling',{}).get('ms_per_step'), l.get('strong_scaling',{}).get('per_gpu_batch'))"
+timeout 600 python -m pytest tests/test_stress_gpu.py tests/test_ops_gpu.py -x -q -k "stress or spmm" > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -3
+timeout 300 python tools/bench_stress.py 2>/dev/null | tail -1 > gpurun_out/r02_stress_gcn.json; python -c "
+import json; d=json.load(open('gpurun_out/r02_stress_gcn.json'))
+for k,v in d.items():
+    if isinstance(v,dict) and 'cold_ms' in v: print(k, v['cold_ms'], v.get('cold_GBps'), v.get('frac_of_8TBps'), v.get('warm_ms_same_buffers'), v.get('copy_cold_GBps'))
+"
