@@ -48,7 +48,7 @@ def test_folded_attention_forward_matches_reference_golden_logits(cfg_name, prec
     if precision == "fp32":
         assert err < TOL
     else:
-        assert err < 5e-2
+        assert err < 2e-2          # measured 7e-3 - 1.3e-2 on the golden batches (bf16 operands carry ~3 digits)
         assert (logits.cpu().argmax(1) == torch.as_tensor(g["logits"]).argmax(1)).float().mean() > 0.97
 
 
@@ -99,7 +99,7 @@ def test_bf16_precision_mode_is_close_and_reports_error():
     logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV)).cpu()
     err = H.maxabs(logits, g["logits"])
     print("bf16 mode max|logit diff| vs fp32 reference: %.3e" % err)
-    assert err < 5e-2
+    assert err < 2e-2              # measured 9.7e-3 on the golden batch, 1.5e-2 over the B=256 bench batch (its own, looser, report in bench.py)
     assert torch.equal(logits.argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
 

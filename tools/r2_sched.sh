@@ -1,7 +1,9 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_stress_gpu.py tests/test_ops_gpu.py -x -q -k "stress or spmm" > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -3
-timeout 300 python tools/bench_stress.py 2>/dev/null | tail -1 > gpurun_out/r02_stress_gcn.json; python -c "
-import json; d=json.load(open('gpurun_out/r02_stress_gcn.json'))
-for k,v in d.items():
-    if isinstance(v,dict) and 'cold_ms' in v: print(k, v['cold_ms'], v.get('cold_GBps'), v.get('frac_of_8TBps'), v.get('warm_ms_same_buffers'), v.get('copy_cold_GBps'))
-"
+t() { timeout 300 python -m pytest tests/test_model_gpu.py -x -q -s -k "bf16_precision" 2>&1 | grep -E "max\|" | tail -1; }
+echo "default: $(t)"
+echo "tail>=96: $(MGNNS_FUSED_TAIL_BF16_MIN_BATCH=96 t)"
+echo "lgcn unfused: $(MGNNS_FUSED_LABEL_GCN=0 t)"
+echo "head unfused: $(MGNNS_FUSED_HEAD=0 t)"
+echo "cluster off: $(MGNNS_LABEL_TAIL_CLUSTER=0 t)"
+echo "all old: $(MGNNS_FUSED_TAIL_BF16_MIN_BATCH=96 MGNNS_FUSED_LABEL_GCN=0 MGNNS_FUSED_HEAD=0 t)"
+echo "lstm f32: $(MGNNS_LSTM_REC=f32 t)"
