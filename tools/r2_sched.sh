@@ -1,5 +1,6 @@
 #!/bin/bash
-export MGNNS_LIB=mgnns_amd/variants/lib_spmmexp.so
-for e in "16 2 1 384" "8 4 1 384" "8 4 1 256" "8 2 1 384" "4 8 1 256" "4 4 1 384" "8 8 1 256" "8 4 2 256" "16 4 1 384"; do
-MGNNS_SPMM_EXP="$e" timeout 100 python tools/dev/spmm_exp.py 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "mha or fused_layer" > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -5
+for v in v2 v1 v2 v1; do
+if [ $v = v1 ]; then export MGNNS_LIB=mgnns_amd/variants/lib_v1.so; else unset MGNNS_LIB; fi
+echo "== $v"; timeout 200 python tools/bench_kernels.py mha_bf16 2>&1 | grep "sq_mha" | head -3
 done
