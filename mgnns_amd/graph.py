@@ -7,7 +7,7 @@ launch.  Inputs live in static device buffers that the caller (or `copy_inputs`)
 
 Two capture modes:
 
-* ``mode="segments"`` (default): the model's forward_plan() -- 11 segments, each a LINEAR chain of launches on one of
+* ``mode="segments"`` (default): the model's forward_plan() -- 13 segments, each a LINEAR chain of launches on one of
   four streams -- is captured as one linear hipGraph per segment; a replay launches them on the model's four streams
   with the plan's event waits in between.  Who runs concurrently with whom is then decided by four in-order HIP
   streams, exactly as in eager execution, at ~11 graph launches per forward instead of ~130 kernel launches.
@@ -28,7 +28,10 @@ class GraphedForward:
         all-gather becomes a node of the last graph)."""
         self.model = model
         self.pick_ms = None
-        self.mode = mode or os.environ.get("MGNNS_GRAPH_MODE", "auto")
+        # default 'segments': with ~33 launches per forward it beat the one-graph form at every batch size measured in round 2
+        # (B=256: 0.86 vs 0.96 ms, B=32: 0.49 vs 0.53), and the one-graph capture is where the runtime can segfault (below);
+        # 'auto' still times both
+        self.mode = mode or os.environ.get("MGNNS_GRAPH_MODE", "segments")
         if self.mode not in ("segments", "single", "auto"):
             raise ValueError("mode must be 'segments', 'single' or 'auto'")
         if self.mode == "auto" and post is not None:

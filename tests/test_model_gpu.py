@@ -142,13 +142,17 @@ def test_every_schedule_gives_the_same_logits_eager_and_graphed():
     ref = model(*a).clone()
     model.use_streams = True
     for name in sorted(model.SCHEDULES):
-        if name.startswith("exp_"):
-            continue
         model.schedule = name
         assert torch.equal(model(*a), ref), name
         gf = GraphedForward(model, a)
-        assert gf.mode == "segments" or name == "channels", (name, gf.mode)
+        assert gf.mode == "segments", (name, gf.mode)                  # the default
         assert torch.equal(gf.replay(), ref), name
+        ga = GraphedForward(model, a, mode="auto")                      # times both forms -- only for 'channels'
+        assert (ga.pick_ms is not None) == (name == "channels"), (name, ga.mode, ga.pick_ms)
+        assert torch.equal(ga.replay(), ref), name
+    model.schedule = "channels"
+    gs = GraphedForward(model, a, mode="single")
+    assert gs.mode == "single" and torch.equal(gs.replay(), ref)
     model.schedule = "nope"
     with pytest.raises(ValueError):
         model(*a)

@@ -1,6 +1,7 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "mha or fused_layer" > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -5
-for v in v2 v1 v2 v1; do
-if [ $v = v1 ]; then export MGNNS_LIB=mgnns_amd/variants/lib_v1.so; else unset MGNNS_LIB; fi
-echo "== $v"; timeout 200 python tools/bench_kernels.py mha_bf16 2>&1 | grep "sq_mha" | head -3
+mkdir -p gpurun_out
+one() { python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', l['value'], l['ms_per_step'], l['config']['launch'][:50])"; }
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q > gpurun_out/t.log 2>&1; grep -E "passed|failed|rror" gpurun_out/t.log | tail -3
+for b in 256 32; do
+timeout 300 python bench.py --batch $b --no-variants --no-cpu-baseline 2>gpurun_out/s.err | one B$b
 done
