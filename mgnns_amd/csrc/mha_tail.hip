@@ -332,8 +332,11 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_bf16_fwd: needs %zu B of LDS", lds);
     MG_DYN_LDS(mha_tail_bf16_kernel<1>, 160 * 1024);
     MG_DYN_LDS(mha_tail_bf16_kernel<3>, 160 * 1024);
-    // with a next-layer projection: four workgroups per 16-sample tile (MGNNS_TAIL_CLUSTER overrides: 1 = none)
-    int cl = packed[6] ? 4 : 1;
+    // with a next-layer projection: a cluster of workgroups per 16-sample tile, each recomputing the front part and taking a
+    // share of the projection (MGNNS_TAIL_CLUSTER overrides: 1 = none).  Four while the chip has CUs to spare; TWO from 256
+    // samples on, where the forward is bound by CU time and 64 workgroups x 21 us cost more than the shorter chain returns
+    // (B=256: 0.811-0.820 ms per forward with 2, 0.830 with 4; B=128: equal; B=64: 0.453-0.458 with 4, 0.464-0.467 with 2)
+    int cl = packed[6] ? (B >= 256 ? 2 : 4) : 1;
     if (const char* e = getenv("MGNNS_TAIL_CLUSTER")) cl = packed[6] ? atoi(e) : 1;
     if (cl < 1) cl = 1;
     if (cl > 8) cl = 8;
