@@ -125,6 +125,31 @@ int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float*
 int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
                        const float* X, int F, float* Y, int act, mgnns_stream_t stream);
 
+/* ---- a3/a4 at BASELINE configs[4] scale: bf16-feature sparse propagation ---------------------------------
+ * Y[i,:] = act(sum_p val[p] * X[col[p],:]) as above (MODEL:54, adjacency of UTIL:421-426 held sparse) with the
+ * adjacency values and X in bf16, fp32 accumulation in ascending column order, Y bf16 (y_bf16 = 1) or fp32.
+ * Algorithmic bytes: nnz * (4 + 2) + n_cols * F * 2 + n_rows * F * 2.  X must be finite.
+ *
+ * mgnns_spmm_csr_bf16_fwd: one gather per non-zero from the XCD's L2 (feature slabs of 128 owned by XCDs); the path for
+ *   PMI-like graphs (a few non-zeros per row).  F % 8 == 0; nnz = row_ptr[n_rows]; val_bf16 must be readable up to an
+ *   even number of elements (the values travel as aligned dwords).  variant = 0 (default: the pipelined ring form) or a
+ *   sweep code selecting one of the three kernel forms and its launch geometry (csrc/spmm_bf16.hip, tools/dev).
+ * mgnns_spmm_tiled_bf16_fwd: dense-ish graphs (tens of non-zeros per row): X staged through LDS tiles of `tile_cols`
+ *   columns by LDS-DMA, a workgroup of 16 waves owns 16 * rows_per_wave rows x 32 * lane_bytes features of Y in
+ *   registers.  The adjacency comes as the one-off re-ordered stream of mgnns_amd/spmm_plan.py (format documented
+ *   there): wave_off [(ceil(n_rows / (16 rows_per_wave)) * 16) * (ceil(n_cols / tile_cols) + 1)] uint32, ent uint32
+ *   (64 dwords of slack at the end).  Built geometries (lane_bytes, rows_per_wave, tile_cols): (8, 10, 128),
+ *   (8, 20, 128), (4, 10, 256), (4, 20, 256).  F % (32 lane_bytes) == 0.
+ * mgnns_cast_bf16: fp32 -> bf16 (round to nearest even), n elements (adjacency values, features).
+ */
+int mgnns_cast_bf16(const float* src, long long n, void* dst_bf16, mgnns_stream_t stream);
+int mgnns_spmm_csr_bf16_fwd(const int32_t* row_ptr, const int32_t* col, const void* val_bf16, int n_rows, int nnz,
+                            const void* X_bf16, int F, void* Y, int y_bf16, int act, int variant,
+                            mgnns_stream_t stream);
+int mgnns_spmm_tiled_bf16_fwd(const uint32_t* wave_off, const uint32_t* ent, int lane_bytes, int rows_per_wave,
+                              int tile_cols, int n_rows, int n_cols, const void* X_bf16, int F, void* Y, int y_bf16,
+                              int act, mgnns_stream_t stream);
+
 /* ---- nn.Linear -------------------------------------------------------------------------------
  * Y[M,N] = act(X[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N]);  bias/residual may be NULL.
  * Serves every nn.Linear / Conv1d(k=1) on the path (MODEL:78-82,320-335; submodules.py:24-26,
@@ -324,12 +349,13 @@ int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, con
 
 /* ---- dense bf16 GEMM (BASELINE configs[4] (i): dense [N,N] adjacency x support on the bf16 MFMA; any large X.W) ------
  * C[M,N] = act(A[M,K] . Bt[N,K]^T + bias): A and Bt are bf16 with K-contiguous rows of Kp elements (Kp % 64 == 0, zero
- * padded: build A with mgnns_cast_pad_bf16, Bt from a [K,N] fp32 matrix with mgnns_transpose_cast_bf16), C fp32 with
- * row stride ldc.  N % 4 == 0, ldc % 4 == 0.  UTIL:421-426 (`adj @ support`), MODEL:52-58.
+ * padded: build A with mgnns_cast_pad_bf16, Bt from a [K,N] fp32 matrix with mgnns_transpose_cast_bf16), C fp32
+ * (c_bf16 = 0) or bf16 (c_bf16 = 1: the K-contiguous operand of the next product, no cast pass) with row stride ldc
+ * elements.  N % 4 == 0, ldc % 4 == 0.  UTIL:421-426 (`adj @ support`), MODEL:52-58.
  */
 int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int ld, void* y, mgnns_stream_t stream);
-int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc,
-                           int act, mgnns_stream_t stream);
+int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
+                           int c_bf16, int act, mgnns_stream_t stream);
 
 /* ---- f4 (metrics half): the evaluation tail after the logits (ENGINE:828-838) -------------------------------------
  * probs = softmax(logits, dim=1) (max-subtracted), pred = first arg-max of probs; when target (int64 [B]) and
@@ -384,6 +410,12 @@ int mgnns_sq_mha_layer_bf16_fwd(const float* qh, const void* bank_bf16, const fl
  * timeline of the concurrent branches of a replay (rocprofv3 serialises / perturbs them): tools/graph_timeline.py.
  */
 int mgnns_debug_stamp(uint64_t* slots, int idx, mgnns_stream_t stream);
+
+/* Access-pattern measurement aid (tools/dev/slabcopy_exp.py): copy / read / write a [n_rows, pitch] byte matrix in pieces of
+ * `piece` bytes dealt to XCDs the way the slab SpMM kernels deal their row segments (mode: 0 copy, 1 read, 2 write; +16 plain
+ * instead of non-temporal stores; +256 ignore XCDs).  wgx = workgroups per XCD. */
+int mgnns_debug_slabcopy(const void* src, void* dst, int n_rows, int pitch, int piece, int mode, int wgx,
+                         mgnns_stream_t stream);
 
 /* One thread that spins for `microseconds` of the same counter, then (slots != NULL) stamps slots[idx].  Used once per
  * process by mgnns_amd.streams to find HIP streams that sit on DIFFERENT hardware queues: a stamp on stream Y that lands

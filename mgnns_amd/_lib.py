@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c = ctypes
 _P = _c.c_void_p
@@ -29,6 +29,9 @@ SIGNATURES = {
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
     "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P, _SZ, _P],
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
+    "mgnns_cast_bf16": [_P, _c.c_longlong, _P, _P],
+    "mgnns_spmm_csr_bf16_fwd": [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
+    "mgnns_spmm_tiled_bf16_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _SZ, _P],
     "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_imgbank_pack_weights_bf16": [_P, _I, _I, _P, _P],
@@ -52,12 +55,13 @@ SIGNATURES = {
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
     "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
-    "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P],
+    "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "mgnns_conv_fold_bn_bf16": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P],
     "mgnns_stem_conv7_fwd": [_P, _I, _I, _I, _P, _P, _P, _P],
     "mgnns_maxpool3x3s2_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P],
     "mgnns_conv_bf16_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    "mgnns_debug_slabcopy": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mgnns_debug_stamp": [_P, _I, _P],
     "mgnns_debug_spin": [_I, _P, _I, _P],
     "mgnns_layernorm_fwd": [_P, _I, _I, _P, _P, _F, _P, _P],

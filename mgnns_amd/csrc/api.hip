@@ -32,7 +32,7 @@ int mg_ensure_dyn_lds(const void* fn, int bytes) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 9; }
+extern "C" int mgnns_abi_version(void) { return 10; }
 
 namespace {
 __global__ void stamp_kernel(unsigned long long* slots, int idx) { slots[idx] = __builtin_amdgcn_s_memrealtime(); }

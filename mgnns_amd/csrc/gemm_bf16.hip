@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
                                                                const unsigned short* __restrict__ Bt, int M, int N, int Kp,
                                                                const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                                int act, int nrb, int nct, int rps, int jmax,
-                                                               const int32_t* __restrict__ m_dev) {
+                                                               const int32_t* __restrict__ m_dev, int c_bf16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (m_dev) {                                                   // row count produced on the device (ragged batches): M is its bound
         const int md = *m_dev;
@@ -214,7 +214,17 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
                 acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m < M && n < N) *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+                if (m < M && n < N) {
+                    if (c_bf16) {                                  // C is a bf16 matrix (ldc in elements): the operand of the next product
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                    } else {
+                        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+                    }
+                }
             }
         }
         cj = next_valid(cj + jstep, cm0, cn0);
@@ -236,7 +246,7 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
 // internal launcher (also used by the bf16-mode LSTM input projections): m_dev != nullptr -> the row count is read on the
 // device and M is only its upper bound
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
-                        const int32_t* m_dev, hipStream_t stream) {
+                        const int32_t* m_dev, hipStream_t stream, int c_bf16) {
     MG_REQUIRE(A && Bt && C, "mgnns_gemm_bf16_nt_fwd: null pointer");
     MG_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && Kp > 0 && Kp % BK == 0 && ldc >= N && ldc % 4 == 0,
                "mgnns_gemm_bf16_nt_fwd: need N %% 4 == 0, Kp %% %d == 0, ldc %% 4 == 0 (M=%d N=%d Kp=%d ldc=%d)", BK, M, N, Kp, ldc);
@@ -261,12 +271,12 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     if (per_xcd > jmax) per_xcd = jmax;
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM_BYTES, stream,
                        reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
-                       ldc, act, nrb, nct, rps, jmax, m_dev);
+                       ldc, act, nrb, nct, rps, jmax, m_dev, c_bf16);
     MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd");
     return 0;
 }
 
-extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc,
-                                      int act, mgnns_stream_t stream) {
-    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, C, ldc, act, nullptr, (hipStream_t)stream);
+extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
+                                      int c_bf16, int act, mgnns_stream_t stream) {
+    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, static_cast<float*>(C), ldc, act, nullptr, (hipStream_t)stream, c_bf16 ? 1 : 0);
 }

@@ -260,6 +260,89 @@ def spmm_csr(csr, x, act=ACT_NONE, out=None):
     return y
 
 
+# ---- bf16-feature sparse propagation (BASELINE configs[4]) -------------------------------------------------
+def cast_bf16(x):
+    """fp32 tensor -> bf16 tensor of the same shape (round to nearest even), on the device."""
+    _chk(x, "x")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    if x.numel() == 0:
+        return y
+    _lib.check(_lib.lib().mgnns_cast_bf16(_p(x), x.numel(), _p(y), _stream()), "mgnns_cast_bf16")
+    return y
+
+
+class SparseAdjBf16:
+    """A static sparse adjacency for `spmm_bf16`: CSR with bf16 values on the device, plus -- for graphs with tens of
+    non-zeros per row -- the re-ordered entry stream of the LDS-tiled kernel (mgnns_amd/spmm_plan.py), built once per
+    feature width on first use.  csr = (row_ptr int32 [n+1], col int32 [nnz], val fp32 or bf16 [nnz]) device tensors."""
+
+    TILED_MIN_AVG_NNZ = 32.0
+
+    def __init__(self, csr, n_cols=None):
+        rp, col, val = csr
+        _chk(rp, "row_ptr", torch.int32, 1)
+        _chk(col, "col", torch.int32, 1)
+        if val.dtype == torch.float32:
+            val = cast_bf16(_chk(val, "val", torch.float32, 1))
+        _chk(val, "val", torch.bfloat16, 1)
+        if val.numel() % 2:                                  # the kernels fetch the values as aligned dwords
+            val = torch.cat([val, val.new_zeros(1)])[:-1]    # same values, storage readable one element further
+        self.row_ptr, self.col, self.val = rp, col, val
+        self.n_rows = rp.shape[0] - 1
+        self.n_cols = self.n_rows if n_cols is None else int(n_cols)
+        self.nnz = int(col.shape[0])
+        self._plans = {}
+
+    @property
+    def avg_nnz(self):
+        return self.nnz / max(1, self.n_rows)
+
+    def plan(self, F, geometry=None):
+        """Device copy of the tiled plan for feature width F (built on the host once; the adjacency is static)."""
+        from . import spmm_plan
+        geo = tuple(geometry) if geometry is not None else spmm_plan.geometry_for(self.n_rows, F)
+        hit = self._plans.get(geo)
+        if hit is None:
+            bits = self.val.view(torch.int16).cpu().numpy().view("uint16")
+            pl = spmm_plan.build_tiled_plan(self.row_ptr.cpu().numpy(), self.col.cpu().numpy(), bits, self.n_cols, *geo)
+            dev = self.col.device
+            hit = (torch.from_numpy(pl.wave_off.view("int32")).to(dev), torch.from_numpy(pl.ent.view("int32")).to(dev), geo)
+            self._plans[geo] = hit
+        return hit
+
+
+def spmm_bf16(adj, x, act=ACT_NONE, out=None, out_dtype=torch.bfloat16, path=None, variant=0, geometry=None):
+    """act(adj @ x): adj a SparseAdjBf16, x [n_cols, F] bf16 -> [n_rows, F] bf16 (or fp32), fp32 accumulation.
+    path: None (by density) | "direct" | "tiled"."""
+    if not isinstance(adj, SparseAdjBf16):
+        raise TypeError("adj must be a SparseAdjBf16")
+    _chk(x, "x", torch.bfloat16, 2)
+    if x.shape[0] != adj.n_cols:
+        raise ValueError("x has %d rows, the adjacency %d columns" % (x.shape[0], adj.n_cols))
+    F = x.shape[1]
+    if out is None:
+        y = torch.empty(adj.n_rows, F, device=x.device, dtype=out_dtype)
+    else:
+        y = out
+        if y.dtype not in (torch.bfloat16, torch.float32) or tuple(y.shape) != (adj.n_rows, F) or not y.is_contiguous() \
+                or not y.is_cuda or y.data_ptr() == x.data_ptr():
+            raise ValueError("out must be a contiguous [%d, %d] bf16 / fp32 device tensor distinct from x" % (adj.n_rows, F))
+    ybf = 1 if y.dtype == torch.bfloat16 else 0
+    if path is None:
+        path = "tiled" if (adj.avg_nnz >= SparseAdjBf16.TILED_MIN_AVG_NNZ and F % 256 == 0) else "direct"
+    L = _lib.lib()
+    if path == "tiled":
+        wo, ent, geo = adj.plan(F, geometry)
+        _launch("mgnns_spmm_tiled_bf16_fwd", ("mgnns_spmm_tiled_bf16_fwd", adj.n_rows, F), L.mgnns_spmm_tiled_bf16_fwd,
+                _p(wo), _p(ent), geo[0], geo[1], geo[2], adj.n_rows, adj.n_cols, _p(x), F, _p(y), ybf, act, _stream())
+    elif path == "direct":
+        _launch("mgnns_spmm_csr_bf16_fwd", ("mgnns_spmm_csr_bf16_fwd", adj.n_rows, F), L.mgnns_spmm_csr_bf16_fwd,
+                _p(adj.row_ptr), _p(adj.col), _p(adj.val), adj.n_rows, adj.nnz, _p(x), F, _p(y), ybf, act, int(variant), _stream())
+    else:
+        raise ValueError("path must be None, 'direct' or 'tiled'")
+    return y
+
+
 # ---- gathers -------------------------------------------------------------------------------
 def embedding(idx, table):
     _chk(idx, "idx", torch.int64)
@@ -780,8 +863,10 @@ def transpose_cast_bf16(x):
     return y
 
 
-def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None):
-    """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 [M, N] (out: optional preallocated)."""
+def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None, out_dtype=torch.float32):
+    """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 or bf16 [M, N].
+    out: optional preallocated result; it may be a column slice [M, N] of a wider row-major matrix (row stride = its stride(0)),
+    e.g. the K-padded operand of the next product."""
     _chk(a_bf16, "A", torch.bfloat16, 2)
     _chk(bt_bf16, "Bt", torch.bfloat16, 2)
     M, Kp = a_bf16.shape
@@ -791,13 +876,14 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=Non
     if bias is not None:
         _chk(bias, "bias", ndim=1)
     if out is None:
-        c = torch.empty(M, N, device=a_bf16.device, dtype=torch.float32)
+        c = torch.empty(M, N, device=a_bf16.device, dtype=out_dtype)
     else:
-        c = _chk(out, "out", ndim=2)
-        if tuple(c.shape) != (M, N):
-            raise ValueError("out must be [%d, %d]" % (M, N))
-    _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), N, act, _stream()),
-               "mgnns_gemm_bf16_nt_fwd")
+        c = out
+        if not (torch.is_tensor(c) and c.is_cuda and c.dim() == 2 and tuple(c.shape) == (M, N) and c.stride(1) == 1
+                and c.dtype in (torch.float32, torch.bfloat16)):
+            raise ValueError("out must be a [%d, %d] fp32 / bf16 device matrix with unit column stride" % (M, N))
+    _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), c.stride(0),
+                                                 1 if c.dtype == torch.bfloat16 else 0, act, _stream()), "mgnns_gemm_bf16_nt_fwd")
     return c
 
 

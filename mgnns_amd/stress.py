@@ -43,57 +43,151 @@ def csr_to_device(csr, dev):
     return tuple(torch.from_numpy(a).to(dev) for a in csr)
 
 
-def time_cold(fn, arg_sets, reps=3):
-    """Mean ms per launch of fn(*args) cycling over arg_sets (see module docstring); one warm-up cycle, `reps` timed
-    cycles, HIP events on the launch stream."""
+def time_cold(fn, arg_sets, reps=3, graph=True):
+    """Mean ms per launch of fn(*args) cycling over arg_sets (see module docstring).  graph=True (default): one rotation is
+    captured into a hipGraph and `reps` replays are timed -- a 10-20 us kernel launched from Python would otherwise measure
+    the host (ctypes + hipLaunchKernel ~ 7-10 us per call); best of three.  HIP events on the launch stream."""
     for a in arg_sets:
         fn(*a)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        for a in arg_sets:
-            fn(*a)
-    e1.record()
+    if not graph:
+        e0.record()
+        for _ in range(reps):
+            for a in arg_sets:
+                fn(*a)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * len(arg_sets))
+    gr = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr, stream=side):
+            for a in arg_sets:
+                fn(*a)
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (reps * len(arg_sets))
+    gr.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / (reps * len(arg_sets)))
+    return best
 
 
 def time_warm(fn, args, reps=10):
-    return time_cold(fn, [args], reps)
+    return time_cold(fn, [args], reps, graph=False)
 
 
 def _sets_for(bytes_per_set):
     return max(4, -(-COLD_BYTES // int(bytes_per_set)))
 
 
-class StressChannel:
-    """One label-graph channel at stress size.  forward(pooled) -> read-out [B, N] like MODEL:461-474."""
+N_CHANNELS = 3
 
-    def __init__(self, n=N_NODES, density=DENSITIES[0], dense=False, seed=0, dev="cuda:0"):
+
+class StressChannel:
+    """One label-graph channel at stress size.  forward(pooled) -> read-out [B, N] like MODEL:461-474.
+
+    dtype "bf16" (BASELINE configs[4]): every operand of every product is bf16, accumulation fp32, and each product writes
+    the K-contiguous bf16 operand of the next one (no cast / transpose pass in between):
+      sparse   S1 = X.W1 -> X1 = lrelu(adj @ S1) -> S2 = X1.W2 -> G = adj @ S2 -> pooled.G^T       (GEMM, SpMM, GEMM, SpMM, GEMM)
+      dense    S1^T = W1^T.X^T -> X1 = lrelu(adj . S1) -> S2^T = W2^T.X1^T -> G = adj . S2 -> pooled.G^T   (five GEMMs)
+    dtype "f32": fp32 features on the exact-f32 MFMA + the fp32 CSR SpMM (the arithmetic of the model's own label GCN)."""
+
+    def __init__(self, n=N_NODES, density=DENSITIES[0], dense=False, seed=0, dev="cuda:0", dtype="bf16"):
         g = torch.Generator(device=dev).manual_seed(seed)
-        self.n = n
+        self.n, self.dense, self.dtype = n, dense, dtype
         self.X = torch.randn(n, 300, device=dev, generator=g) * 0.45
         self.W1 = torch.randn(300, 1024, device=dev, generator=g) * 0.05
         self.W2 = torch.randn(1024, 2048, device=dev, generator=g) * 0.05
-        self.dense = dense
         if dense:
-            adj = torch.rand(n, n, device=dev, generator=g) * (2.0 / n)
-            self.adj_bf16 = ops.cast_pad_bf16(adj, ld=(n + 63) // 64 * 64)
+            self.adj = torch.rand(n, n, device=dev, generator=g) * (2.0 / n)
+            self.kp = (n + 63) // 64 * 64
+            self.adj_bf16 = ops.cast_pad_bf16(self.adj, ld=self.kp)
+            if dtype == "f32":
+                del self.adj
         else:
             self.csr = csr_to_device(random_csr(n, density, seed + 1), dev)
-
-    def _prop(self, support, act):
-        if self.dense:
-            return ops.dense_adj_matmul_bf16(self.adj_bf16, support, act=act)
-        return ops.spmm_csr(self.csr, support, act=act)
+        if dtype == "bf16":
+            self.Xb = ops.cast_pad_bf16(self.X, ld=320)                   # [n, 320]: K = 300 padded to five 64-wide slices
+            self.W1t = ops.transpose_cast_bf16(self.W1)                   # [1024, 320]
+            self.W2t = ops.transpose_cast_bf16(self.W2)                   # [2048, 1024]
+            if dense:
+                self.S1t = torch.zeros(1024, self.kp, device=dev, dtype=torch.bfloat16)    # K padding stays zero
+                self.S2t = torch.zeros(2048, self.kp, device=dev, dtype=torch.bfloat16)
+            else:
+                self.sadj = ops.SparseAdjBf16(self.csr)
 
     def gcn(self):
-        x = self._prop(ops.matmul(self.X, self.W1), ops.ACT_LRELU2)
-        return self._prop(ops.matmul(x, self.W2), ops.ACT_NONE)                # G [N, 2048]
+        bf = torch.bfloat16
+        if self.dtype == "bf16" and self.dense:
+            ops.gemm_bf16_nt(self.W1t, self.Xb, out=self.S1t[:, :self.n])
+            x1 = ops.gemm_bf16_nt(self.adj_bf16, self.S1t, None, ops.ACT_LRELU2, out_dtype=bf)
+            ops.gemm_bf16_nt(self.W2t, x1, out=self.S2t[:, :self.n])
+            return ops.gemm_bf16_nt(self.adj_bf16, self.S2t, out_dtype=bf)                       # G [n, 2048] bf16
+        if self.dtype == "bf16":
+            s1 = ops.gemm_bf16_nt(self.Xb, self.W1t, out_dtype=bf)
+            x1 = ops.spmm_bf16(self.sadj, s1, act=ops.ACT_LRELU2)
+            s2 = ops.gemm_bf16_nt(x1, self.W2t, out_dtype=bf)
+            return ops.spmm_bf16(self.sadj, s2)
+        prop = (lambda sup, act: ops.dense_adj_matmul_bf16(self.adj_bf16, sup, act=act)) if self.dense else \
+               (lambda sup, act: ops.spmm_csr(self.csr, sup, act=act))
+        x = prop(ops.matmul(self.X, self.W1), ops.ACT_LRELU2)
+        return prop(ops.matmul(x, self.W2), ops.ACT_NONE)                     # G [n, 2048] fp32
 
     def forward(self, pooled):
-        return ops.linear(pooled, self.gcn())                                 # pooled [B,2048] . G^T -> [B, N]
+        """pooled [B, 2048] fp32 (bf16 mode also takes it already cast) -> pooled . G^T [B, n] fp32."""
+        G = self.gcn()
+        if self.dtype == "bf16":
+            pb = pooled if pooled.dtype == torch.bfloat16 else ops.cast_pad_bf16(pooled, ld=2048)
+            return ops.gemm_bf16_nt(pb, G)
+        return ops.linear(pooled, G)
+
+
+def plan_shards(world, n_channels=N_CHANNELS, batch=BATCH):
+    """configs[4] over `world` ranks -> per rank a list of (channel, b0, b1).  Channels are independent (MODEL:460-506 runs
+    object and scene one after the other): up to n_channels ranks take whole channels; beyond that the ranks that share a
+    channel split its read-out batch (each recomputes the batch-independent G -- 4 of the 5 products -- the way every rank of
+    the model's forward recomputes its label GCN).  No data-path collective: the outputs are disjoint [b1 - b0, N] blocks."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    out = [[] for _ in range(world)]
+    if world <= n_channels:
+        for c in range(n_channels):
+            out[c % world].append((c, 0, batch))
+        return out
+    groups = [[r for r in range(world) if r % n_channels == c] for c in range(n_channels)]
+    for c, ranks in enumerate(groups):
+        k = len(ranks)
+        for i, r in enumerate(ranks):
+            b0, b1 = batch * i // k, batch * (i + 1) // k
+            out[r].append((c, b0, b1))
+    return out
+
+
+class StressWorkload:
+    """The whole of configs[4] as one rank sees it: its share of the 3 channels x batch 512 (plan_shards)."""
+
+    def __init__(self, rank=0, world=1, n=N_NODES, batch=BATCH, density=DENSITIES[0], dense=False, dev="cuda:0", dtype="bf16",
+                 n_channels=N_CHANNELS):
+        self.shards = plan_shards(world, n_channels, batch)[rank]
+        g = torch.Generator(device=dev).manual_seed(1234)
+        self.channels, self.pooled = {}, {}
+        for c, b0, b1 in self.shards:
+            if c not in self.channels:
+                self.channels[c] = StressChannel(n=n, density=density, dense=dense, seed=10 * c, dev=dev, dtype=dtype)
+                full = torch.relu(torch.randn(batch, 2048, device=dev, generator=torch.Generator(device=dev).manual_seed(77 + c)))
+                self.pooled[c] = ops.cast_pad_bf16(full, ld=2048) if dtype == "bf16" else full
+        del g
+
+    def forward(self):
+        """-> {(channel, b0, b1): read-out [b1 - b0, N] fp32}"""
+        return {(c, b0, b1): self.channels[c].forward(self.pooled[c][b0:b1].contiguous()) for c, b0, b1 in self.shards}
 
 
 def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
@@ -102,29 +196,41 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
     streaming ceiling at this size)."""
     g = torch.Generator(device=dev).manual_seed(0)
     out = {"what": "BASELINE configs[4]: N=%d-node label graph, one of 3 identical channels, batch %d; every timed launch "
-                   "rotates over >=4 operand sets totalling >%d MiB (cache-cold); algorithmic bytes = nnz*8 + 2*N*F*4" %
+                   "rotates over >=4 operand sets totalling >%d MiB (cache-cold, hipGraph replays of one rotation)" %
                    (n, batch, COLD_BYTES >> 20), "N": n, "batch": batch, "gemm_tile": GEMM_TILE}
-    # ---- (ii) CSR SpMM, cold ----
+    # ---- (ii) sparse adjacency, cold: bf16 values + features (configs[4]'s dtype), fp32 accumulation ----
+    out["spmm_bytes"] = "nnz*(4+2) + N*F*2 (X) + N*F*2 (Y)  [SURVEY 7-8]; copy_* = a plain device copy of N*F*2 bytes in and out " \
+                        "through the same rotation: the ceiling ANY kernel moving these bytes has at this size"
     for dens in DENSITIES:
         csr_np = random_csr(n, dens, 1)
         csr = csr_to_device(csr_np, dev)
-        nnz = int(csr_np[1].size)
+        adj = ops.SparseAdjBf16(csr)
+        nnz = adj.nnz
         for F in (1024, 2048):
-            by = nnz * 8.0 + 2.0 * n * F * 4
-            k = _sets_for(2.0 * n * F * 4)
-            xs = [torch.randn(n, F, device=dev, generator=g) for _ in range(k)]
-            ys = [torch.empty_like(x) for x in xs]                 # outputs rotate too: a recycled block would stay cached
-            run = lambda x, y: ops.spmm_csr(csr, x, act=ops.ACT_LRELU2, out=y)
+            by = nnz * 6.0 + 2.0 * n * F * 2
+            k = _sets_for(2.0 * n * F * 2)
+            xs = [torch.randn(n, F, device=dev, generator=g).bfloat16() for _ in range(k)]
+            ys = [torch.empty_like(x) for x in xs]
+            run = lambda x, y: ops.spmm_bf16(adj, x, act=ops.ACT_LRELU2, out=y)
             ms = time_cold(run, list(zip(xs, ys)))
-            ms_w = time_warm(run, (xs[0], ys[0]))
-            rec = {"nnz": nnz, "sets": k, "cold_ms": round(ms, 4), "algorithmic_MB": round(by / 1e6, 1),
-                   "cold_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / 8000.0, 4),
-                   "warm_ms_same_buffers": round(ms_w, 4), "warm_GBps": round(by / ms_w / 1e6, 1)}
-            if dens == DENSITIES[0]:
-                ms_c = time_cold(lambda d, s: d.copy_(s), list(zip(ys, xs)))
-                rec["copy_cold_GBps"] = round(2.0 * n * F * 4 / ms_c / 1e6, 1)
-            out["spmm_csr_d%g_F%d" % (dens, F)] = rec
+            ms_c = time_cold(lambda d, s_: d.copy_(s_), list(zip(ys, xs)))
+            out["spmm_bf16_d%g_F%d" % (dens, F)] = {
+                "path": "tiled (LDS-staged X tiles)" if adj.avg_nnz >= ops.SparseAdjBf16.TILED_MIN_AVG_NNZ else "direct (L2 gathers)",
+                "nnz": nnz, "sets": k, "cold_ms": round(ms, 5), "algorithmic_MB": round(by / 1e6, 2),
+                "cold_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / 8000.0, 4),
+                "copy_cold_ms": round(ms_c, 5), "copy_cold_GBps": round(2.0 * n * F * 2 / ms_c / 1e6, 1),
+                "frac_of_copy": round(ms_c / ms * by / (2.0 * n * F * 2), 4)}
             del xs, ys
+        # the fp32-feature kernel of the model's own label GCN (mgnns_spmm_csr_fwd) on the same graph, for reference
+        F = 1024
+        by = nnz * 8.0 + 2.0 * n * F * 4
+        k = _sets_for(2.0 * n * F * 4)
+        xs = [torch.randn(n, F, device=dev, generator=g) for _ in range(k)]
+        ys = [torch.empty_like(x) for x in xs]
+        ms = time_cold(lambda x, y: ops.spmm_csr(csr, x, act=ops.ACT_LRELU2, out=y), list(zip(xs, ys)))
+        out["spmm_f32_d%g_F%d" % (dens, F)] = {"nnz": nnz, "sets": k, "cold_ms": round(ms, 5), "algorithmic_MB": round(by / 1e6, 1),
+                                                "cold_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / 8000.0, 4)}
+        del xs, ys
     # ---- (i) dense bf16 adjacency GEMM ----
     kp = (n + 63) // 64 * 64
     for F in (1024, 2048):
@@ -138,13 +244,21 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
                                          "frac_of_bf16_mfma_peak": round(2.0 * n * n * F / ms / 1e9 / 2500.0, 4),
                                          "operand_GBps": round(by / ms / 1e6, 1)}
         del As, Sts, Cs
-    # ---- the channel end to end (X.W1, prop, X.W2, prop, read-out), CSR 4e-4 and dense ----
+    # ---- the whole workload on this GPU: 3 channels x (gc1 + LeakyReLU + gc2 + read-out of 512 samples), bf16 ----
+    for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("csr_d0.01", dict(density=DENSITIES[1])), ("dense", dict(dense=True))):
+        wl = StressWorkload(n=n, batch=batch, dev=dev, **kw)
+        ms = time_warm(wl.forward, (), reps=5)
+        ch = next(iter(wl.channels.values()))
+        ms1 = time_warm(ch.gcn, (), reps=5)
+        out["workload_bf16_" + name] = {"ms_per_3_channel_forward": round(ms, 4), "samples_per_s": round(batch / ms * 1e3, 1),
+                                        "ms_gcn_of_one_channel": round(ms1, 4),
+                                        "what": "3 channels one after the other on one stream, eager launches, bf16 operands / fp32 "
+                                                "accumulation end to end (5 launches per channel)"}
+        del wl, ch
     pooled = torch.relu(torch.randn(batch, 2048, device=dev, generator=g))
-    for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("dense_bf16", dict(dense=True))):
-        ch = StressChannel(n=n, dev=dev, **kw)
-        ms = time_warm(ch.forward, (pooled,), reps=5)
-        out["channel_" + name] = {"ms": round(ms, 4), "what": "gc1 + LeakyReLU + gc2 + read-out of one channel, eager launches, "
-                                                              "fp32 X.W on the exact-f32 MFMA"}
-        del ch
+    ch = StressChannel(n=n, dev=dev, density=DENSITIES[0], dtype="f32")
+    out["channel_f32_csr_d0.0004"] = {"ms": round(time_warm(ch.forward, (pooled,), reps=3), 4),
+                                      "what": "ONE channel with fp32 features: exact-f32 MFMA X.W + the fp32 CSR SpMM (round 2's figure)"}
+    del ch
     torch.cuda.empty_cache()
     return out

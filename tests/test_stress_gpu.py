@@ -62,24 +62,161 @@ def test_dense_bf16_adjacency_10k_nodes(F):
     assert np.abs(Y[ridx].cpu().numpy() - full).max() / np.abs(full).max() < 2e-2
 
 
-def test_stress_channel_end_to_end_small_vs_fp64():
-    """The whole channel (X.W1 -> adj -> LeakyReLU -> .W2 -> adj -> read-out) at a size fp64 can do in full."""
-    n, B = 1500, 32
-    ch = stress.StressChannel(n=n, density=4e-3, seed=5, dev=DEV)
-    pooled = torch.relu(torch.randn(B, 2048, device=DEV))
-    out = ch.forward(pooled).cpu().numpy()
-    rp, col, val = (a.cpu().numpy() for a in ch.csr)
-    import scipy.sparse as sp
-    A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(n, n))
+def _bf16_ref(rp, col, vbf, Xbf, rows, act=True):
+    """fp64 product on the ROUNDED operands (what the kernels are given), sampled rows -> (ref, scale)."""
+    Xh = Xbf.float().cpu().numpy().astype(np.float64)
+    vh = vbf.float().cpu().numpy().astype(np.float64)
+    ref, scale = [], []
+    for r in rows:
+        lo, hi = rp[r], rp[r + 1]
+        y = (vh[lo:hi, None] * Xh[col[lo:hi]]).sum(0) if hi > lo else np.zeros(Xh.shape[1])
+        ref.append(_lrelu(y) if act else y)
+        scale.append((np.abs(vh[lo:hi]) @ np.abs(Xh[col[lo:hi]])).max() + 1e-30 if hi > lo else 1.0)
+    return np.array(ref), np.array(scale)[:, None]
+
+
+@pytest.mark.parametrize("density", stress.DENSITIES)
+@pytest.mark.parametrize("F", [1024, 2048])
+def test_bf16_spmm_10k_nodes(density, F):
+    """configs[4] (ii) in its stated dtype: bf16 adjacency values and features, fp32 accumulation, at N = 10 000, on the path
+    `ops.spmm_bf16` picks for the density (ring / register gathers at 4e-4, LDS-tiled at 1e-2), bf16 and fp32 outputs."""
+    rp, col, val = stress.random_csr(N, density, seed=3)
+    adj = ops.SparseAdjBf16(stress.csr_to_device((rp, col, val), DEV))
+    assert (adj.avg_nnz >= ops.SparseAdjBf16.TILED_MIN_AVG_NNZ) == (density >= 1e-3)
+    g = torch.Generator(device=DEV).manual_seed(F)
+    X = torch.randn(N, F, device=DEV, generator=g).bfloat16()
+    rows = np.unique(np.concatenate([[0, 1, N - 1], np.random.RandomState(1).randint(0, N, 60),
+                                     np.argsort(np.diff(rp))[-3:], np.argsort(np.diff(rp))[:3]]))
+    ref, scale = _bf16_ref(rp, col, adj.val, X, rows)
+    ridx = torch.from_numpy(rows).to(DEV)
+    Y32 = ops.spmm_bf16(adj, X, act=ops.ACT_LRELU2, out_dtype=torch.float32)
+    assert np.max(np.abs(Y32[ridx].cpu().numpy() - ref) / scale) < 1e-6          # fp32 accumulation order only
+    Y16 = ops.spmm_bf16(adj, X, act=ops.ACT_LRELU2)
+    assert Y16.dtype == torch.bfloat16 and torch.equal(Y16, Y32.bfloat16())        # the bf16 output is the rounded fp32 one
+    Y2 = torch.empty_like(Y16)
+    assert ops.spmm_bf16(adj, X, act=ops.ACT_LRELU2, out=Y2) is Y2 and torch.equal(Y2, Y16)   # deterministic, out= honoured
+    assert torch.isfinite(Y32).all()
+    # the gather forms compute the same fmaf chain per row: bit-identical results; the LDS-tiled kernel accumulates with
+    # v_dot2c_f32_bf16 (same order, its own rounding of the last bit)
+    if density >= 1e-3:
+        Yd = ops.spmm_bf16(adj, X, act=ops.ACT_LRELU2, out_dtype=torch.float32, path="direct")
+        assert float((Yd - Y32).abs().max()) <= 1e-6 * float(Y32.abs().max())
+    else:
+        for var in ((1 << 30) | (384 << 4) | 4, (1 << 30) | (256 << 4) | 1, (1 << 29) | (64 << 8), (1 << 29) | (128 << 8) | 3):
+            assert torch.equal(ops.spmm_bf16(adj, X, act=ops.ACT_LRELU2, out_dtype=torch.float32, path="direct", variant=var), Y32), var
+
+
+@pytest.mark.parametrize("geo", [(8, 10, 128), (8, 20, 128), (4, 10, 256), (4, 20, 256)])
+def test_bf16_spmm_tiled_geometries_ragged_and_multipart(geo):
+    """Every built geometry of the LDS-tiled kernel on a small rectangular problem with empty rows, a full row (records of
+    several parts), row / column counts that are not multiples of the block sizes -- against the full fp64 product."""
+    rs = np.random.RandomState(geo[1])
+    n, ncols, F = 205, 390, 512
+    dense = (rs.rand(n, ncols) < 0.1) * rs.rand(n, ncols)
+    dense[7] = 0
+    dense[n - 1] = 0
+    dense[11, :] = rs.rand(ncols)
+    dense[12, :] = rs.rand(ncols)
+    rp = np.concatenate([[0], np.cumsum((dense != 0).sum(1))]).astype(np.int32)
+    col = np.nonzero(dense)[1].astype(np.int32)
+    val = dense[dense != 0].astype(np.float32)
+    adj = ops.SparseAdjBf16(stress.csr_to_device((rp, col, val), DEV), n_cols=ncols)
+    X = torch.from_numpy(rs.randn(ncols, F).astype(np.float32)).to(DEV).bfloat16()
+    ref, scale = _bf16_ref(rp, col, adj.val, X, range(n), act=False)
+    for path, kw in (("tiled", dict(geometry=geo)), ("direct", {})):
+        Y = ops.spmm_bf16(adj, X, out_dtype=torch.float32, path=path, **kw).cpu().numpy()
+        assert np.max(np.abs(Y - ref) / scale) < 1e-6, path
+        assert not Y[7].any() and not Y[n - 1].any()
+    a, b = ops.spmm_bf16(adj, X, out_dtype=torch.float32, path="tiled", geometry=geo), ops.spmm_bf16(adj, X, out_dtype=torch.float32, path="direct")
+    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    assert torch.equal(a, ops.spmm_bf16(adj, X, out_dtype=torch.float32, path="tiled", geometry=geo))     # deterministic
+
+
+def test_bf16_spmm_direct_edge_cases():
+    """Odd feature widths (partial last slab), odd nnz (values travel as dwords), a single row, an all-empty matrix, and
+    argument errors."""
+    rs = np.random.RandomState(9)
+    for n, F, dens in ((37, 200, 0.3), (1, 8, 1.0), (300, 136, 0.02), (64, 1096, 0.1)):
+        rp, col, val = stress.random_csr(n, dens, seed=n)
+        if col.size % 2 == 0:                                      # force an odd number of non-zeros
+            rp, col, val = rp.copy(), col[:-1], val[:-1]
+            rp[-1] -= 1
+        adj = ops.SparseAdjBf16(stress.csr_to_device((rp, col, val), DEV))
+        X = torch.from_numpy(rs.randn(n, F).astype(np.float32)).to(DEV).bfloat16()
+        ref, scale = _bf16_ref(rp, col, adj.val, X, range(n), act=False)
+        for var in (0, (1 << 30) | (8 << 4), (1 << 30) | (8 << 4) | 5, (1 << 29) | (2 << 8), (1 << 29) | (3 << 8) | 3):
+            Y = ops.spmm_bf16(adj, X, out_dtype=torch.float32, path="direct", variant=var).cpu().numpy()
+            assert np.max(np.abs(Y - ref) / scale) < 1e-6, (n, F, var)
+    empty = ops.SparseAdjBf16((torch.zeros(6, dtype=torch.int32, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV),
+                               torch.zeros(0, device=DEV)))
+    X = torch.ones(5, 16, device=DEV).bfloat16()
+    for var in (0, (1 << 30) | (8 << 4)):
+        assert not ops.spmm_bf16(empty, X, path="direct", variant=var).float().abs().sum().item()
+    rp, col, val = stress.random_csr(16, 0.5, 1)
+    adj = ops.SparseAdjBf16(stress.csr_to_device((rp, col, val), DEV))
+    with pytest.raises(TypeError):
+        ops.spmm_bf16(adj, torch.ones(16, 16, device=DEV))                       # fp32 features
+    with pytest.raises(ValueError):
+        ops.spmm_bf16(adj, torch.ones(15, 16, device=DEV).bfloat16())            # wrong row count
+    with pytest.raises(RuntimeError):
+        ops.spmm_bf16(adj, torch.ones(16, 12, device=DEV).bfloat16())            # F % 8
+    with pytest.raises(RuntimeError):
+        ops.spmm_bf16(adj, torch.ones(16, 256, device=DEV).bfloat16(), path="tiled", geometry=(8, 12, 128))   # no such kernel
+
+
+def _channel_fp64(ch, pooled, A):
     X, W1, W2 = (t.cpu().numpy().astype(np.float64) for t in (ch.X, ch.W1, ch.W2))
     G = A @ (_lrelu(A @ (X @ W1)) @ W2)
-    ref = pooled.cpu().numpy().astype(np.float64) @ G.T
-    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-5
+    return pooled.cpu().numpy().astype(np.float64) @ G.T
 
 
-def test_stress_measure_reports_cold_and_warm():
+def test_stress_channel_end_to_end_small_vs_fp64():
+    """The whole channel (X.W1 -> adj -> LeakyReLU -> .W2 -> adj -> read-out) at a size fp64 can do in full: fp32 features
+    (1e-5) and configs[4]'s bf16 chain, sparse and dense (four bf16 roundings of intermediates: <= 2e-2 of the output scale)."""
+    import scipy.sparse as sp
+    n, B = 1500, 32
+    pooled = torch.relu(torch.randn(B, 2048, device=DEV))
+    ch = stress.StressChannel(n=n, density=4e-3, seed=5, dev=DEV, dtype="f32")
+    rp, col, val = (a.cpu().numpy() for a in ch.csr)
+    A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(n, n))
+    ref = _channel_fp64(ch, pooled, A)
+    assert np.abs(ch.forward(pooled).cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-5
+    for dens in (4e-3, 5e-2):                          # the gather path and the LDS-tiled path (75 non-zeros per row)
+        chb = stress.StressChannel(n=n, density=dens, seed=5, dev=DEV)
+        rp, col, val = (a.cpu().numpy() for a in chb.csr)
+        A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(n, n))
+        assert (chb.sadj.avg_nnz >= ops.SparseAdjBf16.TILED_MIN_AVG_NNZ) == (dens > 1e-2)
+        ref = _channel_fp64(chb, pooled, A)
+        out = chb.forward(pooled)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (B, n)
+        assert np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-2, dens
+    chd = stress.StressChannel(n=n, dense=True, seed=6, dev=DEV)
+    ref = _channel_fp64(chd, pooled, chd.adj.cpu().numpy().astype(np.float64))
+    assert np.abs(chd.forward(pooled).cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-2
+
+
+def test_stress_workload_shards_equal_the_single_rank_result():
+    """configs[4] sharded (plan_shards): every rank's blocks, put together, are the one-rank result bit for bit."""
+    n, B = 1200, 48
+    one = stress.StressWorkload(0, 1, n=n, batch=B, dev=DEV).forward()
+    full = {c: v for (c, b0, b1), v in one.items()}
+    assert sorted(full) == [0, 1, 2] and all(tuple(v.shape) == (B, n) for v in full.values())
+    for world in (2, 3, 5, 8):
+        seen = {c: torch.zeros(B, dtype=torch.bool) for c in full}
+        for rank in range(world):
+            for (c, b0, b1), v in stress.StressWorkload(rank, world, n=n, batch=B, dev=DEV).forward().items():
+                assert torch.equal(v, full[c][b0:b1]), (world, rank, c)
+                assert not seen[c][b0:b1].any()
+                seen[c][b0:b1] = True
+        assert all(m.all() for m in seen.values())
+
+
+def test_stress_measure_reports_cold_figures():
     r = stress.measure(DEV, n=4000, batch=64)
-    for k in ("spmm_csr_d0.0004_F1024", "spmm_csr_d0.01_F2048", "dense_adj_bf16_F1024", "channel_csr_d0.0004", "channel_dense_bf16"):
-        assert k in r
-    s = r["spmm_csr_d0.0004_F2048"]
-    assert s["sets"] >= 4 and s["sets"] * 2 * 4000 * 2048 * 4 >= stress.COLD_BYTES and s["cold_ms"] > 0 and s["warm_ms_same_buffers"] > 0
+    for k in ("spmm_bf16_d0.0004_F1024", "spmm_bf16_d0.01_F2048", "spmm_f32_d0.0004_F1024", "dense_adj_bf16_F1024",
+              "workload_bf16_csr_d0.0004", "workload_bf16_dense", "channel_f32_csr_d0.0004"):
+        assert k in r, k
+    s = r["spmm_bf16_d0.0004_F2048"]
+    assert s["sets"] >= 4 and s["sets"] * 2 * 4000 * 2048 * 2 >= stress.COLD_BYTES and s["cold_ms"] > 0 and 0 < s["frac_of_copy"] < 1.5
+    assert s["algorithmic_MB"] == pytest.approx((s["nnz"] * 6 + 2 * 4000 * 2048 * 2) / 1e6, abs=0.01)
+    assert r["spmm_bf16_d0.01_F1024"]["path"].startswith("tiled") and s["path"].startswith("direct")
