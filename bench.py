@@ -235,6 +235,81 @@ def dry_run(args, rank, world):
     print(json.dumps(line), flush=True)
 
 
+def stress_run(args, rank, local_rank, world):
+    """`--config stress`: BASELINE configs[4] -- three 10 000-node label-graph channels, batch 512, bf16 -- over `world` ranks.
+    The channels are independent and the read-out is per sample, so the work shards with NO data-path collective
+    (mgnns_amd/stress.py::plan_shards: whole channels up to three ranks, the read-out batch of a channel beyond); a step is one
+    forward of the rank's share, bracketed by barriers, MAX over ranks; value = read-out samples per second of the whole job
+    (strong scaling: the 3 x 512 job is fixed).  --dry-launch: the same protocol on gloo with no GPU (the step sleeps)."""
+    from mgnns_amd import stress
+    dry = args.dry_launch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        import torch
+        backend = "gloo" if dry else os.environ.get("MGNNS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    plan = stress.plan_shards(world)
+    mine = plan[rank]
+    n_nodes = int(os.environ.get("MGNNS_STRESS_NODES", stress.N_NODES))
+    density = float(os.environ.get("MGNNS_STRESS_DENSITY", stress.DENSITIES[0]))
+    if dry:
+        device = "cpu"
+
+        def step():
+            time.sleep(1e-3 * sum((b1 - b0) / stress.BATCH for _, b0, b1 in mine))      # 1 ms per full channel
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+        blocks = [(c, b0, b1, b1 - b0, n_nodes) for c, b0, b1 in mine]
+    else:
+        import torch
+        if os.environ.get("MGNNS_BENCH_SAME_GPU") == "1":
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        wl = stress.StressWorkload(rank, world, n=n_nodes, density=density, dev=device)
+        state = {}
+
+        def step():
+            state["out"] = wl.forward()
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+        step()
+        blocks = [(c, b0, b1) + tuple(v.shape) for (c, b0, b1), v in state["out"].items()]
+    dt = timed_steps(step, args.steps, args.warmup, barrier)
+    dt_max, dts = max_over_ranks(dt, dist, device)
+    every = [blocks]
+    if dist is not None:
+        every = [None] * world
+        dist.all_gather_object(every, blocks)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    covered = sum(rows for rb in every for (_, _, _, rows, _) in rb)
+    assert covered == stress.N_CHANNELS * stress.BATCH, "shards cover %d of %d channel-samples" % (covered, stress.N_CHANNELS * stress.BATCH)
+    ms = dt_max / args.steps * 1e3
+    line = {"metric": "configs[4] stress: read-out samples/sec of the 3-channel 10k-node label GCN (batch 512 per channel)",
+            "value": round(stress.N_CHANNELS * stress.BATCH / ms * 1e3, 1), "unit": "channel-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "none" if dry else "bf16", "data": "synthetic", "dry_launch": bool(dry),
+            "config": {"workload": "BASELINE configs[4]: %d-node graph, density %g CSR, 3 channels, batch %d, bf16 operands / fp32 "
+                                   "accumulation, channels (then the read-out batch) sharded over ranks, no data-path collective"
+                                   % (n_nodes, density, stress.BATCH)},
+            "dt_ranks": dts, "shards": [[list(b[:3]) for b in rb] for rb in every],
+            "block_shapes": [[list(b[3:]) for b in rb] for rb in every]}
+    print(json.dumps(line), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # in-graph collective probe (child process, so a hang or a crash cannot take the benchmark down)
 # ------------------------------------------------------------------------------------------------------------------
@@ -587,6 +662,8 @@ def run_rank(args):
     os.environ.setdefault("MASTER_PORT", "29533")
     if os.environ.get("MGNNS_BENCH_TEST_KILL_RANK") == str(rank):      # tests/test_bench_launch_cpu.py: a rank that never joins
         raise SystemExit(3)
+    if args.config == "stress":
+        return stress_run(args, rank, local_rank, world)
     if args.dry_launch:
         return dry_run(args, rank, world)
 

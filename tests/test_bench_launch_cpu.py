@@ -93,3 +93,28 @@ def test_a_dead_rank_fails_the_launch(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "launch failed" in r.stderr
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_stress_config_shards_channels_then_batch(n):
+    """`--config stress` (BASELINE configs[4]) through the same launcher: channels are dealt to ranks, beyond three ranks a
+    channel's read-out batch is split; rank 0's line proves every (channel, sample) is computed exactly once."""
+    cmd = [sys.executable, BENCH, "--config", "stress", "--dry-launch", "--steps", "3", "--warmup", "1"] + (["--gpus", str(n)] if n > 1 else [])
+    r = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["scaling"] == "strong" and line["dry_launch"] is True
+    assert len(line["shards"]) == n and len(line["dt_ranks"]) == n
+    seen = set()
+    for rank_shards, shapes in zip(line["shards"], line["block_shapes"]):
+        assert rank_shards
+        for (c, b0, b1), (rows, cols) in zip(rank_shards, shapes):
+            assert rows == b1 - b0 and cols == 10000
+            for b in range(b0, b1):
+                assert (c, b) not in seen
+                seen.add((c, b))
+    assert len(seen) == 3 * 512
+    assert line["value"] == pytest.approx(3 * 512 / (line["ms_per_step"] * 1e-3), rel=1e-3)
+    assert line["ms_per_step"] == pytest.approx(max(line["dt_ranks"]) / 3 * 1e3, abs=1e-3)
