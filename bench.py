@@ -748,11 +748,19 @@ def run_rank(args):
             gf, fwd = None, None
             if dist is not None and graph_collective:
                 try:                                  # the logits all-gather as a node of the same graph
-                    gf = GraphedForward(model, call, post=sf.gather)
-                    fwd = lambda *a: gf.replay()
-                    launch = "hipGraph replay (RCCL all-gather captured)"
+                    gf = GraphedForward(model, call, post=sf.gather, settle=False)
                 except Exception as e:                # capture of the collective refused: gather right behind the replay
                     print("collective capture failed (%s: %s); gathering after the replay" % (type(e).__name__, e), file=sys.stderr)
+                    gf = None
+                # every rank takes the SAME path: a rank whose capture failed would otherwise issue no all-gathers in the
+                # settle / warm-up replays the others run, and the RCCL sequences would never match again
+                ok = torch.tensor([0 if gf is None else 1], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()):
+                    gf.settle()
+                    fwd = lambda *a: gf.replay()
+                    launch = "hipGraph replay (RCCL all-gather captured)"
+                else:
                     gf = None
             if gf is None:
                 gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers

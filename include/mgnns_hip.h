@@ -35,6 +35,19 @@ typedef struct mgnns_comm_s* mgnns_comm_t;      /* an RCCL communicator (one per
 #define MGNNS_ERR_LAUNCH  (-2)
 #define MGNNS_ERR_UNSUPP  (-3)
 
+/* Status word of the persistent launches.  mgnns_label_gcn_fwd hands work between the workgroups of ONE launch through an
+ * in-order item queue, the fused channel / layer tails exchange partial results inside clusters of adjacent workgroups; none
+ * of them needs the whole grid resident, and every wait is bounded: a wait that runs out (a device in trouble, a debugger
+ * holding a wave) writes one of the codes below into the registered word and the launch drains instead of hanging.  The next
+ * persistent launch of the process returns MGNNS_ERR_LAUNCH with the story in mgnns_last_error() and clears the word;
+ * mgnns_take_status() reads-and-clears it explicitly (e.g. after a stream synchronise).
+ * host_pinned: 4 bytes of host memory that the device can write (hipHostMalloc / a pinned torch tensor), alive until replaced;
+ * NULL unregisters.  Without a registered word the waits are still bounded, only the report is lost. */
+#define MGNNS_STATUS_LABEL_GCN_TIMEOUT 1
+#define MGNNS_STATUS_CLUSTER_TIMEOUT   2
+int mgnns_set_status_word(int32_t* host_pinned);
+int mgnns_take_status(void);
+
 /* Text of the last error on the calling thread ("" if none). */
 const char* mgnns_last_error(void);
 /* ABI version (bumped on any signature change). */
@@ -315,18 +328,24 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
  * gen_adj (utils/util.py:421-426) + GraphConvolution x 2 with LeakyReLU(0.2) between them
  * (Multi_GCN_Multihead_att.py:460-473 / 489-499, 42-58) + optionally w_q(label_query) (MODEL:97):
  *   adj = D^-1/2 A^T D^-1/2;  X1 = lrelu(adj @ (inp @ W1));  G = adj @ (X1 @ W2);  Q = label_query @ wq^T + bq
- * as a grid of `grid` (0 or more than a quarter of the CUs: a quarter of the CUs, 64 on an MI355X -- two channels' launches
- * run side by side and must both fit) co-resident workgroups with grid barriers between the phases
+ * as a grid of `grid` (0: a quarter of the CUs, 64 on an MI355X -- the measured optimum with two channels' launches side by
+ * side) workgroups that pull the phases' work items from one in-order queue
  * instead of 11-12 dependent launches.  split = 0: exact-fp32 MFMA, w1a / w2a = mgnns_pack_weight_f32 of W1^T [N1,K0] /
  * W2^T [N2,N1] (bit-equal to mgnns_gen_adj + mgnns_matmul_fwd + mgnns_spmm_csr_fwd); split = 1: split-bf16 operands
  * (fp32-class), (w1a, w1b) / (w2a, w2b) = the (hi, lo) buffers of mgnns_pack_weight_bf16_split.
  * A [C,C]; inp [C,K0]; G [C,N2]; Gp_hi / Gp_lo (both or neither): the mgnns_pack_weight_bf16_split image of G the fused
  * channel tail reads; Q [NLQ,HQ] or NULL.  C <= 512, K0 % 4 == 0, N1, N2 % 256 == 0, N1 <= 1024.
  * scratch: mgnns_label_gcn_scratch_bytes(C, N1, N2) bytes, 256-byte aligned, its first 256 bytes ZERO before the first
- * launch (every launch leaves them zero); one scratch must not be shared by launches that may run concurrently.
- * The launch must not be queued behind work that needs ITS completion to free CUs (it spins at the barriers until all
- * of its workgroups are resident); other kernels may run beside it.
+ * launch (every launch leaves them zero); one scratch must not be shared by launches that may run concurrently (it holds
+ * the launch's intermediates).  The work items of the four phases are pulled in order from one ticket counter, so the
+ * launch makes progress with ANY number of its workgroups resident: any grid, any neighbours (see the status word above).
  */
+/* Shape limits of the three fused launches as predicates (1 = the launch takes these shapes): the host side routes
+ * everything else to the chain of separate operators, which has no such limits.  K_pool = 0 for mgnns_label_tail_supported:
+ * the read-out x is passed in. */
+int mgnns_label_gcn_supported(int C, int K0, int N1, int N2, int split);
+int mgnns_label_tail_supported(int C, int NLQ, int n_heads, int dh, int N5, int n_out, int K_pool, int with_next_q);
+int mgnns_label_tail_bf16_supported(int C, int NLQ, int n_heads, int dh, int N5, int n_out, int K_pool, int terms, int with_next_q);
 size_t mgnns_label_gcn_scratch_bytes(int C, int N1, int N2);
 int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int K0, int split, const void* w1a, const void* w1b, int N1,
                         const void* w2a, const void* w2b, int N2, float* G, void* Gp_hi, void* Gp_lo,

@@ -61,6 +61,11 @@ SIGNATURES = {
     "mgnns_stem_conv7_fwd": [_P, _I, _I, _I, _P, _P, _P, _P],
     "mgnns_maxpool3x3s2_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P],
     "mgnns_conv_bf16_nhwc_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    "mgnns_label_gcn_supported": [_I, _I, _I, _I, _I],
+    "mgnns_label_tail_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "mgnns_label_tail_bf16_supported": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "mgnns_set_status_word": [_P],
+    "mgnns_take_status": [],
     "mgnns_debug_slabcopy": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mgnns_debug_stamp": [_P, _I, _P],
     "mgnns_debug_spin": [_I, _P, _I, _P],
@@ -120,7 +125,34 @@ def lib():
         fn.restype = _I
         fn.argtypes = args
     _lib = L
+    _register_status_word(L)
     return L
+
+
+_status_word = None
+
+
+def _register_status_word(L):
+    """Hand the library 4 bytes of host-pinned memory for the status of its persistent launches (include/mgnns_hip.h):
+    a bounded wait that runs out is then REPORTED by the next such launch instead of being lost.  Needs a GPU."""
+    global _status_word
+    import torch
+    if _status_word is not None or not torch.cuda.is_available():
+        return
+    try:
+        w = torch.zeros(16, dtype=torch.int32).pin_memory()
+    except RuntimeError:
+        return
+    L.mgnns_set_status_word(w.data_ptr())
+    _status_word = w                     # keeps the allocation alive for the life of the process
+
+
+def take_status():
+    """Read-and-clear the persistent launches' status word (0 = fine); raise if it is set.  Meaningful after a stream
+    synchronise; the next persistent launch reports a raised word on its own."""
+    code = lib().mgnns_take_status()
+    if code:
+        raise RuntimeError("a persistent launch gave up a bounded wait (status %d): results since then are invalid" % code)
 
 
 def check(rc, name):

@@ -31,6 +31,40 @@ int mg_ensure_dyn_lds(const void* fn, int bytes) {
     return 0;
 }
 
+// ---- status word of the persistent launches -----------------------------------------------------------------------
+// The kernels that hand data between workgroups of one launch (label GCN item queue, channel-tail / layer-tail clusters) bound
+// every wait; a wait that runs out raises this word (host-pinned, device-mapped memory registered by the host side) and the
+// launch drains.  The next persistent launch of the process reports it: no hidden synchronisation, no hang.
+static int32_t* g_status = nullptr;
+
+int32_t* mg_status_word() { return g_status; }
+
+int mg_check_status(const char* who) {
+    int32_t* p = g_status;
+    if (!p) return 0;
+    const int32_t code = __atomic_load_n(p, __ATOMIC_RELAXED);
+    if (code == 0) return 0;
+    __atomic_store_n(p, 0, __ATOMIC_RELAXED);
+    mgnns_set_error("%s: an EARLIER persistent launch gave up a bounded wait (status %d: %s) -- its results and everything computed "
+                    "from them since are invalid; the device is fine, re-run the forward",
+                    who, (int)code,
+                    code == MGNNS_STATUS_LABEL_GCN_TIMEOUT ? "label GCN item queue"
+                    : code == MGNNS_STATUS_CLUSTER_TIMEOUT ? "workgroup-cluster exchange" : "unknown");
+    return MGNNS_ERR_LAUNCH;
+}
+
+extern "C" int mgnns_set_status_word(int32_t* host_pinned) {
+    g_status = host_pinned;
+    if (host_pinned) __atomic_store_n(host_pinned, 0, __ATOMIC_RELAXED);
+    return 0;
+}
+
+extern "C" int mgnns_take_status(void) {
+    int32_t* p = g_status;
+    if (!p) return 0;
+    return (int)__atomic_exchange_n(p, 0, __ATOMIC_RELAXED);
+}
+
 extern "C" const char* mgnns_last_error(void) { return g_err; }
 extern "C" int mgnns_abi_version(void) { return 10; }
 

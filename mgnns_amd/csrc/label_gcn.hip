@@ -3,7 +3,8 @@
 // As separate operators this is 11-12 launches (row sums, normalisation, CSR count / scan / fill, two GEMMs, two SpMMs, the
 // split-bf16 image of G, the query projection) that all run at the very start of the forward, in front of the channel's
 // memory-bank kernel on the same stream: ~120 us (object) / ~200 us (scene) before the HBM-bound bank kernels could start, and
-// 135 us of a 0.52-ms forward at B = 32.  Here a grid of G workgroups walks the phases with grid barriers in between:
+// 135 us of a 0.52-ms forward at B = 32.  Here a grid of G workgroups pulls the work items of the four phases, in phase order,
+// from ONE ticket counter:
 //   P0  d = rowsum(A)^-1/2          |  S1 = inp @ W1 (16-row x 256-column MFMA work items)  |  Q = w_q(label_query)
 //   P1  adj row i (normalised, non-zeros compacted in ascending column order -- no count / scan / fill passes: a row's
 //       non-zeros go to an ELL slot of C entries)  and, by the same wave, X1[i,:] = LeakyReLU(sum_p val_p S1[col_p,:])
@@ -16,7 +17,12 @@
 // Cross-workgroup data (d, the ELL rows, S1, X1, S2) moves without fences: system-scope write-through stores, s_waitcnt
 // vmcnt(0) before the barrier's arrival count (one relaxed agent-scope atomic per workgroup), cache-bypassing loads after it
 // (the per-XCD L2s are not coherent with each other; an agent-scope fence per workgroup costs microseconds).
-// The grid must be co-resident: the launcher caps it at the CU count and the forward enqueues it first on its stream.
+// No co-residency requirement: tickets are handed out in item order, so whoever holds an item of phase p + 1 waits (one polling
+// lane, s_sleep) only for items of phase p that workgroups ALREADY RUNNING hold -- a grid of any size makes progress with any
+// number of its workgroups resident, two models / two streams / a second process beside it included.  (Rounds 1-2 used a
+// counting grid barrier, which hangs as soon as one workgroup of the grid cannot be scheduled.)  The wait is bounded all the
+// same: after ~2^24 polls a workgroup raises the abort word (everybody drains) and the library's status word
+// (mgnns_set_status_word), which the next persistent launch reports through mgnns_last_error().
 #include "common.hpp"
 #include "tile_bf16.hpp"
 #include "tile_f32.hpp"
@@ -37,7 +43,9 @@ struct LgArgs {
     const float *lq, *wq, *bq; int NLQ, HQ; float* Q;      // optional: Q = lq @ wq^T + bq
     float* d; int* ell_col; float* ell_val; int* nnz;      // scratch: [C], [C*C], [C*C], [C]
     float *S1, *X1, *S2;                     // scratch: [C,N1], [C,N1], [C,N2]
-    int* counters;                           // [2], zero before the first launch; every launch leaves them zero
+    int* counters;                           // 64 ints (ticket head, done[4], exited, abort: see LG_DONE ...); zero before the first launch, every launch leaves them zero
+    int* status;                             // the library's status word (host-pinned, may be null)
+    int rows_d, outs_q, pcs3;                // wave-granular work per queue item (multiples of 8: one or more per wave), sized to the grid
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* p, size_t bytes) {
@@ -59,16 +67,57 @@ __device__ __forceinline__ void lg_st4(__amdgpu_buffer_rsrc_t r, int off, f32x4 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lg_i32x4, v), r, off, 0, 17);
 }
 
-// every workgroup of the grid has finished the phase and its stores are visible: the k-th barrier waits for k * gridDim.x arrivals
-__device__ __forceinline__ void lg_grid_barrier(int* counters, int k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores are acknowledged
-    __syncthreads();
+// counters (ints, three 64-byte lines so that ticket draws, arrival polls and the exit count do not share one):
+//   [0] ticket head   [16 + p] items of phase p done   [32] workgroups that left   [33] abort
+constexpr int LG_DONE = 16, LG_LEFT = 32, LG_ABORT = 33;
+constexpr int LG_SPIN_LIMIT = 1 << 24;
+// next work item of this workgroup (wave-uniform), -1 once the queue is empty or the launch is being aborted.  Thread 0 draws
+// the ticket AFTER the next one while the current item is being worked on (`ahead`): the atomic's round trip (~1 us) hides
+// behind the item.  Tickets are still handed out in item order, and a workgroup that holds two is running: the progress
+// argument above is unchanged.
+__device__ __forceinline__ int lg_take(int* counters, int total, int* s_ticket, int& ahead) {
+    __syncthreads();                                               // the previous item is finished by every wave (LDS reuse)
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = k * (int)gridDim.x;
-        while (__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        int t = ahead;                                             // (an abort is noticed at the next phase wait)
+        if (t >= total) t = -1;
+        *s_ticket = t;
     }
     __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*s_ticket);
+}
+// draw the ticket after this one; called once the workgroup is about to start on its item (behind the phase hand-over, whose
+// waits would otherwise include this atomic's round trip)
+__device__ __forceinline__ void lg_draw_ahead(int* counters, int& ahead) {
+    if (threadIdx.x == 0) ahead = __hip_atomic_fetch_add(&counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all `need` items of `phase` are done and their write-through stores visible; false = aborted (bounded wait ran out)
+__device__ __forceinline__ bool lg_wait_phase(int* counters, int phase, int need, int* status, int* s_ok) {
+    if (threadIdx.x == 0) {
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(&counters[LG_DONE + phase], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            if (++spins > LG_SPIN_LIMIT ||
+                ((spins & 63) == 0 && __hip_atomic_load(&counters[LG_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&counters[LG_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (status) __hip_atomic_store(status, MGNNS_STATUS_LABEL_GCN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*s_ok) != 0;      // (rewritten only behind the barriers of the next lg_done / lg_take)
+}
+// `n` items of `phase` this workgroup has finished: their stores are acknowledged, then one relaxed arrival for all of them.
+// Called when the workgroup LEAVES the phase (it draws a ticket of a later phase, or the queue is empty), not per item: waiting
+// for the write-through acknowledgements after every item serialised a fabric round trip per item (measured 59 / 124 us per
+// launch at C = 80 / 365 against 42 / 92 us with one wait per phase).  A workgroup that owes arrivals is running and about to
+// deliver them -- before it waits for anything itself -- so the progress argument is unchanged.
+__device__ __forceinline__ void lg_done(int* counters, int phase, int n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&counters[LG_DONE + phase], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int lg_sa(int K) { return ((K + 15) / 16) * 16 + 4; }                  // fp32 LDS row stride: conflict-free A fragments
@@ -138,142 +187,202 @@ __global__ __launch_bounds__(LG_THR) void label_gcn_kernel(LgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = (int)gridDim.x * 8, gw = (int)blockIdx.x * 8 + wave;
     const int C = a.C, K0 = a.K0, N1 = a.N1, N2 = a.N2;
     const int MT = (C + 15) / 16;
     const size_t tile_bytes = SPLIT ? (size_t)2 * 16 * lg_sc(N1 > K0 ? N1 : K0) * 16 : (size_t)16 * lg_sa(N1 > K0 ? N1 : K0) * 4;
     int* s_col = reinterpret_cast<int*>(smem + tile_bytes) + wave * LG_MAXC;           // this wave's ELL row
     float* s_val = reinterpret_cast<float*>(smem + tile_bytes + 8 * LG_MAXC * sizeof(int)) + wave * LG_MAXC;
 
-    const __amdgpu_buffer_rsrc_t r_d = lg_rsrc(a.d, (size_t)C * 4), r_nnz = lg_rsrc(a.nnz, (size_t)C * 4);
-    const __amdgpu_buffer_rsrc_t r_ec = lg_rsrc(a.ell_col, (size_t)C * C * 4), r_ev = lg_rsrc(a.ell_val, (size_t)C * C * 4);
-    const __amdgpu_buffer_rsrc_t r_s1 = lg_rsrc(a.S1, (size_t)C * N1 * 4), r_x1 = lg_rsrc(a.X1, (size_t)C * N1 * 4);
-    const __amdgpu_buffer_rsrc_t r_s2 = lg_rsrc(a.S2, (size_t)C * N2 * 4), r_inp = lg_rsrc(a.inp, (size_t)C * K0 * 4);
+    // buffer resources are built where a phase uses them: eight of them live across the item loop spilled ~90 SGPRs
+#define LG_RSRC_D const __amdgpu_buffer_rsrc_t r_d = lg_rsrc(a.d, (size_t)C * 4)
+#define LG_RSRC_ELL                                                                                          \
+    const __amdgpu_buffer_rsrc_t r_nnz = lg_rsrc(a.nnz, (size_t)C * 4), r_ec = lg_rsrc(a.ell_col, (size_t)C * C * 4), \
+                                 r_ev = lg_rsrc(a.ell_val, (size_t)C * C * 4)
 
-    // ---- P0: degree normalisers, the first support, the label query projection --------------------------------------------------
-    for (int i = gw; i < C; i += NW) {                  // d[i] = (sum_j A[i,j])^-1/2 (utils/util.py:422), one wave per row
-        const float* row = a.A + (size_t)i * C;
-        float s = 0.f;
-        for (int j = lane; j < C; j += 64) s += row[j];
-        s = wave_sum(s);
-        if (lane == 0) lg_st1(r_d, i * 4, powf(s, -0.5f));
-    }
-    if (a.Q) {
-        for (int o = gw; o < a.NLQ * a.HQ; o += NW) {   // MODEL:97 w_q(label query): one wave per output
-            const int l = o / a.HQ, n = o - l * a.HQ;
-            float s = 0.f;
-            for (int k = lane; k < K0; k += 64) s = fmaf(a.lq[(size_t)l * K0 + k], a.wq[(size_t)n * K0 + k], s);
-            s = wave_sum(s);
-            if (lane == 0) a.Q[o] = s + (a.bq ? a.bq[n] : 0.f);
-        }
-    }
-    for (int it = blockIdx.x; it < MT * (N1 / 256); it += gridDim.x)
-        lg_gemm_item<SPLIT, false>(smem, r_inp, C, K0, it / (N1 / 256), it % (N1 / 256), a.w1a, a.w1b, N1, r_s1, tid, wave, lane);
-    lg_grid_barrier(a.counters, 1);
-
-    // ---- P1: normalised adjacency row i -> ELL slot, and X1[i,:] = LeakyReLU(adj[i,:] @ S1) by the same wave ----------------------
-    for (int i = gw; i < C; i += NW) {
-        const float di = lg_ld1(r_d, i * 4);
-        int cnt = 0;
-        for (int j0 = 0; j0 < C; j0 += 64) {
-            const int j = j0 + lane;
-            float v = 0.f;
-            if (j < C) v = (a.A[(size_t)j * C + i] * di) * lg_ld1(r_d, j * 4);      // ((A D)^T D)[i,j], rounding order of gen_adj
-            const bool nz = j < C && v != 0.0f;
-            const unsigned long long m = __ballot(nz);
-            if (nz) {
-                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                s_col[pos] = j;
-                s_val[pos] = v;
-                lg_st1i(r_ec, (i * C + pos) * 4, j);
-                lg_st1(r_ev, (i * C + pos) * 4, v);
-            }
-            cnt += __popcll(m);
-        }
-        if (lane == 0) lg_st1i(r_nnz, i * 4, cnt);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int c0 = 0; c0 < N1; c0 += 256) {
-            const int off = (c0 + lane * 4) * 4;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int p = 0;
-            for (; p + 2 <= cnt; p += 2) {
-                const int c0_ = s_col[p], c1_ = s_col[p + 1];
-                const float w0 = s_val[p], w1 = s_val[p + 1];
-                const f32x4 x0 = lg_ld4<true>(r_s1, c0_ * N1 * 4 + off), x1 = lg_ld4<true>(r_s1, c1_ * N1 * 4 + off);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[q] = fmaf(w0, x0[q], acc[q]);
-                    acc[q] = fmaf(w1, x1[q], acc[q]);
-                }
-            }
-            if (p < cnt) {
-                const f32x4 x0 = lg_ld4<true>(r_s1, s_col[p] * N1 * 4 + off);
-                const float w0 = s_val[p];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0, x0[q], acc[q]);
-            }
-            lg_st4(r_x1, i * N1 * 4 + off, f32x4{mg_act(acc[0], MGNNS_ACT_LRELU2), mg_act(acc[1], MGNNS_ACT_LRELU2),
-                                                 mg_act(acc[2], MGNNS_ACT_LRELU2), mg_act(acc[3], MGNNS_ACT_LRELU2)});
-        }
-        __builtin_amdgcn_wave_barrier();                // the next row of this wave rewrites the LDS list
-    }
-    lg_grid_barrier(a.counters, 2);
-
-    // ---- P2: S2 = X1 @ W2 ------------------------------------------------------------------------------------------------------
-    for (int it = blockIdx.x; it < MT * (N2 / 256); it += gridDim.x)
-        lg_gemm_item<SPLIT, true>(smem, r_x1, C, N1, it / (N2 / 256), it % (N2 / 256), a.w2a, a.w2b, N2, r_s2, tid, wave, lane);
-    lg_grid_barrier(a.counters, 3);
-
-    // ---- P3: G = adj @ S2 (+ its split-bf16 fragment-major image; rows C..16*MT of the image are zero) -----------------------------
+    // ---- the item queue: phase order, the long items of a phase first ------------------------------------------------------
+    //   P0  [0, nG1)           S1 = inp @ W1, 16-row x 256-column MFMA items
+    //       [nG1, nG1 + nD)    degree normalisers d, rows_d rows per item (a wave per row)
+    //       [.., n0)           Q = w_q(label query), outs_q outputs per item (a wave per output)
+    //   P1  n1 items of 8 adjacency rows (a wave per row): normalised row -> ELL slot, X1 row
+    //   P2  n2 MFMA items of S2 = X1 @ W2
+    //   P3  n3 items of pcs3 (row, 256-column chunk) pieces of G = adj @ S2 (a wave per piece)
+    //   (the wave-granular items are sized by the launcher to about two per workgroup and phase)
+    int* s_flags = reinterpret_cast<int*>(smem + tile_bytes + (size_t)8 * LG_MAXC * 8);      // ticket, wait result (dynamic LDS: the launch may take all 160 KiB)
+    int& s_ticket = s_flags[0];
+    int& s_ok = s_flags[1];
     const int NC2 = N2 / 256, KS2 = (N2 + 31) / 32;
-    for (int it = gw; it < MT * 16 * NC2; it += NW) {
-        const int i = it / NC2, c0 = (it - i * NC2) * 256;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (i < C) {
-            const int cnt = lg_ld1i(r_nnz, i * 4);
-            const int off = (c0 + lane * 4) * 4;
-            int p = 0;
-            for (; p + 2 <= cnt; p += 2) {
-                const int c0_ = lg_ld1i(r_ec, (i * C + p) * 4), c1_ = lg_ld1i(r_ec, (i * C + p + 1) * 4);
-                const float w0 = lg_ld1(r_ev, (i * C + p) * 4), w1 = lg_ld1(r_ev, (i * C + p + 1) * 4);
-                const f32x4 x0 = lg_ld4<true>(r_s2, c0_ * N2 * 4 + off), x1 = lg_ld4<true>(r_s2, c1_ * N2 * 4 + off);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[q] = fmaf(w0, x0[q], acc[q]);
-                    acc[q] = fmaf(w1, x1[q], acc[q]);
+    const int RD = a.rows_d, OQ = a.outs_q, P3 = a.pcs3;
+    const int nG1 = MT * (N1 / 256), nD = (C + RD - 1) / RD, nQ = a.Q ? (a.NLQ * a.HQ + OQ - 1) / OQ : 0;
+    const int n0 = nG1 + nD + nQ, n1 = (C + 7) / 8, n2 = MT * NC2, n3 = (MT * 16 * NC2 + P3 - 1) / P3;
+    const int total = n0 + n1 + n2 + n3;
+    int phase_ok = 0;                                          // phases below this one are known to be complete
+    int ahead = 0;                                             // thread 0: the ticket drawn ahead
+    if (tid == 0) ahead = __hip_atomic_fetch_add(&a.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur_phase = 0, pending = 0;                            // finished items of cur_phase not yet reported
+    for (;;) {
+        int it = lg_take(a.counters, total, &s_ticket, ahead);
+        const int ph = it < 0 ? 4 : it < n0 ? 0 : it < n0 + n1 ? 1 : it < n0 + n1 + n2 ? 2 : 3;
+        if (ph != cur_phase) {
+            if (pending) lg_done(a.counters, cur_phase, pending);
+            cur_phase = ph;
+            pending = 0;
+        }
+        if (it < 0) break;
+        if (ph > phase_ok) {                                   // the first item of a later phase: everything before it is complete
+            if (!lg_wait_phase(a.counters, ph - 1, ph == 1 ? n0 : ph == 2 ? n1 : n2, a.status, &s_ok)) break;
+            phase_ok = ph;
+        }
+        lg_draw_ahead(a.counters, ahead);
+        if (it < n0) {
+            // ---- P0 ------------------------------------------------------------------------------------------------------------
+            if (it < nG1) {
+                const __amdgpu_buffer_rsrc_t r_inp = lg_rsrc(a.inp, (size_t)C * K0 * 4), r_s1 = lg_rsrc(a.S1, (size_t)C * N1 * 4);
+                lg_gemm_item<SPLIT, false>(smem, r_inp, C, K0, it / (N1 / 256), it % (N1 / 256), a.w1a, a.w1b, N1, r_s1, tid, wave, lane);
+            } else if (it < nG1 + nD) {
+                LG_RSRC_D;
+                for (int i = (it - nG1) * RD + wave; i < min(C, (it - nG1 + 1) * RD); i += 8) {   // d[i] = (sum_j A[i,j])^-1/2 (utils/util.py:422)
+                    const float* row = a.A + (size_t)i * C;
+                    float sum = 0.f;
+                    for (int j = lane; j < C; j += 64) sum += row[j];
+                    sum = wave_sum(sum);
+                    if (lane == 0) lg_st1(r_d, i * 4, powf(sum, -0.5f));
+                }
+            } else {
+                const int o0 = (it - nG1 - nD) * OQ;
+                for (int o = o0 + wave; o < min(a.NLQ * a.HQ, o0 + OQ); o += 8) {                 // MODEL:97 w_q(label query)
+                    const int l = o / a.HQ, n = o - l * a.HQ;
+                    float sum = 0.f;
+                    for (int k = lane; k < K0; k += 64) sum = fmaf(a.lq[(size_t)l * K0 + k], a.wq[(size_t)n * K0 + k], sum);
+                    sum = wave_sum(sum);
+                    if (lane == 0) a.Q[o] = sum + (a.bq ? a.bq[n] : 0.f);
                 }
             }
-            if (p < cnt) {
-                const f32x4 x0 = lg_ld4<true>(r_s2, lg_ld1i(r_ec, (i * C + p) * 4) * N2 * 4 + off);
-                const float w0 = lg_ld1(r_ev, (i * C + p) * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0, x0[q], acc[q]);
-            }
-            *reinterpret_cast<f32x4*>(a.G + (size_t)i * N2 + c0 + lane * 4) = acc;
+            ++pending;
+            continue;
         }
-        if (a.gp_hi) {
-            const int k = c0 + lane * 4;
-            const size_t e = ((((size_t)(i >> 4) * KS2 + (k >> 5)) * 64 + (i & 15) + 16 * ((k & 31) >> 3)) * 8) + (k & 7);
-            unsigned short h[4], l[4];
+        it -= n0;
+        if (it < n1) {
+            // ---- P1: normalised adjacency row i -> ELL slot, and X1[i,:] = LeakyReLU(adj[i,:] @ S1) by the same wave ----------------
+            const int i = it * 8 + wave;
+            if (i < C) {
+                LG_RSRC_D;
+                LG_RSRC_ELL;
+                const __amdgpu_buffer_rsrc_t r_s1 = lg_rsrc(a.S1, (size_t)C * N1 * 4), r_x1 = lg_rsrc(a.X1, (size_t)C * N1 * 4);
+                const float di = lg_ld1(r_d, i * 4);
+                int cnt = 0;
+                for (int j0 = 0; j0 < C; j0 += 64) {
+                    const int j = j0 + lane;
+                    float v = 0.f;
+                    if (j < C) v = (a.A[(size_t)j * C + i] * di) * lg_ld1(r_d, j * 4);      // ((A D)^T D)[i,j], rounding order of gen_adj
+                    const bool nz = j < C && v != 0.0f;
+                    const unsigned long long m = __ballot(nz);
+                    if (nz) {
+                        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        s_col[pos] = j;
+                        s_val[pos] = v;
+                        lg_st1i(r_ec, (i * C + pos) * 4, j);
+                        lg_st1(r_ev, (i * C + pos) * 4, v);
+                    }
+                    cnt += __popcll(m);
+                }
+                if (lane == 0) lg_st1i(r_nnz, i * 4, cnt);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int c0 = 0; c0 < N1; c0 += 256) {
+                    const int off = (c0 + lane * 4) * 4;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    int p = 0;
+                    for (; p + 2 <= cnt; p += 2) {
+                        const int c0_ = s_col[p], c1_ = s_col[p + 1];
+                        const float w0 = s_val[p], w1 = s_val[p + 1];
+                        const f32x4 x0 = lg_ld4<true>(r_s1, c0_ * N1 * 4 + off), x1 = lg_ld4<true>(r_s1, c1_ * N1 * 4 + off);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                h[q] = f2bf_t(acc[q]);
-                l[q] = f2bf_t(acc[q] - bf2f_t(h[q]));
+                        for (int q = 0; q < 4; ++q) {
+                            acc[q] = fmaf(w0, x0[q], acc[q]);
+                            acc[q] = fmaf(w1, x1[q], acc[q]);
+                        }
+                    }
+                    if (p < cnt) {
+                        const f32x4 x0 = lg_ld4<true>(r_s1, s_col[p] * N1 * 4 + off);
+                        const float w0 = s_val[p];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0, x0[q], acc[q]);
+                    }
+                    lg_st4(r_x1, i * N1 * 4 + off, f32x4{mg_act(acc[0], MGNNS_ACT_LRELU2), mg_act(acc[1], MGNNS_ACT_LRELU2),
+                                                         mg_act(acc[2], MGNNS_ACT_LRELU2), mg_act(acc[3], MGNNS_ACT_LRELU2)});
+                }
             }
-            *reinterpret_cast<uint2*>(a.gp_hi + e) = make_uint2(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16);
-            *reinterpret_cast<uint2*>(a.gp_lo + e) = make_uint2(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16);
+            ++pending;
+            continue;
         }
+        it -= n1;
+        if (it < n2) {
+            // ---- P2: S2 = X1 @ W2 ----------------------------------------------------------------------------------------------
+            {
+                const __amdgpu_buffer_rsrc_t r_x1 = lg_rsrc(a.X1, (size_t)C * N1 * 4), r_s2 = lg_rsrc(a.S2, (size_t)C * N2 * 4);
+                lg_gemm_item<SPLIT, true>(smem, r_x1, C, N1, it / NC2, it % NC2, a.w2a, a.w2b, N2, r_s2, tid, wave, lane);
+            }
+            ++pending;
+            continue;
+        }
+        it -= n2;
+        // ---- P3: G = adj @ S2 (+ its split-bf16 fragment-major image; rows C..16*MT of the image are zero) ---------------------------
+        LG_RSRC_ELL;
+        const __amdgpu_buffer_rsrc_t r_s2 = lg_rsrc(a.S2, (size_t)C * N2 * 4);
+        for (int pc = it * P3 + wave; pc < min(MT * 16 * NC2, (it + 1) * P3); pc += 8) {
+            const int i = pc / NC2, c0 = (pc - i * NC2) * 256;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (i < C) {
+                const int cnt = lg_ld1i(r_nnz, i * 4);
+                const int off = (c0 + lane * 4) * 4;
+                int p = 0;
+                for (; p + 2 <= cnt; p += 2) {
+                    const int c0_ = lg_ld1i(r_ec, (i * C + p) * 4), c1_ = lg_ld1i(r_ec, (i * C + p + 1) * 4);
+                    const float w0 = lg_ld1(r_ev, (i * C + p) * 4), w1 = lg_ld1(r_ev, (i * C + p + 1) * 4);
+                    const f32x4 x0 = lg_ld4<true>(r_s2, c0_ * N2 * 4 + off), x1 = lg_ld4<true>(r_s2, c1_ * N2 * 4 + off);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q] = fmaf(w0, x0[q], acc[q]);
+                        acc[q] = fmaf(w1, x1[q], acc[q]);
+                    }
+                }
+                if (p < cnt) {
+                    const f32x4 x0 = lg_ld4<true>(r_s2, lg_ld1i(r_ec, (i * C + p) * 4) * N2 * 4 + off);
+                    const float w0 = lg_ld1(r_ev, (i * C + p) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0, x0[q], acc[q]);
+                }
+                *reinterpret_cast<f32x4*>(a.G + (size_t)i * N2 + c0 + lane * 4) = acc;
+            }
+            if (a.gp_hi) {
+                const int k = c0 + lane * 4;
+                const size_t e = ((((size_t)(i >> 4) * KS2 + (k >> 5)) * 64 + (i & 15) + 16 * ((k & 31) >> 3)) * 8) + (k & 7);
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = f2bf_t(acc[q]);
+                    l[q] = f2bf_t(acc[q] - bf2f_t(h[q]));
+                }
+                *reinterpret_cast<uint2*>(a.gp_hi + e) = make_uint2(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16);
+                *reinterpret_cast<uint2*>(a.gp_lo + e) = make_uint2(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16);
+            }
+        }
+        ++pending;
     }
 
-    // ---- re-arm the barrier counter: the last workgroup to leave (everyone is past barrier 3 by then) --------------------------------
+#undef LG_RSRC_D
+#undef LG_RSRC_ELL
+    // ---- re-arm the queue: the last workgroup to leave (nobody holds an item or polls a counter by then) ------------------------------
     __syncthreads();
     if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(&a.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = __hip_atomic_fetch_add(&a.counters[LG_LEFT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (int)gridDim.x - 1) {
             __hip_atomic_store(&a.counters[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.counters[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) __hip_atomic_store(&a.counters[LG_DONE + k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.counters[LG_LEFT], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.counters[LG_ABORT], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -285,6 +394,16 @@ extern "C" size_t mgnns_label_gcn_scratch_bytes(int C, int N1, int N2) {
     // d, nnz, ELL (col, val), S1, X1, S2, each padded to 256 B, + the two counters
     auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
     return 2 * pad((size_t)C * 4) + 2 * pad((size_t)C * C * 4) + 2 * pad((size_t)C * N1 * 4) + pad((size_t)C * N2 * 4) + 256;
+}
+
+// The shape limits of mgnns_label_gcn_fwd as a predicate (the host side routes unsupported shapes to the separate operators).
+extern "C" int mgnns_label_gcn_supported(int C, int K0, int N1, int N2, int split) {
+    if (!(C > 0 && C <= LG_MAXC && K0 > 0 && K0 % 4 == 0 && K0 <= 1024)) return 0;
+    if (!(N1 > 0 && N1 % 256 == 0 && N1 <= 1024 && N2 > 0 && N2 % 256 == 0)) return 0;
+    if ((size_t)C * N2 * 4 >= ((size_t)1 << 31)) return 0;
+    const int kmax = N1 > K0 ? N1 : K0;
+    const size_t tile = split ? (size_t)2 * 16 * lg_sc(kmax) * 16 : (size_t)16 * lg_sa(kmax) * 4;
+    return tile + (size_t)8 * LG_MAXC * 8 + 16 <= 160 * 1024 ? 1 : 0;
 }
 
 extern "C" int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int K0, int split, const void* w1a, const void* w1b,
@@ -320,20 +439,27 @@ extern "C" int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int 
     a.lq = label_query; a.wq = wq; a.bq = bq; a.NLQ = NLQ; a.HQ = HQ; a.Q = Q;
     const int kmax = N1 > K0 ? N1 : K0;
     const size_t tile = split ? (size_t)2 * 16 * lg_sc(kmax) * 16 : (size_t)16 * lg_sa(kmax) * 4;
-    const size_t lds = tile + (size_t)8 * LG_MAXC * 8;
+    const size_t lds = tile + (size_t)8 * LG_MAXC * 8 + 16;
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_gcn_fwd: %zu B of LDS needed", lds);
-    // The grid barrier needs every workgroup resident at once (one 512-thread workgroup with this LDS footprint per CU), and
-    // the forward runs TWO of these launches side by side (object and scene channel): two grids that each wait for more than
-    // half of the CUs dead-lock each other (measured: grid 256 on both channels hangs).  Hence at most a QUARTER of the CUs
-    // per launch -- 64 on an MI355X, which is also the default: the phases' work items (23 x 4, 23 x 8 tiles at C = 365)
-    // divide evenly enough and the launch leaves the rest of the chip to the memory-bank kernels that start beside it.
+    // Any grid is CORRECT (the item queue needs no co-residency); the default is a quarter of the CUs -- 64 on an MI355X: the
+    // forward runs two of these launches side by side (object and scene channel) in front of the chip-filling memory-bank
+    // kernels, a workgroup takes a whole CU (LDS), and 32 / 64 / 128 workgroups measured 0.843 / 0.848 / 0.873 ms per B = 256
+    // forward, 0.533 / 0.480 / 0.492 at B = 32 (round 2, with the counting barrier).
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
         mgnns_set_error("mgnns_label_gcn_fwd: cannot query the CU count");
         return MGNNS_ERR_LAUNCH;
     }
-    const int cap = n_cu / 4 > 0 ? n_cu / 4 : 1;
-    if (grid <= 0 || grid > cap) grid = cap;
+    if (grid <= 0) grid = n_cu / 4 > 0 ? n_cu / 4 : 1;
+    if (grid > 4 * n_cu) grid = 4 * n_cu;
+    if (int rc = mg_check_status("mgnns_label_gcn_fwd")) return rc;     // a bounded wait of an earlier persistent launch ran out
+    a.status = mg_status_word();
+    // wave-granular queue items: about two per workgroup and phase (finer costs tickets, coarser leaves workgroups idle at the
+    // end of a phase: 64-piece items in P3 left 18 of 64 workgroups without work at C = 365)
+    auto per_item = [&](int n) { const int k = (n + 16 * grid - 1) / (16 * grid); return 8 * (k > 0 ? k : 1); };
+    a.rows_d = per_item(C);
+    a.outs_q = per_item(NLQ * HQ > 0 ? NLQ * HQ : 1);
+    a.pcs3 = per_item(((C + 15) / 16) * 16 * (N2 / 256));
     if (split) {
         MG_DYN_LDS(label_gcn_kernel<true>, 160 * 1024);
         hipLaunchKernelGGL(label_gcn_kernel<true>, dim3(grid), dim3(LG_THR), lds, (hipStream_t)stream, a);

@@ -220,6 +220,19 @@ __global__ __launch_bounds__(LT_THR) void label_tail_kernel(const float* __restr
 
 }  // namespace
 
+// The shape limits of mgnns_label_tail_fwd as a predicate (the host side routes unsupported shapes to the operator chain
+// instead of running into the launcher's argument errors).  K_pool = 0: the read-out x is passed in.
+extern "C" int mgnns_label_tail_supported(int C, int NLQ, int n_heads, int dh, int N5, int n_out, int K_pool, int with_next_q) {
+    if (!(C > 0 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64 && N5 > 0 && n_out > 0)) return 0;
+    if (K_pool && K_pool % 4) return 0;
+    const int hid = n_heads * dh;
+    if (!(hid <= 16 * LT_MAXKQ && n_heads <= LT_MAXH && N5 <= 128)) return 0;
+    if (with_next_q && n_out != hid) return 0;
+    if (K_pool && lt_stride(NLQ * N5) < lt_stride(LT_KCH)) return 0;
+    const size_t lds = ((size_t)LT_ROWS * (lt_stride(C) + 3 * lt_stride(hid) + lt_stride(NLQ * N5)) + (size_t)NLQ * hid) * sizeof(float);
+    return lds <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int mgnns_label_tail_fwd(const float* x, int B, int C, const float* pooled, int n_parts, int K_pool,
                                     const float* g_wp, const float* Q, int NLQ, int n_heads, int dh,
                                     const float* wk_wp, const float* bk, const float* wv_wp, const float* bv,
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
                                                                  const float* __restrict__ Q, int NLQ, int n_heads, int dh,
                                                                  LabelW w, int N5, int NO, float* __restrict__ out, int HKn,
                                                                  float* __restrict__ qh_next, float* __restrict__ xpart,
-                                                                 int* __restrict__ counters) {
+                                                                 int* __restrict__ counters, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     constexpr int NH = TERMS == 3 ? 4 : 1;                              // passes over the read-out's K (LDS holds K / NH of pooled)
     constexpr int LO = TERMS == 3 ? 1 : 0;
@@ -396,7 +409,18 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(&counters[2 * tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(&counters[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CL) __builtin_amdgcn_s_sleep(4);
+            // The ranks of a tile are ADJACENT in dispatch order, so at most one cluster of a launch straddles the edge of what is
+            // resident and everything in front of it retires without waiting for anybody: no co-residency requirement beyond
+            // in-order dispatch.  The wait is bounded all the same (a device in trouble must not become a hang): when it runs out
+            // the rank goes on with what has arrived and raises the library's status word (mgnns_set_status_word).
+            int spins = 0;
+            while (__hip_atomic_load(&counters[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < CL) {
+                if (++spins > (1 << 24)) {
+                    if (status) __hip_atomic_store(status, MGNNS_STATUS_CLUSTER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -565,6 +589,22 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
 
 }  // namespace
 
+// The shape limits of mgnns_label_tail_bf16_fwd as a predicate (see mgnns_label_tail_supported).
+extern "C" int mgnns_label_tail_bf16_supported(int C, int NLQ, int n_heads, int dh, int N5, int n_out, int K_pool, int terms,
+                                               int with_next_q) {
+    if (!(C > 0 && C <= 384 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64 && N5 > 0 && N5 <= 128 && n_out > 0)) return 0;
+    if (terms != 1 && terms != 3) return 0;
+    if (!(K_pool > 0 && K_pool % 128 == 0)) return 0;
+    const int hid = n_heads * dh;
+    if (!(hid <= 32 * LB_MAXKS && n_out <= 384 && n_heads <= LT_MAXH)) return 0;
+    if (with_next_q && n_out != hid) return 0;
+    const int nh = terms == 3 ? 4 : 1, lo = terms == 3 ? 1 : 0;
+    const int sp = 4 * (K_pool / 32 / nh) + 2, sxc = 4 * ((C + 31) / 32) + 2, shc = 4 * ((hid + 31) / 32) + 2, sfc = 4 * ((NLQ * N5 + 31) / 32) + 2;
+    const size_t lds = (size_t)(1 + lo) * LT_ROWS * ((sp > sfc ? sp : sfc) + sxc + shc) * 16 +
+                       ((size_t)2 * LT_ROWS * lt_stride(hid) + (size_t)NLQ * hid) * sizeof(float);
+    return lds <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts, int K_pool, int C, int terms,
                                          const void* const* packed /* g, wk, wv, wc, xl, wq_next: (hi, lo) pairs */,
                                          const float* Q, int NLQ, int n_heads, int dh, const float* bk, const float* bv,
@@ -596,6 +636,8 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_label_tail_bf16_fwd: K_pool=%d, C=%d need %zu B of LDS (> 160 KiB)", K_pool, C, lds);
     MG_REQUIRE((cluster_scratch != nullptr) == (cluster_counters != nullptr), "mgnns_label_tail_bf16_fwd: cluster scratch and counters go together");
     MG_REQUIRE(!cluster_scratch || mg_aligned16(cluster_scratch), "mgnns_label_tail_bf16_fwd: cluster scratch must be 16-byte aligned");
+    if (cluster_scratch)
+        if (int rc = mg_check_status("mgnns_label_tail_bf16_fwd")) return rc;   // a bounded wait of an earlier persistent launch ran out
     MG_DYN_LDS((label_tail_bf16_kernel<1, 1>), 160 * 1024);
     MG_DYN_LDS((label_tail_bf16_kernel<3, 1>), 160 * 1024);
     MG_DYN_LDS((label_tail_bf16_kernel<3, 4>), 160 * 1024);
@@ -603,13 +645,13 @@ extern "C" int mgnns_label_tail_bf16_fwd(const float* pooled, int B, int n_parts
     const dim3 blk(LT_THR);
     if (terms == 3 && cluster_scratch)
         hipLaunchKernelGGL((label_tail_bf16_kernel<3, 4>), dim3(tiles * 4), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ,
-                           n_heads, dh, w, N5, n_out, out, HK_next, qh_next, cluster_scratch, cluster_counters);
+                           n_heads, dh, w, N5, n_out, out, HK_next, qh_next, cluster_scratch, cluster_counters, mg_status_word());
     else if (terms == 3)
         hipLaunchKernelGGL((label_tail_bf16_kernel<3, 1>), dim3(tiles), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
-                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr);
+                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr, (int*)nullptr);
     else
         hipLaunchKernelGGL((label_tail_bf16_kernel<1, 1>), dim3(tiles), blk, lds, (hipStream_t)stream, pooled, B, n_parts, K_pool, C, Q, NLQ, n_heads, dh,
-                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr);
+                           w, N5, n_out, out, HK_next, qh_next, (float*)nullptr, (int*)nullptr, (int*)nullptr);
     MG_CHECK_LAUNCH("mgnns_label_tail_bf16_fwd");
     return 0;
 }

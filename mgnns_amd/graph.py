@@ -17,12 +17,33 @@ Two capture modes:
   170-252 k samples/s with GPU_MAX_HW_QUEUES.  Kept for comparison.
 """
 import os
+import subprocess
+import sys
+import warnings
 
 import torch
 
+_PROBED = {}
+
+
+def single_graph_probe(schedule, timeout=900):
+    """Can the runtime capture the multi-stream forward of `schedule` as ONE graph?  hipStreamEndCapture has been seen to
+    SEGFAULT on some stream topologies (ROCm 7.0 / 7.2) -- not an exception a process survives -- so the first one-graph
+    capture of a topology is tried in a CHILD process on a small synthetic model (the topology, not the size, is what the
+    runtime trips over).  Cached per process."""
+    if schedule not in _PROBED:
+        env = dict(os.environ, MGNNS_GRAPH_MODE="segments")
+        try:
+            r = subprocess.run([sys.executable, "-m", "mgnns_amd.graph", "--probe-single", schedule], env=env, timeout=timeout,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _PROBED[schedule] = r.returncode == 0
+        except (subprocess.TimeoutExpired, OSError):
+            _PROBED[schedule] = False
+    return _PROBED[schedule]
+
 
 class GraphedForward:
-    def __init__(self, model, example_args, warmup=3, post=None, mode=None):
+    def __init__(self, model, example_args, warmup=3, post=None, mode=None, _probe_child=False, settle=True):
         """example_args: the 7 forward arguments on the GPU (text_lens included, int64 on the device).
         post: optional callable applied to the logits INSIDE the capture (e.g. ShardedForward.gather: the RCCL
         all-gather becomes a node of the last graph)."""
@@ -38,12 +59,35 @@ class GraphedForward:
             self.mode = "segments"                  # a collective inside: every rank must capture the same thing, once
         if not getattr(model, "use_streams", True):
             self.mode = "single"                    # one stream: the forward is one linear chain anyway
-        elif self.mode == "auto" and hasattr(model, "resolve_schedule") and \
-                model.resolve_schedule(example_args[0].shape[0]) != "channels":
+        elif self.mode in ("single", "auto") and hasattr(model, "resolve_schedule") and not _probe_child:
             # hipStreamEndCapture SEGFAULTS inside the runtime (ROCm 7.0 / 7.2) on the single-graph form of every schedule
-            # but 'channels' (lgcn_side, banks_first, channels2: python -X faulthandler points at capture_end) -- not an
-            # exception this process could survive, so the one-graph attempt is only made for the topology known to work
-            self.mode = "segments"
+            # tried but 'channels' (lgcn_side, banks_first, channels2: python -X faulthandler points at capture_end) -- not
+            # an exception this process could survive: the one-graph form of a topology is first captured in a child process
+            sched = model.resolve_schedule(example_args[0].shape[0])
+            if not single_graph_probe(sched):
+                warnings.warn("MGNNS_GRAPH_MODE=%s: the runtime cannot capture schedule %r as one graph (probe child failed); "
+                              "using one graph per segment" % (self.mode, sched))
+                self.mode = "segments"
+        # a fresh scratch epoch: the persistent launches captured below get scratch buffers of their own (ops._scratch_key),
+        # so this graph can be replayed next to any other forward of the same model; the model keeps superseded weight packs
+        # alive while a graph that may hold their addresses exists
+        from . import ops as _ops
+        self._epoch = _ops.new_scratch_epoch()
+        prev_epoch = _ops.set_scratch_epoch(self._epoch)
+        model._live_graphs = getattr(model, "_live_graphs", 0) + 1
+        try:
+            self._build(model, example_args, warmup, post, settle)
+        finally:
+            _ops.set_scratch_epoch(prev_epoch)
+
+    def __del__(self):
+        m = getattr(self, "model", None)
+        if m is not None and getattr(m, "_live_graphs", 0) > 0:
+            m._live_graphs -= 1
+            if m._live_graphs == 0 and hasattr(m, "_wt_retired"):
+                m._wt_retired.clear()
+
+    def _build(self, model, example_args, warmup, post, settle):
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         for a in self.static_in:
             if torch.is_tensor(a) and not a.is_cuda:
@@ -86,6 +130,12 @@ class GraphedForward:
         # The first ~20 replays of a fresh capture run 2-3 % slower than the steady state (B=256: 0.861 ms per forward over
         # replays 6-35, 0.840 over replays 31-130; 'auto' used to look faster than 'segments' only because its mode timing
         # had already replayed 16 times).  Settle here, once, so a short measurement sees the steady state.
+        # (settle=False: the caller settles later -- with a collective captured inside, every rank must first agree that all
+        # of them captured it, or the ranks' collective sequences diverge: bench.py)
+        if settle:
+            self.settle()
+
+    def settle(self):
         for _ in range(int(os.environ.get("MGNNS_GRAPH_SETTLE", "16"))):
             self.replay()
         torch.cuda.synchronize()
@@ -170,3 +220,30 @@ class GraphedForward:
     def __call__(self, *args):
         self.copy_inputs(*args)
         return self.replay()
+
+
+def _probe_single_main(schedule):
+    """Child of single_graph_probe: one-graph capture of `schedule` on a small synthetic model; exit code 0 iff it captured,
+    replayed and reproduced the eager logits."""
+    from . import harness, synth
+    cfg = synth.CONFIGS["tumemo_b64"]
+    dev = "cuda:0"
+    pmi, count = synth.synth_pmi(cfg.V, seed=2)
+    A_obj, A_place = harness.synthetic_adjacencies(cfg)
+    inp = synth.make_inputs(cfg, B=8, seed=3, pmi=pmi)
+    model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
+    model.schedule = schedule
+    args = list(harness.call_args(inp, dev))
+    args[1] = args[1].to(dev)
+    with torch.no_grad():
+        ref = model(*args).clone()
+    g = GraphedForward(model, args, mode="single", _probe_child=True)
+    out = g.replay().clone()
+    torch.cuda.synchronize()
+    return 0 if g.mode == "single" and torch.allclose(out, ref, atol=1e-5) else 1
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--probe-single":
+        sys.exit(_probe_single_main(sys.argv[2]))
+    sys.exit(2)

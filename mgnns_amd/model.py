@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 from torch.nn import Parameter
 
-from . import ops
+from . import _lib, ops
 from .adjacency import gen_A, gen_adj_csr
 from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query_pack,
                      first_query_pack_bf16, run_stack)
@@ -319,7 +319,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         hit = self._wt_cache.get(id(lin))
         if hit is None or hit[0] != key:
             hit = (key, ops.transpose_pad(w.detach().contiguous(), ops.IMGBANK_LDW))
-            self._wt_cache[id(lin)] = hit
+            self._cache_put(id(lin), hit)
         return hit[1]
 
     def _wp(self, lin):
@@ -329,7 +329,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         hit = self._wt_cache.get((id(lin), 'bf16'))
         if hit is None or hit[0] != key:
             hit = (key, ops.pack_imgbank_weights_bf16(w.detach().contiguous()))
-            self._wt_cache[(id(lin), 'bf16')] = hit
+            self._cache_put((id(lin), 'bf16'), hit)
         return hit[1]
 
     def _img_bank_and_pool(self, feats, lin):
@@ -362,6 +362,18 @@ class Multi_GCN_Multihead_Att(nn.Module):
         ops.stamp("  label GCN end")
         return G
 
+    def _cache_put(self, key, value):
+        """Replace a derived-weights cache entry.  While a captured hipGraph of this model exists (GraphedForward counts
+        itself in _live_graphs) the superseded entry is parked, not freed: the graph holds raw addresses of its buffers --
+        packed weights, the persistent launches' scratch with their queue counters -- and a replay after set_precision() /
+        load_state_dict() must not read recycled memory.  The park empties when the last graph goes."""
+        old = self._wt_cache.get(key)
+        if old is not None and getattr(self, "_live_graphs", 0) > 0:
+            if not hasattr(self, "_wt_retired"):
+                self._wt_retired = []
+            self._wt_retired.append(old)
+        self._wt_cache[key] = value
+
     def _tail_pack(self, attention, linear_5, x_linear):
         """Packed weights of one channel's fused label-attention tail, rebuilt when any of them changes:
         w_k / w_v / x_linear in the fragment-major fp32 layout, fc and linear_5 composed into one map (no non-linearity
@@ -380,7 +392,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
                  "xl": ops.pack_weight_f32(x_linear.weight.detach()), "bxl": x_linear.bias.detach(),
                  "n_out": x_linear.out_features, "C": attention.w_k.in_features, "_src": ps}
             hit = (key, d)
-            self._wt_cache[(id(attention), 'tail')] = hit
+            self._cache_put((id(attention), 'tail'), hit)
         return hit[1]
 
     def _lgcn_pack(self, tag):
@@ -395,7 +407,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             d = ops.label_gcn_pack(gc1.weight.detach(), gc2.weight.detach(), split)
             d["_src"] = ps
             hit = (key, d)
-            self._wt_cache[('lgcn', tag)] = hit
+            self._cache_put(('lgcn', tag), hit)
         return hit[1]
 
     def _head_pack(self):
@@ -409,7 +421,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             wc = ops.matmul(l2.weight.detach().contiguous(), l1.weight.detach().contiguous())                # [NL, 1200]
             bc = ops.linear(l1.bias.detach()[None, :].contiguous(), l2.weight.detach(), l2.bias.detach())[0]
             hit = (key, (wc.contiguous(), bc.contiguous(), ps))
-            self._wt_cache['head'] = hit
+            self._cache_put('head', hit)
         return hit[1][0], hit[1][1]
 
     def _tail_pack_bf16(self, attention, linear_5, x_linear):
@@ -429,8 +441,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
                  "xl": sp(x_linear.weight.detach()), "bxl": x_linear.bias.detach(),
                  "n_out": x_linear.out_features, "C": attention.w_k.in_features, "_src": ps}
             hit = (key, d)
-            self._wt_cache[(id(attention), 'tail_bf16')] = hit
+            self._cache_put((id(attention), 'tail_bf16'), hit)
         return hit[1]
+
+    def _lgcn_fused_ok(self, C, K0):
+        """Does the persistent label-GCN launch take this channel?  (mgnns_label_gcn_supported: the launcher's own limits)"""
+        return bool(_lib.lib().mgnns_label_gcn_supported(int(C), int(K0), self.gc1.out_features, self.gc2.out_features,
+                                                         1 if self.precision == 'bf16' else 0))
 
     def _label_q(self, attention):
         """w_q(label query) [NLQ, hid] (MODEL:97): batch independent, computed next to the label GCN."""
@@ -445,10 +462,17 @@ class Multi_GCN_Multihead_Att(nn.Module):
         on an idle chip (B=32: 0.61 vs 0.54 ms).  Below the threshold, or with MGNNS_FUSED_LABEL_TAIL=0: the chain of
         module-level operators.  -> (att [B,300], qh or None)"""
         B = pooled.shape[0]
-        ok = (self.fused_label_tail and B >= self.fused_label_tail_min_batch
-              and x_linear.in_features == Q.shape[0] * linear_5.out_features)
-        if (Gp is not None and self.fused_label_tail and B >= self.fused_label_tail_bf16_min_batch
-                and x_linear.in_features == Q.shape[0] * linear_5.out_features):
+        L = _lib.lib()
+        n_next = 1 if next_stack is not None and len(next_stack) else 0
+        C, NLQ, nh = attention.w_k.in_features, Q.shape[0], attention.n_heads
+        dh, N5, n_out = Q.shape[1] // nh, linear_5.out_features, x_linear.out_features
+        flat_ok = x_linear.in_features == NLQ * N5
+        # the fused launches have shape limits (their argument checks, exported as predicates): other shapes -- e.g. more than
+        # 384 label classes in bf16 mode -- run the chain of module-level operators below
+        bf16_ok = (Gp is not None and flat_ok and pooled.dim() == 3 and
+                   L.mgnns_label_tail_bf16_supported(C, NLQ, nh, dh, N5, n_out, pooled.shape[-1], int(self.label_tail_terms), n_next))
+        f32_ok = flat_ok and L.mgnns_label_tail_supported(C, NLQ, nh, dh, N5, n_out, 0, n_next)
+        if bf16_ok and self.fused_label_tail and B >= self.fused_label_tail_bf16_min_batch:
             # bf16 precision mode: the whole chain, read-out included, as ONE launch on the bf16 MFMA
             pk = self._tail_pack_bf16(attention, linear_5, x_linear)
             nq = first_query_pack_bf16(next_stack) if next_stack is not None and len(next_stack) else None
@@ -457,8 +481,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             return r if nq is not None else (r, None)
         if pooled.dim() == 3:
             pooled = pooled.amax(dim=1) if pooled.shape[1] > 1 else pooled[:, 0].contiguous()
-        if (self.fused_label_tail and B >= self.fused_label_tail_min_batch
-                and x_linear.in_features == Q.shape[0] * linear_5.out_features):
+        if self.fused_label_tail and B >= self.fused_label_tail_min_batch and f32_ok:
             pk = self._tail_pack(attention, linear_5, x_linear)
             nq = first_query_pack(next_stack) if next_stack is not None and len(next_stack) else None
             # the read-out stays a launch of its own: 2*B*2048*C FLOPs on the exact-f32 MFMA want many CUs, the fused
@@ -509,8 +532,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "iot": ("text_bank", "tail_obj"), "ipt": ("text_bank", "tail_place"),
         "head": ("tio", "tip", "iot", "ipt"),
     }
-    # schedules: enqueue order and stream of every segment ('main' = the caller's stream, 's1'..'s3' side streams;
-    # 's3' is created with high priority).  Decided by bench.py measurements.
+    # schedules: enqueue order and stream of every segment ('main' = the caller's stream, 's1'..'s3' side streams, all of
+    # default priority on hardware queues of their own, mgnns_amd/streams.py).  Decided by bench.py measurements
+    # (DESIGN.md section 6).
     SCHEDULES = {
         # one stream per channel, stacks where their producer ran (the round-1 schedule)
         # (the BiLSTM chain is the longest of the forward: it is enqueued FIRST -- at B=32 the single-graph runtime started
@@ -600,15 +624,22 @@ class Multi_GCN_Multihead_Att(nn.Module):
             def run_fused():
                 # gen_adj + both GraphConvolutions + the packed image of G + w_q(label query): ONE persistent launch
                 pk = self._lgcn_pack(tag)
+                # grid: a quarter of the CUs next to the chip-filling kernels of a large batch, 3/8 below (measured with the
+                # item queue, ms per forward at grid 64 / 96 / 128: B=256 0.828 / 0.839 / 0.859, B=128 0.590 / 0.580 / 0.589,
+                # B=32 0.448 / 0.433 / 0.433); any grid is correct
+                n_cu = torch.cuda.get_device_properties(A.device).multi_processor_count
+                grid = ops.LABEL_GCN_GRID or (n_cu // 4 if text.shape[0] >= 192 else 3 * n_cu // 8)
                 G, Gp, Q = ops.label_gcn(A.detach(), inp[0].float().contiguous(), pk, want_packed_g=fused_bf16,
                                          query=(self.label_query.float().contiguous(), attention.w_q.weight.detach(),
-                                                attention.w_q.bias.detach()))
+                                                attention.w_q.bias.detach()), grid=grid)
                 ctx['Q_' + tag], ctx['G_' + tag] = Q, G
                 if fused_bf16:
                     ctx['Gp_' + tag] = Gp
                 ops.stamp("  label GCN end")
 
-            if self.fused_label_gcn:
+            # the one-launch form has shape limits (C <= 512, widths multiples of 256, ...): everything else takes the
+            # separate operators, which have none -- e.g. a 1000-class object model
+            if self.fused_label_gcn and self._lgcn_fused_ok(A.shape[0], inp.shape[-1]):
                 return run_fused
 
             def run():
@@ -775,10 +806,30 @@ def _trunk_init_random():
 
 
 def _load_checkpoint(path):
+    """torch.load with the safe unpickler.  Checkpoints that pickle numpy scalars next to the tensors (Places365 ships
+    'best_prec1' as one) get exactly those globals allow-listed; a file that still needs the full unpickler -- arbitrary code
+    execution by design -- is only loaded on the explicit opt-in MGNNS_TRUST_CHECKPOINTS=1."""
+    import pickle
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception:                       # checkpoints pickled with numpy scalars etc. (Places365: 'best_prec1')
-        return torch.load(path, map_location='cpu', weights_only=False)
+    except pickle.UnpicklingError as first:
+        try:
+            import numpy as np
+            safe = [np.core.multiarray.scalar, np.dtype] if hasattr(np, "core") else []
+            try:
+                from numpy import dtypes as _npd
+                safe += [getattr(_npd, n) for n in dir(_npd) if n.endswith("DType")]
+            except ImportError:
+                pass
+            with torch.serialization.safe_globals(safe):
+                return torch.load(path, map_location='cpu', weights_only=True)
+        except (pickle.UnpicklingError, AttributeError):
+            pass
+        if os.environ.get('MGNNS_TRUST_CHECKPOINTS', '') == '1':
+            import warnings
+            warnings.warn("loading %s with the full (code-executing) unpickler: MGNNS_TRUST_CHECKPOINTS=1" % path)
+            return torch.load(path, map_location='cpu', weights_only=False)
+        raise RuntimeError("%s needs the full unpickler (%s); set MGNNS_TRUST_CHECKPOINTS=1 if you trust the file" % (path, first))
 
 
 def place_resnet(arch='resnet50'):

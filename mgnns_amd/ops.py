@@ -17,6 +17,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Scratch buffers of the persistent launches are keyed by (capture epoch, launch stream): eager launches on one stream
+# are ordered and may share a scratch; every hipGraph capture takes a fresh epoch (mgnns_amd/graph.py), because a captured
+# graph can be replayed on any stream next to any other graph of the same model.
+_SCRATCH_EPOCH = 0
+
+
+def new_scratch_epoch():
+    global _SCRATCH_EPOCH
+    _SCRATCH_EPOCH += 1
+    return _SCRATCH_EPOCH
+
+
+def set_scratch_epoch(e):
+    global _SCRATCH_EPOCH
+    prev, _SCRATCH_EPOCH = _SCRATCH_EPOCH, int(e)
+    return prev
+
+
+def _scratch_key():
+    return (_SCRATCH_EPOCH, _stream())
+
+
 class KernelTimer:
     """Opt-in per-launch HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream
     the kernels are launched on (PyTorch's current stream), around the C-ABI call only."""
@@ -197,12 +219,16 @@ def label_gcn(A, inp, packed, want_packed_g=False, query=None, grid=0):
     N1, N2 = packed["N1"], packed["N2"]
     L = _lib.lib()
     need = L.mgnns_label_gcn_scratch_bytes(C, N1, N2)
-    ws = packed.get("_scratch")
+    # the launch's scratch holds its intermediates and its item queue: one per (capture epoch, launch stream), so that two
+    # forwards of one model in flight at once -- two streams, two captured graphs -- never share one
+    slot = packed.setdefault("_scratch", {})
+    key = _scratch_key()
+    ws = slot.get(key)
     if ws is None or ws.numel() < need or ws.device != A.device:
         if ws is not None:
             packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
         ws = torch.zeros(need, dtype=torch.uint8, device=A.device)        # counters (first 256 B) start at zero
-        packed["_scratch"] = ws
+        slot[key] = ws
     G = torch.empty(C, N2, device=A.device, dtype=torch.float32)
     gh = gl = None
     if want_packed_g:
@@ -617,13 +643,15 @@ def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3, cl
     scratch = counters = None
     if cluster and int(terms) == 3 and B > 0:
         tiles = (B + 15) // 16
-        ws = packed.get("_cluster_ws")
+        slot = packed.setdefault("_cluster_ws", {})
+        key = _scratch_key()                                     # per (capture epoch, launch stream), like the label GCN's
+        ws = slot.get(key)
         if ws is None or ws[0] < tiles or ws[1].device != Q.device:
             if ws is not None:
                 packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(tiles * 4 * 6144, device=Q.device, dtype=torch.float32),
                   torch.zeros(2 * tiles, device=Q.device, dtype=torch.int32))
-            packed["_cluster_ws"] = ws
+            slot[key] = ws
         scratch, counters = ws[1], ws[2]
     L = _lib.lib()
     _launch("mgnns_label_tail_bf16_fwd", ("mgnns_label_tail_bf16_fwd", packed["C"]), L.mgnns_label_tail_bf16_fwd, _p(pooled), B,

@@ -188,7 +188,9 @@ _LSTM_CACHE = {}
 
 
 def _lstm_from_params(p, emb_size, hidden, num_layers):
-    key = (id(p), emb_size, hidden, num_layers)
+    # keyed on the VALUES (a checksum per LSTM tensor): id(p) alone is reused by the allocator for the next dict
+    key = (emb_size, hidden, num_layers) + tuple(float(v.double().sum()) + float(v.double().abs().sum())
+                                                 for k, v in sorted(p.items()) if k.startswith("lstm."))
     if key not in _LSTM_CACHE:
         lstm = torch.nn.LSTM(emb_size, hidden, num_layers, bidirectional=True, batch_first=True)
         sd = {k[len("lstm."):]: v for k, v in p.items() if k.startswith("lstm.")}

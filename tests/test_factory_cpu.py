@@ -145,3 +145,28 @@ def test_text_model_equals_from_parts(tmp_path, monkeypatch):
     assert tm.edges_num == tm2.edges_num == count
     assert np.array_equal(tm.edges_matrix.col, tm2.edges_matrix.col)
     assert {k: tuple(v.shape) for k, v in tm.state_dict().items()} == {k: tuple(v.shape) for k, v in tm2.state_dict().items()}
+
+
+def test_checkpoint_loader_refuses_code_executing_pickles(tmp_path, monkeypatch):
+    """MODEL:589 loads a third-party .pth.tar: numpy scalars next to the tensors (Places365's 'best_prec1') load through the
+    safe unpickler; a pickle that needs the full one is refused unless MGNNS_TRUST_CHECKPOINTS=1."""
+    import numpy as np
+    from mgnns_amd.model import _load_checkpoint
+    p = str(tmp_path / "a.pth.tar")
+    torch.save({"arch": "resnet50", "best_prec1": np.float64(54.7), "state_dict": {"w": torch.ones(3)}}, p)
+    ck = _load_checkpoint(p)
+    assert float(ck["best_prec1"]) == 54.7 and torch.equal(ck["state_dict"]["w"], torch.ones(3))
+    hit = []
+
+    class Evil:
+        def __reduce__(self):
+            return (hit.append, ("executed",))
+
+    torch.save({"x": Evil()}, p)
+    monkeypatch.delenv("MGNNS_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(RuntimeError, match="MGNNS_TRUST_CHECKPOINTS"):
+        _load_checkpoint(p)
+    assert not hit
+    monkeypatch.setenv("MGNNS_TRUST_CHECKPOINTS", "1")
+    with pytest.warns(UserWarning, match="code-executing"):
+        assert "x" in _load_checkpoint(p)          # the explicit opt-in loads it (the reduce call ran on a copy of `hit`)
