@@ -724,7 +724,7 @@ def run_rank(args):
         return {k: (v[lo:hi] if k != "label_query" else v) for k, v in g.items()}, hi - lo
 
     comm = None
-    if dist is not None and backend == "nccl" and os.environ.get("MGNNS_COLLECTIVE", "torch") == "abi":
+    if dist is not None and backend == "nccl" and os.environ.get("MGNNS_COLLECTIVE", "abi") == "abi":
         try:          # the all-gather through the C ABI (mgnns_allgather_logits); torch.distributed is only the rendezvous
             from mgnns_amd.comm import AbiComm
             comm = AbiComm.from_torch_distributed(device=dev)
@@ -805,7 +805,7 @@ def run_rank(args):
     ops.set_timer(None)
 
     variants = {}
-    trunks = stress = textpipe = None
+    trunks = stress = textpipe = small = None
     single = world == 1 and dist is None
     if single and not args.no_variants and not args.no_graph:
         with torch.no_grad():
@@ -823,6 +823,16 @@ def run_rank(args):
                     "same step in fp32 mode: every contraction on the exact-f32 MFMA -- the mode the north-star's 1e-4 "
                     "logit tolerance is gated on (tests/test_model_gpu.py)")
                 model.set_precision("bf16")
+        # the per-GPU shards of a strong-scaling run (global batch 256 over 2 / 4 / 8 GPUs), measured here on one GPU: what the
+        # 1 -> 8 curve of configs[3] is bounded by while no multi-GPU node has run it
+        small = {"what": "ms per forward of a 128 / 64 / 32-sample shard on ONE GPU (hipGraph replay): global batch 256 over "
+                         "2 / 4 / 8 GPUs takes at least this long per step, i.e. strong scaling <= 256-sample ms / shard ms"}
+        with torch.no_grad():
+            for bs in (128, 64, 32):
+                sub = {k: (v[:bs] if k != "label_query" else v) for k, v in inp.items()}
+                r = graphed_variant(model, harness.call_args(sub, dev), bs, args.steps, args.warmup, "")
+                small["B=%d" % bs] = {"ms_per_step": r["ms_per_step"], "samples_per_s": r["value"],
+                                      "strong_scaling_bound_x": round(weak["ms"] / r["ms_per_step"], 2)}
         stress = stress_leg(dev)
         textpipe = text_pipeline_leg(dev)
         trunks = trunk_leg(dev)
@@ -905,6 +915,8 @@ def run_rank(args):
         line["roofline_all"] = rall
     if variants:
         line["variants"] = variants
+    if small is not None:
+        line["small_batch"] = small
     if stress is not None:
         line["stress"] = stress
     if textpipe is not None:

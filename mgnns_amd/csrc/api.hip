@@ -1,5 +1,6 @@
 // Error channel + ABI version of libmgnns_hip.so.
 #include "common.hpp"
+#include <stdlib.h>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -63,6 +64,41 @@ extern "C" int mgnns_take_status(void) {
     int32_t* p = g_status;
     if (!p) return 0;
     return (int)__atomic_exchange_n(p, 0, __ATOMIC_RELAXED);
+}
+
+// CU count of the current device (hipDeviceAttributeMultiprocessorCount), cached per device; 0 on failure (error text set)
+int mg_cu_count() {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        mgnns_set_error("cannot query the current device");
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            mgnns_set_error("cannot query the CU count of device %d", dev);
+            return 0;
+        }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+// integer tuning knob from the environment, read ONCE per process (the launchers sit on the per-forward path)
+int mg_env_int(const char* name, int fallback, int slot) {
+    static std::mutex mu;
+    static bool have[8] = {false};
+    static int val[8] = {0};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!have[slot]) {
+        const char* e = getenv(name);
+        val[slot] = e ? atoi(e) : fallback;
+        have[slot] = true;
+    }
+    return val[slot];
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }

@@ -590,11 +590,8 @@ extern "C" int mgnns_conv_bf16_nhwc_fwd(const void* x, int B, int H, int W, int 
     a.inv_ohw = 1.0f / (float)(a.OH * a.OW);
     a.inv_ow = 1.0f / (float)a.OW;
     a.relu = relu ? 1 : 0;
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
-        mgnns_set_error("mgnns_conv_bf16_nhwc_fwd: cannot query the CU count");
-        return MGNNS_ERR_LAUNCH;
-    }
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     const int rc = Cout <= 64 ? launch_conv<2>(a, out_nchw_f32 != 0, (hipStream_t)stream, n_cu)
                               : launch_conv<4>(a, out_nchw_f32 != 0, (hipStream_t)stream, n_cu);
     if (rc) return rc;

@@ -261,11 +261,8 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     if (rps > nrb) rps = nrb;
     const int supers = (nrb + rps - 1) / rps;
     const int jmax = ((supers + 7) / 8) * rps * nct;               // virtual tiles per XCD
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
-        mgnns_set_error("mgnns_gemm_bf16_nt_fwd: cannot query the CU count");
-        return MGNNS_ERR_LAUNCH;
-    }
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > jmax) per_xcd = jmax;

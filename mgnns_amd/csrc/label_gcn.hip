@@ -445,11 +445,8 @@ extern "C" int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int 
     // forward runs two of these launches side by side (object and scene channel) in front of the chip-filling memory-bank
     // kernels, a workgroup takes a whole CU (LDS), and 32 / 64 / 128 workgroups measured 0.843 / 0.848 / 0.873 ms per B = 256
     // forward, 0.533 / 0.480 / 0.492 at B = 32 (round 2, with the counting barrier).
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
-        mgnns_set_error("mgnns_label_gcn_fwd: cannot query the CU count");
-        return MGNNS_ERR_LAUNCH;
-    }
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     if (grid <= 0) grid = n_cu / 4 > 0 ? n_cu / 4 : 1;
     if (grid > 4 * n_cu) grid = 4 * n_cu;
     if (int rc = mg_check_status("mgnns_label_gcn_fwd")) return rc;     // a bounded wait of an earlier persistent launch ran out

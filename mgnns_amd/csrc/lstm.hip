@@ -622,15 +622,12 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
     const int och = T < 200 ? T : 200;                               // h rows kept in LDS between flushes (one flush per chain for T <= 200)
     if (bf16_rec) {
         MG_DYN_LDS(lstm_rec_bf16_kernel, (size_t)och * HPAD * sizeof(float));                                                  // one persistent workgroup per CU (even count: see the kernel)
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
-            mgnns_set_error("mgnns_bilstm_bf16_fwd: cannot query the CU count");
-            return MGNNS_ERR_LAUNCH;
-        }
+        const int n_cu = mg_cu_count();
+        if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
         // default: half of the CUs (LPT over the length-sorted chains keeps the makespan at ~the longest chain as long
         // as total steps / workgroups stays below it); MGNNS_LSTM_GRID overrides (bench.py decided the default)
         int cap = n_cu / 2;
-        if (const char* e = getenv("MGNNS_LSTM_GRID")) cap = atoi(e);
+        if (const int e = mg_env_int("MGNNS_LSTM_GRID", 0, 0)) cap = e;
         if (cap > n_cu) cap = n_cu;
         cap &= ~1;
         if (cap < 2) cap = 2;

@@ -337,7 +337,7 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     // samples on, where the forward is bound by CU time and 64 workgroups x 21 us cost more than the shorter chain returns
     // (B=256: 0.811-0.820 ms per forward with 2, 0.830 with 4; B=128: equal; B=64: 0.453-0.458 with 4, 0.464-0.467 with 2)
     int cl = packed[6] ? (B >= 256 ? 2 : 4) : 1;
-    if (const char* e = getenv("MGNNS_TAIL_CLUSTER")) cl = packed[6] ? atoi(e) : 1;
+    if (const int e = mg_env_int("MGNNS_TAIL_CLUSTER", 0, 1)) cl = packed[6] ? e : 1;
     if (cl < 1) cl = 1;
     if (cl > 8) cl = 8;
     dim3 grid((B + ROWS - 1) / ROWS, cl);

@@ -527,7 +527,9 @@ extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16
     // one workgroup per sample owns all head pairs when the batch fills the chip; small batches split the pairs
     const int pairs = (H + 1) / 2;
     int gy = 1;
-    while (gy < pairs && B * gy < 256) gy *= 2;
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
+    while (gy < pairs && B * gy < n_cu) gy *= 2;
     if (gy > pairs) gy = pairs;
     const float temp = (float)sqrt((double)dk);
     hipLaunchKernelGGL(sq_mha_core_bf16_kernel, dim3(B, gy), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, qh,
@@ -567,7 +569,9 @@ extern "C" int mgnns_sq_mha_layer_bf16_fwd(const float* qh, const void* bank_bf1
     MG_DYN_LDS(sq_mha_layer_bf16_kernel, SMEM_BYTES);
     const int pairs = (H + 1) / 2;
     int gy = 1;
-    while (gy < pairs && B * gy < 256) gy *= 2;
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
+    while (gy < pairs && B * gy < n_cu) gy *= 2;
     if (gy > pairs) gy = pairs;
     const float temp = (float)sqrt((double)dk);
     hipLaunchKernelGGL(sq_mha_layer_bf16_kernel, dim3(B, gy), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, qh,

@@ -229,6 +229,40 @@ def test_full_size_b256_properties():
     assert H.maxabs(model(*call).cpu()[idx], ref) < TOL
 
 
+def test_full_size_b256_bf16_mode():
+    """BASELINE configs[2] in ITS stated dtype -- "bf16 MFMA", the mode bench.py's headline runs -- at the full B = 256: a
+    32-sample subset against the CPU oracle (bf16 operands carry ~3 digits: <= 2e-2 on the logits, the class unchanged wherever
+    the oracle's margin exceeds that), permutation equivariance, determinism, hipGraph replay == eager."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["mvsa_multiple_b256"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("full_mvsa_multiple_b256.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    B = 256
+    inp = synth.make_inputs(cfg, B=B, seed=4243, pmi=pmi)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    model.set_precision("bf16")
+    call = call_args(inp, DEV)
+    logits = model(*call).cpu()
+    assert logits.shape == (B, cfg.NL) and torch.isfinite(logits).all()
+    idx = np.arange(0, B, 8)
+    sub = {k: (v[idx] if k != "label_query" else v) for k, v in inp.items()}
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in sub.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                    label_query=torch.from_numpy(lq))
+    err = H.maxabs(logits[idx], ref)
+    print("bf16 mode, B=256: max |dlogit| on the 32-sample oracle subset = %.3e" % err)
+    assert err < 2e-2
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4e-2                     # samples whose class cannot flip inside the error bound
+    assert clear.any() and torch.equal(logits[idx].argmax(1)[clear], ref.argmax(1)[clear])
+    perm = np.random.RandomState(2).permutation(B)
+    pin = {k: (v[perm] if k != "label_query" else v) for k, v in inp.items()}
+    assert H.maxabs(model(*call_args(pin, DEV)).cpu(), logits[perm]) < 1e-4   # tile-position dependent rounding only
+    assert torch.equal(model(*call).cpu(), logits)
+    assert torch.equal(GraphedForward(model, call).replay().cpu(), logits)
+
+
 def test_bool_and_int_masks_streams_equal_single_stream():
     """The reference documents text_mask as a bool tensor: the cast to float runs on the main stream BEFORE the side
     streams fork, so the multi-stream forward (and its hipGraph) equals the single-stream forward bit for bit."""
