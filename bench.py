@@ -822,7 +822,13 @@ def run_rank(args):
                     model, call, B, max(5, args.steps // 2), 2,
                     "same step in fp32 mode: every contraction on the exact-f32 MFMA -- the mode the north-star's 1e-4 "
                     "logit tolerance is gated on (tests/test_model_gpu.py)")
-                model.set_precision("bf16")
+                model.set_precision("bf16x3").set_attention("folded")
+                variants["dtype=bf16x3 + folded attention (parity-grade)"] = graphed_variant(
+                    model, call, B, args.steps, args.warmup,
+                    "same step with every heavy product in split-bf16 (bf16 hi + lo operands, three bf16 MFMAs per product, fp32 "
+                    "accumulation: image banks, label GCN, channel and layer tails), exact fp32 LSTM and the exact-fp32 folded "
+                    "attention: inside the 1e-4 logit gate (tests/test_model_gpu.py) without the exact-f32 MFMA's 1/16 rate")
+                model.set_precision("bf16").set_attention("faithful")
         # the per-GPU shards of a strong-scaling run (global batch 256 over 2 / 4 / 8 GPUs), measured here on one GPU: what the
         # 1 -> 8 curve of configs[3] is bounded by while no multi-GPU node has run it
         small = {"what": "ms per forward of a 128 / 64 / 32-sample shard on ONE GPU (hipGraph replay): global batch 256 over "

@@ -198,6 +198,14 @@ int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnn
 int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,
                                 void* bank_bf16, int ld, float* pooled, float* pooled_work, mgnns_stream_t stream);
 
+/* Split-bf16 ("bf16x3") form of the same pass: fp32-class accuracy (every operand as bf16 hi + lo, three MFMAs per product,
+ * fp32 accumulation: ~2^-16 relative per product) at bf16-MFMA speed -- the parity-grade mode's image bank.
+ * (Wp_hi, Wp_lo) = mgnns_pack_weight_bf16_split of liner_img_*.weight [N,K]; bank [B,P,N] fp32 (+ bias);
+ * pooled_halves [B,2,K] fp32 or NULL: exact maxima over the region halves [0,112) / [112,P) (-inf for an empty half).
+ * K % 64 == 0, P % 4 == 0, P <= 224, N <= 304. */
+int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int P, const void* Wp_hi, const void* Wp_lo,
+                                 const float* bias, int N, float* bank, float* pooled_halves, mgnns_stream_t stream);
+
 /* out[c, r] = in[r, c] for r < rows, c < cols; out is [cols, ld] with zero padding. */
 int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld, mgnns_stream_t stream);
 

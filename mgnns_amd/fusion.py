@@ -73,7 +73,7 @@ class MultiHeadAttention(nn.Module):
         if d_k != d_v:
             raise ValueError("d_k must equal d_v (the reference always passes d_kv for both)")
         self.n_head, self.d_k, self.d_v, self.is_regu = n_head, d_k, d_v, is_regu
-        self.precision = 'fp32'      # 'fp32' (exact-f32 MFMA) | 'bf16' (bf16 operands, fp32 accumulate)
+        self.precision = 'fp32'      # 'fp32' (exact-f32 MFMA) | 'bf16' (bf16 operands, fp32 accumulate) | 'bf16x3' (split-bf16 tails)
         self.attention = 'faithful'  # 'faithful' (K/V projected as the reference does) | 'folded' (see _folded)
         self._wp = None
         self.w_qs = nn.Linear(d_model, n_head * d_k)
@@ -296,10 +296,11 @@ def run_stack(layers, q, bank, mask=None, qh=None):
         else:
             o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
                                    a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)
-        if a.precision == 'bf16' and a.n_head * a.d_v % 32 == 0:
-            # split-bf16 MFMA tail: fp32-class accuracy (hi+lo operands) at a fraction of the exact-f32 MFMA cost
+        if a.precision in ('bf16', 'bf16x3') and a.n_head * a.d_v % 32 == 0:
+            # bf16 MFMA tail; split-bf16 (hi + lo operands, fp32-class) with MGNNS_TAIL_TERMS=3 and always in 'bf16x3' mode
             nxt = _wq_pack_bf16(layers[i + 1]) if i + 1 < len(layers) else None
-            q, qh = ops.mha_tail_bf16(o, q, _tail_pack_bf16(layer), a.layer_norm.eps, nxt, terms=TAIL_TERMS)
+            q, qh = ops.mha_tail_bf16(o, q, _tail_pack_bf16(layer), a.layer_norm.eps, nxt,
+                                      terms=3 if a.precision == 'bf16x3' else TAIL_TERMS)
         else:
             nxt = _wq_pack(layers[i + 1]) if i + 1 < len(layers) else None
             q, qh = ops.mha_tail(o, q, _tail_pack(layer), a.layer_norm.eps, nxt)

@@ -219,9 +219,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
         Measured |logit - fp32 CPU oracle| at B=256: 1.6e-2 (not inside the 1e-4 gate, which is the fp32 mode's).
         A feature map whose position count P is not in (104, 200] or not a multiple of 4 uses the fp32 bank kernel
         for that projection in either mode (the bf16 bank kernel is tiled for 14x14 maps); results then carry fp32
-        accuracy, never less."""
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        accuracy, never less.
+        'bf16x3' (split-bf16): the parity-grade mode that is not 8x slower.  Every fp32 operand of the heavy products is carried
+        as bf16 hi + lo and a product is three bf16 MFMAs (~2^-16 relative, fp32 accumulation): the image-bank projection
+        (csrc/imgbank_split.hip), the label GCN, the channel tails and the fusion layers' tails; the text bank runs the exact
+        fp32 LSTM; scores, softmax, LayerNorms, residuals fp32.  The fusion attention's K/V projection has no split form (the
+        bank's hi + lo images for 196 positions are 263 KB, LDS holds 160): with set_attention('folded') -- the pairing
+        bench.py reports -- the attention is the exact-fp32 folded kernel; with 'faithful' it is the exact-f32 MFMA core."""
+        if precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
         self.precision = precision
         for m in self.modules():
             if isinstance(m, MultiHeadAttention):
@@ -283,7 +289,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
     def _text_bank(self, text, text_lens):
         """MemoryBank of the text (fp32 + bf16 copy in bf16 mode, both written by the LSTM kernel)."""
         lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
-        if self.precision == 'bf16':
+        if self.precision == 'bf16':                        # ('bf16x3': the exact fp32 recurrence below)
             f32, bf = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
                                  self.hidden_size, self.lstm.num_layers, want_bf16=True,
                                  recurrence=os.environ.get("MGNNS_LSTM_REC", "bf16"), cache=self._lstm_cache)
@@ -332,6 +338,16 @@ class Multi_GCN_Multihead_Att(nn.Module):
             self._cache_put((id(lin), 'bf16'), hit)
         return hit[1]
 
+    def _wp_split(self, lin):
+        """The same weight as split-bf16 (hi, lo) fragment-major buffers for the bf16x3 bank kernel."""
+        w = lin.weight
+        key = (w.data_ptr(), w._version, str(w.device), 'split')
+        hit = self._wt_cache.get((id(lin), 'split'))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weight_bf16_split(w.detach().contiguous()))
+            self._cache_put((id(lin), 'split'), hit)
+        return hit[1]
+
     def _img_bank_and_pool(self, feats, lin):
         """-> (MemoryBank, pooled [B,2048]); one pass over the feature map."""
         B = feats.shape[0]
@@ -340,6 +356,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
             keep_halves = (self.fused_label_tail and self.fused_label_tail_bf16 and B >= self.fused_label_tail_bf16_min_batch)
             bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features, combine=not keep_halves)
             return MemoryBank(bf16=bank), pooled
+        if self.precision == 'bf16x3' and f3.shape[2] % 4 == 0 and f3.shape[2] <= 224 and f3.shape[1] % 64 == 0 \
+                and lin.out_features <= 304:
+            bank, pooled = ops.imgbank_pool_split(f3, self._wp_split(lin), lin.bias.detach(), lin.out_features)
+            return MemoryBank(f32=bank), pooled            # pooled: [B, 2, K] region-half maxima (the fused tail combines them)
         bank, pooled = ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)
         return MemoryBank(f32=bank), pooled
 
@@ -400,7 +420,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         mode, split-bf16 pairs in bf16 mode), rebuilt when a weight or the precision changes; carries the launch's scratch."""
         gc1, gc2 = (self.gc1, self.gc2)
         ps = (gc1.weight, gc2.weight)
-        split = self.precision == 'bf16'
+        split = self.precision in ('bf16', 'bf16x3')
         key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (str(ps[0].device), split)
         hit = self._wt_cache.get(('lgcn', tag))
         if hit is None or hit[0] != key:
@@ -447,7 +467,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
     def _lgcn_fused_ok(self, C, K0):
         """Does the persistent label-GCN launch take this channel?  (mgnns_label_gcn_supported: the launcher's own limits)"""
         return bool(_lib.lib().mgnns_label_gcn_supported(int(C), int(K0), self.gc1.out_features, self.gc2.out_features,
-                                                         1 if self.precision == 'bf16' else 0))
+                                                         1 if self.precision in ('bf16', 'bf16x3') else 0))
 
     def _label_q(self, attention):
         """w_q(label query) [NLQ, hid] (MODEL:97): batch independent, computed next to the label GCN."""
@@ -599,7 +619,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
         ctx = {}
-        fused_bf16 = (self.precision == 'bf16' and self.fused_label_tail and self.fused_label_tail_bf16
+        fused_bf16 = (self.precision in ('bf16', 'bf16x3') and self.fused_label_tail and self.fused_label_tail_bf16
                       and text.shape[0] >= self.fused_label_tail_bf16_min_batch)
 
         def text_gcn():

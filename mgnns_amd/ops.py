@@ -552,6 +552,24 @@ def imgbank_pool_bf16(feat, wp, bias, n_out, combine=True):
 
 
 # ---- label attention core ---------------------------------------------------------------------------
+def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True):
+    """Split-bf16 (fp32-class) image bank + max-pool: feat [B,K,P] fp32, w_pair = pack_weight_bf16_split(liner_img.weight
+    [n_out,K]) -> (bank [B,P,n_out] fp32, pooled halves [B,2,K] fp32 or None)."""
+    _chk(feat, "feature map", ndim=3)
+    B, K, P = feat.shape
+    hi, lo = w_pair
+    _chk(hi, "packed hi", torch.uint8, 1)
+    _chk(lo, "packed lo", torch.uint8, 1)
+    if bias is not None:
+        _chk(bias, "bias", ndim=1)
+    bank = torch.empty(B, P, n_out, device=feat.device, dtype=torch.float32)
+    pooled = torch.empty(B, 2, K, device=feat.device, dtype=torch.float32) if want_pool else None
+    L = _lib.lib()
+    _launch("mgnns_imgbank_pool_split_fwd", ("mgnns_imgbank_pool_split_fwd", P), L.mgnns_imgbank_pool_split_fwd, _p(feat), B, K, P,
+            _p(hi), _p(lo), _p(bias), n_out, _p(bank), _p(pooled), _stream())
+    return bank, pooled
+
+
 def label_attn_core(Q, K, V, n_heads):
     _chk(Q, "Q", ndim=2)
     _chk(K, "K", ndim=2)

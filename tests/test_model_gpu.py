@@ -52,6 +52,54 @@ def test_folded_attention_forward_matches_reference_golden_logits(cfg_name, prec
         assert (logits.cpu().argmax(1) == torch.as_tensor(g["logits"]).argmax(1)).float().mean() > 0.97
 
 
+@pytest.mark.parametrize("cfg_name", ["mvsa_single_b8", "tumemo_b64", "mvsa_multiple_b256"])
+@pytest.mark.parametrize("attention", ["folded", "faithful"])
+def test_bf16x3_mode_stays_inside_the_parity_gate(cfg_name, attention):
+    """precision 'bf16x3' (split-bf16: three bf16 MFMAs per product, fp32 accumulation) against the REFERENCE's golden logits
+    under the same 1e-4 gate as the fp32 mode, with the folded (exact fp32) attention it is meant to run with and with the
+    faithful exact-f32 core."""
+    g = H.load_golden("full_%s.npz" % cfg_name)
+    adj = H.load_golden("adjacency.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    B = int(g["B"])
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], g["label_query"], DEV)
+    model.set_precision("bf16x3").set_attention(attention)
+    logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV))
+    err = H.maxabs(logits.cpu(), g["logits"])
+    print("bf16x3 + %s attention, %s: max |dlogit| vs reference golden = %.3e" % (attention, cfg_name, err))
+    assert err < TOL
+
+
+def test_bf16x3_full_size_b256():
+    """bf16x3 + folded attention at BASELINE's full B = 256: oracle subset under the 1e-4 gate, permutation equivariance,
+    determinism, hipGraph replay == eager."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["mvsa_multiple_b256"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("full_mvsa_multiple_b256.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    B = 256
+    inp = synth.make_inputs(cfg, B=B, seed=4244, pmi=pmi)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    model.set_precision("bf16x3").set_attention("folded")
+    call = call_args(inp, DEV)
+    logits = model(*call).cpu()
+    idx = np.arange(0, B, 16)
+    sub = {k: (v[idx] if k != "label_query" else v) for k, v in inp.items()}
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = R.forward(p, {k: torch.from_numpy(v) for k, v in sub.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
+                    label_query=torch.from_numpy(lq))
+    err = H.maxabs(logits[idx], ref)
+    print("bf16x3 + folded, B=256: max |dlogit| on the oracle subset = %.3e" % err)
+    assert err < TOL
+    perm = np.random.RandomState(3).permutation(B)
+    pin = {k: (v[perm] if k != "label_query" else v) for k, v in inp.items()}
+    assert H.maxabs(model(*call_args(pin, DEV)).cpu(), logits[perm]) < 2e-5
+    assert torch.equal(model(*call).cpu(), logits)
+    assert H.maxabs(GraphedForward(model, call).replay().cpu(), logits) < 1e-6
+
+
 def test_forward_matches_oracle_batch32_ragged():
     cfg = synth.CONFIGS["tumemo_b64"]
     adj = H.load_golden("adjacency.npz")

@@ -796,3 +796,26 @@ def test_bilstm_bf16_mfma_recurrence_vs_fp32_recurrence():
             r1 = ops.bilstm(t, l, emb, weights[:2], Hh, 1)
             o1, o1b = ops.bilstm(t, l, emb, weights[:2], Hh, 1, want_bf16=True, recurrence="bf16")
             assert (o1 - r1).abs().max().item() < 5e-3 and (o1b[:, :, :2 * Hh].float() - o1).abs().max().item() <= 2.0 ** -8
+
+
+@pytest.mark.parametrize("B,P,N", [(5, 196, 300), (2, 100, 300), (3, 224, 304), (1, 112, 17)])
+def test_imgbank_pool_split_vs_fp64(B, P, N):
+    """Split-bf16 image bank (csrc/imgbank_split.hip): bank within fp32-class error of fp64 (three bf16 MFMAs per product:
+    ~2^-16 relative per product, K = 2048 products per output), per-half maxima exact."""
+    rs = np.random.RandomState(P + N)
+    K = 2048
+    feat = np.maximum(rs.standard_normal((B, K, P)), 0).astype(np.float32)
+    W = (0.05 * rs.standard_normal((N, K))).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    bank, pooled = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), dev(bias), N)
+    ref = np.einsum("bkp,nk->bpn", feat.astype(np.float64), W.astype(np.float64)) + bias
+    scale = np.einsum("bkp,nk->bpn", np.abs(feat).astype(np.float64), np.abs(W).astype(np.float64)).max()
+    assert tuple(bank.shape) == (B, P, N)
+    assert np.abs(bank.cpu().numpy() - ref).max() / scale < 2e-5
+    assert torch.equal(pooled[:, 0], dev(feat[:, :, :112].max(2)))
+    if P > 112:
+        assert torch.equal(pooled[:, 1], dev(feat[:, :, 112:].max(2)))
+    else:
+        assert torch.isinf(pooled[:, 1]).all() and (pooled[:, 1] < 0).all()
+    b2, _ = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), None, N, want_pool=False)
+    assert np.abs(b2.cpu().numpy() - (ref - bias)).max() / scale < 2e-5
