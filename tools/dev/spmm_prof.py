@@ -20,8 +20,8 @@ k = max(4, -(-stress.COLD_BYTES // (2 * n * F * 2)))
 xs = [torch.randn(n, F, device=dev, generator=g).bfloat16() for _ in range(k)]
 ys = [torch.empty_like(x) for x in xs]
 for i in range(launches):
-    if path == "tiled":
-        ops.spmm_bf16(adj, xs[i % k], act=ops.ACT_LRELU2, out=ys[i % k], path="tiled")
+    if path in ("tiled", "sell"):
+        ops.spmm_bf16(adj, xs[i % k], act=ops.ACT_LRELU2, out=ys[i % k], path=path)
     else:
         ops.spmm_bf16(adj, xs[i % k], act=ops.ACT_LRELU2, out=ys[i % k], path="direct", variant=variant)
 torch.cuda.synchronize()
