@@ -17,4 +17,10 @@ timeout 400 tools/prof.sh ${tag}_folded --steps 20 --warmup 5 --no-cpu-baseline 
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout 400 tools/pmc.sh ${tag}_$c $c --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-graph > /dev/null
 done
-ls gpurun_out | grep ${tag} | head -40
+# configs[4] SpMM kernels: kernel trace + FETCH_SIZE / WRITE_SIZE / TCC hit-miss passes (tools/dev/spmm_pmc.sh)
+timeout 300 tools/dev/spmm_pmc.sh ${tag}_spmm_d4e-4_F1024 random 1024 direct 0 > gpurun_out/${tag}_spmm_pmc_d4e-4_F1024.txt 2>&1
+timeout 300 tools/dev/spmm_pmc.sh ${tag}_spmm_d4e-4_F2048 random 2048 direct 0 > gpurun_out/${tag}_spmm_pmc_d4e-4_F2048.txt 2>&1
+timeout 300 tools/dev/spmm_pmc.sh ${tag}_spmm_d1e-2_F1024 dense 1024 tiled 0 12 > gpurun_out/${tag}_spmm_pmc_d1e-2_F1024.txt 2>&1
+timeout 300 python tools/dev/slabcopy_exp.py > gpurun_out/${tag}_slabcopy.jsonl 2>/dev/null
+timeout 300 python tools/dev/gather_exp.py > gpurun_out/${tag}_gather.jsonl 2>/dev/null
+ls gpurun_out | grep ${tag} | head -60

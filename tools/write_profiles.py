@@ -12,7 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO = os.path.join(ROOT, "gpurun_out")
-PR = os.path.join(ROOT, "profiles")
+PR = os.environ.get("MGNNS_PROFILES_OUT") or os.path.join(ROOT, "profiles")     # on the GPU box: a directory under gpurun_out/ (only that is merged back)
+os.makedirs(PR, exist_ok=True)
 
 
 def tables(cur):
@@ -124,6 +125,53 @@ def main():
         if traffic:
             with open(os.path.join(PR, "pmc_traffic.json"), "w") as f:
                 json.dump(traffic, f, indent=1)
+    # ---- configs[4] SpMM: PMC traffic vs algorithmic bytes --------------------------------------------------------
+    spmm_rows = []
+    for case, label, alg in (("spmm_d4e-4_F1024", "spmm_bf16 ring kernel, N=10000, density 4e-4, F=1024", 40036 * 6 + 2 * 10000 * 1024 * 2),
+                             ("spmm_d4e-4_F2048", "spmm_bf16 register kernel (2 slabs per pass), density 4e-4, F=2048", 40036 * 6 + 2 * 10000 * 2048 * 2),
+                             ("spmm_d1e-2_F1024", "spmm_bf16 LDS-tiled kernel, density 1e-2, F=1024", 994841 * 6 + 2 * 10000 * 1024 * 2)):
+        vals = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
+            d = os.path.join(GO, "pmc_%s_%s_%s" % (tag, case, ctr))
+            dbs2 = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")] if os.path.isdir(d) else []
+            if dbs2:
+                cur = sqlite3.connect(dbs2[0]).cursor()
+                t = tables(cur)
+                q = ("select i.name, sum(p.value) from %s p join %s d on p.event_id = d.event_id join %s s on d.kernel_id = s.id join %s i on "
+                     "p.pmc_id = i.id where s.kernel_name like '%%spmm_bf16%%' group by i.name, d.event_id"
+                     % (t("rocpd_pmc_event"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol"), t("rocpd_info_pmc")))
+                acc = {}
+                for nm, v in cur.execute(q):
+                    acc.setdefault(nm, []).append(v)
+                for nm, v in acc.items():
+                    vals[nm] = sum(v) / len(v)
+        kt = os.path.join(GO, "kt_%s_%s" % (tag, case))
+        dur = None
+        dbs2 = [os.path.join(dp, f) for dp, _, fs in os.walk(kt) for f in fs if f.endswith(".db")] if os.path.isdir(kt) else []
+        if dbs2:
+            cur = sqlite3.connect(dbs2[0]).cursor()
+            t = tables(cur)
+            r = cur.execute("select avg(d.end - d.start), count(*) from %s d join %s s on d.kernel_id = s.id where s.kernel_name like '%%spmm_bf16%%'"
+                            % (t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol"))).fetchone()
+            dur = (r[0] / 1e3, r[1]) if r and r[0] else None
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            rd, wr = 2 * vals["FETCH_SIZE"] * 1024 / 1e6, vals["WRITE_SIZE"] * 1024 / 1e6
+            hit = vals.get("TCC_HIT_sum"), vals.get("TCC_MISS_sum")
+            spmm_rows.append("| %s | %.1f | %.1f | %.1f | %.2f | %s | %s |" % (
+                label, rd, wr, alg / 1e6, (rd + wr) / (alg / 1e6),
+                "%.0f / %.0f" % hit if hit[0] is not None else "-", "%.2f us x %d" % dur if dur else "-"))
+    if spmm_rows:
+        with open(os.path.join(PR, "%s_spmm_pmc.md" % pre), "w") as f:
+            f.write("# configs[4] sparse propagation, rocprofv3 PMC passes (%s)\n\n" % pre)
+            f.write("`tools/dev/spmm_pmc.sh`: separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum + TCC_MISS_sum) + one `--kernel-trace --stats` "
+                    "pass of `tools/dev/spmm_prof.py` (cache-cold: every launch takes the next of >= 9 operand sets totalling > 640 MiB). "
+                    "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md); values per launch.\n\n")
+            f.write("| kernel / case | HBM read MB (2 x FETCH) | write MB | algorithmic MB | traffic / algorithmic | L2 hits / misses per launch | rocprofv3 duration |\n|---|---|---|---|---|---|---|\n")
+            f.write("\n".join(spmm_rows) + "\n")
+    for name in ("slabcopy", "gather"):
+        src = os.path.join(GO, "%s_%s.jsonl" % (tag, name))
+        if os.path.exists(src) and os.path.getsize(src):
+            shutil.copy(src, os.path.join(PR, "%s_%s.jsonl" % (pre, name)))
     for name in ("bench_bf16", "bench_f32", "stress_gcn"):
         src = os.path.join(GO, "%s_%s.json" % (tag, name))
         if os.path.exists(src):
