@@ -22,6 +22,10 @@ __device__ unsigned long long g_img_trace[4][8];
 #define IMG_T() __builtin_amdgcn_s_memtime()
 #endif
 
+#ifndef MG_IMG_AUX
+#define MG_IMG_AUX 2          // cache policy of the map loads (aux bits of buffer_load): 2 = non-temporal
+#endif
+
 namespace {
 
 constexpr int BK = 128;                 // k-slice (4 MFMA k-steps): every lane of a wave streams 8 feature rows
@@ -105,7 +109,7 @@ __device__ __forceinline__ void imgbank_producer(uint4* __restrict__ Fs, float* 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             // streamed once: non-temporal (aux bit 1), so the map does not evict the W fragments every workgroup re-reads from L2
-            s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, loff, (c * BK + urow0 + i) * P * (int)sizeof(float), 2));
+            s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, loff, (c * BK + urow0 + i) * P * (int)sizeof(float), MG_IMG_AUX));
         }
     };
     // slice (in registers) -> max-pool of its 16 feature rows + bf16 transpose-write into LDS buffer `buf`
