@@ -13,6 +13,9 @@
 #include "common.hpp"
 #include "mha_tail_body.hpp"      // (defines bf16x8)
 
+#ifndef MG_MHA_ABLATE
+#define MG_MHA_ABLATE 0      // measurement builds only (tools/dev/build_variant.py): 1 = no weight-fragment reloads, 2 = no bank-fragment reloads
+#endif
 #ifdef MG_MHA_TRACE
 // profiling aid (off by default): s_memtime stamps of wave 0 / wave 4 of two workgroups at every phase boundary
 __device__ unsigned long long g_mha_trace[4][64];
@@ -89,17 +92,33 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
     }
 }
 
-// sum over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), result in every lane: two
-// v_permlane{32,16}_swap + add steps, pure VALU (the ds_bpermute form costs an LDS round trip per step)
-__device__ __forceinline__ float rows4_sum(float v) {
-    // inline asm: both registers of a swap are read AND written (hipcc 7.2's builtin loses the second result here);
-    // the s_nop 1 on either side cover the VALU-write -> swap-read and swap-write -> VALU-read hazards, which the
-    // compiler's hazard recogniser does not see through an asm block
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));      // a = [lo, lo], b = [hi, hi]
-    float c = a + b, d = c;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));      // c = [r0 r0 r2 r2], d = [r1 r1 r3 r3]
-    return c + d;
+// Sum over the four 16-lane rows of the wave for FOUR values at once (a transposing reduction): on return the rows of the
+// result hold the row sums of [a, c, b, d] -- row 0: a, row 1: c, row 2: b, row 3: d.  v_permlane32_swap exchanges the upper
+// half of its first operand with the lower half of its second, v_permlane16_swap the odd rows of the first with the even rows
+// of the second, so one swap + one add folds TWO values by one level: 3 swaps + 3 adds for four tiles (the one-value form, both
+// operands the same register, cost 2 swaps + 2 adds per tile).  Inline asm: both registers of a swap are read AND written (hipcc
+// 7.2's builtin loses the second result here); the s_nop 1 on either side cover the VALU-write -> swap-read and swap-write ->
+// VALU-read hazards, which the compiler's hazard recogniser does not see through an asm block.
+__device__ __forceinline__ float rows4_sum4(float a, float b, float c, float d) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // a = [a.lo, b.lo], b = [a.hi, b.hi] (same for c, d)
+    float ab = a + b, cd = c + d;                             // halves: [a: r0+r2, r1+r3 | b: r0+r2, r1+r3]
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ab), "+v"(cd));
+    return ab + cd;                                           // rows: [a, c, b, d]
+}
+
+// Barrier among the FOUR waves of one head (half of the workgroup): a monotonic LDS counter, one arrival per wave, every
+// wave polls it.  The two halves of the workgroup work on different heads and share nothing but the staged bank (read only),
+// and the waves w / w + 4 of the two halves share a SIMD: with a workgroup-wide s_barrier they run in lock step, so the
+// VALU-only epilogues of both (scores, softmax, weighted sum: ~3.5 k cycles per head pair) leave the SIMD's matrix pipe idle;
+// with per-half barriers the halves drift apart and one half's epilogue runs under the other's MFMAs.
+// LDS operations of a wave complete in order: lgkmcnt(0) before the arrival publishes this wave's LDS writes.
+__device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
 }
 
 // Fragments that are in flight ACROSS a phase boundary: the first k-step's A fragments (the staged bank is the
@@ -108,12 +127,11 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // phase's operands already on their way instead of exposing an L2 + LDS round trip at every phase start.
 template <int NMT>
 struct Frags {
-    static constexpr int HA = (NMT + 1) / 2, HB = NMT - HA;
     static constexpr int BD = NMT <= 4 ? 5 : 2;      // must divide KSTEPS (ring slots carry over phases)
     // the 13-tile class has no registers to spare (104 accumulators): only its B fragments cross the phase
     // boundary, the A fragments of k-step 0 are re-requested right after the epilogue
     static constexpr bool CROSS_A = NMT <= 7;
-    uint4 ga[HA], gb[HB > 0 ? HB : 1];
+    uint4 ga[NMT];
     uint4 bq[BD][2];
 };
 
@@ -141,27 +159,25 @@ template <int NMT>
 __device__ __forceinline__ void frags_prime_a(Frags<NMT>& f, const uint4* __restrict__ a_base) {
     if (Frags<NMT>::CROSS_A) {
 #pragma unroll
-        for (int i = 0; i < Frags<NMT>::HA; ++i) f.ga[i] = a_base[i * 16 * LSTR];
-#pragma unroll
-        for (int i = 0; i < Frags<NMT>::HB; ++i) f.gb[i] = a_base[(Frags<NMT>::HA + i) * 16 * LSTR];
+        for (int i = 0; i < NMT; ++i) f.ga[i] = a_base[i * 16 * LSTR];
     }
 }
 
 // acc[i][j] += X[tile i] * W^T[tile j] over the padded model dim, for a COMPILE-TIME number of live row tiles.
-// Fully unrolled, software pipelined in two half-groups of row tiles: while the MFMAs of one half run, the A
-// fragments (ds_read_b128 from the staged bank) of the OTHER half / next k-step are in flight, so an LDS read is
-// issued >= 12 MFMAs (~200 cycles) ahead of its use; B fragments (global, fragment-major, L2 resident) run BD
-// k-steps ahead.  The last k-steps prefetch the NEXT phase's first fragments from `wb_next` (see Frags).
-// sched_barrier(0) fences keep the compiler from sinking the prefetches back to their uses.
+// Fully unrolled.  One A fragment register set per row tile: the two MFMAs that consume tile i's fragment of k-step ks are
+// followed at once by the ds_read_b128 that refills it for k-step ks + 1, i.e. the LDS reads are spread ONE per two MFMAs
+// (an LDS read issued in the shadow of a 16-cycle MFMA costs the matrix pipe nothing; round 1-2's bursts of 6-7 reads
+// between two half-groups of MFMAs left the pipe idle for ~200 cycles per k-step: a wave alone on its SIMD ran at
+// 25 cycles per MFMA, the pair at 19.5) and every read is issued a whole k-step (2 * NMT MFMAs) ahead of its use.
+// B fragments (global, fragment-major, L2 resident) run BD k-steps ahead.  The last k-steps prefetch the NEXT phase's
+// first fragments from `wb_next` (see Frags).  sched_barrier(0) fences pin the interleave.
 template <int NMT>
 __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, const uint4* __restrict__ a_base,
                                         const WStream& w, int wb, int wb_next, int trace_base = -1) {
-    constexpr int HA = Frags<NMT>::HA, HB = Frags<NMT>::HB, BD = Frags<NMT>::BD;
+    constexpr int BD = Frags<NMT>::BD;
     if (!Frags<NMT>::CROSS_A) {
 #pragma unroll
-        for (int i = 0; i < HA; ++i) f.ga[i] = a_base[i * 16 * LSTR];
-#pragma unroll
-        for (int i = 0; i < HB; ++i) f.gb[i] = a_base[(HA + i) * 16 * LSTR];
+        for (int i = 0; i < NMT; ++i) f.ga[i] = a_base[i * 16 * LSTR];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -172,31 +188,17 @@ __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, cons
         if (trace_base >= 0) MG_STAMP(trace_base + ks);
 #endif
         const int ksn = (ks + 1) % KSTEPS;          // k-step whose A fragments are requested next (wraps to the next phase)
-        // ---- half A: MFMAs on ga (k-step ks), then refill ga ---------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < HA; ++i) {
+        for (int i = 0; i < NMT; ++i) {
             const bf16x8 av = __builtin_bit_cast(bf16x8, f.ga[i]);
             acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[i][0], 0, 0, 0);
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[i][1], 0, 0, 0);
+#if !(MG_MHA_ABLATE & 2)
+            if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) f.ga[i] = a_base[i * 16 * LSTR + ksn * 4];
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) {
-#pragma unroll
-            for (int i = 0; i < HA; ++i) f.ga[i] = a_base[i * 16 * LSTR + ksn * 4];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- half B ------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const bf16x8 av = __builtin_bit_cast(bf16x8, f.gb[i]);
-            acc[HA + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[HA + i][0], 0, 0, 0);
-            acc[HA + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[HA + i][1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) {
-#pragma unroll
-            for (int i = 0; i < HB; ++i) f.gb[i] = a_base[(HA + i) * 16 * LSTR + ksn * 4];
-        }
+#if !(MG_MHA_ABLATE & 1)
         if (ks + BD < KSTEPS) {
             f.bq[ks % BD][0] = wfrag(w, wb + (ks + BD) * FRAG);
             f.bq[ks % BD][1] = wfrag(w, wb + (KSTEPS + ks + BD) * FRAG);
@@ -204,6 +206,7 @@ __device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, cons
             f.bq[ks % BD][0] = wfrag(w, wb_next + (ks + BD - KSTEPS) * FRAG);
             f.bq[ks % BD][1] = wfrag(w, wb_next + (KSTEPS + ks + BD - KSTEPS) * FRAG);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -220,6 +223,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
     float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
     float* s_red = s_p + 2 * LMAX;                                                // [16]
+    int* s_ctr = reinterpret_cast<int*>(s_red + 16) + 1;                          // [2] per-half barrier counters (s_red[16] is s_lvalid)
     const float* s_q = s_red + 16 + 4;                                            // [QMAX] this sample's projected query
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values live in SGPRs
@@ -231,6 +235,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     // weight stream of (head, phase) for this wave (byte offset of its first fragment, wave-uniform); heads beyond H
     // (odd H) read head 0's stream and are discarded
     const int hp_wave_s = hp_wave, wq_s = wq;
+    const float inv_temp = 1.0f / temp;
     WStream wsr;
     wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wp), 0, 0x7fffffff, 0x00027000);
     wsr.voff = lane * 16;
@@ -252,6 +257,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
     int stamp = 3;
     (void)stamp;
 
+    int nbar = 0;                           // arrivals expected at this half's next barrier
     for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
         const int h = hp * 2 + hp_wave;
         const bool head_on = h < H;
@@ -267,6 +273,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
         // adds per head out of the loop; differences to the literal form are at fp32 rounding level)
         const int hp_next = (hp + gridDim.y) * 2 < H ? hp + gridDim.y : hp;     // last pair: harmless re-read
 
+        float e_keep = 0.f;             // this thread's unnormalised probability (phase 0 -> the `attn` store of phase 1)
         for (int phase = 0; phase < 2; ++phase) {
             f32x4 acc[MT][2];
 #pragma unroll
@@ -283,59 +290,86 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
             MG_STAMP(stamp++);
 
             if (phase == 0) {
-                // ---- partial scores of this wave's 32 head dims: in-register over the 8 dims of the lane, then
-                //      across the four 16-lane groups (2 exchanges per row tile instead of 4 DPP steps per element)
+                // ---- partial scores of this wave's 32 head dims: in-register over the 8 dims of the lane, then across
+                //      the four 16-lane groups, four row tiles per transposing reduction (rows4_sum4); the result register
+                //      holds tiles [4g, 4g+2, 4g+1, 4g+3] in its rows: one 64-lane LDS write per four tiles
                 if (head_on) {
+                    float v[(NMT + 3) / 4 * 4];
 #pragma unroll
-                    for (int i = 0; i < NMT; ++i) {
-                        float v = 0.f;
+                    for (int i = 0; i < (NMT + 3) / 4 * 4; ++i) {
+                        float a = 0.f, c = 0.f;
+                        if (i < NMT) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v = fmaf(qd0[r], acc[i][0][r], v);
-                            v = fmaf(qd1[r], acc[i][1][r], v);
+                            for (int r = 0; r < 4; ++r) {
+                                a = fmaf(qd0[r], acc[i][0][r], a);
+                                c = fmaf(qd1[r], acc[i][1][r], c);
+                            }
                         }
-#ifdef MG_NO_PERMLANE
-                        v += __shfl_xor(v, 16, 64);
-                        v += __shfl_xor(v, 32, 64);
-#else
-                        v = rows4_sum(v);
-#endif
-                        if (lane < 16) s_part[wave * LMAX + i * 16 + lane] = v;
+                        v[i] = a + c;
+                    }
+                    const int rt = ((lane >> 4) & 1) * 2 + (lane >> 5);          // row tile (inside a group of 4) of this lane's row
+#pragma unroll
+                    for (int g = 0; g < (NMT + 3) / 4; ++g) {
+                        const float s4 = rows4_sum4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                        if (4 * g + 3 < NMT || 4 * g + rt < NMT) s_part[wave * LMAX + (4 * g + rt) * 16 + (lane & 15)] = s4;
                     }
                 }
-                __syncthreads();
-                // ---- masked softmax, one head per 256-thread half ----------------------------------------------
+                half_barrier(s_ctr + hh, (nbar += 4), lane);       // (1) of 2 per head pair: the partial scores are visible
+                // ---- masked softmax, one head per 256-thread half, WITHOUT a workgroup-wide max / sum: every wave
+                //      normalises its 64 positions against its OWN maximum m_w and publishes (m_w, z_w = sum e) next to the
+                //      unnormalised e; the consumers of the probabilities (weighted sum below, `attn` store) merge the
+                //      four waves' pairs -- p = e * exp(m_w - M) / Z, the online-softmax identity.  That takes the two
+                //      reduction barriers and the "p is visible" barrier out of the K epilogue: the V projection starts
+                //      right here and the ONE barrier behind it publishes e / m / z.
                 const int hs = hp * 2 + hh;
-                float s = -INFINITY;
+                float sc = -INFINITY;
                 if (pos < lvalid && hs < H) {
                     const float* sp = s_part + (hh * 4) * LMAX + pos;
-                    s = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) / temp;
-                    if (pos_masked) s = -INFINITY;
+                    sc = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) * inv_temp;
+                    if (pos_masked) sc = -INFINITY;
                 }
-                float m = wave_max_dpp(s);
-                if (lane == 0) s_red[wave] = m;
-                __syncthreads();
-                m = fmaxf(fmaxf(s_red[hh * 4], s_red[hh * 4 + 1]), fmaxf(s_red[hh * 4 + 2], s_red[hh * 4 + 3]));
-                const float e = (s != -INFINITY) ? expf(s - m) : 0.f;
-                float z = wave_sum_dpp(e);
-                if (lane == 0) s_red[8 + wave] = z;
-                __syncthreads();
-                z = (s_red[8 + hh * 4] + s_red[8 + hh * 4 + 1]) + (s_red[8 + hh * 4 + 2] + s_red[8 + hh * 4 + 3]);
-                const float p = (hs < H) ? e / z : 0.f;
-                if (pos < LMAX) s_p[hh * LMAX + pos] = p;
-                if (attn && hs < H && pos < L)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, p), attn_rsrc, pos * 4, (hs * B + b) * L * 4, 0);
-                __syncthreads();
+                const float m_w = wave_max_dpp(sc);
+                e_keep = (sc != -INFINITY) ? __expf(sc - m_w) : 0.f;
+                const float z_w = wave_sum_dpp(e_keep);
+                if (pos < LMAX) s_p[hh * LMAX + pos] = e_keep;
+                if (lane == 0) { s_red[wave * 2] = m_w; s_red[wave * 2 + 1] = z_w; }
                 MG_STAMP(stamp++);
             } else {
+                half_barrier(s_ctr + hh, (nbar += 4), lane);       // (2) of 2: e / (m_w, z_w) of this head pair are visible; every wave of the half is done with the
+                                        // partial scores, so the next pair may overwrite them
+                // ---- merge factors of the four softmax waves of a head: f_w = exp(m_w - M) / Z
+                auto merge = [&](int head_half, float (&fw)[4]) {
+                    const f32x4 mz0 = *reinterpret_cast<const f32x4*>(s_red + head_half * 8);        // m0 z0 m1 z1
+                    const f32x4 mz1 = *reinterpret_cast<const f32x4*>(s_red + head_half * 8 + 4);    // m2 z2 m3 z3
+                    const float M = fmaxf(fmaxf(mz0[0], mz0[2]), fmaxf(mz1[0], mz1[2]));
+                    fw[0] = __expf(mz0[0] - M);          // exp(-inf) = 0: a wave without a live position drops out;
+                    fw[1] = __expf(mz0[2] - M);          // all masked: -inf - -inf = NaN, like the reference's softmax
+                    fw[2] = __expf(mz1[0] - M);
+                    fw[3] = __expf(mz1[2] - M);
+                    const float Z = (mz0[1] * fw[0] + mz0[3] * fw[1]) + (mz1[1] * fw[2] + mz1[3] * fw[3]);
+                    const float rz = __builtin_amdgcn_rcpf(Z);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fw[k] *= rz;
+                };
+                if (attn) {             // optional output: the softmax thread of a position normalises its own e
+                    const int hs = hp * 2 + hh;
+                    float fw[4];
+                    merge(hh, fw);
+                    const float p = e_keep * fw[wave & 3];
+                    if (hs < H && pos < L)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, p), attn_rsrc, pos * 4, (hs * B + b) * L * 4, 0);
+                }
                 // ---- o[d] = sum_l p[l] * (V[l,d] + bv[d]): p is per column here, 8 dims per lane accumulate in
-                //      registers over the row tiles, one 16-lane DPP sum per dim at the end ---------------------------
+                //      registers over the row tiles (four tiles = one softmax wave = one merge factor), one 16-lane DPP sum
+                //      per dim at the end -----------------------------------------------------------------------------
                 if (head_on) {
+                    float fw[4];
+                    merge(hp_wave, fw);
                     const float* pp = s_p + hp_wave * LMAX + (lane & 15);
                     f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
-                        const float p = pp[i * 16];
+                        const float p = pp[i * 16] * fw[i >> 2];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             t0[r] = fmaf(p, acc[i][0][r], t0[r]);
@@ -359,7 +393,6 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, const float* __res
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, COH ? 17 : 0);
                     }
                 }
-                __syncthreads();      // s_p / s_part are rewritten by the next head pair
                 MG_STAMP(stamp++);
             }
         }
@@ -382,7 +415,11 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
     MG_STAMP(0);
 
     // ---- live rows -------------------------------------------------------------------------------------
-    if (tid == 0) *s_lvalid = mask ? 0 : L;
+    if (tid == 0) {
+        *s_lvalid = mask ? 0 : L;
+        s_lvalid[1] = 0;                // the two per-half barrier counters (mha_body)
+        s_lvalid[2] = 0;
+    }
     __syncthreads();
     if (mask) {
         int last = 0;
