@@ -107,31 +107,45 @@ __device__ __forceinline__ float rows4_sum4(float a, float b, float c, float d) 
     return ab + cd;                                           // rows: [a, c, b, d]
 }
 
-// Barrier among the FOUR waves of one head (half of the workgroup): a monotonic LDS counter, one arrival per wave, every
-// wave polls it.  The two halves of the workgroup work on different heads and share nothing but the staged bank (read only),
-// and the waves w / w + 4 of the two halves share a SIMD: with a workgroup-wide s_barrier they run in lock step, so the
-// VALU-only epilogues of both (scores, softmax, weighted sum: ~3.5 k cycles per head pair) leave the SIMD's matrix pipe idle;
-// with per-half barriers the halves drift apart and one half's epilogue runs under the other's MFMAs.
-// LDS operations of a wave complete in order: lgkmcnt(0) before the arrival publishes this wave's LDS writes.
-__device__ __forceinline__ void half_barrier(int* ctr, int target, int lane) {
+// Cross-wave hand-over inside the workgroup goes through LDS counters, not s_barrier (see mha_body).  LDS operations of a wave
+// complete in order: lgkmcnt(0) in front of an arrival publishes this wave's LDS writes to whoever sees the count.
+__device__ __forceinline__ int lds_arrive(int* ctr, int lane) {          // -> the count before this arrival (wave-uniform)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(old);
+}
+__device__ __forceinline__ void lds_wait_ge(int* ctr, int target) {
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
         __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
 
-// Fragments that are in flight ACROSS a phase boundary: the first k-step's A fragments (the staged bank is the
-// same for every head and phase) and the first BD k-steps' B fragments of the NEXT weight stream are requested at
-// the tail of the current GEMM, so the score / softmax / weighted-sum epilogue and its barriers run with the next
-// phase's operands already on their way instead of exposing an L2 + LDS round trip at every phase start.
+// LDS map behind the staged bank
+constexpr int NSLOT_P = 8;                                               // probability rows kept (heads between softmax and weighted sum)
+constexpr int MAXH = QMAX / DK;                                          // heads a workgroup can own
+constexpr size_t OFF_PART = (size_t)LMAX * LSTR * 16;                    // float [2][4][LMAX] partial scores (head parity, slice)
+constexpr size_t OFF_P = OFF_PART + 2 * 4 * LMAX * sizeof(float);       // float [NSLOT_P][LMAX] probabilities
+constexpr size_t OFF_MB = OFF_P + NSLOT_P * LMAX * sizeof(float);       // float [LMAX] mask bias: 0 or -inf
+constexpr size_t OFF_INT = OFF_MB + LMAX * sizeof(float);               // int [16 + 3 * MAXH]: live rows, tickets, arrival counts
+constexpr size_t OFF_Q = OFF_INT + (16 + 3 * MAXH) * sizeof(int);       // float [QMAX] this sample's projected query
+constexpr size_t SMEM_BYTES = OFF_Q + QMAX * sizeof(float);
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+static_assert(OFF_Q % 16 == 0 && OFF_P % 16 == 0, "LDS alignment");
+
+// Weight fragments in flight ACROSS a unit boundary: the first BD k-steps' B fragments of the NEXT unit's weight stream
+// are requested at the tail of the current GEMM, so the epilogue runs with the next unit's first operands already on their
+// way instead of exposing an L2 round trip at every unit start.
 template <int NMT>
 struct Frags {
-    static constexpr int BD = NMT <= 4 ? 5 : 2;      // must divide KSTEPS (ring slots carry over phases)
-    // the 13-tile class has no registers to spare (104 accumulators): only its B fragments cross the phase
-    // boundary, the A fragments of k-step 0 are re-requested right after the epilogue
-    static constexpr bool CROSS_A = NMT <= 7;
-    uint4 ga[NMT];
+    static constexpr int BD = NMT <= 4 ? 5 : 2;      // must divide KSTEPS (ring slots carry over units)
+#ifndef MG_MHA_RING
+#define MG_MHA_RING 8
+#endif
+    // bank fragments in flight inside a GEMM: a ring over the (k-step, row tile) sequence -- a fragment is requested RA tiles
+    // (2 RA MFMAs) ahead of its use; the 13-tile class (104 accumulators) has room for MG_MHA_RING of them
+    static constexpr int TOTAL = KSTEPS * NMT;
+    static constexpr int RA = TOTAL < MG_MHA_RING ? TOTAL : MG_MHA_RING;
     uint4 bq[BD][2];
 };
 
@@ -155,249 +169,286 @@ __device__ __forceinline__ void frags_prime_b(Frags<NMT>& f, const WStream& w, i
         f.bq[d][1] = wfrag(w, wb + (KSTEPS + d) * FRAG);
     }
 }
-template <int NMT>
-__device__ __forceinline__ void frags_prime_a(Frags<NMT>& f, const uint4* __restrict__ a_base) {
-    if (Frags<NMT>::CROSS_A) {
-#pragma unroll
-        for (int i = 0; i < NMT; ++i) f.ga[i] = a_base[i * 16 * LSTR];
+// compile-time loop: f(IC<0>{}), f(IC<1>{}), ... -- the index is a constant expression inside f (immediate offsets / counts of
+// inline-asm instructions need one)
+template <int N> struct IC { static constexpr int v = N; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
 // acc[i][j] += X[tile i] * W^T[tile j] over the padded model dim, for a COMPILE-TIME number of live row tiles.
-// Fully unrolled.  One A fragment register set per row tile: the two MFMAs that consume tile i's fragment of k-step ks are
-// followed at once by the ds_read_b128 that refills it for k-step ks + 1, i.e. the LDS reads are spread ONE per two MFMAs
-// (an LDS read issued in the shadow of a 16-cycle MFMA costs the matrix pipe nothing; round 1-2's bursts of 6-7 reads
-// between two half-groups of MFMAs left the pipe idle for ~200 cycles per k-step: a wave alone on its SIMD ran at
-// 25 cycles per MFMA, the pair at 19.5) and every read is issued a whole k-step (2 * NMT MFMAs) ahead of its use.
-// B fragments (global, fragment-major, L2 resident) run BD k-steps ahead.  The last k-steps prefetch the NEXT phase's
-// first fragments from `wb_next` (see Frags).  sched_barrier(0) fences pin the interleave.
-template <int NMT>
-__device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, const uint4* __restrict__ a_base,
-                                        const WStream& w, int wb, int wb_next, int trace_base = -1) {
-    constexpr int BD = Frags<NMT>::BD;
-    if (!Frags<NMT>::CROSS_A) {
-#pragma unroll
-        for (int i = 0; i < NMT; ++i) f.ga[i] = a_base[i * 16 * LSTR];
-    }
+// The kernel is bound by instruction ISSUE, not by the matrix pipe alone: a SIMD issues ~1.3 other instructions in the shadow
+// of one 16-cycle MFMA (tools/dev/micro/mfma_valu.hip), and the compiler-scheduled form of this loop carried 2.2 per MFMA --
+// an s_waitcnt in front of every row tile, a v_add per LDS address beyond the 64-KiB immediate range.  So the loop is written
+// out: bank fragments are read with inline-asm ds_read_b128 from TWO base registers with immediate offsets (rows 0-111 /
+// 112-207), into a ring that runs RA tiles ahead of the MFMAs, and ONE hand-counted s_waitcnt lgkmcnt per pair of row tiles
+// (LDS operations of a wave complete in order; an extra younger LDS operation in flight only makes a counted wait stricter).
+// Two MFMAs consume a fragment and the ds_read that refills its ring slot follows them at once: one LDS read per two MFMAs.
+// B fragments (global, fragment-major, L2 resident, compiler-visible loads) run BD k-steps ahead; the last k-steps prefetch
+// the NEXT unit's first fragments (next_stream() draws that unit).  sched_barrier(0) fences pin the order: nothing ties the
+// MFMAs to the asm reads' waits except that no instruction is scheduled across a fence.
+template <int NMT, typename NextStream>
+__device__ __forceinline__ void kv_gemm(f32x4 (&acc)[MT][2], Frags<NMT>& f, unsigned a_lo, unsigned a_hi,
+                                        const WStream& w, int wb, NextStream&& next_stream, int trace_base = -1) {
+    constexpr int BD = Frags<NMT>::BD, RA = Frags<NMT>::RA, TOTAL = Frags<NMT>::TOTAL;
+    constexpr int HOOK_KS = KSTEPS - BD - 1 > 0 ? KSTEPS - BD - 1 : 0;      // k-step in front of which the next unit is drawn
+    constexpr int SPLIT = 7;                            // row tiles 0..6 from a_lo, 7..12 from a_hi = a_lo + 7 * 16 rows
+#ifndef MG_MHA_GROUP
+#define MG_MHA_GROUP 2
+#endif
+    constexpr int GRP = MG_MHA_GROUP < RA ? MG_MHA_GROUP : 1;       // row tiles per counted wait
+    u32x4 ga[RA];
+    int wb_next = 0;
+    // fragment n of the (k-step, row tile) sequence -> ring slot n % RA
+    auto fetch = [&](auto nc) {
+        constexpr int n = decltype(nc)::v;
+        constexpr int ks = n / NMT, i = n % NMT;
+        if constexpr (i < SPLIT) ga[n % RA] = mg_lds_read128<(i * 16 * LSTR + ks * 4) * 16>(a_lo);
+        else ga[n % RA] = mg_lds_read128<((i - SPLIT) * 16 * LSTR + ks * 4) * 16>(a_hi);
+    };
+    static_for<0, RA>(fetch);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+    static_for<0, KSTEPS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::v;
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][0]);
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, f.bq[ks % BD][1]);
 #ifdef MG_MHA_TRACE
         if (trace_base >= 0) MG_STAMP(trace_base + ks);
 #endif
-        const int ksn = (ks + 1) % KSTEPS;          // k-step whose A fragments are requested next (wraps to the next phase)
-#pragma unroll
-        for (int i = 0; i < NMT; ++i) {
-            const bf16x8 av = __builtin_bit_cast(bf16x8, f.ga[i]);
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[i][1], 0, 0, 0);
+        if (ks == HOOK_KS) wb_next = next_stream();
+        static_for<0, (NMT + GRP - 1) / GRP>([&](auto gc) {
+            constexpr int i0 = decltype(gc)::v * GRP;
+            constexpr int cnt = i0 + GRP <= NMT ? GRP : NMT - i0;      // row tiles of this group
+            constexpr int n0 = ks * NMT + i0;
+            // reads issued so far: fragments 0 .. min(n0 + RA, TOTAL) - 1; fragments n0 .. n0 + cnt - 1 must have landed
+            constexpr int issued = n0 + RA < TOTAL ? n0 + RA : TOTAL;
+            mg_lds_wait<issued - n0 - cnt>();
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, cnt>([&](auto jc) {
+                constexpr int i = i0 + decltype(jc)::v;
+                const bf16x8 av = __builtin_bit_cast(bf16x8, ga[(ks * NMT + i) % RA]);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, av, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, av, acc[i][1], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
 #if !(MG_MHA_ABLATE & 2)
-            if (Frags<NMT>::CROSS_A || ks + 1 < KSTEPS) f.ga[i] = a_base[i * 16 * LSTR + ksn * 4];
+            static_for<0, cnt>([&](auto jc) {
+                constexpr int n2 = n0 + decltype(jc)::v + RA;
+                if constexpr (n2 < TOTAL) fetch(IC<n2>{});
+            });
 #endif
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
 #if !(MG_MHA_ABLATE & 1)
         if (ks + BD < KSTEPS) {
             f.bq[ks % BD][0] = wfrag(w, wb + (ks + BD) * FRAG);
             f.bq[ks % BD][1] = wfrag(w, wb + (KSTEPS + ks + BD) * FRAG);
-        } else {                                     // next phase's k-steps 0..BD-1
+        } else {                                     // next unit's k-steps 0..BD-1
             f.bq[ks % BD][0] = wfrag(w, wb_next + (ks + BD - KSTEPS) * FRAG);
             f.bq[ks % BD][1] = wfrag(w, wb_next + (KSTEPS + ks + BD - KSTEPS) * FRAG);
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
-// everything after the bank is staged: all head pairs of this workgroup, for a compile-time tile-count class
+// Everything after the bank is staged, for a compile-time tile-count class.
+//
+// Work is cut into UNITS = (head, K or V projection) x (slice of 32 head dims).  The two waves of a slice (w and w + 4: they
+// share a SIMD, hence its matrix pipe) draw the slice's units from an LDS ticket counter in the order K(h0) K(h1) V(h0) V(h1)
+// K(h2) ..., so whichever wave is free takes the next one: while one wave is in a VALU-only epilogue (scores, weighted sum:
+// ~1.5 k cycles) its partner's MFMAs keep the pipe busy, and the two finish within one unit of each other however the
+// hardware arbitrates between them (rounds 1-2: fixed heads per half-workgroup in lock step through five s_barriers per head
+// pair: the pipe idled through every epilogue; per-half barriers alone let the older half run away and finish 14 k cycles early).
+// No s_barrier after the staging one; hand-over through LDS counters:
+//   K unit   GEMM -> this slice's partial scores of the head -> arrival at the head's count; the LAST of the four slices to
+//            arrive runs the head's softmax (one wave, four positions per lane) and publishes the probabilities
+//   V unit   GEMM -> wait for the head's probabilities (published a whole GEMM earlier, as a rule) -> weighted sum -> o
+// Guards make the ring slots safe under ANY progress order: partial scores of local head n reuse the slot of head n - 2 (wait
+// for its softmax), probabilities of head n the row of head n - 8 (wait for its four weighted sums).  A unit never waits for a
+// later ticket, so the queue cannot deadlock.
 // COH: `o` is stored with system-scope write-through stores (aux sc0 | sc1) because ANOTHER workgroup of this launch reads it
 // (the fused layer kernel below); otherwise ordinary stores
 template <int NMT, bool COH>
-__device__ __forceinline__ void mha_body(unsigned char* smem, const float* __restrict__ qh, const float* __restrict__ mask,
-                                         int B, int L, int H, const unsigned short* __restrict__ Wp,
-                                         const float* __restrict__ bk, const float* __restrict__ bv, float temp,
-                                         float* __restrict__ o, float* __restrict__ attn, int lvalid, int n_mt) {
+__device__ __forceinline__ void mha_body(unsigned char* smem, int B, int L, int H, const unsigned short* __restrict__ Wp,
+                                         const float* __restrict__ bv, float temp, float* __restrict__ o,
+                                         float* __restrict__ attn, int lvalid) {
     uint4* Xs = reinterpret_cast<uint4*>(smem);
-    float* s_part = reinterpret_cast<float*>(smem + (size_t)LMAX * LSTR * 16);    // [8][LMAX]
-    float* s_p = s_part + 8 * LMAX;                                               // [2][LMAX]
-    float* s_red = s_p + 2 * LMAX;                                                // [16]
-    int* s_ctr = reinterpret_cast<int*>(s_red + 16) + 1;                          // [2] per-half barrier counters (s_red[16] is s_lvalid)
-    const float* s_q = s_red + 16 + 4;                                            // [QMAX] this sample's projected query
+    float* s_part = reinterpret_cast<float*>(smem + OFF_PART);
+    float* s_p = reinterpret_cast<float*>(smem + OFF_P);
+    const float* s_mb = reinterpret_cast<const float*>(smem + OFF_MB);
+    int* s_int = reinterpret_cast<int*>(smem + OFF_INT);
+    int* s_ticket = s_int + 4;                          // [4] next unit of a slice
+    int* s_kdone = s_int + 16;                          // [MAXH] slices that delivered their partial scores of local head n
+    int* s_smdone = s_int + 16 + MAXH;                  // [MAXH] 1 = probabilities of local head n published
+    int* s_pvdone = s_int + 16 + 2 * MAXH;              // [MAXH] slices done with the probabilities of local head n
+    const float* s_q = reinterpret_cast<const float*>(smem + OFF_Q);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values live in SGPRs
+    const int wq = wave & 3;                                        // slice: head dims 32 wq ... 32 wq + 31
     const int b = blockIdx.x;
-    const int hp_wave = wave >> 2, wq = wave & 3;
-    const uint4* a_base = Xs + (lane & 15) * LSTR + (lane >> 4);     // + i*16*LSTR + ks*4
-    const int pos = tid & 255, hh = wave >> 2;
-    const bool pos_masked = mask && pos < L && mask[(size_t)b * L + pos] == 0.0f;
-    // weight stream of (head, phase) for this wave (byte offset of its first fragment, wave-uniform); heads beyond H
-    // (odd H) read head 0's stream and are discarded
-    const int hp_wave_s = hp_wave, wq_s = wq;
+    // LDS byte address of this lane's 16 bytes of row tile 0 / 7, k-step 0 (+ i*16*LSTR*16 + ks*64 as immediates)
+    const unsigned a_lo = mg_lds_addr(Xs + (lane & 15) * LSTR + (lane >> 4)), a_hi = a_lo + 7 * 16 * LSTR * 16;
     const float inv_temp = 1.0f / temp;
     WStream wsr;
     wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wp), 0, 0x7fffffff, 0x00027000);
     wsr.voff = lane * 16;
-    auto wstream = [&](int hp, int phase) {
-        int h = hp * 2 + hp_wave_s;
-        if (h >= H) h = 0;
-        return (((h * 2 + phase) * 8 + wq_s * 2) * KSTEPS) * FRAG;
+    // this workgroup's head pairs: blockIdx.y, + gridDim.y, ...; ticket t -> pair t / 4, head t & 1 of the pair, V if t & 2
+    const int pairs = (H + 1) / 2;
+    const int npairs = (pairs - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int nunits = npairs * 4;
+    auto head_of = [&](int t) { return ((int)blockIdx.y + (t >> 2) * (int)gridDim.y) * 2 + (t & 1); };
+    auto draw = [&]() {                                 // next unit of this slice; tickets of a head beyond H (odd H) are skipped
+        int t;
+        do {
+            int v = 0;
+            if (lane == 0) v = __hip_atomic_fetch_add(s_ticket + wq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(v);
+        } while (t < nunits && head_of(t) >= H);
+        return t;
+    };
+    // weight stream of a unit for this wave (byte offset of its first fragment, wave-uniform); past the last unit: a harmless re-read
+    auto wstream = [&](int t) {
+        const int h = t < nunits ? head_of(t) : 0;
+        return (((h * 2 + ((t >> 1) & 1)) * 8 + wq * 2) * KSTEPS) * FRAG;
     };
     // o row of this sample / b_v: buffer resources (uniform base, 32-bit per-lane offsets)
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o + (size_t)b * H * DK, 0, H * DK * 4, 0x00027000);
     const __amdgpu_buffer_rsrc_t bv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bv), 0, bv ? H * DK * 4 : 0, 0x00027000);
     const __amdgpu_buffer_rsrc_t attn_rsrc = __builtin_amdgcn_make_buffer_rsrc(attn, 0, attn ? 0x7fffffff : 0, 0x00027000);
+    // the tiles are computed TRANSPOSED (rows = head dims, columns = bank rows): this lane's accumulator element
+    // [i][j][r] is head dim d(j,r) = wq*32 + 16j + 4*(lane>>4) + r of bank row 16i + (lane&15)
+    const int dbase = wq * 32 + (lane >> 4) * 4;
+
+    int t = draw();
     Frags<NMT> f;
-    frags_prime_b<NMT>(f, wsr, wstream(blockIdx.y, 0));     // weight fragments on their way while the bank DMA lands
+    frags_prime_b<NMT>(f, wsr, wstream(t));             // weight fragments on their way while the bank DMA lands
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA pieces of the bank (not tracked by hipcc)
     __syncthreads();                                    // ... and every other wave's
-    frags_prime_a<NMT>(f, a_base);
     MG_STAMP(2);
     int stamp = 3;
     (void)stamp;
 
-    int nbar = 0;                           // arrivals expected at this half's next barrier
-    for (int hp = blockIdx.y; hp * 2 < H; hp += gridDim.y) {
-        const int h = hp * 2 + hp_wave;
-        const bool head_on = h < H;
-        // the query row sits in LDS since the prologue: no global read (and no 64-bit address) in the head-pair loop
-        const float* qv = s_q + (head_on ? h : 0) * DK;
-        // the tiles are computed TRANSPOSED (rows = head dims, columns = bank rows): this lane's accumulator element
-        // [i][j][r] is head dim d(j,r) = wq*32 + 16j + 4*(lane>>4) + r of bank row 16i + (lane&15)
-        const int dbase = wq * 32 + (lane >> 4) * 4;
-        const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv + dbase), qd1 = *reinterpret_cast<const f32x4*>(qv + dbase + 16);
-        // Biases: q.(K_l + b_k) = q.K_l + q.b_k shifts every score of the head by the same constant, which the
-        // softmax cancels exactly, so b_k never enters; sum_l p_l (V_l + b_v) = sum_l p_l V_l + b_v because the
-        // probabilities sum to 1, so b_v is added once to the 8 outputs of the lane (keeps 16 VGPRs and ~200 VALU
-        // adds per head out of the loop; differences to the literal form are at fp32 rounding level)
-        const int hp_next = (hp + gridDim.y) * 2 < H ? hp + gridDim.y : hp;     // last pair: harmless re-read
-
-        float e_keep = 0.f;             // this thread's unnormalised probability (phase 0 -> the `attn` store of phase 1)
-        for (int phase = 0; phase < 2; ++phase) {
-            f32x4 acc[MT][2];
+    while (t < nunits) {
+        const int n = (t >> 2) * 2 + (t & 1);           // workgroup-local index of the head
+        const int h = head_of(t);
+        const bool vunit = (t & 2) != 0;
+        int t_next = nunits;
+        f32x4 acc[MT][2];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#ifdef MG_MHA_TRACE
-            kv_gemm<NMT>(acc, f, a_base, wsr, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0),
-                         hp == 1 ? 32 + 12 * phase : -1);
-#else
-            kv_gemm<NMT>(acc, f, a_base, wsr, wstream(hp, phase), phase == 0 ? wstream(hp, 1) : wstream(hp_next, 0));
+        for (int i = 0; i < MT; ++i) {
+            acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        kv_gemm<NMT>(acc, f, a_lo, a_hi, wsr, wstream(t), [&]() { t_next = draw(); return wstream(t_next); });
+        MG_STAMP(stamp++);
+#ifdef MG_MHA_EPI_PRIO
+        __builtin_amdgcn_s_setprio(MG_MHA_EPI_PRIO);
 #endif
-            MG_STAMP(stamp++);
 
-            if (phase == 0) {
-                // ---- partial scores of this wave's 32 head dims: in-register over the 8 dims of the lane, then across
-                //      the four 16-lane groups, four row tiles per transposing reduction (rows4_sum4); the result register
-                //      holds tiles [4g, 4g+2, 4g+1, 4g+3] in its rows: one 64-lane LDS write per four tiles
-                if (head_on) {
-                    float v[(NMT + 3) / 4 * 4];
+        if (!vunit) {
+            // ---- partial scores of this slice's 32 head dims: in-register over the 8 dims of the lane, then across
+            //      the four 16-lane groups, four row tiles per transposing reduction (rows4_sum4); the result register
+            //      holds tiles [4g, 4g+2, 4g+1, 4g+3] in its rows: one 64-lane LDS write per four tiles.
+            // Biases: q.(K_l + b_k) = q.K_l + q.b_k shifts every score of the head by the same constant, which the
+            // softmax cancels exactly, so b_k never enters; sum_l p_l (V_l + b_v) = sum_l p_l V_l + b_v because the
+            // probabilities sum to 1, so b_v is added once to the 8 outputs of the lane.
+            const float* qv = s_q + h * DK;             // the query row sits in LDS since the prologue
+            const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv + dbase), qd1 = *reinterpret_cast<const f32x4*>(qv + dbase + 16);
+            float v[(NMT + 3) / 4 * 4];
 #pragma unroll
-                    for (int i = 0; i < (NMT + 3) / 4 * 4; ++i) {
-                        float a = 0.f, c = 0.f;
-                        if (i < NMT) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                a = fmaf(qd0[r], acc[i][0][r], a);
-                                c = fmaf(qd1[r], acc[i][1][r], c);
-                            }
-                        }
-                        v[i] = a + c;
-                    }
-                    const int rt = ((lane >> 4) & 1) * 2 + (lane >> 5);          // row tile (inside a group of 4) of this lane's row
-#pragma unroll
-                    for (int g = 0; g < (NMT + 3) / 4; ++g) {
-                        const float s4 = rows4_sum4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-                        if (4 * g + 3 < NMT || 4 * g + rt < NMT) s_part[wave * LMAX + (4 * g + rt) * 16 + (lane & 15)] = s4;
-                    }
-                }
-                half_barrier(s_ctr + hh, (nbar += 4), lane);       // (1) of 2 per head pair: the partial scores are visible
-                // ---- masked softmax, one head per 256-thread half, WITHOUT a workgroup-wide max / sum: every wave
-                //      normalises its 64 positions against its OWN maximum m_w and publishes (m_w, z_w = sum e) next to the
-                //      unnormalised e; the consumers of the probabilities (weighted sum below, `attn` store) merge the
-                //      four waves' pairs -- p = e * exp(m_w - M) / Z, the online-softmax identity.  That takes the two
-                //      reduction barriers and the "p is visible" barrier out of the K epilogue: the V projection starts
-                //      right here and the ONE barrier behind it publishes e / m / z.
-                const int hs = hp * 2 + hh;
-                float sc = -INFINITY;
-                if (pos < lvalid && hs < H) {
-                    const float* sp = s_part + (hh * 4) * LMAX + pos;
-                    sc = (sp[0] + sp[LMAX] + sp[2 * LMAX] + sp[3 * LMAX]) * inv_temp;
-                    if (pos_masked) sc = -INFINITY;
-                }
-                const float m_w = wave_max_dpp(sc);
-                e_keep = (sc != -INFINITY) ? __expf(sc - m_w) : 0.f;
-                const float z_w = wave_sum_dpp(e_keep);
-                if (pos < LMAX) s_p[hh * LMAX + pos] = e_keep;
-                if (lane == 0) { s_red[wave * 2] = m_w; s_red[wave * 2 + 1] = z_w; }
-                MG_STAMP(stamp++);
-            } else {
-                half_barrier(s_ctr + hh, (nbar += 4), lane);       // (2) of 2: e / (m_w, z_w) of this head pair are visible; every wave of the half is done with the
-                                        // partial scores, so the next pair may overwrite them
-                // ---- merge factors of the four softmax waves of a head: f_w = exp(m_w - M) / Z
-                auto merge = [&](int head_half, float (&fw)[4]) {
-                    const f32x4 mz0 = *reinterpret_cast<const f32x4*>(s_red + head_half * 8);        // m0 z0 m1 z1
-                    const f32x4 mz1 = *reinterpret_cast<const f32x4*>(s_red + head_half * 8 + 4);    // m2 z2 m3 z3
-                    const float M = fmaxf(fmaxf(mz0[0], mz0[2]), fmaxf(mz1[0], mz1[2]));
-                    fw[0] = __expf(mz0[0] - M);          // exp(-inf) = 0: a wave without a live position drops out;
-                    fw[1] = __expf(mz0[2] - M);          // all masked: -inf - -inf = NaN, like the reference's softmax
-                    fw[2] = __expf(mz1[0] - M);
-                    fw[3] = __expf(mz1[2] - M);
-                    const float Z = (mz0[1] * fw[0] + mz0[3] * fw[1]) + (mz1[1] * fw[2] + mz1[3] * fw[3]);
-                    const float rz = __builtin_amdgcn_rcpf(Z);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) fw[k] *= rz;
-                };
-                if (attn) {             // optional output: the softmax thread of a position normalises its own e
-                    const int hs = hp * 2 + hh;
-                    float fw[4];
-                    merge(hh, fw);
-                    const float p = e_keep * fw[wave & 3];
-                    if (hs < H && pos < L)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, p), attn_rsrc, pos * 4, (hs * B + b) * L * 4, 0);
-                }
-                // ---- o[d] = sum_l p[l] * (V[l,d] + bv[d]): p is per column here, 8 dims per lane accumulate in
-                //      registers over the row tiles (four tiles = one softmax wave = one merge factor), one 16-lane DPP sum
-                //      per dim at the end -----------------------------------------------------------------------------
-                if (head_on) {
-                    float fw[4];
-                    merge(hp_wave, fw);
-                    const float* pp = s_p + hp_wave * LMAX + (lane & 15);
-                    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
-#pragma unroll
-                    for (int i = 0; i < NMT; ++i) {
-                        const float p = pp[i * 16] * fw[i >> 2];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            t0[r] = fmaf(p, acc[i][0][r], t0[r]);
-                            t1[r] = fmaf(p, acc[i][1][r], t1[r]);
-                        }
-                    }
+            for (int i = 0; i < (NMT + 3) / 4 * 4; ++i) {
+                float a = 0.f, c = 0.f;
+                if (i < NMT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        t0[r] = row16_sum(t0[r]);
-                        t1[r] = row16_sum(t1[r]);
-                    }
-                    if ((lane & 15) == 0) {
-                        const int hoff = (hp * 2 + hp_wave_s) * DK * 4;          // wave-uniform byte offset of the head
-                        if (bv) {
-                            const f32x4 vb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4, hoff, 0));
-                            const f32x4 vb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4 + 64, hoff, 0));
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { t0[r] += vb0[r]; t1[r] += vb1[r]; }
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t0), o_rsrc, dbase * 4, hoff, COH ? 17 : 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, COH ? 17 : 0);
+                        a = fmaf(qd0[r], acc[i][0][r], a);
+                        c = fmaf(qd1[r], acc[i][1][r], c);
                     }
                 }
-                MG_STAMP(stamp++);
+                v[i] = a + c;
+            }
+            if (n >= 2) lds_wait_ge(s_smdone + n - 2, 1);           // the slot's previous head has been consumed
+            float* part = s_part + ((n & 1) * 4 + wq) * LMAX;
+            const int rt = ((lane >> 4) & 1) * 2 + (lane >> 5);      // row tile (inside a group of 4) of this lane's row
+#pragma unroll
+            for (int g = 0; g < (NMT + 3) / 4; ++g) {
+                const float s4 = rows4_sum4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                if (4 * g + 3 < NMT || 4 * g + rt < NMT) part[(4 * g + rt) * 16 + (lane & 15)] = s4;
+            }
+            if (lds_arrive(s_kdone + n, lane) == 3) {
+                // ---- last slice of the head: masked softmax over all positions, four per lane (lane, +64, +128, +192)
+                if (n >= NSLOT_P) lds_wait_ge(s_pvdone + n - NSLOT_P, 4);
+                const float* sp = s_part + (n & 1) * 4 * LMAX + lane;
+                float sc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = lane + 64 * j;
+                    sc[j] = -INFINITY;
+                    if (pos < lvalid)
+                        sc[j] = ((sp[64 * j] + sp[64 * j + LMAX]) + (sp[64 * j + 2 * LMAX] + sp[64 * j + 3 * LMAX])) * inv_temp + s_mb[pos];
+                }
+                const float m = wave_max_dpp(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (sc[j] != -INFINITY) ? __expf(sc[j] - m) : 0.f;
+                const float z = wave_sum_dpp((e[0] + e[1]) + (e[2] + e[3]));
+                const float rz = 1.0f / z;              // all masked: 0 * inf = NaN, like the reference's softmax of -inf
+                float* prow = s_p + (n & (NSLOT_P - 1)) * LMAX;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = lane + 64 * j;
+                    const float p = e[j] * rz;
+                    if (pos < LMAX) prow[pos] = p;
+                    if (attn && pos < L)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, p), attn_rsrc, pos * 4, (h * B + b) * L * 4, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(s_smdone + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            // ---- o[d] = sum_l p[l] * (V[l,d] + bv[d]): p is per column here, 8 dims per lane accumulate in
+            //      registers over the row tiles, one 16-lane DPP sum per dim at the end
+            lds_wait_ge(s_smdone + n, 1);
+            const float* pp = s_p + (n & (NSLOT_P - 1)) * LMAX + (lane & 15);
+            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const float p = pp[i * 16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    t0[r] = fmaf(p, acc[i][0][r], t0[r]);
+                    t1[r] = fmaf(p, acc[i][1][r], t1[r]);
+                }
+            }
+            if (npairs * 2 > NSLOT_P) lds_arrive(s_pvdone + n, lane);       // (only then is the row ever reused)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t0[r] = row16_sum(t0[r]);
+                t1[r] = row16_sum(t1[r]);
+            }
+            if ((lane & 15) == 0) {
+                const int hoff = h * DK * 4;            // wave-uniform byte offset of the head
+                if (bv) {
+                    const f32x4 vb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4, hoff, 0));
+                    const f32x4 vb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4 + 64, hoff, 0));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { t0[r] += vb0[r]; t1[r] += vb1[r]; }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t0), o_rsrc, dbase * 4, hoff, COH ? 17 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, t1), o_rsrc, dbase * 4 + 64, hoff, COH ? 17 : 0);
             }
         }
+#ifdef MG_MHA_EPI_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        MG_STAMP(stamp++);
+        t = t_next;
     }
-    (void)n_mt;
 }
 
 template <bool COH>
@@ -407,24 +458,23 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
                                                                 const unsigned short* __restrict__ Wp,
                                                                 const float* __restrict__ bk, const float* __restrict__ bv,
                                                                 float temp, float* __restrict__ o, float* __restrict__ attn) {
-    uint4* Xs = reinterpret_cast<uint4*>(smem);                                   // [LMAX][LSTR] chunks
-    int* s_lvalid = reinterpret_cast<int*>(smem + (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float));
+    int* s_lvalid = reinterpret_cast<int*>(smem + OFF_INT);
+    float* s_mb = reinterpret_cast<float*>(smem + OFF_MB);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const uint4* xb = reinterpret_cast<const uint4*>(bank) + (size_t)b * L * CH;
     MG_STAMP(0);
 
-    // ---- live rows -------------------------------------------------------------------------------------
-    if (tid == 0) {
-        *s_lvalid = mask ? 0 : L;
-        s_lvalid[1] = 0;                // the two per-half barrier counters (mha_body)
-        s_lvalid[2] = 0;
-    }
+    // ---- live rows, mask bias, the unit queue's counters ---------------------------------------------------
+    if (tid < 16 + 3 * MAXH) s_lvalid[tid] = (tid == 0 && !mask) ? L : 0;
     __syncthreads();
-    if (mask) {
+    {
         int last = 0;
-        for (int t = tid; t < L; t += NTHR)
-            if (mask[(size_t)b * L + t] != 0.0f) last = t + 1;
+        for (int t = tid; t < LMAX; t += NTHR) {
+            const bool live = t < L && (!mask || mask[(size_t)b * L + t] != 0.0f);
+            if (mask && live) last = t + 1;
+            s_mb[t] = (t < L && !live) ? -INFINITY : 0.0f;
+        }
         if (last) atomicMax(s_lvalid, last);
         __syncthreads();
     }
@@ -453,19 +503,18 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
             }
         }
     }
-    (void)Xs;
     {                                   // this sample's query row -> LDS (visible after the staging barrier in mha_body)
-        float* s_q = reinterpret_cast<float*>(s_lvalid) + 4;
+        float* s_q = reinterpret_cast<float*>(smem + OFF_Q);
         for (int i = tid * 4; i < H * DK; i += NTHR * 4)
             *reinterpret_cast<f32x4*>(s_q + i) = *reinterpret_cast<const f32x4*>(qh + (size_t)b * H * DK + i);
     }
 
     switch (n_sel) {
-        case 1: mha_body<1, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 2: mha_body<2, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 4: mha_body<4, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        case 7: mha_body<7, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
-        default: mha_body<MT, COH>(smem, qh, mask, B, L, H, Wp, bk, bv, temp, o, attn, lvalid, n_mt); break;
+        case 1: mha_body<1, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+        case 2: mha_body<2, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+        case 4: mha_body<4, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+        case 7: mha_body<7, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+        default: mha_body<MT, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
     }
 }
 
@@ -511,9 +560,6 @@ __global__ __launch_bounds__(NTHR) void sq_mha_layer_bf16_kernel(const float* __
     if (!s_last) return;
     mg_tail::tail_bf16_body<1, true>(smem, o, H * DK, q_in, B, w, eps, out, HKn, qh_next, tile, 0, 1);
 }
-
-constexpr size_t SMEM_BYTES = (size_t)LMAX * LSTR * 16 + (8 * LMAX + 2 * LMAX + 16) * sizeof(float) + 16 + QMAX * sizeof(float);
-static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 
 }  // namespace
 
