@@ -190,9 +190,14 @@ int mgnns_imgbank_pool_fwd(const float* feat, int B, int K, int P,
 /* bf16-operand variant (BASELINE config 3): same reads (the fp32 map crosses HBM once, max-pool exact fp32),
  * W pre-packed by mgnns_imgbank_pack_weights_bf16 into mgnns_imgbank_packed_weight_bytes(K) bytes, the bank is
  * emitted as bf16 [B, P, ld] with ld == 320 (zero padded) -- the layout mgnns_sq_mha_core_bf16_fwd consumes.
- * pooled_work: [B, 2, K] floats: the per-half maxima (pooled may be NULL: the caller then consumes these itself,
- * e.g. mgnns_label_tail_fwd with n_parts = 2).  104 < P <= 200, P % 4 == 0, N <= 304, K % 128 == 0.
+ * pooled_work: [B, 2, K] floats: two partial maxima whose max is the pooled value (pooled may be NULL: the caller then
+ * consumes these itself, e.g. mgnns_label_tail_fwd with n_parts = 2).  16 <= P <= 208, P % 4 == 0, N <= 304, K % 64 == 0.
+ * Two forms, chosen by the batch: one workgroup per sample streaming the map through an LDS-DMA ring (chip-filling batches),
+ * two workgroups per sample (region halves; needs 104 < P <= 200, K % 128 == 0) up to half a chip of samples.
+ * mgnns_imgbank_set_form: 0 = by batch (default; also MGNNS_IMGBANK_FORM), 1 = always the stream form, 2 = always the pair form
+ * where its limits allow -- for tests and measurements; process-wide.
  */
+int mgnns_imgbank_set_form(int form);
 size_t mgnns_imgbank_packed_weight_bytes(int K);
 int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, void* Wp, mgnns_stream_t stream);
 int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,

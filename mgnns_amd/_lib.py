@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _P = _c.c_void_p
@@ -36,6 +36,7 @@ SIGNATURES = {
     "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_imgbank_pack_weights_bf16": [_P, _I, _I, _P, _P],
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
+    "mgnns_imgbank_set_form": [_I],
     "mgnns_imgbank_pool_split_fwd": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],

@@ -5,12 +5,17 @@
 //   pooled[b,k] = max_p feat[b,k,p]                 (exact fp32)
 // The kernel is HBM bound on the fp32 map (1.6 MB per sample-channel, read exactly once).
 //
-// Two 512-thread workgroups per sample, one per half of the 196 regions (7 | 6 row tiles of 16), each streams
-// its half of every feature row (448-B segments) in BK = 128 slices: global -> registers (fp32; the max-pool is
-// taken here) -> bf16 -> LDS transposed to [p][k] (XOR-swizzled 16-B chunks: conflict-free for both the
-// ds_write_b128 of the transpose and the ds_read_b128 MFMA A fragments).  8 waves split the 19 column tiles
-// (300 outputs) 3,3,3,2,2,2,2,2; the B operand (W) comes straight from L2 in a pre-packed fragment-major layout.
-// v_mfma_f32_16x16x32_bf16, fp32 accumulation; epilogue transposes through LDS so bank rows leave as 16-B lanes.
+// Round 3 design: ONE 512-thread workgroup per sample; the map never touches a VGPR on its way in.  The sample is a
+// contiguous 1.6-MB block whose rows (one feature k, all P regions: 784 B) arrive by LDS-DMA (buffer_load_dwordx4 ... lds) into a
+// ring of five k-step slots (32 rows = 24.5 KB each): ~75 KB in flight per CU without a register or a producer wave tied up,
+// which is what the stream needs -- the same ring with a trivial consumer moves 6.6 TB/s (tools/dev/micro/dma_stream.hip),
+// against 3.5 TB/s for rounds 1-2's register path (two workgroups per sample, each reading 448-B half rows: 1.19x sector
+// over-fetch; producer waves whose every computing cycle was a cycle the memory pipe was not refilled).
+// Per k-step all eight waves (a) turn the landed fp32 slot into the bf16 MFMA operand image [p][32 k] (LDS -> registers ->
+// v_cvt_pk_bf16_f32 -> LDS, 16-B chunks swizzled so that both sides are conflict-free), (b) take the max-pool of its 32 rows,
+// (c) after ONE barrier run the k-step's MFMAs: wave (rg, cg) owns row tiles 7 rg .. and column tiles 5 cg .. (7 x 5 tiles,
+// v_mfma_f32_16x16x32_bf16, W fragments fragment-major from L2, two k-steps ahead).  Epilogue through LDS: bank rows leave
+// as 16-B lanes.
 #include "common.hpp"
 #include <type_traits>
 
@@ -28,16 +33,13 @@ __device__ unsigned long long g_img_trace[4][8];
 
 namespace {
 
-constexpr int BK = 128;                 // k-slice (4 MFMA k-steps): every lane of a wave streams 8 feature rows
-constexpr int MTH = 7;                  // row tiles per half (112 rows)
-constexpr int ROWS = MTH * 16;
-constexpr int FSTR = 18;                // LDS row stride of the staged slice in 16-B chunks (16 data + 2 pad)
+constexpr int BK = 64;                  // K must be a multiple of this (two k-steps per trip of the main loop)
+constexpr int MT = 13;                  // row tiles of 16 regions (P <= 208)
 constexpr int NT = 19;                  // 304 / 16
 constexpr int OUT_LD = 320;             // bank row length (bf16)
 constexpr int OCH = OUT_LD / 8;         // 40 chunks per output row
 constexpr int OSTR = OUT_LD * 2 + 16;   // epilogue LDS row stride in bytes (656: rows land on distinct banks)
 constexpr int NTHR = 512;
-constexpr int P_SPLIT = 104;            // half 0: regions [0,104) (tiles 0..6), half 1: [104,196) (tiles 0..5)
 
 // two fp32 -> packed bf16x2 (round to nearest even) in ONE instruction; there is no builtin for it on gfx950
 __device__ __forceinline__ unsigned int pack2(float a, float b) {
@@ -69,324 +71,287 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
     }
 }
 
-// ---- roles ------------------------------------------------------------------------------------------------------------
-// Waves 4-7 are PRODUCERS: they own the HBM stream.  Each keeps THREE k-slices of its share of the map in flight in
-// registers (a quarter of the 128 feature rows x its 28 region quads: 16 x 16 B per lane and slice), takes the max-pool,
-// converts to bf16 and transposes into the LDS double buffer.  With the loads issued by the same waves that also ran the
-// MFMAs (round 1) only one slice could be in flight per CU and the memory pipe idled through every conversion:
-// ~56 KB in flight per CU at ~4 us per slice = 3.5 TB/s.
-// Waves 0-3 are CONSUMERS: MFMA only (7 row tiles x 5 | 5 | 5 | 4 column tiles), A fragments from LDS through a 3-deep
-// register ring, B fragments (W, L2 resident) of the NEXT slice requested as soon as the current slice's MFMAs are issued,
-// so they fly across the slice barrier.  One LDS-only barrier per slice orders the two groups.
-struct ImgGeom {
-    int b, mh, p0, p_store_end, K, P, KS, nchunk;
-};
+// ---- LDS map ------------------------------------------------------------------------------------------------------------
+constexpr int KROWS = 32;                                // feature rows per k-step
+constexpr int HROWS = 16;                                // ... per ring slot (half a k-step)
+constexpr int NHS = 7;                                   // slots of the fp32 ring
+constexpr int PMAX = MT * 16;                            // 208 regions at most
+constexpr int HSLOT = HROWS * PMAX * 4;                  // 13,312 B: a slot holds 16 rows of P * 4 bytes, packed
+constexpr int ABUF = PMAX * 64;                          // 13,312 B: bf16 operand image of one k-step, [p][4 chunks of 8 k]
+constexpr int WBUF = (NT + 1) * 1024;                    // 20 KB: the 19 W fragments of one k-step (+ 1 KB that takes a dummy request)
+constexpr size_t OFF_A = (size_t)NHS * HSLOT;
+constexpr size_t OFF_W = OFF_A + 2 * ABUF;
+constexpr size_t SMEM_BYTES = OFF_W + 2 * WBUF;
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+static_assert((size_t)PMAX * OSTR <= SMEM_BYTES, "the epilogue stages the bank rows over the ring");
 
-constexpr int PMS = 36;                 // row stride (floats) of a producer wave's partial-maxima tile [32 rows][28 -> 36]
-
-__device__ __forceinline__ void imgbank_producer(uint4* __restrict__ Fs, float* __restrict__ s_pm_all, const float* __restrict__ feat,
-                                                 const ImgGeom& gm, float* __restrict__ pooled_part, int pw, int lane) {
-    float* s_pm = s_pm_all + pw * 32 * PMS;
-    const int pq = lane & 31, hw = lane >> 5;
-    const int kc0 = 4 * pw + 2 * hw;                                    // this half-wave's two 8-row groups: kc0, kc0 + 1
-    const int npq = gm.mh ? (gm.P - P_SPLIT + 3) / 4 : ROWS / 4;        // 23 | 28 quads carry data
-    const bool st_on = pq < ROWS / 4;                                   // lanes that own LDS rows (28 per half-wave)
-    const bool ld_on = st_on && pq < npq && (gm.p0 + 4 * pq + 3 < gm.P);
-    // The map is read through a buffer resource: ONE per-lane byte offset (a single VGPR for all 48 loads in flight) plus
-    // a wave-uniform row offset in an SGPR.  With flat 64-bit per-load addresses the compiler recycled address registers
-    // between the sets and put s_waitcnt vmcnt(31..39) in front of every refill, i.e. a refill waited for the NEXT set.
-    // lanes without data (pq >= npq) load what lane npq - 1 loads and ignore it: the loads must be UNCONDITIONAL -- behind a
-    // branch the compiler no longer knows how many are outstanding and every wait becomes vmcnt(0)
-    const int pqc = pq < npq ? pq : npq - 1;
-    const int loff = (int)((16 * hw * gm.P + gm.p0 + 4 * pqc) * sizeof(float));
-    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(feat + (size_t)gm.b * gm.K * gm.P), 0, gm.K * gm.P * (int)sizeof(float), 0x00027000);
-    const int urow0 = 32 * pw;                                           // first feature row of this wave inside a slice
-    const int P = gm.P, nchunk = gm.nchunk;
-
-    f32x4 st[3][16];
-    auto gload = [&](f32x4 (&s)[16], int c) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            // streamed once: non-temporal (aux bit 1), so the map does not evict the W fragments every workgroup re-reads from L2
-            s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, loff, (c * BK + urow0 + i) * P * (int)sizeof(float), MG_IMG_AUX));
-        }
-    };
-    // slice (in registers) -> max-pool of its 16 feature rows + bf16 transpose-write into LDS buffer `buf`
-    auto emit = [&](f32x4 (&s)[16], int c, int buf) {
-#ifdef MG_IMG_NO_EMIT
-#pragma unroll
-        for (int gi = 0; gi < 16; ++gi) asm volatile("" ::"v"(s[gi]));
-        return;
-#endif
-        // max-pool (exact fp32): in-lane over the lane's 4 regions, then across the half-wave's 28 lanes THROUGH LDS -- the
-        // wave writes its 32 x 32 partial maxima, 32 of its lanes read a feature row each (7 x 16 B) and finish it.  (The
-        // cross-lane form -- 4 DPP steps + 4 v_readlane per row -- was most of the ~5 k cycles per slice a producer spent here,
-        // and a producer that computes is a producer that does not refill the memory pipe.)
-#pragma unroll
-        for (int gi = 0; gi < 16; ++gi)
-            s_pm[(16 * hw + gi) * PMS + pq] = ld_on ? fmaxf(fmaxf(s[gi][0], s[gi][1]), fmaxf(s[gi][2], s[gi][3])) : -INFINITY;
-        if (st_on) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // lanes past the half's last region quad hold a copy of the last quad: their LDS rows are never stored
-                    uint4 pk;
-                    pk.x = pack2(s[8 * g + 0][j], s[8 * g + 1][j]);
-                    pk.y = pack2(s[8 * g + 2][j], s[8 * g + 3][j]);
-                    pk.z = pack2(s[8 * g + 4][j], s[8 * g + 5][j]);
-                    pk.w = pack2(s[8 * g + 6][j], s[8 * g + 7][j]);
-                    Fs[(buf * ROWS + 4 * pq + j) * FSTR + ((kc0 + g) ^ (pq & 7))] = pk;
-                }
-        }
-        if (lane < 32) {                                       // same wave wrote s_pm: LDS operations of a wave complete in order
-            const f32x4* r4 = reinterpret_cast<const f32x4*>(s_pm + lane * PMS);
-            f32x4 m = r4[0];
-#pragma unroll
-            for (int q = 1; q < 7; ++q) {
-                const f32x4 v = r4[q];
-                m = f32x4{fmaxf(m[0], v[0]), fmaxf(m[1], v[1]), fmaxf(m[2], v[2]), fmaxf(m[3], v[3])};
-            }
-            pooled_part[((size_t)gm.b * 2 + gm.mh) * gm.K + c * BK + 32 * pw + lane] = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
-        }
-    };
-    gload(st[0], 0);
-    if (nchunk > 1) gload(st[1], 1);
-    if (nchunk > 2) gload(st[2], 2);
-    emit(st[0], 0, 0);
-    if (nchunk > 3) gload(st[0], 3);
-    mg_lds_barrier();
-    // iteration c: slice c + 1 leaves its registers (set (c+1) % 3), which take slice c + 4 at once.  The steady-state
-    // loop is branch-free: with a conditional load in it the compiler's wait for "the loads of this set" has to assume
-    // the fewest newer loads any path issued, i.e. it waits for the NEXT set too and the third slice in flight is lost.
-#ifdef MG_IMG_TRACE
-    unsigned long long t_emit = 0, t_issue = 0, t_bar = 0, t_first = 0;
-#define MG_TT(v) const unsigned long long v = IMG_T(); __builtin_amdgcn_sched_barrier(0)
-#else
-#define MG_TT(v)
-#endif
-#define MG_PFULL(S, c)                                                      \
-    do {                                                                    \
-        MG_TT(ta_);                                                         \
-        asm volatile("" ::"v"(st[S][0]));   /* wait for the set's FIRST row only */ \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        MG_TT(tb_);                                                         \
-        emit(st[S], (c) + 1, ((c) + 1) & 1);                                \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        MG_TT(tc_);                                                         \
-        gload(st[S], (c) + 4);                                              \
-        __builtin_amdgcn_sched_barrier(0); /* nothing of the NEXT emit is hoisted between / above these loads: it would wait for the next set */ \
-        MG_TT(td_);                                                         \
-        mg_lds_barrier();                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        MG_TT(te_);                                                         \
-        MG_TACC();                                                          \
-    } while (0)
-#define MG_PSTEP(S, c)                                                      \
-    do {                                                                    \
-        if ((c) < nchunk) {                                                 \
-            if ((c) + 1 < nchunk) {                                         \
-                emit(st[S], (c) + 1, ((c) + 1) & 1);                        \
-                if ((c) + 4 < nchunk) gload(st[S], (c) + 4);                \
-            }                                                               \
-            mg_lds_barrier();                                               \
-        }                                                                   \
-    } while (0)
-#ifdef MG_IMG_TRACE
-#define MG_TACC() do { t_first += tb_ - ta_; t_emit += tc_ - tb_; t_issue += td_ - tc_; t_bar += te_ - td_; } while (0)
-#else
-#define MG_TACC() do { } while (0)
-#endif
-    int c = 0;
-    for (; c + 6 < nchunk; c += 3) {
-        MG_PFULL(1, c);
-        MG_PFULL(2, c + 1);
-        MG_PFULL(0, c + 2);
+// LDS accesses of the main loop are inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an
+// LDS-DMA may be in flight, which would drain the ring at every step.  The caller orders them (lgkmcnt / barriers).
+__device__ __forceinline__ void wait_vm(int n) {         // s_waitcnt vmcnt(n) for a run-time n (the immediate is an instruction field)
+    switch (n) {
+#define MG_VM_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
+        MG_VM_CASE(1) MG_VM_CASE(2) MG_VM_CASE(3) MG_VM_CASE(4) MG_VM_CASE(5) MG_VM_CASE(6) MG_VM_CASE(7) MG_VM_CASE(8)
+        MG_VM_CASE(12) MG_VM_CASE(13) MG_VM_CASE(14) MG_VM_CASE(15) MG_VM_CASE(16) MG_VM_CASE(17) MG_VM_CASE(18) MG_VM_CASE(19)
+        MG_VM_CASE(20) MG_VM_CASE(21) MG_VM_CASE(22) MG_VM_CASE(23) MG_VM_CASE(24)
+#undef MG_VM_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
-    for (; c < nchunk; c += 3) {
-        MG_PSTEP(1, c);
-        MG_PSTEP(2, c + 1);
-        MG_PSTEP(0, c + 2);
-    }
-#undef MG_PFULL
-#ifdef MG_IMG_TRACE
-    if (lane == 0 && pw == 0 && (blockIdx.x == 0 || blockIdx.x == 301)) {
-        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + 1];
-        g[0] = t_first; g[1] = t_emit; g[2] = t_issue; g[3] = t_bar;
-    }
-#endif
-#undef MG_PSTEP
 }
 
-template <int NTN>
-__device__ __forceinline__ void imgbank_consumer(unsigned char* smem, const ImgGeom& gm, const unsigned short* __restrict__ Wp,
-                                                 const float* __restrict__ bias, int N, int wave, int lane) {
-    const uint4* Fs = reinterpret_cast<const uint4*>(smem);
-    uint4* Os = reinterpret_cast<uint4*>(smem) + 2 * ROWS * FSTR;
-    const int nt0 = 5 * wave, KS = gm.KS, nchunk = gm.nchunk;
-    f32x4 acc[MTH][NTN];
-#pragma unroll
-    for (int i = 0; i < MTH; ++i)
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint4* wu = reinterpret_cast<const uint4*>(Wp) + (size_t)nt0 * KS * 64;      // wave-uniform: SGPR base + lane*16
-    // B fragments: a ring of THREE k-steps (the four of a slice at once do not fit beside 140 accumulators); k-step g of
-    // the whole K (= 4 c + kk) lives in ring[g % 3] and is requested when k-step g - 3 has issued its MFMAs, i.e. two
-    // k-steps (70 MFMAs, ~0.5 us) ahead, across slice barriers too.  A consumer wave is alone on its SIMD's MFMA pipe, so what
-    // the ring does not cover of the L2 latency is exposed -- the consumers have slack for it: a slice is ~1 us of MFMAs
-    // against >= 3 us of HBM time.  (With a 2-deep ring they did not: 5.3 us per slice, 171 us per launch.)
-    constexpr int RD = 3;
-    uint4 bq[RD][NTN];
-    const int nks = nchunk * (BK / 32);
-    // A fragment of (k-step kk, row tile i): row = 16 i + (lane & 15), chunk = (4 kk + (lane >> 4)) ^ ((row >> 2) & 7).
-    // (row >> 2) & 7 = (lane & 15) >> 2 for even i, + 4 for odd i, so the address is ONE per-lane base plus a
-    // compile-time offset per (kk, i): no per-fragment address registers.
-    const int abase_l = (lane & 15) * FSTR + ((lane >> 4) ^ ((lane & 15) >> 2));
-    auto afrag = [&](const uint4* fb, int kk, int i) { return fb[abase_l + i * 16 * FSTR + ((4 * kk) ^ (4 * (i & 1)))]; };
-#pragma unroll
-    for (int d = 0; d < RD; ++d)
-#pragma unroll
-        for (int j = 0; j < NTN; ++j) bq[d][j] = (wu + ((size_t)j * KS + min(d, nks - 1)) * 64)[lane];
-    mg_lds_barrier();
-    // 12 k-steps (three slices) per trip so that ring slots are compile-time: K / 32 is a multiple of 4, the trip handles
-    // slices c, c+1, c+2 with slot = (4 (c % 3) + kk) % 3
-#ifdef MG_IMG_TRACE
-    unsigned long long t_work = 0, t_cbar = 0;
-#endif
-    auto slice = [&](int c, auto slot0) {
-        constexpr int S0 = decltype(slot0)::value;
-        MG_TT(ta_);
-        const uint4* fb = Fs + (size_t)(c & 1) * ROWS * FSTR;
-        constexpr int AD = 6;                                    // A ring depth: fragments AD - 1 (k-step, row tile) pairs ahead
-        uint4 ar[AD];
-#pragma unroll
-        for (int d = 0; d < AD - 1; ++d) ar[d] = afrag(fb, d / MTH, d % MTH);
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            constexpr int dummy = 0;
-            (void)dummy;
-#pragma unroll
-            for (int i = 0; i < MTH; ++i) {
-                const int sidx = kk * MTH + i;                       // A ring over the (k-step, row tile) pairs: a consumer wave is
-                // alone on its SIMD, nothing else hides an LDS round trip (~130 cycles idle, more behind the producers' writes)
-                if (sidx + AD - 1 < (BK / 32) * MTH)
-                    ar[(sidx + AD - 1) % AD] = afrag(fb, (sidx + AD - 1) / MTH, (sidx + AD - 1) % MTH);
-                const bf16x8 av = __builtin_bit_cast(bf16x8, ar[sidx % AD]);
-#ifndef MG_IMG_NO_MFMA
-#pragma unroll
-                for (int j = 0; j < NTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[(S0 + kk) % RD][j]), av,
-                                                                       acc[i][j], 0, 0, 0);
-#else
-                asm volatile("" ::"v"(av));
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // unconditional (the last RD requests re-read the last k-step and are never used): behind a branch the
-            // compiler cannot count the outstanding loads and every wait for a ring slot becomes vmcnt(0)
-            const int gk = min(c * (BK / 32) + kk + RD, nks - 1);
-#ifndef MG_IMG_NO_W
-#pragma unroll
-            for (int j = 0; j < NTN; ++j) bq[(S0 + kk) % RD][j] = (wu + ((size_t)j * KS + gk) * 64)[lane];
-#else
-            (void)gk;
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        MG_TT(tb_);
-        mg_lds_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        MG_TT(tc_);
-#ifdef MG_IMG_TRACE
-        t_work += tb_ - ta_; t_cbar += tc_ - tb_;
-#endif
-    };
-    for (int c = 0; c < nchunk; c += 3) {
-        slice(c, std::integral_constant<int, 0>{});
-        if (c + 1 < nchunk) slice(c + 1, std::integral_constant<int, (BK / 32) % RD>{});
-        if (c + 2 < nchunk) slice(c + 2, std::integral_constant<int, (2 * (BK / 32)) % RD>{});
+template <int N> struct ICI { static constexpr int v = N; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_img(F&& f) {
+    if constexpr (I < N) {
+        f(ICI<I>{});
+        static_for_img<I + 1, N>(f);
     }
-#ifdef MG_IMG_TRACE
-    if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 301)) {
-        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0)];
-        g[0] = t_work; g[1] = t_cbar;
-    }
-#endif
+}
 
-    // ---- epilogue: + bias, bf16, through LDS, 16-B row stores; columns N..319 are zero -----------------------
-    // The tiles were computed TRANSPOSED (A operand = W fragment, B operand = map fragment): this lane's accumulator
-    // element [i][j][r] is output column (nt0+j)*16 + 4*(lane>>4) + r of region row 16i + (lane&15), i.e. four
-    // CONSECUTIVE bank columns per tile -> one 8-byte LDS write (the untransposed layout needs four 2-byte writes).
-    unsigned char* osb = reinterpret_cast<unsigned char*>(Os);
+// One wave's share of a sample.  NR x NW accumulator tiles: row tiles 7 rg .. 7 rg + NR - 1, column tiles 5 cg .. 5 cg + NW - 1.
+// STAGER (row group 1 = waves 4-7): the wave requests map rows; otherwise (waves 0-3) the W fragments.  Vector-memory
+// operations of a wave complete IN ORDER: a wave that has map rows in flight (HBM latency, several k-steps ahead) would get
+// nothing else back before them -- W fragments requested into registers behind the rows made every k-step wait out the
+// latency of rows it needs four steps later (122 us).  So the two streams are issued by DIFFERENT waves, both into LDS, and
+// each wave's counted wait covers only its own stream.
+template <int NR, int NW, bool STAGER, int PT>
+__device__ __forceinline__ void img_wave(unsigned char* smem, const float* __restrict__ feat, int b, int K, int Prt,
+                                         const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
+                                         unsigned short* __restrict__ bank, float* __restrict__ pooled_part,
+                                         float* __restrict__ pooled, int wave, int lane, int tid) {
+    const int rg = wave >> 2, cg = wave & 3;
+    const int nks = K / KROWS;
+    const int P = PT ? PT : Prt;                         // PT: the region count as a compile-time constant (row offsets become immediates)
+    const int RB = P * 4;                                // bytes of a map row
+    const unsigned ring = mg_lds_addr(smem), abuf = ring + (unsigned)OFF_A, wbuf = ring + (unsigned)OFF_W;
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(feat + (size_t)b * K * P), 0, K * P * (int)sizeof(float), 0x00027000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Wp), 0, NT * nks * 1024, 0x00027000);
+
+    // ---- the map stream (waves 4-7): slot h of the ring takes the 16 rows of half-step h, wave w rows 4 (w - 4) .. + 3, one
+    //      row (P / 4 lanes x 16 B) per DMA instruction; half-steps past the end are out of range and arrive as zeros in a slot
+    //      nobody reads (the request count per step stays constant: the counted waits depend on it)
+    const bool dma_lane = lane < (P >> 2);
+    auto dma_half = [&](int h) {
+        if (dma_lane) {
 #pragma unroll
-    for (int j = 0; j < NTN; ++j) {
-        const int n = (nt0 + j) * 16 + (lane >> 4) * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const int r = (wave - 4) * 4 + j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    f_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)(h % NHS) * HSLOT + r * RB), 16,
+                    lane * 16, (h * HROWS + r) * RB, 0, MG_IMG_AUX);
+            }
+        }
+    };
+    // ---- the W stream (waves 0-3): the 19 fragments (1 KiB each, fragment-major in memory) of k-step s -> W image s & 1; wave w
+    //      takes fragments w, w + 4, ..: five requests each, the 20th is a dummy (out of range: zeros into the image's spare KB)
+    auto dma_w = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int t = wave + 4 * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                w_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + OFF_W + (size_t)(s & 1) * WBUF + t * 1024), 16,
+                lane * 16, t < NT && s < nks ? (t * nks + s) * 1024 : 0x7ffffc00, 0, 0);
+        }
+    };
+
+    f32x4 acc[NR][NW];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int t = 0; t < NW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // conversion task (threads of waves 0-3 only: the map waves carry eight DMA requests per step, the W waves five cheap ones, so
+    // the conversion is the W waves' to keep the two sides of a SIMD level): (k-octet ko, region quad pq): 8 rows x 4 regions
+    // -> four 16-B chunks of the operand image
+    const int nquad = P >> 2;
+    const bool cv_on = !STAGER && tid < 4 * nquad;
+    const int ko = cv_on ? tid / nquad : 0, pq = cv_on ? tid - ko * nquad : 0;
+    const unsigned cv_src = (unsigned)((ko & 1) * 8 * RB + pq * 16);         // inside half-slot ko >> 1 of the k-step
+    // image: [p][4 chunks], chunk c of row p at slot (c + 2 (p >> 2)) & 3: conflict-free for the MFMA operand reads
+    // (a ds_read_b128's 16-lane groups take rows 0-3 / 12-15 of chunk c and rows 4-11 of chunk c + 1)
+    auto a_off = [](int p, int c) { return (unsigned)(p * 64 + (((c + 2 * (p >> 2)) & 3) << 4)); };
+    const unsigned cv_dst = a_off(4 * pq, ko);           // rows 4 pq .. 4 pq + 3 share (p >> 2): consecutive 64-B rows, same slot
+    // max-pool task: row tid >> 4 of the k-step, region quads (tid & 15) + 16 m
+    const int pk = tid >> 4, psub = tid & 15;
+    // MFMA operand reads: map fragment = row 16 (7 rg + i) + (lane & 15), chunk lane >> 4; W fragment t of this wave
+    const unsigned a_rd = abuf + (unsigned)(rg * 7 * 16 * 64) + a_off(lane & 15, lane >> 4);
+    const unsigned w_rd = wbuf + (unsigned)(cg * 5 * 1024 + lane * 16);
+
+    float* const pp0 = pooled_part + ((size_t)b * 2) * K + pk;
+    float* const pp1 = pp0 + K;
+    float* const ppo = pooled ? pooled + (size_t)b * K + pk : nullptr;
+    // ---- (a) fp32 half-slots of k-step s -> bf16 operand image A[s & 1], (b) max-pool of the k-step's 32 rows
+    auto convert = [&](int s) {
+        const unsigned ab = abuf + (unsigned)((s & 1) * ABUF);
+        f32x4 v[8];
+        f32x4 q[4];
+        if (cv_on) {
+            const unsigned src = ring + (unsigned)(((2 * s + (ko >> 1)) % NHS) * HSLOT) + cv_src;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (PT > 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(src), "n"(j * PT * 4) : "memory");
+                else asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(src + j * RB) : "memory");
+            }
+        }
+        {
+            const unsigned src = ring + (unsigned)(((2 * s + (pk >> 4)) % NHS) * HSLOT) + (unsigned)((pk & 15) * RB + psub * 16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                q[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (psub + 16 * m < nquad) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (cv_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x4 c;
+                c[0] = pack2(v[0][e], v[1][e]); c[1] = pack2(v[2][e], v[3][e]); c[2] = pack2(v[4][e], v[5][e]); c[3] = pack2(v[6][e], v[7][e]);
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ab + cv_dst), "v"(c), "n"(e * 64) : "memory");
+            }
+        }
+        auto max3 = [](float a, float b2, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c)); return r; };
+        float mx = max3(max3(q[0][0], q[0][1], q[0][2]), max3(q[0][3], q[1][0], q[1][1]), max3(q[1][2], q[1][3], q[2][0]));
+        mx = max3(mx, max3(q[2][1], q[2][2], q[2][3]), max3(q[3][0], q[3][1], max3(q[3][2], q[3][3], q[3][3])));
+        mx = row16_max(mx);
+        if (psub == 0) {                                 // every wave: `nst` store instructions per k-step (counted below)
+            const int kk = s * KROWS;
+            pp0[kk] = mx;
+            pp1[kk] = mx;
+            if (pooled) ppo[kk] = mx;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- (c) the MFMAs of k-step s: map fragments from A[s & 1], W fragments from W[s & 1]
+    auto mfma_step = [&](int s) {
+        const unsigned ab = (unsigned)((s & 1) * ABUF), wb = (unsigned)((s & 1) * WBUF);
+        u32x4 wf[NW], bf[NR];
+#pragma unroll
+        for (int t = 0; t < NW; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[t]) : "v"(w_rd + wb), "n"(t * 1024) : "memory");
+#pragma unroll
+        for (int i = 0; i < NR; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[i]) : "v"(a_rd + ab), "n"(i * 1024) : "memory");
+        // LDS reads of a wave complete in order: row tile i's MFMAs wait for the W fragments and map fragments 0 .. i only
+        static_for_img<0, NR>([&](auto ic) {
+            constexpr int i = decltype(ic)::v;
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, bf[i]);
+#pragma unroll
+            for (int t = 0; t < NW; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), bv, acc[i][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    const int nst = pooled ? 3 : 2;                      // pool store instructions per converted k-step
+    // "My requests up to x have landed" is a COUNT (in-order completion): at most as many operations outstanding as this wave
+    // has issued after them.  Request order of a step j -- map waves: [rows of half-steps 2j+7, 2j+8 (4 + 4)] [stores of
+    // convert(j+1)]; W waves: [5 fragments of k-step j+1] [stores of convert(j+1)].
+    if (STAGER) {
+#pragma unroll
+        for (int h = 0; h < NHS; ++h) dma_half(h);
+        wait_vm(4 * (NHS - 2));                          // own rows of k-step 0 (half-steps 0, 1)
+    } else {
+        dma_w(0);
+        wait_vm(0);
+    }
+    asm volatile("s_barrier" ::: "memory");              // ... everyone's
+    convert(0);
+    if (STAGER) wait_vm(4 * (NHS - 4) + nst);            // own rows of k-step 1
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MG_IMG_TRACE
+    unsigned long long tt[6] = {0, 0, 0, 0, 0, 0};
+#define MG_TT(i, t0) { const unsigned long long t1_ = IMG_T(); tt[i] += t1_ - t0; t0 = t1_; }
+#else
+#define MG_TT(i, t0)
+#endif
+    // Step s: the MFMAs of k-step s and the conversion of k-step s + 1 (into the other operand image) in OPPOSITE order on the
+    // two waves of a SIMD (w, w + 4 = row groups 0, 1), so that one's LDS / VALU work runs under the other's MFMAs; one barrier.
+    for (int s = 0; s < nks; ++s) {
+#ifdef MG_IMG_TRACE
+        unsigned long long t0 = IMG_T();
+#endif
+        if (STAGER) { dma_half(2 * s + NHS); dma_half(2 * s + NHS + 1); }     // the half-slots of k-step s were converted in the step before
+        else dma_w(s + 1);                                                  // the other W image was read by the MFMAs of the step before
+        __builtin_amdgcn_sched_barrier(0);
+        MG_TT(0, t0);
+        if (STAGER && s + 1 < nks) convert(s + 1);
+        MG_TT(1, t0);
+        mfma_step(s);
+        MG_TT(2, t0);
+        if (!STAGER && s + 1 < nks) convert(s + 1);
+        MG_TT(1, t0);
+        // map waves: own rows of k-step s + 2 (half-steps 2s+4, 2s+5; the latter requested first in step s - 1 or, s = 0, sixth
+        // in the prologue): younger are 4 rows + the stores of that step and all of this step.  W waves: own fragments of
+        // k-step s + 1: younger are this step's stores.
+        wait_vm(STAGER ? 12 + 2 * nst : nst);
+        MG_TT(3, t0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MG_TT(4, t0);
+    }
+#ifdef MG_IMG_TRACE
+    if (lane == 0 && (wave == 0 || wave == 4) && (blockIdx.x == 0 || blockIdx.x == 129)) {
+        unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + (wave >> 2)];
+        for (int i = 0; i < 5; ++i) g[i] = tt[i];
+    }
+#endif
+    // ---- epilogue: + bias, bf16, through LDS (over the ring: every request has landed), 16-B row stores; columns N..319 zero.
+    // The tiles were computed TRANSPOSED (A operand = W fragment, B operand = map fragment): this lane's accumulator element
+    // [i][t][r] is output column (5 cg + t) * 16 + 4 * (lane >> 4) + r of region row 16 (7 rg + i) + (lane & 15), i.e. four
+    // CONSECUTIVE bank columns per tile -> one 8-byte LDS write.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned char* osb = smem;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+        const int n = (cg * 5 + t) * 16 + (lane >> 4) * 4;
+        f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
         if (bias) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (n + r < N) ? bias[n + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bvv[r] = (n + r < N) ? bias[n + r] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < MTH; ++i) {
-            const int row = i * 16 + (lane & 15);
+        for (int i = 0; i < NR; ++i) {
+            const int row = (rg * 7 + i) * 16 + (lane & 15);
             uint2 o;
-            o.x = pack2(n + 0 < N ? acc[i][j][0] + bv[0] : 0.f, n + 1 < N ? acc[i][j][1] + bv[1] : 0.f);
-            o.y = pack2(n + 2 < N ? acc[i][j][2] + bv[2] : 0.f, n + 3 < N ? acc[i][j][3] + bv[3] : 0.f);
+            o.x = pack2(n + 0 < N ? acc[i][t][0] + bvv[0] : 0.f, n + 1 < N ? acc[i][t][1] + bvv[1] : 0.f);
+            o.y = pack2(n + 2 < N ? acc[i][t][2] + bvv[2] : 0.f, n + 3 < N ? acc[i][t][3] + bvv[3] : 0.f);
             *reinterpret_cast<uint2*>(osb + (size_t)row * OSTR + n * 2) = o;
         }
     }
 }
 
+template <int PT>
 __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __restrict__ feat, int Bn, int K, int P,
                                                                  const unsigned short* __restrict__ Wp,
                                                                  const float* __restrict__ bias, int N,
                                                                  unsigned short* __restrict__ bank,
-                                                                 float* __restrict__ pooled_part) {
+                                                                 float* __restrict__ pooled_part, float* __restrict__ pooled) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* Fs = reinterpret_cast<uint4*>(smem);                            // [2][ROWS][FSTR] chunks
-    unsigned char* osb = smem + (size_t)2 * ROWS * FSTR * 16;              // [ROWS][OSTR] bytes (epilogue)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the two halves of a sample share the 128-B lines at their seam and the same W stream: keep the pair on ONE
-    // XCD (workgroup id % 8 is the XCD in practice) so those lines are served by one L2; any mapping is correct
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    ImgGeom gm;
-    gm.b = (jq >> 1) * 8 + xcd;
-    gm.mh = jq & 1;
-    if (gm.b >= Bn) return;                    // tail when B % 8 != 0 (whole workgroup exits together)
-    gm.p0 = gm.mh ? P_SPLIT : 0;
-    gm.p_store_end = gm.mh ? P : P_SPLIT;      // rows [p0, p_store_end) are ours
-    gm.K = K; gm.P = P; gm.KS = K / 32; gm.nchunk = K / BK;
-
-    float* s_pm_all = reinterpret_cast<float*>(osb + (size_t)ROWS * OSTR);      // [4][32][PMS]
-    if (wave >= 4) imgbank_producer(Fs, s_pm_all, feat, gm, pooled_part, wave - 4, lane);
-    else if (wave == 3) imgbank_consumer<4>(smem, gm, Wp, bias, N, wave, lane);
-    else imgbank_consumer<5>(smem, gm, Wp, bias, N, wave, lane);
-
+    const int b = blockIdx.x;
+    if ((wave >> 2) == 0) {
+        if ((wave & 3) == 3) img_wave<7, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        else img_wave<7, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+    } else {
+        if ((wave & 3) == 3) img_wave<6, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        else img_wave<6, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+    }
     // zero the pad columns 304..319 (two chunks per row), then the rows leave as 16-B lanes (all eight waves)
-    for (int q = tid; q < ROWS * 2; q += NTHR)
+    unsigned char* osb = smem;
+    for (int q = tid; q < P * 2; q += NTHR)
         *reinterpret_cast<uint4*>(osb + (size_t)(q >> 1) * OSTR + (NT * 2 + (q & 1)) * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)gm.b * P * OCH;
-    const int nrows = gm.p_store_end - gm.p0;
-    for (int q = tid; q < nrows * OCH; q += NTHR) {
+    uint4* ob = reinterpret_cast<uint4*>(bank) + (size_t)b * P * OCH;
+    for (int q = tid; q < P * OCH; q += NTHR) {
         const int row = q / OCH, ch = q - row * OCH;
-        ob[(size_t)(gm.p0 + row) * OCH + ch] = *reinterpret_cast<const uint4*>(osb + (size_t)row * OSTR + ch * 16);
+        ob[(size_t)row * OCH + ch] = *reinterpret_cast<const uint4*>(osb + (size_t)row * OSTR + ch * 16);
     }
 }
-
-// pooled[b,k] = max(part[b,0,k], part[b,1,k])
-__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ part, int B, int K, float* __restrict__ pooled) {
-    const size_t total = (size_t)B * K;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t b = i / K, k = i - b * K;
-        pooled[i] = fmaxf(part[(b * 2) * K + k], part[(b * 2 + 1) * K + k]);
-    }
-}
-
-constexpr size_t SMEM_BYTES = (size_t)(2 * ROWS * FSTR) * 16 + (size_t)ROWS * OSTR + (size_t)4 * 32 * PMS * sizeof(float);
-static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 
 }  // namespace
 
@@ -408,30 +373,49 @@ extern "C" int mgnns_imgbank_pack_weights_bf16(const float* W, int N, int K, voi
     return 0;
 }
 
+// imgbank_bf16_pairs.hip: two workgroups per sample (region halves), for batches that do not fill the chip
+int mg_imgbank_pool_bf16_pairs(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N, void* bank_bf16, int ld,
+                               float* pooled, float* pooled_work, mgnns_stream_t stream);
+
+static int g_imgbank_form = -1;          // -1: not set (MGNNS_IMGBANK_FORM or 0)
+extern "C" int mgnns_imgbank_set_form(int form) {
+    MG_REQUIRE(form >= 0 && form <= 2, "mgnns_imgbank_set_form: form=%d (0 by batch, 1 stream, 2 pairs)", form);
+    g_imgbank_form = form;
+    return 0;
+}
+
 extern "C" int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const void* Wp, const float* bias, int N,
                                            void* bank_bf16, int ld, float* pooled, float* pooled_work,
                                            mgnns_stream_t stream) {
     MG_REQUIRE(feat && Wp && bank_bf16 && pooled_work, "mgnns_imgbank_pool_bf16_fwd: null pointer");
     MG_REQUIRE(B >= 0 && K > 0 && K % BK == 0, "mgnns_imgbank_pool_bf16_fwd: K=%d must be a positive multiple of %d", K, BK);
-    MG_REQUIRE(P % 4 == 0 && P > P_SPLIT && P <= P_SPLIT + (MTH - 1) * 16,
-               "mgnns_imgbank_pool_bf16_fwd: P=%d unsupported (multiple of 4 in (%d, %d])", P, P_SPLIT, P_SPLIT + (MTH - 1) * 16);
+    MG_REQUIRE(P % 4 == 0 && P >= 16 && P <= PMAX, "mgnns_imgbank_pool_bf16_fwd: P=%d unsupported (multiple of 4 in [16, %d])", P, PMAX);
+    MG_REQUIRE((double)K * P * 4 < 2147483648.0, "mgnns_imgbank_pool_bf16_fwd: a sample's map must stay below 2 GiB");
     MG_REQUIRE(N > 0 && N <= NT * 16, "mgnns_imgbank_pool_bf16_fwd: N=%d unsupported (<= %d)", N, NT * 16);
     MG_REQUIRE(ld == OUT_LD, "mgnns_imgbank_pool_bf16_fwd: bank row length must be %d", OUT_LD);
     MG_REQUIRE(mg_aligned16(feat) && mg_aligned16(Wp) && mg_aligned16(bank_bf16),
                "mgnns_imgbank_pool_bf16_fwd: feat/Wp/bank must be 16-byte aligned");
     if (B == 0) return 0;
-    MG_DYN_LDS(imgbank_pool_bf16_kernel, SMEM_BYTES);
-    hipStream_t s = (hipStream_t)stream;
-    const int nblk = ((B + 7) / 8) * 16;      // pairs laid out XCD-major, padded to a multiple of 8 samples
-    hipLaunchKernelGGL(imgbank_pool_bf16_kernel, dim3(nblk), dim3(NTHR), SMEM_BYTES, s, feat, B, K, P,
-                       reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
-                       pooled_work);
-    if (pooled) {                              // pooled == NULL: the caller consumes the two halves in pooled_work itself
-        const size_t total = (size_t)B * K;
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(pool_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)pooled_work, B, K, pooled);
-    }
+    // A workgroup of the stream kernel needs ~95 us for its sample whatever the batch; up to half a chip of samples the
+    // two-workgroups-per-sample form (half the chain per workgroup) is the faster one.  MGNNS_IMGBANK_FORM=1 / 2 forces one.
+    const int n_cu = mg_cu_count();
+    if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
+    const int form = g_imgbank_form >= 0 ? g_imgbank_form : mg_env_int("MGNNS_IMGBANK_FORM", 0, 3);
+    const bool pairs_ok = K % 128 == 0 && P > 104 && P <= 200;
+    if (pairs_ok && (form == 2 || (form == 0 && 2 * B <= n_cu)))
+        return mg_imgbank_pool_bf16_pairs(feat, B, K, P, Wp, bias, N, bank_bf16, ld, pooled, pooled_work, stream);
+    MG_DYN_LDS(imgbank_pool_bf16_kernel<196>, SMEM_BYTES);
+    MG_DYN_LDS(imgbank_pool_bf16_kernel<0>, SMEM_BYTES);
+    // one workgroup per sample; the two halves of pooled_work get the same (complete) maxima -- callers that combine them
+    // themselves (label_tail) keep working --, `pooled` (optional) is written directly
+    if (P == 196)             // the model's 14 x 14 maps: row offsets as instruction immediates
+        hipLaunchKernelGGL(imgbank_pool_bf16_kernel<196>, dim3(B), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, feat, B, K, P,
+                           reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
+                           pooled_work, pooled);
+    else
+        hipLaunchKernelGGL(imgbank_pool_bf16_kernel<0>, dim3(B), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, feat, B, K, P,
+                           reinterpret_cast<const unsigned short*>(Wp), bias, N, reinterpret_cast<unsigned short*>(bank_bf16),
+                           pooled_work, pooled);
     MG_CHECK_LAUNCH("mgnns_imgbank_pool_bf16_fwd");
     return 0;
 }

@@ -551,6 +551,12 @@ def imgbank_pool_bf16(feat, wp, bias, n_out, combine=True):
     return bank, (pooled if combine else work)
 
 
+def imgbank_set_form(form):
+    """Which bf16 image-bank kernel runs: 0 = chosen by the batch (default), 1 = the stream form (one workgroup per sample),
+    2 = the pair form (two workgroups per sample) where its shape limits allow.  Process-wide; tests and measurements."""
+    _lib.check(_lib.lib().mgnns_imgbank_set_form(int(form)), "mgnns_imgbank_set_form")
+
+
 # ---- label attention core ---------------------------------------------------------------------------
 def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True):
     """Split-bf16 (fp32-class) image bank + max-pool: feat [B,K,P] fp32, w_pair = pack_weight_bf16_split(liner_img.weight

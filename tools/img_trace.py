@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-phase cycle sums of imgbank_pool_bf16 (library built with MGNNS_HIPCC_FLAGS=-DMG_IMG_TRACE): time a wave spends
-waiting for / converting the next map slice, in the MFMAs, and in the LDS write + barrier, over the 16 slices."""
+issuing the DMA rows, converting a k-step, in its MFMAs, waiting for its own rows and in the barrier, over the 64 k-steps."""
 import ctypes
 import os
 import sys
@@ -24,10 +24,7 @@ buf = (ctypes.c_ulonglong * 32)()
 fn = _lib.lib().mgnns_debug_img_trace
 fn.argtypes = [ctypes.c_void_p]
 assert fn(ctypes.addressof(buf)) == 0
-for i, name in enumerate(["wg0 consumer0", "wg0 producer0", "wg301 consumer0", "wg301 producer0"]):
+for i, name in enumerate(["wg0 wave0 (MFMAs first)", "wg0 wave4 (conversion first)", "wg129 wave0", "wg129 wave4"]):
     t = buf[i * 8:(i + 1) * 8]
-    if i % 2 == 0:
-        print("%s: work (A reads + MFMAs + W requests) %d  barrier wait %d   [s_memtime ticks, 16 slices]" % (name, t[0], t[1]))
-    else:
-        print("%s: wait for the set's first row %d  emit (rest of the waits + pool + cvt + LDS write) %d  refill issue %d  barrier wait %d"
-              % (name, t[0], t[1], t[2], t[3]))
+    print("%s: DMA issue %d  convert + pool %d  MFMAs + W requests %d  wait for own rows %d  barrier %d   [s_memtime ticks, 64 k-steps]"
+          % (name, t[0], t[1], t[2], t[3], t[4]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel timeline of ONE forward out of a rocprofv3 --kernel-trace rocpd database: start / duration / queue of every
-dispatch between two consecutive lstm_pack_kernel launches (one per forward).
+dispatch between two consecutive lstm_prep_kernel launches (one per forward).
 
     python tools/trace_timeline.py <results.db> [forward index, default: the median-length one] [--gantt]
 """
@@ -17,7 +17,7 @@ def main():
     sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = cur.execute("select d.start, d.end, d.queue_id, d.grid_size_x, d.workgroup_size_x, s.kernel_name from %s d join %s s "
                        "on d.kernel_id = s.id order by d.start" % (disp, sym)).fetchall()
-    marks = [i for i, r in enumerate(rows) if "lstm_pack_kernel" in r[5]]
+    marks = [i for i, r in enumerate(rows) if "lstm_prep_kernel" in r[5] or "lstm_pack_kernel(" in r[5]]
     spans = [(rows[marks[i + 1]][0] - rows[marks[i]][0]) / 1e3 for i in range(len(marks) - 1)]
     print("forwards:", len(marks), "spacing us:", " ".join("%.0f" % s for s in spans))
     if pick is None:
