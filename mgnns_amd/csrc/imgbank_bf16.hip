@@ -199,7 +199,9 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 q[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                if (psub + 16 * m < nquad) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
+                // (a compile-time region count: the first quads of every thread exist, no branch around their reads)
+                if ((PT > 0 && 16 * m + 15 < PT / 4) || psub + 16 * m < nquad)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
