@@ -181,53 +181,59 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
     float* const pp0 = pooled_part + ((size_t)b * 2) * K + pk;
     float* const pp1 = pp0 + K;
     float* const ppo = pooled ? pooled + (size_t)b * K + pk : nullptr;
-    // ---- (a) fp32 half-slots of k-step s -> bf16 operand image A[s & 1], (b) max-pool of the k-step's 32 rows
+    auto max3 = [](float a, float b2, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c)); return r; };
+    // ---- (a) fp32 half-slots of k-step s -> bf16 operand image A[s & 1] (W waves)
     auto convert = [&](int s) {
+        if (!cv_on) return;
         const unsigned ab = abuf + (unsigned)((s & 1) * ABUF);
+        const unsigned src = ring + (unsigned)(((2 * s + (ko >> 1)) % NHS) * HSLOT) + cv_src;
         f32x4 v[8];
-        f32x4 q[4];
-        if (cv_on) {
-            const unsigned src = ring + (unsigned)(((2 * s + (ko >> 1)) % NHS) * HSLOT) + cv_src;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (PT > 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(src), "n"(j * PT * 4) : "memory");
-                else asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(src + j * RB) : "memory");
-            }
-        }
-        {
-            const unsigned src = ring + (unsigned)(((2 * s + (pk >> 4)) % NHS) * HSLOT) + (unsigned)((pk & 15) * RB + psub * 16);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                q[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                // (a compile-time region count: the first quads of every thread exist, no branch around their reads)
-                if ((PT > 0 && 16 * m + 15 < PT / 4) || psub + 16 * m < nquad)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
-            }
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (PT > 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(src), "n"(j * PT * 4) : "memory");
+            else asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(src + j * RB) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (cv_on) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32x4 c;
-                c[0] = pack2(v[0][e], v[1][e]); c[1] = pack2(v[2][e], v[3][e]); c[2] = pack2(v[4][e], v[5][e]); c[3] = pack2(v[6][e], v[7][e]);
-                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ab + cv_dst), "v"(c), "n"(e * 64) : "memory");
-            }
-        }
-        auto max3 = [](float a, float b2, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c)); return r; };
-        float mx = max3(max3(q[0][0], q[0][1], q[0][2]), max3(q[0][3], q[1][0], q[1][1]), max3(q[1][2], q[1][3], q[2][0]));
-        mx = max3(mx, max3(q[2][1], q[2][2], q[2][3]), max3(q[3][0], q[3][1], max3(q[3][2], q[3][3], q[3][3])));
-        mx = row16_max(mx);
-        if (psub == 0) {                                 // every wave: `nst` store instructions per k-step (counted below)
-            const int kk = s * KROWS;
-            pp0[kk] = mx;
-            pp1[kk] = mx;
-            if (pooled) ppo[kk] = mx;
+        for (int e = 0; e < 4; ++e) {
+            u32x4 c;
+            c[0] = pack2(v[0][e], v[1][e]); c[1] = pack2(v[2][e], v[3][e]); c[2] = pack2(v[4][e], v[5][e]); c[3] = pack2(v[6][e], v[7][e]);
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ab + cv_dst), "v"(c), "n"(e * 64) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- (c) the MFMAs of k-step s: map fragments from A[s & 1], W fragments from W[s & 1]
-    auto mfma_step = [&](int s) {
+    // ---- (b) max-pool of the 32 rows of k-step s: row pk, quads psub + 16 m.  In pieces, so that it can be spread over the gaps
+    //      of an MFMA stream: reads | first maxima | second maxima + the 16-lane reduction | stores
+    f32x4 q[4];
+    float pmx = 0.f;
+    auto pool_reads = [&](int s) {
+        const unsigned src = ring + (unsigned)(((2 * s + (pk >> 4)) % NHS) * HSLOT) + (unsigned)((pk & 15) * RB + psub * 16);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            // (a compile-time region count: the first quads of every thread exist, no branch around their reads, no default)
+            if (!(PT > 0 && 16 * m + 15 < PT / 4)) q[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if ((PT > 0 && 16 * m + 15 < PT / 4) || psub + 16 * m < nquad)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
+        }
+    };
+    auto pool_max_a = [&]() { pmx = max3(max3(q[0][0], q[0][1], q[0][2]), max3(q[0][3], q[1][0], q[1][1]), max3(q[1][2], q[1][3], q[2][0])); };
+    auto pool_max_b = [&]() {
+        pmx = max3(pmx, max3(q[2][1], q[2][2], q[2][3]), max3(q[3][0], q[3][1], max3(q[3][2], q[3][3], q[3][3])));
+        pmx = row16_max(pmx);
+    };
+    // after the 16-lane reduction every lane of a row holds the maximum: lanes 0 / 1 / 2 of the row store it to the two partial
+    // arrays and (if asked for) the combined one -- ONE store instruction per wave and k-step (counted below)
+    float* const pdst = psub == 0 ? pp0 : psub == 1 ? pp1 : ppo;
+    const bool pst_on = psub < (pooled ? 3 : 2);
+    auto pool_store = [&](int s) {
+        if (pst_on) pdst[s * KROWS] = pmx;
+    };
+    // ---- (c) the MFMAs of k-step s (map fragments from A[s & 1], W fragments from W[s & 1]), and IN THEIR GAPS -- a SIMD
+    //      issues about one other instruction in the shadow of a 16-cycle MFMA -- this wave's requests of the step and the
+    //      max-pool of k-step s + 1 (PT > 0: the number of LDS reads in flight is known at compile time, which the counted
+    //      waits for the operand fragments need; otherwise the pool runs behind the MFMAs)
+    auto mfma_step = [&](int s, bool pool) {
         const unsigned ab = (unsigned)((s & 1) * ABUF), wb = (unsigned)((s & 1) * WBUF);
         u32x4 wf[NW], bf[NR];
 #pragma unroll
@@ -237,19 +243,45 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
         // LDS reads of a wave complete in order: row tile i's MFMAs wait for the W fragments and map fragments 0 .. i only
         static_for_img<0, NR>([&](auto ic) {
             constexpr int i = decltype(ic)::v;
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i) : "memory");
+            constexpr int NPR = 4;                       // pool reads behind the operand reads (PT > 0: all four are issued)
+            if constexpr (PT > 0 && i == 1) {
+                if (pool) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2 + NPR) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2) : "memory");
+            }
+            else if constexpr (PT > 0 && i >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 bv = __builtin_bit_cast(bf16x8, bf[i]);
 #pragma unroll
             for (int t = 0; t < NW; ++t)
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), bv, acc[i][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            // the gap behind row tile i
+            if constexpr (i == 0) {
+                if (STAGER) dma_half(2 * s + NHS);       // the half-slots of k-step s were converted in the step before
+                else dma_w(s + 1);                       // the other W image was read by the MFMAs of the step before
+                if (PT > 0 && pool) pool_reads(s + 1);
+            }
+            if constexpr (i == 1) { if (STAGER) dma_half(2 * s + NHS + 1); }
+            if constexpr (PT > 0 && i == 2) { if (pool) pool_max_a(); }
+            if constexpr (PT > 0 && i == 3) { if (pool) pool_max_b(); }
+            if constexpr (PT > 0 && i == 4) { if (pool) pool_store(s + 1); }
+            __builtin_amdgcn_sched_barrier(0);
         });
+        if (PT == 0 && pool) {
+            pool_reads(s + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            pool_max_a();
+            pool_max_b();
+            pool_store(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
-    const int nst = pooled ? 3 : 2;                      // pool store instructions per converted k-step
+    const int nst = 1;                                   // pool store instructions per wave and k-step
     // "My requests up to x have landed" is a COUNT (in-order completion): at most as many operations outstanding as this wave
-    // has issued after them.  Request order of a step j -- map waves: [rows of half-steps 2j+7, 2j+8 (4 + 4)] [stores of
-    // convert(j+1)]; W waves: [5 fragments of k-step j+1] [stores of convert(j+1)].
+    // has issued after them.  Request order of a step j -- map waves: [rows of half-steps 2j+7, 2j+8 (4 + 4)] [pool stores of
+    // k-step j+1]; W waves: [5 fragments of k-step j+1] [pool stores of k-step j+1].
     if (STAGER) {
 #pragma unroll
         for (int h = 0; h < NHS; ++h) dma_half(h);
@@ -260,6 +292,13 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
     }
     asm volatile("s_barrier" ::: "memory");              // ... everyone's
     convert(0);
+    pool_reads(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pool_max_a();
+    pool_max_b();
+    pool_store(0);
+    __builtin_amdgcn_sched_barrier(0);
     if (STAGER) wait_vm(4 * (NHS - 4) + nst);            // own rows of k-step 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -269,19 +308,13 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #else
 #define MG_TT(i, t0)
 #endif
-    // Step s: the MFMAs of k-step s and the conversion of k-step s + 1 (into the other operand image) in OPPOSITE order on the
-    // two waves of a SIMD (w, w + 4 = row groups 0, 1), so that one's LDS / VALU work runs under the other's MFMAs; one barrier.
+    // Step s: the MFMAs of k-step s (with the step's requests and the pool of k-step s + 1 in their gaps) on every wave; the W
+    // waves then convert k-step s + 1 into the other operand image; one barrier.
     for (int s = 0; s < nks; ++s) {
 #ifdef MG_IMG_TRACE
         unsigned long long t0 = IMG_T();
 #endif
-        if (STAGER) { dma_half(2 * s + NHS); dma_half(2 * s + NHS + 1); }     // the half-slots of k-step s were converted in the step before
-        else dma_w(s + 1);                                                  // the other W image was read by the MFMAs of the step before
-        __builtin_amdgcn_sched_barrier(0);
-        MG_TT(0, t0);
-        if (STAGER && s + 1 < nks) convert(s + 1);
-        MG_TT(1, t0);
-        mfma_step(s);
+        mfma_step(s, s + 1 < nks);
         MG_TT(2, t0);
         if (!STAGER && s + 1 < nks) convert(s + 1);
         MG_TT(1, t0);

@@ -614,6 +614,7 @@ extern "C" int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16
     if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     while (gy < pairs && B * gy < n_cu) gy *= 2;
     if (const int e = mg_env_int("MGNNS_MHA_SPLIT", 0, 4)) gy = e;        // measurement knob: workgroups per sample
+    if (mask) { if (const int e = mg_env_int("MGNNS_MHA_SPLIT_MASKED", 0, 5)) gy = e; }
     if (gy > pairs) gy = pairs;
     const float temp = (float)sqrt((double)dk);
     hipLaunchKernelGGL(sq_mha_core_bf16_kernel, dim3(B, gy), dim3(NTHR), SMEM_BYTES, (hipStream_t)stream, qh,
