@@ -577,6 +577,37 @@ def test_sq_mha_core_bf16_random_batches_vs_fp32_core(Hn):
         assert H.maxabs(o.cpu(), o32.cpu()) < 2e-2, (B, L)
 
 
+@pytest.mark.parametrize("Hn", [11, 16])
+def test_sq_mha_core_bf16_more_heads_than_probability_rows(Hn):
+    """A workgroup that owns more than eight heads (chip-filling batch, 11 / 16 heads) recycles the LDS rows of the head
+    probabilities and the partial-score slots behind their guard counters (unit queue of csrc/sq_mha_bf16.hip); a masked
+    batch with ragged lengths and one fully live row next to it; repeated launches give identical bits."""
+    rs = np.random.RandomState(7 + Hn)
+    wq, wk, wv = (dev((0.05 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
+    bq, bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(3))
+    wp = ops.pack_kv_weights_bf16(wk, wv, Hn, 128)
+    for B, L, masked in ((256, 40, False), (256, 100, True)):
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        bank32 = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+        mask = None
+        if masked:
+            lens = np.clip(np.round(np.exp(rs.normal(2.4, 0.75, B))), 1, L).astype(int)
+            lens[0] = L
+            m = np.zeros((B, L), np.float32)
+            for b in range(B):
+                m[b, :lens[b]] = 1
+            mask = dev(m)
+        qh = ops.linear(q, wq, bq)
+        bb = ops.cast_pad_bf16(bank32)
+        o, attn = ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp, bk, bv)
+        o2, attn2 = ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp, bk, bv)
+        assert torch.equal(o, o2) and torch.equal(attn, attn2)
+        o32, attn32 = ops.sq_mha_core(qh, bank32, mask, Hn, 128, wk, bk, wv, bv)
+        assert torch.isfinite(attn).all() and torch.isfinite(o).all()
+        assert H.maxabs(attn.cpu(), attn32.cpu()) < 5e-3, (B, L)
+        assert H.maxabs(o.cpu(), o32.cpu()) < 2e-2, (B, L)
+
+
 @pytest.mark.parametrize("form,B,P,K", [(1, 1, 196, 2048), (1, 3, 196, 2048), (2, 1, 196, 2048), (2, 3, 196, 2048),
                                         (1, 2, 208, 128), (1, 2, 64, 192), (1, 2, 16, 64), (2, 2, 108, 256), (0, 131, 196, 256)])
 def test_imgbank_pool_bf16(form, B, P, K):
