@@ -275,6 +275,12 @@ int mgnns_sq_mha_core_fwd(const float* qh, const float* bank, const float* mask,
                           const float* Wk, const float* bk, const float* Wv, const float* bv,
                           float* o, float* attn, mgnns_stream_t stream);
 
+/* Head-difference term of MultiHeadAttention(is_regu=True) (models/submodules.py:38-52, 84-93): o [B, H*dv] = the per-head
+ * attention outputs (the `o` of mgnns_sq_mha_core_*_fwd) -> out [B] = mean over ordered head pairs i != j of
+ * cos^2(o_i, o_j) (n_head == 1: 0 / 0 = NaN, as in the reference).  H <= 16.
+ */
+int mgnns_head_diff_fwd(const float* o, int B, int H, int dv, float* out, mgnns_stream_t stream);
+
 /* ---- a8, bf16-operand variant (BASELINE config 3: "bf16 MFMA") ------------------------------------------
  * Same contract as mgnns_sq_mha_core_fwd, but the projections run on v_mfma_f32_16x16x32_bf16 (bf16 operands,
  * fp32 accumulation; scores/softmax/weighted sum fp32).  The memory bank is bf16 [B, L, ld] with ld == 320

@@ -154,6 +154,48 @@ extern "C" int mgnns_classifier_head_fwd(const float* f0, const float* f1, const
     return 0;
 }
 
+// head-difference term of a multi-head attention output (diff_outputs, submodules.py:38-52, is_regu=True): per sample the mean
+// over the ordered head pairs i != j of cos^2(o_i, o_j), o_h = the head's output vector [dv] (F.normalize: x / max(|x|, 1e-12)).
+// One wave per sample: the H head norms and the H (H - 1) / 2 dot products are wave reductions over dv.
+template <int HMAX>
+__global__ __launch_bounds__(256) void head_diff_kernel(const float* __restrict__ o, int B, int H, int dv, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* ob = o + (size_t)b * H * dv;
+    float inv[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        float s = 0.f;
+        if (h < H)
+            for (int d = lane; d < dv; d += 64) s = fmaf(ob[h * dv + d], ob[h * dv + d], s);
+        inv[h] = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < HMAX; ++i)
+#pragma unroll
+        for (int j = i + 1; j < HMAX; ++j) {
+            if (j < H) {
+                float s = 0.f;
+                for (int d = lane; d < dv; d += 64) s = fmaf(ob[i * dv + d] * inv[i], ob[j * dv + d] * inv[j], s);
+                const float c = wave_sum(s);
+                acc += 2.0f * c * c;                      // (i, j) and (j, i)
+            }
+        }
+    // n_head = 1: 0 / 0 = NaN, like the reference's sum(...).div_(0)
+    if (lane == 0) out[b] = acc / (float)(H * (H - 1));
+}
+
+extern "C" int mgnns_head_diff_fwd(const float* o, int B, int H, int dv, float* out, mgnns_stream_t stream) {
+    MG_REQUIRE(o && out, "mgnns_head_diff_fwd: null pointer");
+    MG_REQUIRE(B >= 0 && H > 0 && H <= 16 && dv > 0, "mgnns_head_diff_fwd: bad dims B=%d n_head=%d (<= 16) d_v=%d", B, H, dv);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(head_diff_kernel<16>, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, o, B, H, dv, out);
+    MG_CHECK_LAUNCH("mgnns_head_diff_fwd");
+    return 0;
+}
+
 extern "C" int mgnns_embedding_fwd(const int64_t* idx, int64_t n, const float* table, int V, int D,
                                    float* out, mgnns_stream_t stream) {
     MG_REQUIRE(idx && table && out, "mgnns_embedding_fwd: null pointer");

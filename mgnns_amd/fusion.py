@@ -90,8 +90,6 @@ class MultiHeadAttention(nn.Module):
     def forward(self, q, k, v, mask=None):
         """q [B,1,d]; k = v = memory bank [B,L,d]; mask [B,1,L] or None -> (out [B,1,d], attn [H*B,1,L])."""
         _require_eval(self)
-        if self.is_regu:
-            raise NotImplementedError("is_regu=True (head-difference regulariser, training only) is not on the HIP path")
         if q.dim() != 3 or q.shape[1] != 1:
             raise ValueError("the fusion attention is single-query: q must be [B,1,d], got %s" % (tuple(q.shape),))
         if k is not v and (isinstance(k, MemoryBank) or isinstance(v, MemoryBank) or
@@ -115,6 +113,8 @@ class MultiHeadAttention(nn.Module):
                                       self.w_vs.weight.detach(), self.w_vs.bias.detach())
         y = ops.linear(o, self.fc.weight.detach(), self.fc.bias.detach(), residual=q2)
         y = self.layer_norm(y)
+        if self.is_regu:                    # submodules.py:84-93: the head-difference term as a third result
+            return y.view(B, 1, -1), attn, ops.head_diff(o, self.n_head)
         return y.view(B, 1, -1), attn
 
 
@@ -170,6 +170,10 @@ class MyMultiHeadAttention(nn.Module):
             mask = mask.unsqueeze(1)
         if self.need_mask:
             assert mask is not None, 'Please pass the attention mask to the multi-head'
+        if self.is_regu:                    # moudles.py:220-229
+            enc_output, enc_slf_attn, head_diff = self.slf_attn(q, k, v, mask)
+            enc_output = self.pos_ffn(enc_output)
+            return enc_output.squeeze(1), enc_slf_attn, head_diff
         enc_output, enc_slf_attn = self.slf_attn(q, k, v, mask)
         enc_output = self.pos_ffn(enc_output)
         return enc_output.squeeze(1), enc_slf_attn
@@ -270,7 +274,8 @@ def run_stack(layers, q, bank, mask=None, qh=None):
         if m.need_mask:
             assert mask is not None, 'Please pass the attention mask to the multi-head'
         if m.is_regu:
-            raise NotImplementedError("is_regu=True (training-only regulariser) is not on the HIP path")
+            raise NotImplementedError("run_stack drops the head-difference term (the reference's model forward unpacks two values "
+                                      "per layer and cannot run with is_regu=True either, MODEL:508-527); call the layers themselves")
     if not isinstance(bank, MemoryBank):
         bank = MemoryBank(f32=bank.contiguous())
     B = q.shape[0]

@@ -551,6 +551,20 @@ def imgbank_pool_bf16(feat, wp, bias, n_out, combine=True):
     return bank, (pooled if combine else work)
 
 
+def head_diff(o, n_head):
+    """o [B, n_head*d_v] (per-head attention outputs) -> [B]: mean over head pairs i != j of cos^2(o_i, o_j)
+    (diff_outputs, submodules.py:38-52)."""
+    _chk(o, "attention output", ndim=2)
+    B = o.shape[0]
+    if o.shape[1] % n_head:
+        raise ValueError("attention output width %d is not a multiple of n_head=%d" % (o.shape[1], n_head))
+    out = torch.empty(B, device=o.device, dtype=torch.float32)
+    L = _lib.lib()
+    _launch("mgnns_head_diff_fwd", ("mgnns_head_diff_fwd",), L.mgnns_head_diff_fwd, _p(o), B, n_head, o.shape[1] // n_head, _p(out),
+            _stream())
+    return out
+
+
 def imgbank_set_form(form):
     """Which bf16 image-bank kernel runs: 0 = chosen by the batch (default), 1 = the stream form (one workgroup per sample),
     2 = the pair form (two workgroups per sample) where its shape limits allow.  Process-wide; tests and measurements."""

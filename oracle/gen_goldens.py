@@ -152,6 +152,15 @@ def gold_mha(ns):
         assert maxdiff(mo, o) < 2e-5 and maxdiff(ma, attn) < 1e-5, (maxdiff(mo, o), maxdiff(ma, attn))
         out[name + "_out"] = o
         out[name + "_attn"] = attn
+        if H > 1:
+            # is_regu=True (submodules.py:38-52, 84-93; moudles.py:220-229): the same layer with the head-difference term
+            regu = ns.MOUD.MyMultiHeadAttention(H, 300, 128, dropout=0.5, need_mask=masked, is_regu=True).eval()
+            regu.load_state_dict(layer.state_dict())
+            with torch.no_grad():
+                o2, attn2, hd = regu(q=q, k=bank, v=bank, mask=mask)
+            assert maxdiff(o2, o) == 0.0 and maxdiff(attn2, attn) == 0.0
+            assert maxdiff(R.sq_mha_layer(p, name, q, bank, mask, H, 128, return_head_diff=True)[2], hd) < 1e-6
+            out[name + "_head_diff"] = hd
     save("mha.npz", **out)
 
 

@@ -109,7 +109,7 @@ def layer_norm(x, gamma, beta, eps=1e-6):
     return gamma * (x - mean) / (std + eps) + beta
 
 
-def sq_mha_layer(p, prefix, q, bank, mask, n_head, d_kv):
+def sq_mha_layer(p, prefix, q, bank, mask, n_head, d_kv, return_head_diff=False):
     """MyMultiHeadAttention.forward (moudles.py:207-230) with len_q == 1.
 
     q [B,300], bank [B,L,300] (key = value), mask [B,L] float (1 token / 0 pad) or None.
@@ -135,7 +135,20 @@ def sq_mha_layer(p, prefix, q, bank, mask, n_head, d_kv):
     z = F.linear(F.relu(F.linear(y, w1, p[f + "w_1.bias"])), w2, p[f + "w_2.bias"])
     out = layer_norm(z + y, p[f + "layer_norm.gamma"], p[f + "layer_norm.beta"])
     attn = pa.permute(1, 0, 2).reshape(H * B, 1, L)
+    if return_head_diff:
+        return out, attn, head_diff(o.view(B, H, dk))
     return out, attn
+
+
+def head_diff(o):
+    """MultiHeadAttention.diff_outputs (submodules.py:38-52), is_regu=True: o [B,H,dv] per-head attention outputs ->
+    [B] mean over the ordered head pairs i != j of cos^2(o_i, o_j)  (H = 1: 0 / 0)."""
+    x = F.normalize(o, p=2, dim=-1)
+    c2 = torch.bmm(x, x.permute(0, 2, 1)) ** 2
+    H = o.shape[1]
+    idx = torch.arange(H)
+    c2[:, idx, idx] = 0
+    return c2.sum(dim=[1, 2]) / (H * (H - 1))
 
 
 def mha_stack(p, stack, q, bank, mask, n_head, d_kv, stack_num):

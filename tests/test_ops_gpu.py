@@ -670,6 +670,38 @@ def test_run_stack_fused_tail_matches_layer_by_layer_and_golden(Hn):
 
 
 @pytest.mark.parametrize("Hn", [4, 8])
+def test_is_regu_head_difference_against_the_reference_golden(Hn):
+    """MyMultiHeadAttention(is_regu=True) returns the head-difference term as a third value (moudles.py:220-229,
+    submodules.py:38-52, 84-93): the reference's own output (golden), every attention variant; the operator alone against
+    the oracle incl. a zero head (F.normalize's eps) and one head (0 / 0 = NaN, like the reference)."""
+    from mgnns_amd.fusion import MyMultiHeadAttention
+    g = H.load_golden("mha.npz")
+    for tag, L, masked in (("text", 100, True), ("img", 196, False)):
+        name = "h%d_%s" % (Hn, tag)
+        pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+        layer = MyMultiHeadAttention(Hn, 300, 128, dropout=0.5, need_mask=masked, is_regu=True).eval()
+        layer.load_state_dict({k[len(name) + 1:]: v for k, v in pc.items()})
+        layer = layer.to(DEV)
+        q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+        dm = None if mask is None else dev(mask)
+        dbank = dev(bank)
+        out, attn, hd = layer(q=dev(q), k=dbank, v=dbank, mask=dm)
+        assert hd.shape == (q.shape[0],)
+        assert H.maxabs(out.cpu(), g[name + "_out"]) < 2e-5 and H.maxabs(attn.cpu(), g[name + "_attn"]) < 1e-5
+        assert H.maxabs(hd.cpu(), g[name + "_head_diff"]) < 1e-6
+        layer.slf_attn.attention = 'folded'
+        hd_f = layer(q=dev(q), k=dbank, v=dbank, mask=dm)[2]
+        assert H.maxabs(hd_f.cpu(), g[name + "_head_diff"]) < 1e-6
+        layer.slf_attn.attention = 'faithful'
+    rs = np.random.RandomState(3 + Hn)
+    o = rs.standard_normal((9, Hn, 128)).astype(np.float32)
+    o[2, 1] = 0.0                                          # a zero head vector: normalised to 0, not NaN
+    got = ops.head_diff(dev(o.reshape(9, -1)), Hn).cpu()
+    assert H.maxabs(got, R.head_diff(torch.from_numpy(o))) < 1e-6
+    assert torch.isnan(ops.head_diff(dev(o[:, 0].copy()), 1)).all()
+
+
+@pytest.mark.parametrize("Hn", [4, 8])
 def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
     """split-bf16 fused tail (3 MFMA terms) vs the exact-fp32 fused tail on the same inputs: fp32-class agreement;
     the 1-term (plain bf16) tail only bf16-class."""

@@ -72,6 +72,9 @@ def test_single_query_mha_layer(Hn, tag, L, masked):
     if masked:   # padded positions carry exactly zero probability
         m = torch.from_numpy(np.tile(GI.mha_case(Hn, tag, L, masked)[2], (Hn, 1)))
         assert float((attn[:, 0, :] * (1 - m)).abs().max()) == 0.0
+    if Hn > 1:   # is_regu=True: the head-difference term of the same layer (reference output)
+        hd = R.sq_mha_layer(p, name, q, bank, mask, Hn, 128, return_head_diff=True)[2]
+        assert H.maxabs(hd, g[name + "_head_diff"]) < 1e-6
 
 
 @pytest.mark.parametrize("ngram", [1, 4])
