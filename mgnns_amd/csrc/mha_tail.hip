@@ -308,6 +308,12 @@ extern "C" int mgnns_pack_weight_bf16_split(const float* W, int N, int K, void* 
     return 0;
 }
 
+#ifdef MG_TAIL_TRACE
+extern "C" int mgnns_debug_tail_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_tail::g_tail_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d_model, int terms,
                                        const void* const* packed /* fc_h,fc_l,w1_h,w1_l,w2_h,w2_l,wq_h,wq_l */,
                                        const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,

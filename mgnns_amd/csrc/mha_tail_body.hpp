@@ -7,6 +7,14 @@
 
 namespace mg_tail {
 
+#ifdef MG_TAIL_TRACE
+// profiling aid (off by default): s_memtime stamps of wave 0 of workgroup (0, 0) at the phase boundaries of the tail
+__device__ unsigned long long g_tail_trace[16];
+#define MG_TSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_tail_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MG_TSTAMP(i) do { } while (0)
+#endif
+
 constexpr int NTHR = 512;
 constexpr int ROWS = 16;
 constexpr int D = 300;                       // d_model (host checks)
@@ -46,6 +54,52 @@ __device__ __forceinline__ void ln_rows_r(float* __restrict__ buf, const float (
     }
 }
 
+// LayerNorm of the tile's rows (two per wave) with the results going straight where the next step wants them, out of the
+// registers that hold them: the fp32 row (residual / output), its bf16 hi (+ lo for TERMS == 3) image as the next GEMM's A
+// operand, and optionally the global output row -- instead of a second pass over LDS with an integer division per element
+// (the phase timer: 7.5 k + 8.5 k cycles of a 53 k-cycle tail for the two LayerNorm + conversion passes).
+template <int TERMS>
+__device__ __forceinline__ void ln_rows_emit(float* __restrict__ buf, const float (&gamma)[5], const float (&beta)[5], float eps,
+                                             int wave, int lane, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                             bool emit_bf16, float* __restrict__ gout, int rows_valid) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+        float* row = buf + r * SD;
+        float v[5];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < D ? row[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum_dpp(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < D ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float inv = 1.0f / (sqrtf(wave_sum_dpp(q) / (float)(D - 1)) + eps);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float y = gamma[i] * (v[i] - mean) * inv + beta[i];
+                row[c] = y;
+                if (emit_bf16) {
+                    const unsigned short h = f2bf_t(y);
+                    hi[r * SCD * 8 + c] = h;
+                    if (TERMS == 3) lo[r * SCD * 8 + c] = f2bf_t(y - bf2f_t(h));
+                }
+                if (gout && r < rows_valid) gout[(size_t)r * D + c] = y;
+            }
+        }
+    }
+}
+
 struct TailW {            // packed hi/lo pairs + fp32 vectors of one layer
     const unsigned short *fc_h, *fc_l, *w1_h, *w1_l, *w2_h, *w2_l, *wq_h, *wq_l;
     const float *fc_b, *g1, *be1, *b1, *b2, *g2, *be2, *bq;
@@ -69,6 +123,7 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tile * ROWS;
     const int KSo = (HK + 31) / 32, KSd = (D + 31) / 32;
+    MG_TSTAMP(0);
 
     // per-lane parameter vectors first: b_1 / b_2 of this lane's output columns, gamma / beta of its LayerNorm columns
     const int ccol0 = lane & 15;
@@ -136,7 +191,8 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
         }
     }
     for (int i = tid; i < 2 * ROWS * SCD; i += NTHR) s_ah[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
+    mg_lds_barrier();        // (LDS only: __syncthreads() would also wait for the weight fragments requested ahead)
+    MG_TSTAMP(1);
 
     unsigned short* ah16 = reinterpret_cast<unsigned short*>(s_ah);
     unsigned short* al16 = reinterpret_cast<unsigned short*>(s_al);
@@ -159,6 +215,7 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
         }
     }
     ring_gemm(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
+    MG_TSTAMP(2);
     ring_prime(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -168,30 +225,33 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
             for (int r = 0; r < 4; ++r) s_y[(crow + r) * SD + n] = acc[t][r] + qb[t][r];
         }
     }
-    __syncthreads();
-    ln_rows_r(s_y, lg1, lb1, eps, wave, lane);
-    __syncthreads();
-    for (int i = tid; i < ROWS * D; i += NTHR) {
-        const int r = i / D, c = i - r * D;
-        split_store(ah16, al16, r * SCD * 8 + c, s_y[r * SD + c]);
-    }
-    __syncthreads();
+    mg_lds_barrier();
+    ln_rows_emit<TERMS>(s_y, lg1, lb1, eps, wave, lane, ah16, al16, true, nullptr, 0);
+    mg_lds_barrier();
+    MG_TSTAMP(3);
     // ---- 2. h = relu(w_1 y + b_1) ----------------------------------------------------------------------------------------
     ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w1_h, w.w1_l, lane);
+    MG_TSTAMP(4);
     ring_prime(ring, KSd, w.w2_h, w.w2_l, DT, wave, lane, 0);          // w_2 flies through the ReLU / barrier
-    __syncthreads();                                   // all A reads of y done before h overwrites the buffer
+    mg_lds_barrier();                                   // all A reads of y done before h overwrites the buffer
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
         if (wave + 8 * t < DT && n < D) {
             const float bv = pb1[t];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) split_store(ah16, al16, (crow + r) * SCD * 8 + n, fmaxf(acc[t][r] + bv, 0.f));
+            for (int r = 0; r < 4; ++r) {
+                const float x = fmaxf(acc[t][r] + bv, 0.f);
+                if (TERMS == 3) split_store(ah16, al16, (crow + r) * SCD * 8 + n, x);
+                else ah16[(crow + r) * SCD * 8 + n] = f2bf_t(x);
+            }
         }
     }
-    __syncthreads();
+    mg_lds_barrier();
+    MG_TSTAMP(5);
     // ---- 3. out = LN2(w_2 h + b_2 + y) --------------------------------------------------------------------------------------
     ring_gemm(acc, ring, s_ah, s_al, SCD, KSd, w.w2_h, w.w2_l, lane);
+    MG_TSTAMP(6);
     // the projection's first column-tile pair flies through LayerNorm 2
     const int NTq = (HKn + 15) / 16;
     const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
@@ -208,21 +268,16 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
             for (int r = 0; r < 4; ++r) s_t[(crow + r) * SD + n] = acc[t][r] + bv + s_y[(crow + r) * SD + n];
         }
     }
-    __syncthreads();
-    ln_rows_r(s_t, lg2, lb2, eps, wave, lane);
-    __syncthreads();
-    for (int i = tid; i < ROWS * D; i += NTHR) {
-        const int r = i / D, c = i - r * D;
-        const float v = s_t[r * SD + c];
-        if (r0 + r < B && crank == 0) out[(size_t)(r0 + r) * D + c] = v;
-        if (w.wq_h) split_store(ah16, al16, r * SCD * 8 + c, v);
-    }
+    mg_lds_barrier();
+    ln_rows_emit<TERMS>(s_t, lg2, lb2, eps, wave, lane, ah16, al16, w.wq_h != nullptr, crank == 0 ? out + (size_t)r0 * D : nullptr,
+                        B - r0);
+    MG_TSTAMP(7);
     // ---- 4. next layer's query projection -------------------------------------------------------------------------------------
     // gridDim.y workgroups share a 16-sample tile: each recomputes steps 1-3 (identical results; rank 0 stores `out`) and
     // takes 1 / gridDim.y of the projection's column tiles.  The projection is 40 % of the weight bytes a workgroup streams
     // at the per-CU L2 rate, and the only part of the chain whose columns are independent.
     if (w.wq_h) {
-        __syncthreads();
+        mg_lds_barrier();
         for (int t0 = s_lo; t0 < s_hi; t0 += 2) {
             f32x4 a2[2];
             if (t0 != s_lo) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, t0);
@@ -242,6 +297,7 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
             }
         }
     }
+    MG_TSTAMP(8);
 }
 
 
