@@ -177,16 +177,16 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
         for (int it = 0; it < MAXIT; ++it) {
             const int i = tid + it * NTHR;
             if (i < ROWS * so) {
-                unsigned short h[8], l[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = v[it][j >> 2][j & 3];
-                    h[j] = f2bf_t(x);
-                    l[j] = TERMS == 3 ? f2bf_t(x - bf2f_t(h[j])) : (unsigned short)0;
+                uint4 hq, lq = make_uint4(0u, 0u, 0u, 0u);
+                const f32x4 x0 = v[it][0], x1 = v[it][1];
+                hq.x = f2bf2_t(x0[0], x0[1]); hq.y = f2bf2_t(x0[2], x0[3]); hq.z = f2bf2_t(x1[0], x1[1]); hq.w = f2bf2_t(x1[2], x1[3]);
+                if (TERMS == 3) {
+                    auto res = [](float x, unsigned int packed, int half) { return x - bf2f_t((unsigned short)(half ? packed >> 16 : packed & 0xFFFFu)); };
+                    lq.x = f2bf2_t(res(x0[0], hq.x, 0), res(x0[1], hq.x, 1)); lq.y = f2bf2_t(res(x0[2], hq.y, 0), res(x0[3], hq.y, 1));
+                    lq.z = f2bf2_t(res(x1[0], hq.z, 0), res(x1[1], hq.z, 1)); lq.w = f2bf2_t(res(x1[2], hq.w, 0), res(x1[3], hq.w, 1));
                 }
-                s_oh[i] = make_uint4(h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16);
-                if (TERMS == 3)
-                    s_ol[i] = make_uint4(l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16);
+                s_oh[i] = hq;
+                if (TERMS == 3) s_ol[i] = lq;
             }
         }
     }

@@ -9,10 +9,18 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// fp32 -> bf16, round to nearest even: ONE v_cvt_pk_bf16_f32 (there is no builtin for it on gfx950) instead of the five-instruction
+// integer form -- these kernels are made of small latency-bound phases in which every VALU instruction shows
 __device__ __forceinline__ unsigned short f2bf_t(float x) {
-    unsigned int u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return (unsigned short)r;
+}
+// two values -> packed bf16x2 (lo half = a)
+__device__ __forceinline__ unsigned int f2bf2_t(float a, float b) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 __device__ __forceinline__ float bf2f_t(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
 __device__ __forceinline__ void split_store(unsigned short* hi, unsigned short* lo, int idx, float x) {
