@@ -118,7 +118,8 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
                                          const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
                                          unsigned short* __restrict__ bank, float* __restrict__ pooled_part,
                                          float* __restrict__ pooled, int wave, int lane, int tid) {
-    const int rg = wave >> 2, cg = wave & 3;
+    // row group: the W waves also convert, so they take the 6-tile group and the map waves the 7-tile one
+    const int rg = STAGER ? 0 : 1, cg = wave & 3;
     const int nks = K / KROWS;
     const int P = PT ? PT : Prt;                         // PT: the region count as a compile-time constant (row offsets become immediates)
     const int RB = P * 4;                                // bytes of a map row
@@ -370,11 +371,11 @@ __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     if ((wave >> 2) == 0) {
-        if ((wave & 3) == 3) img_wave<7, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
-        else img_wave<7, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        if ((wave & 3) == 3) img_wave<6, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        else img_wave<6, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
     } else {
-        if ((wave & 3) == 3) img_wave<6, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
-        else img_wave<6, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        if ((wave & 3) == 3) img_wave<7, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        else img_wave<7, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
     }
     // zero the pad columns 304..319 (two chunks per row), then the rows leave as 16-B lanes (all eight waves)
     unsigned char* osb = smem;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase timeline of sq_mha_core_bf16 from in-kernel s_memtime stamps (library built with
 MGNNS_HIPCC_FLAGS=-DMG_MHA_TRACE).  Prints, for wave 0 / wave 4 of workgroups 0 and 129, the cycles spent in staging,
-each K/V GEMM and each epilogue."""
+each unit's GEMM and epilogue (unit queue: csrc/sq_mha_bf16.hip)."""
 import ctypes
 import os
 import sys
@@ -27,14 +27,19 @@ buf = (ctypes.c_ulonglong * 256)()
 fn = _lib.lib().mgnns_debug_mha_trace
 fn.argtypes = [ctypes.c_void_p]
 assert fn(ctypes.addressof(buf)) == 0
-names = ["entry", "dma issued", "staged"] + [x for hp in range(4) for x in ("K gemm %d" % hp, "K epi %d" % hp, "V gemm %d" % hp, "V epi %d" % hp)]
+# stamps: 0 entry, 2 staged, then (GEMM end, epilogue end) per unit this wave drew from its slice's queue (K and V units of
+# the heads in ticket order, shared with the other wave of the SIMD: waves 0 and 4 are such a pair)
+NU = 8
 for w in range(4):
     t = list(buf[w * 64:(w + 1) * 64])
-    print("workgroup %d wave %d: total %d ticks" % (0 if w < 2 else 129, 0 if w % 2 == 0 else 4, t[len(names) - 1] - t[0]))
-    print("  " + "  ".join("%s %d" % (names[i], t[i] - t[i - 1]) for i in range(1, len(names))))
-    print("  pair 1 K gemm k-steps: " + " ".join(str(t[32 + k + 1] - t[32 + k]) for k in range(9)) + "  (from epilogue end to k0: %d)" % (t[32] - t[6]))
-    print("  pair 1 V gemm k-steps: " + " ".join(str(t[44 + k + 1] - t[44 + k]) for k in range(9)) + "  (from epilogue end to k0: %d)" % (t[44] - t[8]))
-base = buf[2 * 64 + 0]
-for w in (2, 3):
-    t = list(buf[w * 64:(w + 1) * 64])
-    print("wg129 wave %d absolute (k cycles): " % (0 if w == 2 else 4) + " ".join("%.1f" % ((t[i] - base) / 1e3) for i in range(2, 19)))
+    units = []
+    for u in range(NU):
+        g, e = t[3 + 2 * u], t[4 + 2 * u]
+        prev = t[2 + 2 * u] if u else t[2]
+        if g <= prev or e < g:
+            break
+        units.append((g - prev, e - g))
+    end = t[2 + 2 * len(units)] if units else t[2]
+    print("workgroup %d wave %d: staged after %d ticks, %d units recorded, last stamp at %d"
+          % (0 if w < 2 else 129, 0 if w % 2 == 0 else 4, t[2] - t[0], len(units), end - t[0]))
+    print("  (GEMM, epilogue) per unit: " + "  ".join("(%d, %d)" % u for u in units))
