@@ -352,7 +352,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         """-> (MemoryBank, pooled [B,2048]); one pass over the feature map."""
         B = feats.shape[0]
         f3 = feats.float().contiguous().view(B, feats.shape[1], -1)
-        if self.precision == 'bf16' and 104 < f3.shape[2] <= 200 and f3.shape[2] % 4 == 0:
+        if self.precision == 'bf16' and 16 <= f3.shape[2] <= 208 and f3.shape[2] % 4 == 0 and f3.shape[1] % 64 == 0 \
+                and lin.out_features <= 304:        # (the bf16 bank kernels' limits; other shapes take the fp32 kernel)
             keep_halves = (self.fused_label_tail and self.fused_label_tail_bf16 and B >= self.fused_label_tail_bf16_min_batch)
             bank, pooled = ops.imgbank_pool_bf16(f3, self._wp(lin), lin.bias.detach(), lin.out_features, combine=not keep_halves)
             return MemoryBank(bf16=bank), pooled
