@@ -593,7 +593,7 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
     H, dk, D, T = cfg.n_head, cfg.d_kv, cfg.emb_size, cfg.T
     rows = []
 
-    def add(kernel, key, bound, work, note):
+    def add(kernel, key, bound, work, note, pmc_key=None):
         v = d.get(key, [])
         if not v:
             return
@@ -602,9 +602,12 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
             ach, peak, unit = work / us / 1e3, PEAK_HBM_GBPS, "GB/s"
         else:
             ach, peak, unit = work / us / 1e6, PEAK_TFLOPS["f32" if bound == "mfma_f32" else "bf16"], "TFLOP/s"
-        rows.append({"kernel": kernel, "bound": "mfma" if bound.startswith("mfma") else bound, "algorithmic": work,
-                     "algorithmic_unit": "B" if bound == "hbm" else "FLOP", "avg_us": round(us, 2), "launches": len(v),
-                     "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "note": note})
+        row = {"kernel": kernel, "bound": "mfma" if bound.startswith("mfma") else bound, "algorithmic": work,
+               "algorithmic_unit": "B" if bound == "hbm" else "FLOP", "avg_us": round(us, 2), "launches": len(v),
+               "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "note": note}
+        if pmc_key:                      # HBM bytes per launch of the committed PMC passes (refused when the kernel changed since)
+            row["traffic"], row["traffic_source"] = pmc_traffic(pmc_key)
+        rows.append(row)
 
     bf = dtype == "bf16"
     core = "mgnns_sq_mha_core_bf16_fwd" if bf else "mgnns_sq_mha_core_fwd"
@@ -616,7 +619,7 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
                                         "the unmasked figure")
     if bf:
         add("imgbank_pool_bf16", ("mgnns_imgbank_pool_bf16_fwd",), "hbm", B * (2048.0 * P * 4 + P * D * 2 + 2048 * 4),
-            "fp32 map read once + bf16 bank + pooled row written")
+            "fp32 map read once + bf16 bank + pooled row written", pmc_key="imgbank_pool_bf16@B%d" % B)
         add("mha_tail_bf16", ("mgnns_mha_tail_bf16_fwd",), "mfma_bf16",
             B * 2.0 * (H * dk * D + 2 * D * D) + B * 2.0 * D * H * dk / 2,
             "fc + FFN per launch; the next layer's w_qs is fused into every other launch (averaged in)")

@@ -107,6 +107,12 @@ def main():
                     "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre,
                     "kernel_source": "mgnns_amd/csrc/sq_mha_bf16.hip",
                     "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/sq_mha_bf16.hip"), "rb").read()).hexdigest()[:16]}
+            if label == "imgbank_pool_bf16":
+                traffic["imgbank_pool_bf16@B256"] = {
+                    "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
+                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre,
+                    "kernel_source": "mgnns_amd/csrc/imgbank_bf16.hip",
+                    "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/imgbank_bf16.hip"), "rb").read()).hexdigest()[:16]}
         busy = pmc(dbs["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_mha_core_bf16_kernel")
         with open(os.path.join(PR, "%s_pmc_summary.md" % pre), "w") as f:
             f.write("# rocprofv3 PMC passes, %s (bf16 mode, eager single forwards: `bench.py --steps 3 --warmup 1 --no-cpu-baseline "
