@@ -642,6 +642,30 @@ def test_imgbank_pool_bf16(form, B, P, K):
         print("bf16 bank max abs err vs fp32: %.3e (|bank| max %.2f)" % (H.maxabs(got, ref32), float(ref32.abs().max())))
 
 
+def test_imgbank_forms_agree_at_full_batch_and_repeat():
+    """configs[2]'s bank shape (256 x 2048 x 196): the stream form (counted waits on two in-order request streams per workgroup)
+    gives the same bits launch after launch with every compute unit busy, and agrees with the pair form (same products, same
+    fp32 accumulation order per output) to bf16 rounding; pooled maxima identical."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    feat = torch.relu(torch.randn(256, 2048, 196, device=DEV, generator=g))
+    w = torch.randn(300, 2048, device=DEV, generator=g) * 0.05
+    bias = torch.randn(300, device=DEV, generator=g) * 0.05
+    wp = ops.pack_imgbank_weights_bf16(w)
+    try:
+        ops.imgbank_set_form(1)
+        bank1, pooled1 = ops.imgbank_pool_bf16(feat, wp, bias, 300)
+        for _ in range(10):
+            bank, pooled = ops.imgbank_pool_bf16(feat, wp, bias, 300)
+            assert torch.equal(bank, bank1) and torch.equal(pooled, pooled1)
+        ops.imgbank_set_form(2)
+        bank2, pooled2 = ops.imgbank_pool_bf16(feat, wp, bias, 300)
+    finally:
+        ops.imgbank_set_form(0)
+    assert torch.equal(pooled1, pooled2) and torch.equal(pooled1, feat.amax(dim=2))
+    d = (bank1.float() - bank2.float()).abs()
+    assert float((d / (bank2.float().abs() + 1e-2)).max()) < 1.2e-2          # at most one bf16 ulp apart
+
+
 @pytest.mark.parametrize("Hn", [1, 4, 8])
 def test_run_stack_fused_tail_matches_layer_by_layer_and_golden(Hn):
     """fusion.run_stack (fused core + fused tail + chained query projection) == the per-layer module path ==
