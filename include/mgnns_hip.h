@@ -378,6 +378,14 @@ int mgnns_label_gcn_fwd(const float* A, int C, const float* inp, int K0, int spl
  */
 int mgnns_classifier_head_fwd(const float* f0, const float* f1, const float* f2, const float* f3, int B, int D,
                               const float* W, const float* bias, int NL, float* logits, mgnns_stream_t stream);
+/* The same classifier as nparts launches, one behind each producer of a feature (the four fusion stacks run on different streams):
+ * launch `part` adds  parts[part][b][:] = W[:, part*D:(part+1)*D] . f[b]  and the launch that finishes LAST adds the parts in index
+ * order + bias into logits [B, NL] -- no launch (and no stream join) of its own behind the slowest stack.  parts [nparts, B, NL],
+ * counter: one int32, zero before the first of the nparts launches (the last launch re-arms it).  All nparts launches must use the
+ * same B, D, NL, parts, counter, logits.
+ */
+int mgnns_classifier_part_fwd(const float* f, int part, int nparts, int B, int D, const float* W, const float* bias,
+                              int NL, float* parts, int* counter, float* logits, mgnns_stream_t stream);
 
 /* ---- custom LayerNorm (submodules.py:153-156): unbiased std, eps added to std ---------------------------
  * y[r,:] = gamma * (x[r,:] - mean) / (std_unbiased + eps) + beta,  x,y [rows, D], D <= 1024.

@@ -137,6 +137,55 @@ __global__ __launch_bounds__(256) void classifier_head_kernel(const float* __res
     }
 }
 
+// The classifier WITHOUT a launch of its own behind the four fusion stacks: logits = bias + sum_p W[:, pD:(p+1)D] f_p is linear in
+// the four features, so each stack's chain ends with ITS part -- one wave per sample writes parts[p][b][:] -- and whichever
+// of the nparts launches finishes last adds the parts in index order (deterministic) and writes the logits.  Saves the
+// segment boundary in front of the head: dependent work behind events of three other streams started 15-28 us after the last
+// of them (profiles/r03_timeline.txt, tools/dev/boundary_gap.py).  Hand-over without fences, like the fused layer kernel: the
+// parts leave through system-scope write-through stores (sc0 | sc1), every thread waits for its own acknowledgements
+// (vmcnt(0)), ONE relaxed agent-scope atomic per workgroup counts arrivals, the last arriver reads with loads that bypass the
+// non-coherent caches and re-arms the counter.
+template <int NI>
+__global__ __launch_bounds__(256) void classifier_part_kernel(const float* __restrict__ f, int part, int nparts, int B, int D,
+                                                              const float* __restrict__ W, const float* __restrict__ bias, int NL,
+                                                              float* __restrict__ parts, int* __restrict__ counter,
+                                                              float* __restrict__ logits) {
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(parts, 0, nparts * B * NL * 4, 0x00027000);
+    if (b < B) {
+        const float* fb = f + (size_t)b * D;
+        float x[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) x[i] = lane + 64 * i < D ? fb[lane + 64 * i] : 0.f;
+        for (int n = 0; n < NL; ++n) {
+            const float* w = W + (size_t)n * nparts * D + (size_t)part * D;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) s = fmaf(x[i], lane + 64 * i < D ? w[lane + 64 * i] : 0.f, s);
+            s = wave_sum(s);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s), prs, ((part * B + b) * NL + n) * 4, 0, 17);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = nparts * (int)gridDim.x;
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == total - 1;
+        if (s_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next forward
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < B * NL; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p)
+            s += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (p * B * NL + i) * 4, 0, 17));
+        logits[i] = s + bias[i % NL];
+    }
+}
+
 }  // namespace
 
 extern "C" int mgnns_classifier_head_fwd(const float* f0, const float* f1, const float* f2, const float* f3, int B, int D,
@@ -151,6 +200,23 @@ extern "C" int mgnns_classifier_head_fwd(const float* f0, const float* f1, const
     else
         hipLaunchKernelGGL(classifier_head_kernel<16>, grid, blk, 0, (hipStream_t)stream, f0, f1, f2, f3, B, D, W, bias, NL, logits);
     MG_CHECK_LAUNCH("mgnns_classifier_head_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_classifier_part_fwd(const float* f, int part, int nparts, int B, int D, const float* W, const float* bias,
+                                         int NL, float* parts, int* counter, float* logits, mgnns_stream_t stream) {
+    MG_REQUIRE(B >= 0 && D > 0 && NL > 0 && nparts > 0 && part >= 0 && part < nparts,
+               "mgnns_classifier_part_fwd: bad dims B=%d D=%d NL=%d part=%d/%d", B, D, NL, part, nparts);
+    if (B == 0) return 0;
+    MG_REQUIRE(f && W && bias && parts && counter && logits, "mgnns_classifier_part_fwd: null pointer");
+    MG_REQUIRE(D <= 1024, "mgnns_classifier_part_fwd: feature width %d unsupported (<= 1024)", D);
+    MG_REQUIRE((double)nparts * B * NL * 4 < 2147483648.0, "mgnns_classifier_part_fwd: parts beyond 2 GiB");
+    const dim3 grid((B + 3) / 4), blk(256);
+    if (D <= 320)
+        hipLaunchKernelGGL(classifier_part_kernel<5>, grid, blk, 0, (hipStream_t)stream, f, part, nparts, B, D, W, bias, NL, parts, counter, logits);
+    else
+        hipLaunchKernelGGL(classifier_part_kernel<16>, grid, blk, 0, (hipStream_t)stream, f, part, nparts, B, D, W, bias, NL, parts, counter, logits);
+    MG_CHECK_LAUNCH("mgnns_classifier_part_fwd");
     return 0;
 }
 

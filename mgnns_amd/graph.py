@@ -161,7 +161,10 @@ class GraphedForward:
         model = self.model
         dev = self.static_in[0].device
         self._side = dict(model._side_streams(dev))
-        plan, ctx = model.forward_plan(*self.static_in)
+        # (a `post` step -- the sharded forward's all-gather -- is captured behind the head: keep the head a segment then)
+        plan, ctx = model.forward_plan(*self.static_in, split_head=None if post is None else False)
+        plan = [seg for seg in plan if seg[3] is not None]
+        ctx.prepare()                               # ordinary memory, before any capture (the split head's buffers)
         self._ctx = ctx                             # keeps every cross-segment tensor (graph outputs) alive
         needed = {d for _, _, deps, _ in plan for d in deps}
         self._segs = []

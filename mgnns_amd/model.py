@@ -103,6 +103,14 @@ def _trunk(m):
     return ResNetFeatures(m)
 
 
+class _PlanCtx(dict):
+    """Results of a forward plan's segments by name; prepare(): what must exist before the first segment runs (nothing, or the
+    split classifier head's buffers)."""
+
+    def prepare(self):
+        pass
+
+
 class Multi_GCN_Multihead_Att(nn.Module):
     def __init__(self, opt, num_labels, text_model, object_model, place_model,
                  object_num_classes, place_num_classes, object_t=0, place_t=0, in_channel=300,
@@ -197,6 +205,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.use_streams = bool(opt.get('use_streams', True))
         # 'auto': 'channels' for batches of at least 128 samples, 'channels2' below (resolve_schedule)
         self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'auto'))
+        # the classifier as four shares behind the four stacks instead of a segment of its own (forward_plan)
+        self.split_head = os.environ.get('MGNNS_SPLIT_HEAD', '1') == '1'
         self.fused_label_tail = os.environ.get('MGNNS_FUSED_LABEL_TAIL', '1') == '1'
         self.fused_label_tail_min_batch = int(os.environ.get('MGNNS_FUSED_TAIL_MIN_BATCH', '96'))      # fp32 fused tail (16 CUs per 256 samples)
         # the bf16 fused tail runs as 4-workgroup clusters: it wins at every batch size (B=32: 0.471 -> 0.431 ms, B=16: 0.438 -> 0.419)
@@ -609,7 +619,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
             raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
         return name
 
-    def forward_plan(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp, schedule=None):
+    def forward_plan(self, text, text_lens, text_mask, object_feature, place_feature, object_inp, place_inp, schedule=None,
+                     split_head=None):
         """The forward as SEGMENTS: a list of (name, stream key, names of the segments on OTHER streams it waits for,
         callable) in enqueue order.  The channels and the four fusion stacks are independent of each other
         (MODEL:444-546); each segment is a linear chain of launches on one stream and every cross-stream dependency is
@@ -619,7 +630,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         context dict (ctx['logits'] at the end)."""
         if not self.bidirectional:
             raise NotImplementedError("the HIP text bank implements the bidirectional LSTM the reference configures")
-        ctx = {}
+        ctx = _PlanCtx()
         fused_bf16 = (self.precision in ('bf16', 'bf16x3') and self.fused_label_tail and self.fused_label_tail_bf16
                       and text.shape[0] >= self.fused_label_tail_bf16_min_batch)
 
@@ -687,11 +698,30 @@ class Multi_GCN_Multihead_Att(nn.Module):
                 ops.stamp("%s: label-attention tail end" % tag)
             return run
 
+        # The classifier is linear in the four fusion features: with split_head every stack's chain ends with ITS share of the
+        # logits (ops.classifier_head_part) and the last share to land completes them -- no head segment, i.e. no launch behind
+        # events of three other streams at the very end of the forward (15-28 us in the timelines).  Not with a `post` step
+        # captured behind the head (the sharded forward's all-gather): that needs the head as a segment.
+        if split_head is None:
+            split_head = self.split_head
+        split_head = bool(split_head and self.fused_head)
+        if split_head:
+            # building the plan launches nothing: the executor calls ctx.prepare() on the caller's stream before it forks
+            def prepare():
+                wc, bc = self._head_pack()
+                ctx['_head'] = (wc, bc, ops.classifier_head_state(text.shape[0], wc.shape[0], 4, wc.device))
+                ctx['logits'] = ctx['_head'][2][2]
+            ctx.prepare = prepare
+        part_of = {"tio": 0, "tip": 1, "iot": 2, "ipt": 3}                # order of the reference's torch.cat (MODEL:560)
+
         def stack(name, layers, q_key, bank_key, masked):
             def run():
                 ops.stamp("%s stack start" % name)
                 ctx[name] = run_stack(layers, ctx[q_key], ctx[bank_key], ctx['text_mask'] if masked else None,
                                       qh=ctx.get('qh_' + name))
+                if split_head:
+                    wc, bc, hstate = ctx['_head']
+                    ops.classifier_head_part(ctx[name], part_of[name], 4, wc, bc, hstate)
                 ops.stamp("%s stack end" % name)
             return run
 
@@ -723,7 +753,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # image->text stacks need the text bank (and the mask cast next to it) and the channel's tail
             "iot": stack("iot", self.img_object_text_multi_head_att, 'att_obj', 'text_bank', True),
             "ipt": stack("ipt", self.img_place_text_multi_head_att, 'att_place', 'text_bank', True),
-            "head": head,
+            "head": None if split_head else head,       # (None: nothing left to launch)
         }
         sched = self.SCHEDULES[self.resolve_schedule(text.shape[0], schedule)]
         where, plan = {}, []
@@ -746,12 +776,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
         streams = dict(side, main=main)
         for k in {k for _, k in self.SCHEDULES[self.resolve_schedule(args[0].shape[0])]}:
             streams.setdefault(k, main)              # use_streams = False: everything on the caller's stream
+        plan, ctx = self.forward_plan(*args)
+        ctx.prepare()                                # (the split head's zeroed counter: on `main`, before the fork)
         for st in side.values():
             st.wait_stream(main)                     # the caller produced the inputs on `main`
-        plan, ctx = self.forward_plan(*args)
         needed = {d for _, _, deps, _ in plan for d in deps}
         done = {}
         for name, skey, deps, fn in plan:
+            if fn is None:
+                continue
             st = streams[skey]
             for d in deps:
                 if done[d][1] is not st:

@@ -153,6 +153,30 @@ def classifier_head(feats, weight, bias):
     return out
 
 
+def classifier_head_state(B, NL, nparts, device):
+    """Buffers of one forward's split classifier head (classifier_head_part): parts [nparts,B,NL], arrival counter (zero),
+    logits [B,NL]."""
+    return (torch.empty(nparts, B, NL, device=device, dtype=torch.float32), torch.zeros(1, device=device, dtype=torch.int32),
+            torch.empty(B, NL, device=device, dtype=torch.float32))
+
+
+def classifier_head_part(feat, part, nparts, weight, bias, state):
+    """This feature's share of logits = cat(feats) @ weight.T + bias (mgnns_classifier_part_fwd): call once per feature, from
+    whichever stream produced it; the call that finishes last completes state[2] (the logits)."""
+    _chk(feat, "feature", ndim=2)
+    _chk(weight, "weight", ndim=2)
+    _chk(bias, "bias", ndim=1)
+    B, D = feat.shape
+    parts, counter, logits = state
+    NL = weight.shape[0]
+    if weight.shape[1] != nparts * D or tuple(parts.shape) != (nparts, B, NL) or tuple(logits.shape) != (B, NL):
+        raise ValueError("classifier_head_part: weight %s / state do not match %d features [B=%d,%d]" % (tuple(weight.shape), nparts, B, D))
+    L = _lib.lib()
+    _lib.check(L.mgnns_classifier_part_fwd(_p(feat), int(part), int(nparts), B, D, _p(weight), _p(bias), NL, _p(parts), _p(counter),
+                                           _p(logits), _stream()), "mgnns_classifier_part_fwd")
+    return logits
+
+
 def matmul(x, w, act=ACT_NONE):
     """act(x @ w); x [M, K], w [K, N] (GraphConvolution weight layout)."""
     _chk(x, "x", ndim=2)

@@ -642,6 +642,34 @@ def test_imgbank_pool_bf16(form, B, P, K):
         print("bf16 bank max abs err vs fp32: %.3e (|bank| max %.2f)" % (H.maxabs(got, ref32), float(ref32.abs().max())))
 
 
+@pytest.mark.parametrize("B,D,NL", [(1, 300, 3), (37, 300, 3), (256, 300, 3), (9, 512, 7)])
+def test_classifier_head_as_four_shares_equals_the_single_launch(B, D, NL):
+    """mgnns_classifier_part_fwd: the four shares launched from four streams in any order complete the same logits as the
+    one-launch classifier (fp32 association differs: 1e-5), launch after launch on the same buffers (the last share re-arms
+    the arrival counter), and bit-identically whichever share lands last."""
+    rs = np.random.RandomState(B + D)
+    feats = [dev(rs.standard_normal((B, D)).astype(np.float32)) for _ in range(4)]
+    w = dev((0.05 * rs.standard_normal((NL, 4 * D))).astype(np.float32))
+    bias = dev(rs.standard_normal(NL).astype(np.float32))
+    ref = ops.classifier_head(feats, w, bias)
+    state = ops.classifier_head_state(B, NL, 4, w.device)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    first = None
+    for order in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3]):
+        torch.cuda.synchronize()
+        state[2].fill_(float("nan"))
+        torch.cuda.synchronize()
+        for p in order:
+            with torch.cuda.stream(streams[p]):
+                ops.classifier_head_part(feats[p], p, 4, w, bias, state)
+        torch.cuda.synchronize()
+        assert int(state[1].item()) == 0
+        assert H.maxabs(state[2].cpu(), ref.cpu()) < 1e-5
+        if first is None:
+            first = state[2].clone()
+        assert torch.equal(state[2], first)
+
+
 def test_imgbank_forms_agree_at_full_batch_and_repeat():
     """configs[2]'s bank shape (256 x 2048 x 196): the stream form (counted waits on two in-order request streams per workgroup)
     gives the same bits launch after launch with every compute unit busy, and agrees with the pair form (same products, same
