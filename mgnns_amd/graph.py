@@ -164,6 +164,20 @@ class GraphedForward:
         # (a `post` step -- the sharded forward's all-gather -- is captured behind the head: keep the head a segment then)
         plan, ctx = model.forward_plan(*self.static_in, split_head=None if post is None else False)
         plan = [seg for seg in plan if seg[3] is not None]
+        # Consecutive segments of ONE stream become one graph when nothing has to happen between them: the later one waits
+        # for no other stream, and no other stream waits for the earlier one (an event cannot be recorded inside a graph).
+        # E.g. a channel's label GCN + memory bank: one graph launch and one boundary less on the bank -> tail -> stack chain.
+        merged = []
+        for name, skey, deps, fn in plan:
+            prev = next((m for m in reversed(merged) if m[1] == skey), None)
+            prev_needed_elsewhere = prev is not None and any(prev[0][-1] in d and k != skey for _, k, d, _ in plan)
+            if prev is not None and not deps and not prev_needed_elsewhere and merged[-1] is prev:
+                prev[0].append(name)
+                prev[3].append(fn)
+            else:
+                merged.append(([name], skey, deps, [fn]))
+        plan = [(names[-1], skey, deps, (lambda fs=fns: [f() for f in fs])) for names, skey, deps, fns in merged]
+        self.segment_names = [names for names, _, _, _ in merged]
         ctx.prepare()                               # ordinary memory, before any capture (the split head's buffers)
         self._ctx = ctx                             # keeps every cross-segment tensor (graph outputs) alive
         needed = {d for _, _, deps, _ in plan for d in deps}
