@@ -10,7 +10,8 @@ Two capture modes:
 * ``mode="segments"`` (default): the model's forward_plan() -- 13 segments, each a LINEAR chain of launches on one of
   four streams -- is captured as one linear hipGraph per segment; a replay launches them on the model's four streams
   with the plan's event waits in between.  Who runs concurrently with whom is then decided by four in-order HIP
-  streams, exactly as in eager execution, at ~11 graph launches per forward instead of ~130 kernel launches.
+  streams, exactly as in eager execution, at ~10 graph launches per forward instead of ~36 kernel launches (consecutive
+  segments of one stream with nothing between them share a graph; the classifier head rides at the end of the four stacks).
 * ``mode="single"``: the whole multi-stream forward as ONE graph with four parallel branches.  The graph runtime maps
   branches onto its own internal streams; on this stack it ran at most three of the four fusion-stack chains at a
   time (tools/graph_timeline.py: the fourth started when a sibling had finished, ~200 us late) and the result moved
