@@ -57,6 +57,9 @@ def parse_args(argv=None):
                                                                "configs[4] stress, CNN trunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="forwards in flight: captures of the forward replayed round robin without a join between them "
+                         "(mgnns_amd.graph.GraphedPipeline); 1 = one capture, every replay joins the four streams before the next")
     ap.add_argument("--single-stream", action="store_true",
                     help="with --no-graph: every kernel on one stream (no concurrent kernels) -- the setting the rocprofv3 "
                          "per-kernel averages under profiles/ are taken in, comparable with roofline.avg_launch_ms")
@@ -571,7 +574,7 @@ def text_pipeline_leg(dev):
 
 def graphed_variant(model, call, B, steps, warmup, what):
     import torch
-    from mgnns_amd.graph import GraphedForward
+    from mgnns_amd.graph import GraphedForward, GraphedPipeline
     gv = GraphedForward(model, call)
     for _ in range(warmup):
         vout = gv.replay()
@@ -581,7 +584,7 @@ def graphed_variant(model, call, B, steps, warmup, what):
         vout = gv.replay()
     torch.cuda.synchronize()
     dv = (time.perf_counter() - tv) / steps
-    return {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "what": what,
+    return {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "forwards_in_flight": 1, "what": what,
             "_out": vout[:B].float().cpu()}
 
 
@@ -684,7 +687,7 @@ def run_rank(args):
     import numpy as np
     import torch
     from mgnns_amd import harness, ops, synth
-    from mgnns_amd.graph import GraphedForward
+    from mgnns_amd.graph import GraphedForward, GraphedPipeline
     from mgnns_amd.sharded import ShardedForward, shard_bounds
 
     torch.cuda.set_device(local_rank)
@@ -744,45 +747,69 @@ def run_rank(args):
             raise SystemExit("strong scaling needs the global batch %d divisible by %d ranks" % (GLOBAL_BATCH, world))
         call = harness.call_args(inp, dev)
         launch = "eager"
+        pipe = None
         if args.no_graph:
             fwd = ShardedForward(lambda *a: model(*a), comm=comm)
         else:
             sf = ShardedForward(lambda *a: gf.replay(), comm=comm)
             gf, fwd = None, None
+            depth = max(1, args.in_flight) if getattr(model, "use_streams", True) else 1
             if dist is not None and graph_collective:
                 try:                                  # the logits all-gather as a node of the same graph
-                    gf = GraphedForward(model, call, post=sf.gather, settle=False)
+                    caps = [GraphedForward(model, call, post=sf.gather, settle=False, mode="segments" if depth > 1 else None)
+                            for _ in range(depth)]
                 except Exception as e:                # capture of the collective refused: gather right behind the replay
                     print("collective capture failed (%s: %s); gathering after the replay" % (type(e).__name__, e), file=sys.stderr)
-                    gf = None
+                    caps = None
                 # every rank takes the SAME path: a rank whose capture failed would otherwise issue no all-gathers in the
                 # settle / warm-up replays the others run, and the RCCL sequences would never match again
-                ok = torch.tensor([0 if gf is None else 1], device=dev)
+                ok = torch.tensor([0 if caps is None else 1], device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()):
-                    gf.settle()
+                    for c in caps:
+                        c.settle()
+                    gf = caps[0]
                     fwd = lambda *a: gf.replay()
                     launch = "hipGraph replay (RCCL all-gather captured)"
+                    if depth > 1:
+                        pipe = GraphedPipeline.of(caps)
                 else:
                     gf = None
             if gf is None:
-                gf = GraphedForward(model, call)      # inputs are resident in the graph's static buffers
+                gf = GraphedForward(model, call, mode="segments" if (depth > 1 and dist is None) else None)      # inputs are resident in the graph's static buffers
                 fwd = sf
                 launch = "hipGraph replay" + ((" + %s all-gather behind it" % ("RCCL" if backend == "nccl" else backend)) if dist is not None else "")
+                if depth > 1 and dist is None:        # (a gather BEHIND the replay joins the streams anyway: one capture then)
+                    pipe = GraphedPipeline.of([gf] + [GraphedForward(model, call, mode="segments") for _ in range(depth - 1)])
             launch += " [%s%s]" % (gf.mode, "; auto timed %s ms" % gf.pick_ms if gf.pick_ms else "")
+            if pipe is not None:
+                launch += " x %d in flight (captures with buffers of their own, replayed round robin without a join)" % depth
         out = {}
 
-        def step():
+        def step_serial():
             out["logits"] = fwd(*call)
 
+        def step():
+            if pipe is None:
+                return step_serial()
+            out["logits"] = pipe.replay().static_out
+
+        serial = None
         with torch.no_grad():
+            if pipe is not None:
+                # the same forward one at a time (every replay joins the four streams before the next starts): reported next
+                # to the headline as `serial_replay`
+                ds = timed_steps(step_serial, args.steps, args.warmup, barrier)
+                ds, _ = max_over_ranks(ds, dist, dev)
+                serial = {"ms_per_step": round(ds / args.steps * 1e3, 4), "value": round(world * b_local / (ds / args.steps), 1),
+                          "unit": "samples/s", "what": "one forward in flight: a join of the four streams between replays"}
             # after the warm-up: RCCL's banner out of every rank's C stdio buffer, long before the JSON line
             dt = timed_steps(step, args.steps, args.warmup, barrier, flush_c_stdio if dist is not None else None)
         dt, dts = max_over_ranks(dt, dist, dev)
         total = world * b_local
         return {"inp": inp, "call": call, "b_local": b_local, "dt": dt, "dt_ranks": dts, "launch": launch,
                 "value": total / (dt / args.steps), "ms": dt / args.steps * 1e3, "global_batch": total,
-                "logits": out["logits"]}
+                "logits": out["logits"], "serial": serial, "in_flight": 1 if pipe is None else len(pipe.items)}
 
     if os.environ.get("MGNNS_BENCH_ORDER") == "strong_first" and world > 1:      # test hook: order effects
         strong = measure("strong")
@@ -915,6 +942,9 @@ def run_rank(args):
                                   else "RCCL all-gather via torch.distributed" if backend == "nccl" else backend)},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
+    line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
+    if head.get("serial"):
+        line["serial_replay"] = head["serial"]
     if strong is not None:
         for nm, r in (("weak_scaling", weak), ("strong_scaling", strong)):
             line[nm] = {"value": round(r["value"], 1), "unit": "samples/s", "ms_per_step": round(r["ms"], 4),

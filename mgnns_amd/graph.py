@@ -235,9 +235,90 @@ class GraphedForward:
             main.wait_stream(st)
         return self._seg_out
 
+    def replay_async(self, inputs_ready=None):
+        """Replay WITHOUT the end-of-forward join (segments mode): the caller's stream is not made to wait for the side streams,
+        so the next replay of ANOTHER GraphedForward (buffers of its own) can start on a stream as soon as that stream's own
+        work of this one is done -- two forwards in flight (GraphedPipeline).  Each stream first waits for the end of THIS
+        instance's previous replay on the other streams (its buffers are reused) and for `inputs_ready` (an event behind
+        copy_inputs; None: the static inputs are unchanged).  Returns the static logits; wait() before reading them."""
+        if self.mode == "single":
+            raise RuntimeError("replay_async needs one graph per segment (mode 'segments')")
+        main = torch.cuda.current_stream()
+        streams = dict(self._side, main=main)
+        if not hasattr(self, "_end"):
+            self._end = {k: torch.cuda.Event() for k in streams}
+        for skey, st in streams.items():
+            for k2, ev in self._end.items():
+                if k2 != skey:
+                    st.wait_event(ev)
+            if inputs_ready is not None:
+                st.wait_event(inputs_ready)
+        done = {}
+        for name, skey, deps, g, ev in self._segs:
+            st = streams[skey]
+            for d in deps:
+                if done[d][1] is not st:
+                    st.wait_event(done[d][0])
+            with torch.cuda.stream(st):
+                g.replay()
+                if ev is not None:
+                    ev.record(st)
+                    done[name] = (ev, st)
+        for skey, st in streams.items():
+            self._end[skey].record(st)
+        return self._seg_out
+
+    def wait(self):
+        """Make the caller's stream wait for the last replay_async()."""
+        main = torch.cuda.current_stream()
+        for ev in getattr(self, "_end", {}).values():
+            main.wait_event(ev)
+
     def __call__(self, *args):
         self.copy_inputs(*args)
         return self.replay()
+
+
+class GraphedPipeline:
+    """`depth` captures of the same forward (buffers of their own, the model's four streams shared), replayed round robin
+    without a join between them: while the fusion stacks of one batch still run on three streams, the BiLSTM chain / memory
+    banks of the next start on the streams that are done -- the seam between two forwards (join, fork, first graph launch:
+    ~33 us of a 0.76-ms forward in profiles/r03_timeline.txt) and the idle compute units at both ends of a forward are filled
+    with the neighbouring batch's work.  Throughput, not latency: every forward still does all of its work on its own batch."""
+
+    def __init__(self, model, example_args, depth=2, **kw):
+        self.items = [GraphedForward(model, example_args, mode="segments", **kw) for _ in range(depth)]
+        self.i = 0
+
+    @classmethod
+    def of(cls, items):
+        """From existing captures (mode 'segments') of the same forward."""
+        if any(it.mode != "segments" for it in items):
+            raise ValueError("GraphedPipeline needs captures with one graph per segment")
+        self = cls.__new__(cls)
+        self.items, self.i = list(items), 0
+        return self
+
+    def copy_inputs(self, *args):
+        """New inputs for the NEXT replay (on the caller's stream); returns the event the replay must wait for."""
+        self.items[self.i].wait()                   # its previous replay may still be reading the static inputs
+        self.items[self.i].copy_inputs(*args)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def replay(self, inputs_ready=None):
+        """Start the next forward; returns its GraphedForward (item.wait() orders the caller's stream behind it, its
+        static_out holds the logits)."""
+        it = self.items[self.i]
+        self.i = (self.i + 1) % len(self.items)
+        it.replay_async(inputs_ready)
+        return it
+
+    def wait(self):
+        for it in self.items:
+            it.wait()
+
 
 
 def _probe_single_main(schedule):

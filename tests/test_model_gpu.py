@@ -174,6 +174,38 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
         assert torch.equal(gf(*a1), ref1)
 
 
+def test_pipelined_replays_two_forwards_in_flight_equal_serial_ones():
+    """GraphedPipeline: captures with buffers of their own replayed round robin WITHOUT a join between them (the next batch
+    starts on a stream as soon as that stream is done with the current one) give, batch by batch, the bits of the serial
+    forward -- alternating inputs copied in behind an event, three captures deep, both precisions; an instance reused while its
+    previous replay may still be running waits for it."""
+    from mgnns_amd.graph import GraphedPipeline
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    sets = [call_args(synth.make_inputs(cfg, B=16, seed=s, pmi=pmi), DEV) for s in (1, 2, 3, 4, 5)]
+    for prec in ("fp32", "bf16"):
+        model.set_precision(prec)
+        refs = [model(*a).clone() for a in sets]
+        for depth in (2, 3):
+            pipe = GraphedPipeline(model, sets[0], depth=depth)
+            outs = []
+            for rep in range(2):
+                for a in sets:
+                    it = pipe.replay(pipe.copy_inputs(*a))
+                    outs.append((it, len(outs) % len(sets)))
+                    if len(outs) >= depth:                       # the instance about to be reused: read its result first
+                        old, k = outs[len(outs) - depth]
+                        old.wait()
+                        assert torch.equal(old.static_out, refs[k]), (prec, depth, rep, k)
+            pipe.wait()
+            torch.cuda.synchronize()
+            for old, k in outs[-depth:]:
+                assert torch.equal(old.static_out, refs[k])
+
+
 def test_every_schedule_gives_the_same_logits_eager_and_graphed():
     """The schedules only place the forward's segments on streams: same kernels, same operands -> bit-equal logits, eager and
     as per-segment hipGraphs; 'auto' resolves by batch size; the one-graph form of a schedule is only attempted after a CHILD
