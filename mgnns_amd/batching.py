@@ -154,6 +154,48 @@ class PipelinedForward:
             if nxt is None:
                 return i
 
+    def run_in_flight(self, pipeline, batches, from_ids=False, on_logits=None):
+        """run() on a graph.GraphedPipeline: batch i is launched on a capture of its own without joining the streams behind
+        batch i-1 (two forwards in flight); on_logits(i-1, logits) runs -- on the caller's stream, behind a wait for that
+        capture -- AFTER batch i has been launched, so the consumer never holds up the next launch."""
+        main = torch.cuda.current_stream()
+        it = iter(batches)
+        try:
+            nxt = next(it)
+        except StopIteration:
+            return 0
+        self._stage(0, nxt, from_ids)
+        i, pending = 0, None
+        while True:
+            k = i & 1
+            try:
+                nxt = next(it)
+            except StopIteration:
+                nxt = None
+            item = pipeline.items[pipeline.i]
+            item.wait()                              # its previous replay may still be reading its static inputs
+            main.wait_event(self.h2d_done[k])
+            text, lens, mask = self.asm[k].dev
+            item.static_in[0].copy_(text, non_blocking=True)
+            item.static_in[1].copy_(lens, non_blocking=True)
+            item.static_in[2].copy_(mask, non_blocking=True)
+            self.consumed[k].record(main)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            pipeline.replay(ready)
+            if nxt is not None:
+                self._stage(k ^ 1, nxt, from_ids)    # overlaps the replay just enqueued
+            if pending is not None and on_logits is not None:
+                pending[1].wait()
+                on_logits(pending[0], pending[1].static_out)
+            pending = (i, item)
+            i += 1
+            if nxt is None:
+                if on_logits is not None:
+                    pending[1].wait()
+                    on_logits(pending[0], pending[1].static_out)
+                return i
+
     def run_serial(self, batches, from_ids=False, on_logits=None):
         """The same work without overlap (assemble -> blocking H2D -> replay -> wait), the reference's order."""
         i = 0

@@ -19,7 +19,7 @@ def measure(dev="cuda:0", n_batches=60, B=256, dtype="bf16"):
     import torch
     from mgnns_amd import harness, synth
     from mgnns_amd.batching import PipelinedForward, TokenCache
-    from mgnns_amd.graph import GraphedForward
+    from mgnns_amd.graph import GraphedForward, GraphedPipeline
     from mgnns_amd.pmi import build_pmi
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hostside.npz")
     g = np.load(golden)
@@ -52,6 +52,30 @@ def measure(dev="cuda:0", n_batches=60, B=256, dtype="bf16"):
         dt = time.perf_counter() - t0
         res[name] = {"samples_per_s": round(n * B / dt, 1), "ms_per_batch": round(dt / n * 1e3, 4)}
         sums[name] = acc.cpu().tolist()
+    # two forwards in flight (graph.GraphedPipeline): the host pipeline feeding captures with buffers of their own
+    gp = GraphedPipeline.of([gf, GraphedForward(model, harness.call_args(inp, dev), mode="segments")]) if gf.mode == "segments" else None
+    if gp is not None:
+        for name, src, ids in (("in_flight2_cached_ids", id_batches, True),):
+            acc = torch.zeros(cfg.NL, device=dev, dtype=torch.float64)
+            hook = lambda i, out: acc.add_(out.double().sum(0))
+            pipe.run_in_flight(gp, src(), from_ids=ids, on_logits=hook)
+            torch.cuda.synchronize()
+            acc.zero_()
+            t0 = time.perf_counter()
+            n = pipe.run_in_flight(gp, src(), from_ids=ids, on_logits=hook)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[name] = {"samples_per_s": round(n * B / dt, 1), "ms_per_batch": round(dt / n * 1e3, 4)}
+            sums[name] = acc.cpu().tolist()
+        for _ in range(6):
+            gp.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_batches):
+            gp.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["device_only_in_flight2"] = {"samples_per_s": round(n_batches * B / dt, 1), "ms_per_batch": round(dt / n_batches * 1e3, 4)}
     # device-only rate of the same forward (inputs resident): the ceiling
     for _ in range(5):
         gf.replay()
