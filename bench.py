@@ -50,9 +50,11 @@ def parse_args(argv=None):
                     help="which figure is the headline `value` at N>1 (both are always measured)")
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
-    ap.add_argument("--attn", default="faithful", choices=["faithful", "folded"],
-                    help="faithful = K/V projected from the memory bank as the reference does (the headline number); "
-                         "folded = the projections folded into the query side (separately reported variant)")
+    ap.add_argument("--attn", default="auto", choices=["auto", "faithful", "folded"],
+                    help="fusion attention: folded = the projections folded away algebraically (one read of the memory bank); "
+                         "faithful = K/V projected from the memory bank as the reference does (the kernels the north-star's MFMA "
+                         "figure is quoted on; always reported next to the headline as a variant and in roofline_all); "
+                         "auto = the model's default: folded in bf16 mode, faithful in fp32 mode")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra legs (fp32 parity mode, folded attention, "
                                                                "configs[4] stress, CNN trunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -572,10 +574,10 @@ def text_pipeline_leg(dev):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def graphed_variant(model, call, B, steps, warmup, what):
+def graphed_variant(model, call, B, steps, warmup, what, in_flight=1):
     import torch
     from mgnns_amd.graph import GraphedForward, GraphedPipeline
-    gv = GraphedForward(model, call)
+    gv = GraphedForward(model, call, mode="segments" if in_flight > 1 else None)
     for _ in range(warmup):
         vout = gv.replay()
     torch.cuda.synchronize()
@@ -584,8 +586,23 @@ def graphed_variant(model, call, B, steps, warmup, what):
         vout = gv.replay()
     torch.cuda.synchronize()
     dv = (time.perf_counter() - tv) / steps
-    return {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "forwards_in_flight": 1, "what": what,
-            "_out": vout[:B].float().cpu()}
+    r = {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "forwards_in_flight": 1, "what": what,
+         "_out": vout[:B].float().cpu()}
+    if in_flight > 1:       # the same measurement as the headline: captures with buffers of their own, replayed without a join
+        pipe = GraphedPipeline.of([gv] + [GraphedForward(model, call, mode="segments") for _ in range(in_flight - 1)])
+        for _ in range(warmup):
+            pipe.replay()
+        pipe.wait()
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(steps):
+            pipe.replay()
+        pipe.wait()
+        torch.cuda.synchronize()
+        dp = (time.perf_counter() - tv) / steps
+        r["serial_replay"] = {"value": r["value"], "ms_per_step": r["ms_per_step"]}
+        r.update({"value": round(B / dp, 1), "ms_per_step": round(dp * 1e3, 4), "forwards_in_flight": in_flight})
+    return r
 
 
 def roofline_all(timer, cfg, B, P, inp, dtype, model):
@@ -621,6 +638,17 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
         mha_core_flops(B, T, D, H, dk), "FLOPs counted over all T rows; masked row tiles are skipped, so this can exceed "
                                         "the unmasked figure")
     if bf:
+        for L_, nm in ((P, "image bank"), (T, "text bank, masked")):
+            add("sq_mha_folded_bf16 (L=%d %s)" % (L_, nm), ("mgnns_sq_mha_folded_bf16_fwd", L_), "hbm",
+                B * (L_ * 320 * 2.0 + H * D * 4 + H * D * 2),
+                "folded attention: one read of the bf16 bank [B, L, 320] + the composed query rows in, the weighted bank rows out"
+                + ("; bytes counted over all T rows, masked row tiles are never read" if L_ == T else ""),
+                pmc_key="folded_attn_bf16@L%d" % L_ if L_ == P else None)
+        add("mha_tail_c16", ("mgnns_mha_tail_c16_fwd",), "mfma_bf16",
+            B * 2.0 * (H * D * D + 2 * D * D) + B * 2.0 * D * H * D / 2,
+            "the layer tail behind the folded attention: composed output map (H*D -> D) + FFN per launch; the next layer's "
+            "composed query map (D -> H*D) is fused into every other launch (averaged in); bound by streaming the packed "
+            "weights from L2 (1.44 MB per composed map), not by the matrix pipe")
         add("imgbank_pool_bf16", ("mgnns_imgbank_pool_bf16_fwd",), "hbm", B * (2048.0 * P * 4 + P * D * 2 + 2048 * 4),
             "fp32 map read once + bf16 bank + pooled row written", pmc_key="imgbank_pool_bf16@B%d" % B)
         add("mha_tail_bf16", ("mgnns_mha_tail_bf16_fwd",), "mfma_bf16",
@@ -710,11 +738,13 @@ def run_rank(args):
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, label_query, dev)
     model.set_precision("bf16" if args.dtype == "bf16" else "fp32")
     model.set_attention(args.attn)
+    attn = model.attention                         # 'auto' resolved: folded in bf16 mode, faithful in fp32 mode
+    folded_c16 = attn == "folded" and args.dtype == "bf16"      # the composed-map kernels (sq_mha_folded_bf16.hip + the c16 tail)
     if args.single_stream:
         model.use_streams = False
     core = "mgnns_sq_mha_core_bf16_fwd" if args.dtype == "bf16" else "mgnns_sq_mha_core_fwd"
-    if args.attn == "folded":
-        core = "mgnns_sq_mha_folded_fwd"
+    if attn == "folded":
+        core = "mgnns_sq_mha_folded_bf16_fwd" if folded_c16 else "mgnns_sq_mha_folded_fwd"
 
     def barrier():
         if dist is not None:
@@ -830,6 +860,11 @@ def run_rank(args):
         for _ in range(3):          # the label GCN as separate operators (gen_adj / GEMM / CSR SpMM): their own roofline rows
             model._label_gcn(model.object_A, call[5])
             model._label_gcn(model.place_A, call[6])
+        if attn == "folded":        # the reference's own formulation too: the MFMA rows of roofline_all are measured on it
+            model.set_attention("faithful")
+            for _ in range(min(args.steps, 5)):
+                model(*call)
+            model.set_attention(args.attn)
     torch.cuda.synchronize()
     model.use_streams = not args.single_stream
     ops.set_timer(None)
@@ -839,13 +874,20 @@ def run_rank(args):
     single = world == 1 and dist is None
     if single and not args.no_variants and not args.no_graph:
         with torch.no_grad():
-            if args.attn == "faithful":
+            if attn == "faithful":
                 model.set_attention("folded")
                 variants["attention=folded"] = graphed_variant(
                     model, call, B, args.steps, args.warmup,
-                    "same step, fusion attention with the K/V projections folded into the query (csrc/sq_mha_folded.hip); "
-                    "not the formulation the MFMA target is quoted on")
+                    "same step, fusion attention with the projections folded away algebraically (bf16 mode: "
+                    "csrc/sq_mha_folded_bf16.hip + the c16 tail; fp32 mode: csrc/sq_mha_folded.hip): one read of the memory bank "
+                    "instead of the K/V projection GEMMs", in_flight=max(1, args.in_flight))
+            else:
                 model.set_attention("faithful")
+                variants["attention=faithful (the north-star's MFMA formulation)"] = graphed_variant(
+                    model, call, B, args.steps, args.warmup,
+                    "same step with K and V projected from the memory bank as the reference does (csrc/sq_mha_bf16.hip: the kernel "
+                    "the >= 40 % MFMA target is quoted on; its rows in roofline_all)", in_flight=max(1, args.in_flight))
+            model.set_attention(args.attn)
             if args.dtype == "bf16":
                 model.set_precision("fp32")
                 variants["dtype=f32 (parity-grade)"] = graphed_variant(
@@ -858,7 +900,7 @@ def run_rank(args):
                     "same step with every heavy product in split-bf16 (bf16 hi + lo operands, three bf16 MFMAs per product, fp32 "
                     "accumulation: image banks, label GCN, channel and layer tails), exact fp32 LSTM and the exact-fp32 folded "
                     "attention: inside the 1e-4 logit gate (tests/test_model_gpu.py) without the exact-f32 MFMA's 1/16 rate")
-                model.set_precision("bf16").set_attention("faithful")
+                model.set_precision("bf16").set_attention(args.attn)
         # the per-GPU shards of a strong-scaling run (global batch 256 over 2 / 4 / 8 GPUs), measured here on one GPU: what the
         # 1 -> 8 curve of configs[3] is bounded by while no multi-GPU node has run it
         small = {"what": "ms per forward of a 128 / 64 / 32-sample shard on ONE GPU (hipGraph replay): global batch 256 over "
@@ -879,11 +921,26 @@ def run_rank(args):
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: the image-bank fused MHA launches (L = 196, unmasked) ----
+    # ---- roofline of the dominant kernel (largest share of the forward's CU time) ----
     P = inp["object_feature"].shape[2] * inp["object_feature"].shape[3]
-    durs = timer.durations_ms().get((core, P, False), [])
     roofline = None
-    if args.attn == "folded":
+    if folded_c16:
+        # folded attention: the K/V projection GEMMs are gone and the image-bank kernel (2 launches x 256 CUs x ~90 us of a
+        # ~0.6 ms forward) is the largest block; HBM-bound on one read of the fp32 feature map
+        durs = timer.durations_ms().get(("mgnns_imgbank_pool_bf16_fwd",), [])
+        if durs:
+            avg_ms = float(np.mean(durs))
+            by = B * (2048.0 * P * 4 + P * cfg.emb_size * 2 + 2048 * 4)
+            roofline = {"bound": "hbm", "kernel": "imgbank_pool_bf16_kernel (B=%d, %d positions x 2048 -> 300)" % (B, P),
+                        "achieved": round(by / (avg_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(by / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs), "bytes_per_launch": by}
+            if B == GLOBAL_BATCH:
+                tr, src = pmc_traffic("imgbank_pool_bf16@B%d" % B)
+                roofline["traffic"] = tr
+                if src:
+                    roofline["traffic_source"] = src
+    elif attn == "folded":
         # three launches per call (U = qh.Wk, the bank pass, o = C.Wv^T); the bank pass is HBM-bound on one read of the bank
         is_bf16 = args.dtype == "bf16"
         durs = timer.durations_ms().get((core, P, is_bf16), [])
@@ -894,22 +951,24 @@ def run_rank(args):
                         "achieved": round(by / (avg_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(by / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs), "bytes_per_launch": by}
-    elif durs:
-        avg_ms = float(np.mean(durs))
-        fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
-        ach = fl / (avg_ms * 1e-3) / 1e12
-        kname = "sq_mha_core_bf16_kernel" if args.dtype == "bf16" else "sq_mha_core_kernel"
-        roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % (kname, P, cfg.n_head),
-                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),
-                    "flops_per_launch": fl}
-        if B == GLOBAL_BATCH:
-            tr, src = pmc_traffic("%s@L%d" % (kname, P))
-            roofline["traffic"] = tr
-            if src:
-                roofline["traffic_source"] = src
-    rall = roofline_all(timer, cfg, B, P, inp, args.dtype, model) if args.attn == "faithful" else None
+    else:
+        durs = timer.durations_ms().get((core, P, False), [])
+        if durs:
+            avg_ms = float(np.mean(durs))
+            fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            kname = "sq_mha_core_bf16_kernel" if args.dtype == "bf16" else "sq_mha_core_kernel"
+            roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % (kname, P, cfg.n_head),
+                        "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(durs),
+                        "flops_per_launch": fl}
+            if B == GLOBAL_BATCH:
+                tr, src = pmc_traffic("%s@L%d" % (kname, P))
+                roofline["traffic"] = tr
+                if src:
+                    roofline["traffic_source"] = src
+    rall = roofline_all(timer, cfg, B, P, inp, args.dtype, model)
 
     cpu = None
     parity = None
@@ -937,7 +996,10 @@ def run_rank(args):
                                "feature maps [B,2048,14,14] fp32 resident in HBM, logits all-gathered"
                                % (cfg.name, head["b_local"], cfg.T, cfg.V, cfg.n_head, cfg.stack_num, cfg.C_obj, cfg.C_place),
                    "global_batch": head["global_batch"], "parallelism": "batch-shard x%d" % world,
-                   "launch": head["launch"], "attention": args.attn,
+                   "launch": head["launch"],
+                   "attention": attn + (" (K/V and query/output projections composed into the maps either side of the attention: "
+                                        "one read of the memory bank per layer; the reference's explicit formulation is "
+                                        "variants['attention=faithful ...'])" if folded_c16 else ""),
                    "collective": (None if dist is None else "RCCL all-gather via the C ABI (mgnns_allgather_logits)" if comm is not None
                                   else "RCCL all-gather via torch.distributed" if backend == "nccl" else backend)},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,

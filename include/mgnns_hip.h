@@ -311,6 +311,19 @@ int mgnns_sq_mha_folded_fwd(const float* qh, const void* bank, int bank_is_bf16,
                             int B, int L, int D, int H, int dk, const float* Wk, const float* Wv, const float* bv,
                             void* workspace, size_t workspace_bytes, float* o, float* attn, mgnns_stream_t stream);
 
+/* ---- a8, folded variant on the bf16 matrix pipe (bf16 precision mode) ----------------------------------------------
+ * The same attention (submodules.py:55-119, len_q == 1) with ALL FOUR projections composed into the maps either side of it
+ * (the host mirror builds them once per weight version, fusion.py):
+ *   u_h = (Wk_h^T Wq_h) x + Wk_h^T bq_h                                     -- the previous tail's "next projection"
+ *   p   = softmax_l(u_h . bank[b,l,:] / sqrt(dk)) (masked);   c_h = sum_l p_l bank[b,l,:]            -- this kernel
+ *   fc(o) = sum_h (fc_h Wv_h) c_h + (fc bv + b_fc)                          -- the tail's first map (mgnns_mha_tail_c16_fwd)
+ * U: fp32 [B, H*D] (head h at h*D); bank: bf16 [B, L, 320] zero padded; mask: fp32 [B, L] (0 = masked) or NULL;
+ * C: bf16 [B, ldc] (ldc >= H*D, ldc % 8 == 0; head h at h*D, zeros behind H*D -- ldc = H*D rounded up to 32 is what
+ * mgnns_mha_tail_c16_fwd takes); attn: fp32 [H*B, L] or NULL.  D <= 320, D % 4 == 0, H <= 8, L <= 208.  One read of the bank.
+ */
+int mgnns_sq_mha_folded_bf16_fwd(const float* U, const void* bank_bf16, const float* mask, int B, int L, int D, int H,
+                                 float inv_temp, void* C_bf16, int ldc, float* attn, mgnns_stream_t stream);
+
 /* ---- a8, rest of the layer: fc + residual + LayerNorm + position-wise FFN + residual + LayerNorm in ONE launch ----
  * MultiHeadAttention.forward after the attention (submodules.py:88-94) and PositionwiseFeedForward.forward
  * (submodules.py:132-139), optionally followed by the NEXT layer's query projection w_qs (submodules.py:68):
@@ -342,6 +355,16 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
                             const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
                             const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
                             const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
+
+/* The bf16 tail (terms = 1) behind mgnns_sq_mha_folded_bf16_fwd: `c` = bf16 [B, HC] (HC = n_head * d_model rounded up to a
+ * multiple of 32, <= 2560; zeros behind n_head * d_model) instead of the fp32 head outputs; packed[0] = the composed map fc . blockdiag(Wv) [d_model, HC], fc_b = fc bv + b_fc;
+ * packed[6] / bq_next = the NEXT layer's composed query map [HC_next, d_model] and its bias (NULL: none); only the hi buffers
+ * (even entries of `packed`) are read.  Everything else as mgnns_mha_tail_bf16_fwd.
+ */
+int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q, int B, int d_model, const void* const* packed,
+                           const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
+                           const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                           const float* bq_next, int HC_next, float* u_next, mgnns_stream_t stream);
 
 /* ---- a3 + a4 (+ a7's w_q): one image channel's label GCN as ONE persistent launch ---------------------------------
  * gen_adj (utils/util.py:421-426) + GraphConvolution x 2 with LeakyReLU(0.2) between them

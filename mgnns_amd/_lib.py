@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c = ctypes
 _P = _c.c_void_p
@@ -58,6 +58,8 @@ SIGNATURES = {
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
     "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
+    "mgnns_mha_tail_c16_fwd": [_P, _I, _P, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
+    "mgnns_sq_mha_folded_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P],
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
     "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],

@@ -291,6 +291,16 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     mg_tail::tail_bf16_body<TERMS, false>(smem_b, o, HK, q, B, w, eps, out, HKn, qh_next, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
+// the same tail behind the folded attention (sq_mha_folded_bf16.hip): `c` = bf16 [B, HC] weighted bank rows per head, `fc` = the
+// composed map fc . blockdiag(W_v) [300, HC], the next projection = the composed W_k^T W_q rows [HCn, 300]
+__global__ __launch_bounds__(NTHR) void mha_tail_c16_kernel(const unsigned short* __restrict__ c, int HC, const float* __restrict__ q,
+                                                            int B, TailW w, float eps, float* __restrict__ out, int HCn,
+                                                            float* __restrict__ u_next) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    mg_tail::tail_bf16_body<1, false, true>(smem_b, reinterpret_cast<const float*>(c), HC, q, B, w, eps, out, HCn, u_next,
+                                            (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
 }  // namespace
 
 extern "C" size_t mgnns_packed_bf16_weight_bytes(int N, int K) {      // ONE of the two (hi / lo) buffers
@@ -352,5 +362,39 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     else
         hipLaunchKernelGGL(mha_tail_bf16_kernel<1>, grid, dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w, eps, out, HK_next, qh_next);
     MG_CHECK_LAUNCH("mgnns_mha_tail_bf16_fwd");
+    return 0;
+}
+
+extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q, int B, int d_model,
+                                      const void* const* packed /* fc_h,-,w1_h,-,w2_h,-,wq_h,- (hi parts only are read) */,
+                                      const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
+                                      const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
+                                      const float* bq_next, int HC_next, float* u_next, mgnns_stream_t stream) {
+    MG_REQUIRE(c_bf16 && q && packed && fc_b && ln1_gamma && ln1_beta && b1 && b2 && ln2_gamma && ln2_beta && out,
+               "mgnns_mha_tail_c16_fwd: null pointer");
+    MG_REQUIRE(d_model == D, "mgnns_mha_tail_c16_fwd: d_model=%d unsupported (300 only)", d_model);
+    MG_REQUIRE(HC > 0 && HC % 32 == 0 && HC <= 2560, "mgnns_mha_tail_c16_fwd: n_head*d_model=%d unsupported (multiple of 32, <= 2560)", HC);
+    MG_REQUIRE(mg_aligned16(c_bf16), "mgnns_mha_tail_c16_fwd: c must be 16-byte aligned");
+    for (int i = 0; i < 6; i += 2) MG_REQUIRE(packed[i], "mgnns_mha_tail_c16_fwd: packed weight %d missing", i);
+    MG_REQUIRE(!packed[6] || (u_next && HC_next > 0), "mgnns_mha_tail_c16_fwd: next-layer projection incomplete");
+    if (B <= 0) return 0;
+    TailW w;
+    w.fc_h = (const unsigned short*)packed[0]; w.fc_l = nullptr;
+    w.w1_h = (const unsigned short*)packed[2]; w.w1_l = nullptr;
+    w.w2_h = (const unsigned short*)packed[4]; w.w2_l = nullptr;
+    w.wq_h = (const unsigned short*)packed[6]; w.wq_l = nullptr;
+    w.fc_b = fc_b; w.g1 = ln1_gamma; w.be1 = ln1_beta; w.b1 = b1; w.b2 = b2; w.g2 = ln2_gamma; w.be2 = ln2_beta; w.bq = bq_next;
+    const int so = (HC >> 3) + 2;
+    const size_t lds = (size_t)(ROWS * so + 2 * ROWS * SCD) * 16 + 2 * (size_t)ROWS * SD * sizeof(float);
+    MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_c16_fwd: needs %zu B of LDS", lds);
+    MG_DYN_LDS(mha_tail_c16_kernel, 160 * 1024);
+    int cl = packed[6] ? (B >= 256 ? 2 : 4) : 1;
+    if (const int e = mg_env_int("MGNNS_TAIL_CLUSTER", 0, 1)) cl = packed[6] ? e : 1;
+    if (cl < 1) cl = 1;
+    if (cl > 8) cl = 8;
+    dim3 grid((B + ROWS - 1) / ROWS, cl);
+    hipLaunchKernelGGL(mha_tail_c16_kernel, grid, dim3(NTHR), lds, (hipStream_t)stream, static_cast<const unsigned short*>(c_bf16), HC,
+                       q, B, w, eps, out, HC_next, u_next);
+    MG_CHECK_LAUNCH("mgnns_mha_tail_c16_fwd");
     return 0;
 }

@@ -109,13 +109,16 @@ struct TailW {            // packed hi/lo pairs + fp32 vectors of one layer
 // (rank 0 stores `out`, the next layer's projection is split over the ranks).  O_COHERENT: `o` was written by OTHER
 // workgroups of the same launch with system-scope write-through stores: read it with loads that bypass the non-coherent
 // caches (raw buffer loads, aux sc0 | sc1).
-template <int TERMS, bool O_COHERENT>
+// O_BF16: `o` is already a bf16 matrix [B, HK] (the folded attention's weighted bank rows, sq_mha_folded_bf16.hip): it is copied
+// into the A image as it is, any HK that fits LDS (TERMS == 1 only: there is no lo image).
+template <int TERMS, bool O_COHERENT, bool O_BF16 = false>
 __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const float* __restrict__ o, int HK, const float* __restrict__ q,
                                                int B, const TailW& w, float eps, float* __restrict__ out, int HKn,
                                                float* __restrict__ qh_next, int tile, int crank, int csize) {
+    static_assert(!O_BF16 || TERMS == 1, "a bf16 o has no lo part");
     const int so = (HK >> 3) + 2;                                   // chunk stride of the o tile: == 2 (mod 4)
     uint4* s_oh = reinterpret_cast<uint4*>(smem_b);                 // [16][so]
-    uint4* s_ol = s_oh + ROWS * so;
+    uint4* s_ol = s_oh + (O_BF16 ? 0 : ROWS * so);
     uint4* s_ah = s_ol + ROWS * so;                                 // [16][SCD] activation hi (y, h, out in turn)
     uint4* s_al = s_ah + ROWS * SCD;
     float* s_y = reinterpret_cast<float*>(s_al + ROWS * SCD);       // [16][SD] fp32 y (residual of the FFN)
@@ -149,7 +152,24 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
     // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
     // item by item: ~30 % of the kernel), converted afterwards
-    {
+    if (O_BF16) {
+        const uint4* ob = reinterpret_cast<const uint4*>(o);               // bf16 [B][HK]: HK / 8 chunks per row
+        const int cpr = HK >> 3;
+        constexpr int MAXB = (ROWS * (2560 / 8 + 2) + NTHR - 1) / NTHR;     // HK <= 2560; every load requested before the first store
+        uint4 v[MAXB];
+#pragma unroll
+        for (int it = 0; it < MAXB; ++it) {
+            const int i = tid + it * NTHR;
+            const int r = i / so, c = i - r * so;
+            v[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < ROWS * so && r0 + r < B && c < cpr) v[it] = ob[(size_t)(r0 + r) * cpr + c];
+        }
+#pragma unroll
+        for (int it = 0; it < MAXB; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < ROWS * so) s_oh[i] = v[it];
+        }
+    } else {
         constexpr int MAXIT = (ROWS * (2048 / 8 + 2) + NTHR - 1) / NTHR;      // HK <= 2048
         const int rows_here = B - r0 < ROWS ? B - r0 : ROWS;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(

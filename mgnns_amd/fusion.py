@@ -23,6 +23,9 @@ TAIL_TERMS = int(_os.environ.get('MGNNS_TAIL_TERMS', '1'))   # bf16-mode tail: 3
 # bit-identical (tests), but OFF by default: 100 us per L=196 layer stand-alone against 91 us for the two launches (the in-kernel
 # tail has no 4-workgroup cluster for the next projection) and 0.99 against 0.91 ms per forward -- DESIGN.md section 6
 FUSED_LAYER = _os.environ.get('MGNNS_FUSED_LAYER', '0') == '1'
+# bf16 mode + set_attention('folded'): the composed-map kernels (sq_mha_folded_bf16.hip + mgnns_mha_tail_c16_fwd); 0 = the three
+# exact-fp32 launches of sq_mha_folded.hip as in fp32 / bf16x3 mode
+FOLDED_BF16 = _os.environ.get('MGNNS_FOLDED_BF16', '1') == '1'
 
 
 def _require_eval(mod):
@@ -230,6 +233,59 @@ def _wq_pack_bf16(layer):
     return hit[1]
 
 
+def _use_folded_bf16(a):
+    """bf16 mode + folded attention: the composed-map form (sq_mha_folded_bf16.hip) instead of the three exact-fp32 launches."""
+    return a.attention == 'folded' and a.precision == 'bf16' and not a.is_regu and FOLDED_BF16
+
+
+def composed_query_map(layer):
+    """((hi, lo), bias, H*D) of u_h = (W_k,h^T W_q,h) x + W_k,h^T b_q,h for every head h, stacked [H*D, D]: what a producer of x
+    (the previous layer's tail, a channel tail) applies instead of w_qs so that the folded attention starts from u.  Built in
+    fp32 (ops.matmul) once per weight version (submodules.py:64-72: q = w_qs(x), k = w_ks(bank))."""
+    a = layer.slf_attn
+    key = _versions(a.w_qs.weight, a.w_qs.bias, a.w_ks.weight)
+    hit = getattr(layer, "_uq_cache", None)
+    if hit is None or hit[0] != key:
+        H, dk = a.n_head, a.d_k
+        wq, bq, wk = a.w_qs.weight.detach(), a.w_qs.bias.detach(), a.w_ks.weight.detach()
+        rows, bias = [], []
+        for h in range(H):
+            wkt = wk[h * dk:(h + 1) * dk].t().contiguous()                                   # [D, dk]
+            rows.append(ops.matmul(wkt, wq[h * dk:(h + 1) * dk].contiguous()))               # [D, D]
+            bias.append(ops.matmul(wkt, bq[h * dk:(h + 1) * dk].reshape(dk, 1).contiguous()).reshape(-1))
+        m = torch.cat(rows, 0).contiguous()
+        hit = (key, (ops.pack_weight_bf16_split(m), torch.cat(bias).contiguous(), m.shape[0]), m)
+        layer._uq_cache = hit
+    return hit[1]
+
+
+def _composed_query_weight(layer):
+    composed_query_map(layer)
+    return layer._uq_cache[2]
+
+
+def _tail_pack_folded(layer):
+    """_tail_pack_bf16 with `fc` replaced by fc . blockdiag(W_v) [D, H*D] and its bias by fc b_v + b_fc (submodules.py:74-90:
+    the head outputs W_v,h c_h + b_v,h go straight into fc)."""
+    a, f = layer.slf_attn, layer.pos_ffn
+    ps = (a.fc.weight, a.fc.bias, a.w_vs.weight, a.w_vs.bias, a.layer_norm.gamma, a.layer_norm.beta, f.w_1.weight, f.w_1.bias,
+          f.w_2.weight, f.w_2.bias, f.layer_norm.gamma, f.layer_norm.beta)
+    key = _versions(*ps)
+    hit = getattr(layer, "_tail_cache_folded", None)
+    if hit is None or hit[0] != key:
+        H, dv = a.n_head, a.d_v
+        fc, wv = a.fc.weight.detach(), a.w_vs.weight.detach()
+        cols = [ops.matmul(fc[:, h * dv:(h + 1) * dv].contiguous(), wv[h * dv:(h + 1) * dv].contiguous()) for h in range(H)]
+        n = torch.cat(cols, 1).contiguous()                                                    # [D, H*D]
+        nb = ops.linear(a.w_vs.bias.detach()[None, :].contiguous(), fc.contiguous(), a.fc.bias.detach())[0].contiguous()
+        d = dict(_tail_pack_bf16(layer))
+        d["fc"] = ops.pack_weight_bf16_split(n)
+        d["fc_b"] = nb
+        hit = (key, d)
+        layer._tail_cache_folded = hit
+    return hit[1]
+
+
 def _tile_counters(layer, B, device):
     """int32 zeros [ceil(B/16)] owned by the layer: arrival counters of the fused layer kernel (it leaves them zero)."""
     n = (B + 15) // 16
@@ -257,8 +313,23 @@ def first_query_pack(layers):
 
 
 def first_query_pack_bf16(layers):
-    """The same with the split-bf16 (hi, lo) packed weight, for the bf16-mode producer (ops.label_tail_bf16)."""
-    return _wq_pack_bf16(list(layers)[0])
+    """The same with the split-bf16 (hi, lo) packed weight, for the bf16-mode producer (ops.label_tail_bf16).  With the folded bf16
+    attention the producer applies the composed query map instead (its output feeds sq_mha_folded_bf16 directly)."""
+    first = list(layers)[0]
+    if _use_folded_bf16(first.slf_attn):
+        return composed_query_map(first)
+    return _wq_pack_bf16(first)
+
+
+def first_query(layers, q):
+    """What run_stack(..., qh=...) expects for this stack's first layer, computed from q [B, d]: the projected query
+    w_qs(q) + b, or the composed query rows when the stack runs the folded bf16 attention."""
+    first = list(layers)[0]
+    a0 = first.slf_attn
+    if _use_folded_bf16(a0):
+        _pack, ub, _n = composed_query_map(first)
+        return ops.linear(q, _composed_query_weight(first), ub)
+    return ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
 
 
 def run_stack(layers, q, bank, mask=None, qh=None):
@@ -282,8 +353,18 @@ def run_stack(layers, q, bank, mask=None, qh=None):
     q = q.reshape(B, -1).contiguous()
     m2 = None if mask is None else mask.reshape(B, -1).float().contiguous()
     a0 = layers[0].slf_attn
+    if _use_folded_bf16(a0):
+        # bf16 mode, folded attention: per layer the one-bank-read attention kernel + the tail with the composed maps; qh is the
+        # composed query rows u (first_query_pack_bf16 hands the producer the composed map)
+        u = qh if qh is not None else first_query(layers, q)
+        for i, layer in enumerate(layers):
+            a = layer.slf_attn
+            c, _ = ops.sq_mha_folded_bf16(u, bank.bf16, m2, a.n_head, a.d_k, want_attn=False)
+            nxt = composed_query_map(layers[i + 1]) if i + 1 < len(layers) else None
+            q, u = ops.mha_tail_c16(c, q, _tail_pack_folded(layer), a.layer_norm.eps, nxt)
+        return q
     if qh is None:
-        qh = ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
+        qh = first_query(layers, q)
     for i, layer in enumerate(layers):
         a = layer.slf_attn
         if a.attention == 'folded':

@@ -17,8 +17,8 @@ from torch.nn import Parameter
 
 from . import _lib, ops
 from .adjacency import gen_A, gen_adj_csr
-from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query_pack,
-                     first_query_pack_bf16, run_stack)
+from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query,
+                     first_query_pack, first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
@@ -216,9 +216,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.fused_label_gcn = os.environ.get('MGNNS_FUSED_LABEL_GCN', '1') == '1'      # label GCN as one persistent launch
         self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
-        self.set_precision(opt.get('precision', 'fp32'))
+        self.attention_choice = 'auto'
         self.attention = 'faithful'
-        self.set_attention(opt.get('attention', 'faithful'))
+        self.set_precision(opt.get('precision', 'fp32'))
+        self.set_attention(opt.get('attention', 'auto'))
 
     def set_precision(self, precision):
         """'fp32': every contraction on the exact-f32 MFMA (the parity path, <=1e-4 on logits).
@@ -242,18 +243,24 @@ class Multi_GCN_Multihead_Att(nn.Module):
         for m in self.modules():
             if isinstance(m, MultiHeadAttention):
                 m.precision = precision
-        return self
+        return self.set_attention(self.attention_choice)
 
     def set_attention(self, attention):
-        """'faithful': the fusion attention projects K and V from the memory bank as the reference does (the MFMA
-        kernels the utilisation target is quoted on).  'folded': the same attention with both projections folded
-        into the query side (fp32, ~1/100 of the FLOPs; a separately reported variant)."""
-        if attention not in ('faithful', 'folded'):
-            raise ValueError("attention must be 'faithful' or 'folded'")
-        self.attention = attention
+        """'faithful': the fusion attention projects K and V from the memory bank as the reference does (submodules.py:64-72;
+        the MFMA kernels the north-star's utilisation figure is quoted on).  'folded': the same attention with the projections
+        folded away algebraically (len_q == 1: q.(W_k x_l) = (W_k^T q).x_l and sum_l p_l W_v x_l = W_v sum_l p_l x_l) -- one read
+        of the memory bank instead of 242 MFLOP per sample and layer, same results to rounding (tests: the reference's goldens).
+        In bf16 mode the query / output projections are composed with them too (csrc/sq_mha_folded_bf16.hip + the c16 tail); in
+        fp32 / bf16x3 mode it is the exact-fp32 kernel of csrc/sq_mha_folded.hip.
+        'auto' (default): 'folded' in the bf16 modes, 'faithful' in fp32 mode (the parity path keeps the reference's own
+        formulation)."""
+        if attention not in ('auto', 'faithful', 'folded'):
+            raise ValueError("attention must be 'auto', 'faithful' or 'folded'")
+        self.attention_choice = attention
+        self.attention = attention if attention != 'auto' else ('faithful' if self.precision == 'fp32' else 'folded')
         for m in self.modules():
             if isinstance(m, MultiHeadAttention):
-                m.attention = attention
+                m.attention = self.attention
         return self
 
     # ---- construction helpers -------------------------------------------------------------------
@@ -640,8 +647,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # first projected queries of the two text->image stacks: here, early, instead of in front of their cores
             for nm, layers in (('tio', self.text_img_object_multi_head_att), ('tip', self.text_img_place_multi_head_att)):
                 if len(layers):
-                    a0 = layers[0].slf_attn
-                    ctx['qh_' + nm] = ops.linear(tf, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
+                    ctx['qh_' + nm] = first_query(layers, tf)
             ops.stamp("text GCN end")
 
         def text_bank():

@@ -857,6 +857,31 @@ def sq_mha_folded(qh, bank, mask, n_head, d_kv, wk, wv, bv, want_attn=True):
     return o, attn
 
 
+def sq_mha_folded_bf16(u, bank_bf16, mask, n_head, d_kv, want_attn=True):
+    """Folded single-query attention on the bf16 matrix pipe (mgnns_sq_mha_folded_bf16_fwd).  u: fp32 [B, H*D] composed query
+    rows (fusion.composed_query_map); bank: bf16 [B, L, 320] zero padded -> (c bf16 [B, H*D rounded up to 32] = per-head
+    probability-weighted bank rows at h*D, zeros behind H*D: what mha_tail_c16 takes; attn [H*B, 1, L] or None)."""
+    _chk(u, "u", ndim=2)
+    _chk(bank_bf16, "memory bank", torch.bfloat16, 3)
+    B, L_, ld = bank_bf16.shape
+    if ld != 320:
+        raise ValueError("bf16 memory bank last dim %d, expected 320 (cast_pad_bf16)" % ld)
+    if u.shape[0] != B or u.shape[1] % n_head:
+        raise ValueError("u shape %s does not match batch %d / %d heads" % (tuple(u.shape), B, n_head))
+    D = u.shape[1] // n_head
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    ldc = (n_head * D + 31) // 32 * 32
+    c = torch.empty(B, ldc, device=u.device, dtype=torch.bfloat16)
+    attn = torch.empty(n_head * B, 1, L_, device=u.device, dtype=torch.float32) if want_attn else None
+    L = _lib.lib()
+    _launch("mgnns_sq_mha_folded_bf16_fwd", ("mgnns_sq_mha_folded_bf16_fwd", L_), L.mgnns_sq_mha_folded_bf16_fwd,
+            _p(u), _p(bank_bf16), _p(mask), B, L_, D, n_head, float(1.0 / (d_kv ** 0.5)), _p(c), ldc, _p(attn), _stream())
+    return c, attn
+
+
 def pack_weight_f32(w):
     """[N, K] fp32 (nn.Linear layout) -> MFMA-fragment-major fp32 buffer for mha_tail."""
     _chk(w, "weight", ndim=2)
@@ -925,6 +950,31 @@ def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3):
             int(terms), arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
             _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qh), _stream())
     return out, qh
+
+
+def mha_tail_c16(c, q, packed, eps, next_packed=None):
+    """The bf16 fused tail behind sq_mha_folded_bf16 (mgnns_mha_tail_c16_fwd): c bf16 [B, H*300]; packed["fc"] = the composed map
+    fc . blockdiag(W_v); next_packed = ((hi, lo), bias, H*300) of the next layer's composed query map or None."""
+    import ctypes
+    _chk(c, "c", torch.bfloat16, 2)
+    _chk(q, "q", ndim=2)
+    B, HC = c.shape
+    if q.shape != (B, 300):
+        raise ValueError("q shape %s, expected (%d, 300)" % (tuple(q.shape), B))
+    out = torch.empty(B, 300, device=c.device, dtype=torch.float32)
+    ptrs = [packed["fc"][0].data_ptr(), None, packed["w1"][0].data_ptr(), None, packed["w2"][0].data_ptr(), None, None, None]
+    bq = un = None
+    hcn = 0
+    if next_packed is not None:
+        (wh, _wl), bq, hcn = next_packed
+        ptrs[6] = wh.data_ptr()
+        un = torch.empty(B, hcn, device=c.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * 8)(*ptrs)
+    L = _lib.lib()
+    _launch("mgnns_mha_tail_c16_fwd", ("mgnns_mha_tail_c16_fwd",), L.mgnns_mha_tail_c16_fwd, _p(c), HC, _p(q), B, 300,
+            arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
+            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hcn, _p(un), _stream())
+    return out, un
 
 
 def layernorm(x, gamma, beta, eps=1e-6):

@@ -133,9 +133,11 @@ def test_module_surface_on_gpu():
         model(*call_args(synth.make_inputs(cfg, B=2, pmi=pmi), DEV))
 
 
-def test_bf16_precision_mode_is_close_and_reports_error():
-    """bf16-operand fusion attention (BASELINE config 3): logits stay within bf16-class error of the fp32
-    reference golden and the predicted class does not change."""
+@pytest.mark.parametrize("attention", ["auto", "faithful"])
+def test_bf16_precision_mode_is_close_and_reports_error(attention):
+    """bf16 mode (BASELINE config 3), with the default attention of the mode (the folded bf16 kernels) and with the reference's
+    own formulation (K / V projected on the bf16 MFMA): logits stay within bf16-class error of the fp32 reference golden and
+    the predicted class does not change."""
     cfg_name = "mvsa_multiple_b256"
     g = H.load_golden("full_%s.npz" % cfg_name)
     adj = H.load_golden("adjacency.npz")
@@ -143,10 +145,11 @@ def test_bf16_precision_mode_is_close_and_reports_error():
     B = int(g["B"])
     pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], g["label_query"], DEV)
-    model.set_precision("bf16")
+    model.set_precision("bf16").set_attention(attention)
+    assert model.attention == ("folded" if attention == "auto" else "faithful")
     logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV)).cpu()
     err = H.maxabs(logits, g["logits"])
-    print("bf16 mode max|logit diff| vs fp32 reference: %.3e" % err)
+    print("bf16 mode (%s attention) max|logit diff| vs fp32 reference: %.3e" % (model.attention, err))
     assert err < 2e-2              # measured 9.7e-3 on the golden batch, 1.5e-2 over the B=256 bench batch (its own, looser, report in bench.py)
     assert torch.equal(logits.argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
@@ -309,7 +312,8 @@ def test_full_size_b256_properties():
     assert H.maxabs(model(*call).cpu()[idx], ref) < TOL
 
 
-def test_full_size_b256_bf16_mode():
+@pytest.mark.parametrize("attention", ["auto", "faithful"])
+def test_full_size_b256_bf16_mode(attention):
     """BASELINE configs[2] in ITS stated dtype -- "bf16 MFMA", the mode bench.py's headline runs -- at the full B = 256: a
     32-sample subset against the CPU oracle (bf16 operands carry ~3 digits: <= 2e-2 on the logits, the class unchanged wherever
     the oracle's margin exceeds that), permutation equivariance, determinism, hipGraph replay == eager."""
@@ -321,7 +325,7 @@ def test_full_size_b256_bf16_mode():
     B = 256
     inp = synth.make_inputs(cfg, B=B, seed=4243, pmi=pmi)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
-    model.set_precision("bf16")
+    model.set_precision("bf16").set_attention(attention)
     call = call_args(inp, DEV)
     logits = model(*call).cpu()
     assert logits.shape == (B, cfg.NL) and torch.isfinite(logits).all()
@@ -331,7 +335,7 @@ def test_full_size_b256_bf16_mode():
     ref = R.forward(p, {k: torch.from_numpy(v) for k, v in sub.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
                     label_query=torch.from_numpy(lq))
     err = H.maxabs(logits[idx], ref)
-    print("bf16 mode, B=256: max |dlogit| on the 32-sample oracle subset = %.3e" % err)
+    print("bf16 mode (%s attention), B=256: max |dlogit| on the 32-sample oracle subset = %.3e" % (model.attention, err))
     assert err < 2e-2
     top2 = ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4e-2                     # samples whose class cannot flip inside the error bound

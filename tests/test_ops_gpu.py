@@ -721,6 +721,100 @@ def test_run_stack_fused_tail_matches_layer_by_layer_and_golden(Hn):
         assert H.maxabs(out2.cpu(), ref) < 3e-5
 
 
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_sq_mha_folded_bf16_against_goldens(Hn, tag, L, masked):
+    """The composed-map folded attention on the bf16 matrix pipe (sq_mha_folded_bf16.hip): attention weights against the
+    reference's golden (bf16 operands: 5e-3 absolute on probabilities), the head outputs rebuilt from its weighted bank rows
+    against the exact fp32 core, and the weighted rows exactly against fp64 on the kernel's own probabilities and bf16 bank."""
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    p = dparams(H.params_for(H.mha_shapes(Hn), prefix=name + "."))
+    q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+    dm = None if mask is None else dev(mask)
+    a = name + ".slf_attn."
+    qh = ops.linear(dev(q), p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    B = q.shape[0]
+    wk = p[a + "w_ks.weight"].double().view(Hn, 128, 300)
+    u = torch.einsum("hdf,bhd->bhf", wk, qh.double().view(B, Hn, 128)).float().reshape(B, Hn * 300).contiguous()
+    bank_bf = ops.cast_pad_bf16(dev(bank))
+    c, attn = ops.sq_mha_folded_bf16(u, bank_bf, dm, Hn, 128)
+    ldc = (Hn * 300 + 31) // 32 * 32
+    assert c.shape == (B, ldc) and attn.shape == (Hn * B, 1, L) and not c[:, Hn * 300:].any()
+    c = c[:, :Hn * 300]
+    assert H.maxabs(attn.cpu(), g[name + "_attn"]) < 5e-3
+    c2, none = ops.sq_mha_folded_bf16(u, bank_bf, dm, Hn, 128, want_attn=False)
+    assert none is None and torch.equal(c2[:, :Hn * 300], c)
+    # weighted bank rows: fp64 on the kernel's probabilities (rounded to bf16 as the kernel feeds them) and the bf16 bank
+    pr = attn.view(Hn, B, L).to(torch.bfloat16).double()
+    want = torch.einsum("hbl,blf->bhf", pr, bank_bf[..., :300].double())
+    got = c.double().reshape(B, Hn, 300)
+    assert float((got - want).abs().max() / want.abs().max()) < 6e-3          # bf16 rounding of the stored result
+    # head outputs W_v c + b_v against the exact fp32 core
+    wv = p[a + "w_vs.weight"].double().view(Hn, 128, 300)
+    o = (torch.einsum("hdf,bhf->bhd", wv, got) + p[a + "w_vs.bias"].double().view(1, Hn, 128)).reshape(B, Hn * 128)
+    o_f, _ = ops.sq_mha_core(qh, dev(bank), dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_ks.bias"],
+                             p[a + "w_vs.weight"], p[a + "w_vs.bias"])
+    assert H.relerr(o.cpu(), o_f.cpu()) < 2e-2
+
+
+def test_sq_mha_folded_bf16_ragged_lengths_and_masked_tiles():
+    """L not a multiple of 16 or 32, a single row, the 208-row maximum, masks that blank whole row tiles (never staged),
+    fewer heads than waves: against the exact fp32 folded kernel on the bf16-rounded bank."""
+    rs = np.random.RandomState(78)
+    for L, Hn, B in ((1, 8, 3), (17, 4, 2), (100, 8, 5), (196, 8, 4), (208, 1, 2), (33, 3, 2)):
+        u = dev((0.3 * rs.standard_normal((B, Hn * 300))).astype(np.float32))
+        bank = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+        bank_bf = ops.cast_pad_bf16(bank)
+        mask = np.ones((B, L), np.float32)
+        for b in range(B):
+            mask[b, rs.randint(1, L + 1):] = 0.0
+        mask[0, :] = 1.0
+        if L > 40:
+            mask[1, 5:37] = 0.0                               # holes in front of live rows
+        dm = dev(mask)
+        c, attn = ops.sq_mha_folded_bf16(u, bank_bf, dm, Hn, 128)
+        xb = bank_bf[..., :300].double()
+        ub = u.to(torch.bfloat16).double().view(B, Hn, 300)
+        sc = torch.einsum("bhf,blf->bhl", ub, xb) / (128 ** 0.5)
+        sc = sc.masked_fill(dm.double()[:, None, :] == 0, float("-inf"))
+        pr = torch.softmax(sc, dim=-1)                                           # [B, H, L]
+        assert H.maxabs(attn.view(Hn, B, L).permute(1, 0, 2).cpu(), pr.cpu()) < 2e-5, L
+        want = torch.einsum("bhl,blf->bhf", pr.to(torch.bfloat16).double(), xb)
+        err = float((c[:, :Hn * 300].double().reshape(B, Hn, 300) - want).abs().max() / want.abs().max())
+        assert err < 8e-3, (L, err)
+
+
+@pytest.mark.parametrize("Hn", [1, 4, 8])
+def test_run_stack_folded_bf16_matches_golden_and_the_explicit_bf16_stack(Hn):
+    """bf16 mode + folded attention through fusion.run_stack (composed query map, one-bank-read attention, tail with the
+    composed output map): the reference layer golden and a two-layer stack against the oracle at bf16 tolerance, and as close to
+    them as the explicit bf16 stack is."""
+    from mgnns_amd.fusion import MyMultiHeadAttention, MemoryBank, run_stack
+    g = H.load_golden("mha.npz")
+    for tag, L, masked in (("text", 100, True), ("img", 196, False)):
+        name = "h%d_%s" % (Hn, tag)
+        pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+        layer = MyMultiHeadAttention(Hn, 300, 128, dropout=0.5, need_mask=masked).eval()
+        layer.load_state_dict({k[len(name) + 1:]: v for k, v in pc.items()})
+        layer = layer.to(DEV)
+        layer.slf_attn.precision = 'bf16'
+        q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+        dm = None if mask is None else dev(mask)
+        ref2 = R.mha_stack({("s.%d." % i) + k[len(name) + 1:]: v for i in range(2) for k, v in pc.items()}, "s",
+                           torch.from_numpy(q), torch.from_numpy(bank), None if mask is None else torch.from_numpy(mask),
+                           Hn, 128, 2)
+        errs = {}
+        for att in ("faithful", "folded"):
+            layer.slf_attn.attention = att
+            mb = MemoryBank(f32=dev(bank))
+            out1 = run_stack([layer], dev(q), mb, dm)
+            out2 = run_stack([layer, layer], dev(q), mb, dm)
+            errs[att] = (H.maxabs(out1.cpu(), g[name + "_out"]), H.maxabs(out2.cpu(), ref2))
+        print("stack h%d %s: explicit bf16 %.2e / %.2e, folded bf16 %.2e / %.2e" % ((Hn, tag) + errs["faithful"] + errs["folded"]))
+        assert errs["folded"][0] < 3e-2 and errs["folded"][1] < 4e-2
+        assert errs["folded"][0] < 2.5 * errs["faithful"][0] + 2e-3 and errs["folded"][1] < 2.5 * errs["faithful"][1] + 2e-3
+
+
 @pytest.mark.parametrize("Hn", [4, 8])
 def test_is_regu_head_difference_against_the_reference_golden(Hn):
     """MyMultiHeadAttention(is_regu=True) returns the head-difference term as a third value (moudles.py:220-229,

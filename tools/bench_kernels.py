@@ -67,6 +67,14 @@ def mha(kind, B=256, L=196, H=8, masked=False):
         bb = ops.cast_pad_bf16(bank)
         wp = ops.pack_kv_weights_bf16(wk, wv, H, 128)
         ms = timeit(lambda: ops.sq_mha_core_bf16(qh, bb, mask, H, 128, wp, bk, bv))
+    elif kind == "folded_c16":
+        bb = ops.cast_pad_bf16(bank)
+        u = torch.randn(B, H * 300, device=DEV, generator=g) * 0.3
+        ms = timeit(lambda: ops.sq_mha_folded_bf16(u, bb, mask, H, 128, want_attn=False))
+        by = bb.numel() * 2
+        print("sq_mha_folded_bf16 B=%d L=%d H=%d masked=%s: %.1f us  %.0f GB/s (one bank read, %.1f MB)"
+              % (B, L, H, masked, ms * 1e3, by / ms / 1e6, by / 1e6))
+        return
     elif kind in ("folded", "folded_bf16"):
         x = ops.cast_pad_bf16(bank) if kind == "folded_bf16" else bank
         ms = timeit(lambda: ops.sq_mha_folded(qh, x, mask, H, 128, wk, wv, bv, want_attn=False))
@@ -114,6 +122,18 @@ def tail(B=256, H=8):
         print("mha_tail bf16 terms=%d (last layer): %.1f us" % (terms, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, None, terms=terms)) * 1e3))
 
 
+def tail_c16(B=256, H=8):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    r = lambda *shape: torch.randn(*shape, device=DEV, generator=g) * 0.05
+    c, q = torch.randn(B, H * 300, device=DEV, generator=g).to(torch.bfloat16), torch.randn(B, 300, device=DEV, generator=g)
+    fc, w1, w2, wq = r(300, H * 300), r(300, 300), r(300, 300), r(H * 300, 300)
+    pk = {"fc_b": r(300), "g1": r(300) + 1, "be1": r(300), "b1": r(300), "b2": r(300), "g2": r(300) + 1, "be2": r(300),
+          "fc": ops.pack_weight_bf16_split(fc), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
+    nx = (ops.pack_weight_bf16_split(wq), r(H * 300), H * 300)
+    print("mha_tail_c16 H=%d (+next composed query map): %.1f us" % (H, timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, nx)) * 1e3))
+    print("mha_tail_c16 H=%d (last layer): %.1f us" % (H, timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, None)) * 1e3))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["mha_bf16", "mha_f32", "imgbank"]
     if "mha_bf16" in what:
@@ -127,6 +147,12 @@ if __name__ == "__main__":
             mha(k)
             mha(k, L=100, masked=True)
             mha(k, H=1)
+    if "folded_c16" in what:
+        mha("folded_c16")
+        mha("folded_c16", L=100, masked=True)
+        mha("folded_c16", B=128)
+        mha("folded_c16", B=512)
+        tail_c16()
     if "imgbank" in what:
         imgbank()
     if "tail" in what:
