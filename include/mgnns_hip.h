@@ -357,14 +357,21 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
                             const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
 
 /* The bf16 tail (terms = 1) behind mgnns_sq_mha_folded_bf16_fwd: `c` = bf16 [B, HC] (HC = n_head * d_model rounded up to a
- * multiple of 32, <= 2560; zeros behind n_head * d_model) instead of the fp32 head outputs; packed[0] = the composed map fc . blockdiag(Wv) [d_model, HC], fc_b = fc bv + b_fc;
- * packed[6] / bq_next = the NEXT layer's composed query map [HC_next, d_model] and its bias (NULL: none); only the hi buffers
- * (even entries of `packed`) are read.  Everything else as mgnns_mha_tail_bf16_fwd.
+ * multiple of 32, <= 2560; zeros behind n_head * d_model) instead of the fp32 head outputs; packed[0] = the composed map
+ * fc . blockdiag(Wv) [d_model, n_head * d_model], fc_b = fc bv + b_fc; packed[6] / bq_next = the NEXT layer's composed query map
+ * [HC_next, d_model] and its bias (NULL: none); only the hi buffers (even entries of `packed`) are read.
+ * cluster: workgroups per 16-sample tile (0 = default: 4 with the exchange buffers; 1..8).  With cluster_scratch
+ * (mgnns_mha_tail_c16_scratch_floats(B, 8) floats, 16-byte aligned) and cluster_counters (2 * ceil(B/16) int32, ZERO before the
+ * first launch; the kernel leaves them zero) the ranks split the K of the first product and exchange partial sums through the
+ * scratch (bounded wait + status word as mgnns_label_tail_bf16_fwd; one pair of buffers per concurrently running launch);
+ * without them every rank streams the whole composed map.  Everything else as mgnns_mha_tail_bf16_fwd.
  */
+size_t mgnns_mha_tail_c16_scratch_floats(int B, int cluster);
 int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q, int B, int d_model, const void* const* packed,
                            const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
                            const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
-                           const float* bq_next, int HC_next, float* u_next, mgnns_stream_t stream);
+                           const float* bq_next, int HC_next, float* u_next, int cluster, float* cluster_scratch,
+                           int* cluster_counters, mgnns_stream_t stream);
 
 /* ---- a3 + a4 (+ a7's w_q): one image channel's label GCN as ONE persistent launch ---------------------------------
  * gen_adj (utils/util.py:421-426) + GraphConvolution x 2 with LeakyReLU(0.2) between them

@@ -58,7 +58,7 @@ SIGNATURES = {
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
     "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
-    "mgnns_mha_tail_c16_fwd": [_P, _I, _P, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
+    "mgnns_mha_tail_c16_fwd": [_P, _I, _P, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_sq_mha_folded_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P],
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
     "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
@@ -97,6 +97,7 @@ SIZE_GETTERS = {
     "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
     "mgnns_bilstm_bf16_prepack_bytes": [_I, _I],
     "mgnns_label_gcn_scratch_bytes": [_I, _I, _I],
+    "mgnns_mha_tail_c16_scratch_floats": [_I, _I],
 }
 
 _lib = None

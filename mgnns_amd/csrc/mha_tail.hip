@@ -295,10 +295,12 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
 // composed map fc . blockdiag(W_v) [300, HC], the next projection = the composed W_k^T W_q rows [HCn, 300]
 __global__ __launch_bounds__(NTHR) void mha_tail_c16_kernel(const unsigned short* __restrict__ c, int HC, const float* __restrict__ q,
                                                             int B, TailW w, float eps, float* __restrict__ out, int HCn,
-                                                            float* __restrict__ u_next) {
+                                                            float* __restrict__ u_next, int cl, float* __restrict__ xpart,
+                                                            int* __restrict__ xcnt, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    // the ranks of a tile are adjacent in dispatch order (see the exchange in tail_bf16_body)
     mg_tail::tail_bf16_body<1, false, true>(smem_b, reinterpret_cast<const float*>(c), HC, q, B, w, eps, out, HCn, u_next,
-                                            (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+                                            (int)blockIdx.x / cl, (int)blockIdx.x % cl, cl, xpart, xcnt, status);
 }
 
 }  // namespace
@@ -365,11 +367,16 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     return 0;
 }
 
+extern "C" size_t mgnns_mha_tail_c16_scratch_floats(int B, int cluster) {
+    return (size_t)((B + ROWS - 1) / ROWS) * (size_t)(cluster < 1 ? 1 : cluster) * (8 * 3 * 64 * 4);
+}
+
 extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q, int B, int d_model,
                                       const void* const* packed /* fc_h,-,w1_h,-,w2_h,-,wq_h,- (hi parts only are read) */,
                                       const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
                                       const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
-                                      const float* bq_next, int HC_next, float* u_next, mgnns_stream_t stream) {
+                                      const float* bq_next, int HC_next, float* u_next, int cluster, float* cluster_scratch,
+                                      int* cluster_counters, mgnns_stream_t stream) {
     MG_REQUIRE(c_bf16 && q && packed && fc_b && ln1_gamma && ln1_beta && b1 && b2 && ln2_gamma && ln2_beta && out,
                "mgnns_mha_tail_c16_fwd: null pointer");
     MG_REQUIRE(d_model == D, "mgnns_mha_tail_c16_fwd: d_model=%d unsupported (300 only)", d_model);
@@ -377,7 +384,12 @@ extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q
     MG_REQUIRE(mg_aligned16(c_bf16), "mgnns_mha_tail_c16_fwd: c must be 16-byte aligned");
     for (int i = 0; i < 6; i += 2) MG_REQUIRE(packed[i], "mgnns_mha_tail_c16_fwd: packed weight %d missing", i);
     MG_REQUIRE(!packed[6] || (u_next && HC_next > 0), "mgnns_mha_tail_c16_fwd: next-layer projection incomplete");
+    MG_REQUIRE(cluster >= 0 && cluster <= 8, "mgnns_mha_tail_c16_fwd: cluster=%d (0 = default, 1..8)", cluster);
+    MG_REQUIRE((cluster_scratch != nullptr) == (cluster_counters != nullptr), "mgnns_mha_tail_c16_fwd: cluster scratch and counters go together");
+    MG_REQUIRE(!cluster_scratch || mg_aligned16(cluster_scratch), "mgnns_mha_tail_c16_fwd: cluster scratch must be 16-byte aligned");
     if (B <= 0) return 0;
+    if (cluster_scratch)
+        if (int rc = mg_check_status("mgnns_mha_tail_c16_fwd")) return rc;     // a bounded wait of an earlier launch ran out
     TailW w;
     w.fc_h = (const unsigned short*)packed[0]; w.fc_l = nullptr;
     w.w1_h = (const unsigned short*)packed[2]; w.w1_l = nullptr;
@@ -388,13 +400,21 @@ extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q
     const size_t lds = (size_t)(ROWS * so + 2 * ROWS * SCD) * 16 + 2 * (size_t)ROWS * SD * sizeof(float);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_c16_fwd: needs %zu B of LDS", lds);
     MG_DYN_LDS(mha_tail_c16_kernel, 160 * 1024);
-    int cl = packed[6] ? (B >= 256 ? 2 : 4) : 1;
-    if (const int e = mg_env_int("MGNNS_TAIL_CLUSTER", 0, 1)) cl = packed[6] ? e : 1;
+    // A cluster of workgroups per 16-sample tile.  With exchange buffers the ranks split the K of the first product (the composed
+    // output map) and exchange partial sums, then each repeats the short LayerNorm / FFN chain and takes a share of the next
+    // composed query map's columns; without buffers (or without a next map and cluster == 0) one workgroup per tile.
+    // (measured at B = 256, two forwards in flight: 442 k samples/s with four ranks, 435 k with two; one at a time 0.624 / 0.643 ms)
+    int cl = cluster ? cluster : (cluster_scratch ? 4 : (packed[6] ? (B >= 256 ? 2 : 4) : 1));
+    if (!cluster) {
+        if (const int e = mg_env_int("MGNNS_TAIL_CLUSTER", 0, 1)) cl = e;
+    }
     if (cl < 1) cl = 1;
     if (cl > 8) cl = 8;
-    dim3 grid((B + ROWS - 1) / ROWS, cl);
+    if (!packed[6] && !cluster_scratch) cl = 1;            // nothing to share
+    dim3 grid((unsigned)((B + ROWS - 1) / ROWS) * cl);
     hipLaunchKernelGGL(mha_tail_c16_kernel, grid, dim3(NTHR), lds, (hipStream_t)stream, static_cast<const unsigned short*>(c_bf16), HC,
-                       q, B, w, eps, out, HC_next, u_next);
+                       q, B, w, eps, out, HC_next, u_next, cl, cluster_scratch, cluster_counters,
+                       cluster_scratch ? mg_status_word() : (int*)nullptr);
     MG_CHECK_LAUNCH("mgnns_mha_tail_c16_fwd");
     return 0;
 }

@@ -114,9 +114,18 @@ struct TailW {            // packed hi/lo pairs + fp32 vectors of one layer
 template <int TERMS, bool O_COHERENT, bool O_BF16 = false>
 __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const float* __restrict__ o, int HK, const float* __restrict__ q,
                                                int B, const TailW& w, float eps, float* __restrict__ out, int HKn,
-                                               float* __restrict__ qh_next, int tile, int crank, int csize) {
+                                               float* __restrict__ qh_next, int tile, int crank, int csize,
+                                               float* __restrict__ xpart = nullptr, int* __restrict__ xcnt = nullptr,
+                                               int* __restrict__ status = nullptr) {
     static_assert(!O_BF16 || TERMS == 1, "a bf16 o has no lo part");
-    const int so = (HK >> 3) + 2;                                   // chunk stride of the o tile: == 2 (mod 4)
+    // K-split (O_BF16 with exchange buffers): the ranks of a tile's cluster each contract a slice of the first product's K
+    // (1.44 MB of composed weights behind the folded attention) and exchange the partial sums (the channel tail's scheme,
+    // label_tail.hip) instead of every rank streaming all of it.
+    const bool ksplit = O_BF16 && xpart != nullptr && csize > 1;
+    const int KSo_all = (HK + 31) / 32;
+    const int ks_lo = ksplit ? crank * KSo_all / csize : 0;
+    const int ks_hi = ksplit ? (crank + 1) * KSo_all / csize : KSo_all;
+    const int so = ksplit ? 4 * ((KSo_all + csize - 1) / csize) + 2 : (HK >> 3) + 2;   // chunk stride of the o tile: == 2 (mod 4)
     uint4* s_oh = reinterpret_cast<uint4*>(smem_b);                 // [16][so]
     uint4* s_ol = s_oh + (O_BF16 ? 0 : ROWS * so);
     uint4* s_ah = s_ol + ROWS * so;                                 // [16][SCD] activation hi (y, h, out in turn)
@@ -125,7 +134,8 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     float* s_t = s_y + ROWS * SD;                                   // [16][SD] fp32 pre-LayerNorm scratch / out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = tile * ROWS;
-    const int KSo = (HK + 31) / 32, KSd = (D + 31) / 32;
+    const int KSo = ks_hi - ks_lo;
+    constexpr int KSd = (D + 31) / 32;
     MG_TSTAMP(0);
 
     // per-lane parameter vectors first: b_1 / b_2 of this lane's output columns, gamma / beta of its LayerNorm columns
@@ -148,13 +158,13 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     }
     // the first GEMM's weights fly through the staging of o
     WRing<3, TERMS> ring;
-    ring_prime(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0);
+    ring_prime(ring, KSo, w.fc_h, w.fc_l, DT, wave, lane, 0, KSo_all, ks_lo);
     // ---- stage o (split), zero the activation buffers (their k-padding must stay zero) ---------------------------
     // every thread's 16-B loads are requested first (the phase timer showed 18 k cycles here with scalar loads consumed
     // item by item: ~30 % of the kernel), converted afterwards
     if (O_BF16) {
-        const uint4* ob = reinterpret_cast<const uint4*>(o);               // bf16 [B][HK]: HK / 8 chunks per row
-        const int cpr = HK >> 3;
+        const uint4* ob = reinterpret_cast<const uint4*>(o) + 4 * ks_lo;   // bf16 [B][HK]: HK / 8 chunks per row; this rank's K slice
+        const int cpr = HK >> 3, cps = 4 * KSo;
         constexpr int MAXB = (ROWS * (2560 / 8 + 2) + NTHR - 1) / NTHR;     // HK <= 2560; every load requested before the first store
         uint4 v[MAXB];
 #pragma unroll
@@ -162,7 +172,7 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
             const int i = tid + it * NTHR;
             const int r = i / so, c = i - r * so;
             v[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < ROWS * so && r0 + r < B && c < cpr) v[it] = ob[(size_t)(r0 + r) * cpr + c];
+            if (i < ROWS * so && r0 + r < B && c < cps) v[it] = ob[(size_t)(r0 + r) * cpr + c];
         }
 #pragma unroll
         for (int it = 0; it < MAXB; ++it) {
@@ -236,6 +246,58 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     }
     ring_gemm(acc, ring, s_oh, s_ol, so, KSo, w.fc_h, w.fc_l, lane);
     MG_TSTAMP(2);
+    if (ksplit) {
+        // partial [tile][rank][wave][t][lane] x 16 B: a lane writes and reads exactly the accumulator slots it owns (write-through
+        // stores, loads that bypass the non-coherent caches, one relaxed agent-scope arrival per rank).  The ranks of a tile are
+        // ADJACENT in dispatch order (blockIdx = tile * csize + rank): at most one cluster of a launch straddles the edge of what
+        // is resident and everything in front of it retires without waiting for anybody.  The wait is bounded all the same; when
+        // it runs out the rank goes on with what has arrived and raises the library's status word.
+        typedef int tl_i32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t xp = __builtin_amdgcn_make_buffer_rsrc(xpart + (size_t)tile * csize * (8 * 3 * 64 * 4), 0,
+                                                                            csize * 8 * 3 * 64 * 16, 0x00027000);
+        const int slot = (wave * 3 * 64 + lane) * 16;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (wave + 8 * t < DT)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tl_i32x4, acc[t]), xp, slot + t * 64 * 16, crank * (8 * 3 * 64 * 16), 17);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&xcnt[2 * tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(&xcnt[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < csize) {
+                if (++spins > (1 << 24)) {
+                    if (status) __hip_atomic_store(status, MGNNS_STATUS_CLUSTER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wave + 8 * t < DT) {
+                f32x4 pr[8];
+#pragma unroll
+                for (int rk = 0; rk < 8; ++rk)
+                    pr[rk] = rk < csize ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xp, slot + t * 64 * 16, rk * (8 * 3 * 64 * 16), 17))
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rk = 0; rk < 8; ++rk) sum += pr[rk];          // rank order: every rank forms the same sum
+            }
+            acc[t] = sum;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials are in registers
+        __syncthreads();
+        if (tid == 0) {        // every thread of this rank has consumed the partials: the last rank to get here re-arms the counters
+            const int old = __hip_atomic_fetch_add(&xcnt[2 * tile + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == csize - 1) {
+                __hip_atomic_store(&xcnt[2 * tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xcnt[2 * tile + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     ring_prime(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -277,8 +339,26 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
     const int per = (slots + csize - 1) / csize;
     const int s_lo = crank * per, s_hi = min(slots, s_lo + per);
+    // TERMS == 1: the projection's weights as ONE stream per wave -- k-step d of the wave's next column tile is requested the
+    // moment k-step d of the current one is consumed (a ring of KSd fragments), so the stream never restarts cold (with a ring
+    // primed per pair of column tiles every pair paid an L2 round trip: 21 us for the 1.44 MB composed query map split over
+    // two ranks).  TERMS == 3 keeps the pairwise ring (hi + lo fragments of a stream do not fit the register budget).
     WRing<2, TERMS> ringq;
-    if (w.wq_h) ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
+    uint4 rq[KSd];
+    const uint4* Wq = reinterpret_cast<const uint4*>(w.wq_h);
+    auto wq_off = [&](int slot) {
+        const int nt = wave + 8 * slot;
+        return ((size_t)(nt < NTq ? nt : 0) * KSd) * 64 + lane;
+    };
+    if (TERMS == 1) {
+        if (w.wq_h && s_lo < s_hi) {
+            const size_t o0 = wq_off(s_lo);
+#pragma unroll
+            for (int d = 0; d < KSd; ++d) rq[d] = Wq[o0 + (size_t)d * 64];
+        }
+    } else if (w.wq_h) {
+        ring_prime(ringq, KSd, w.wq_h, w.wq_l, NTq, wave, lane, s_lo);
+    }
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int n = (wave + 8 * t) * 16 + ccol;
@@ -296,7 +376,33 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     // gridDim.y workgroups share a 16-sample tile: each recomputes steps 1-3 (identical results; rank 0 stores `out`) and
     // takes 1 / gridDim.y of the projection's column tiles.  The projection is 40 % of the weight bytes a workgroup streams
     // at the per-CU L2 rate, and the only part of the chain whose columns are independent.
-    if (w.wq_h) {
+    if (TERMS == 1 && w.wq_h) {
+        mg_lds_barrier();
+        bf16x8 aq[KSd];
+#pragma unroll
+        for (int d = 0; d < KSd; ++d) aq[d] = __builtin_bit_cast(bf16x8, s_ah[(lane & 15) * SCD + (lane >> 4) + 4 * d]);
+        for (int slot = s_lo; slot < s_hi; ++slot) {
+            const int nt = wave + 8 * slot, n = nt * 16 + ccol;
+            const bool live = nt < NTq && n < HKn;
+            const float bv = (live && w.bq) ? w.bq[n] : 0.f;
+            const bool more = slot + 1 < s_hi;
+            const size_t nx = wq_off(more ? slot + 1 : slot);
+            f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < KSd; ++d) {
+                const uint4 c = rq[d];
+                if (more) rq[d] = Wq[nx + (size_t)d * 64];
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[d], __builtin_bit_cast(bf16x8, c), a2, 0, 0, 0);
+            }
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = r0 + crow + r;
+                    if (gr < B) qh_next[(size_t)gr * HKn + n] = a2[r] + bv;
+                }
+            }
+        }
+    } else if (w.wq_h) {
         mg_lds_barrier();
         for (int t0 = s_lo; t0 < s_hi; t0 += 2) {
             f32x4 a2[2];

@@ -58,20 +58,9 @@ static_assert(OFF_U % 16 == 0 && OFF_SC % 16 == 0 && OFF_P % 16 == 0, "LDS align
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// four rows x one feature per lane: lane i of a 16-lane group passes the address of row (i >> 2), features 4 (i & 3) .. + 3
-// of the group's 4 x 16 block and receives feature i of rows 0 .. 3
-template <bool TR>
-__device__ __forceinline__ s16x4 col4(const unsigned char* smem, int row0, int feat0, int i) {
-    if (TR) {
-        const unsigned char* p = smem + (size_t)(row0 + (i >> 2)) * ROWB + (size_t)(feat0 + 4 * (i & 3)) * 2;
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)p);
-    }
-    s16x4 v;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const short*>(smem + (size_t)(row0 + k) * ROWB + (size_t)(feat0 + i) * 2);
-    return v;
-}
-
+// The transposing read (TR): lane i of a 16-lane group passes the address of row (i >> 2), features 4 (i & 3) .. + 3 of the
+// group's 4-row x 16-feature block and receives feature i of rows 0 .. 3.  TR = false reads the same values with 2-byte loads
+// (MGNNS_FOLD_TR=0: the cross-check of the transposing form in the tests).
 template <bool TR>
 __global__ __launch_bounds__(NTHR) void folded_attn_bf16_kernel(const float* __restrict__ U, const unsigned short* __restrict__ bank,
                                                                 const float* __restrict__ mask, int B, int L, int D, int H,
@@ -90,18 +79,21 @@ __global__ __launch_bounds__(NTHR) void folded_attn_bf16_kernel(const float* __r
     // ---- live rows (row tiles behind the last unmasked position are never staged: their probability is exactly 0) and the
     //      mask as a score bias, one global round trip
     float* s_mb = reinterpret_cast<float*>(smem + OFF_MB);
-    if (tid == 0) s_int[0] = mask ? 0 : L;
-    __syncthreads();
-    if (tid < LMAX) {
-        const bool live = tid < L && (!mask || mask[(size_t)b * L + tid] != 0.0f);
-        s_mb[tid] = live ? 0.0f : -INFINITY;
-        if (mask) {
+    int lvalid = L;
+    if (mask) {
+        if (tid == 0) s_int[0] = 0;
+        __syncthreads();
+        if (tid < LMAX) {
+            const bool live = tid < L && mask[(size_t)b * L + tid] != 0.0f;
+            s_mb[tid] = live ? 0.0f : -INFINITY;
             const unsigned long long bal = __ballot(live);
             if (lane == 0 && bal) atomicMax(s_int, 64 * wave + 64 - __builtin_clzll(bal));
         }
+        __syncthreads();
+        lvalid = s_int[0];
+    } else if (tid < LMAX) {
+        s_mb[tid] = tid < L ? 0.0f : -INFINITY;              // (published by the staging barrier below)
     }
-    __syncthreads();
-    const int lvalid = s_int[0];
     const int n_mt = lvalid > 0 ? (lvalid + 15) >> 4 : 1;
     const int rows_live = n_mt * 16;
     MG_FSTAMP(1);
@@ -209,20 +201,52 @@ __global__ __launch_bounds__(NTHR) void folded_attn_bf16_kernel(const float* __r
         f32x4 acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nks; ++ks) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s_p + n * PROW + ((ks * 4 + g) << 3)));
-            const bool hi_on = 2 * ks + 1 < n_mt;               // the second 16 rows of this k-step are staged
+        // Branch-free: a wave's missing third tile re-reads its first one (result dropped), rows behind the staged ones are
+        // clamped to the last staged row (their probabilities are exactly zero in the P image; staged data is finite), so that
+        // every read of a k-step is in flight before the first MFMA waits.
+        int ft[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ft[t] = 16 * (wave + 8 * t < NT2 ? wave + 8 * t : wave);
+        const int last_row = rows_live - 1;
+        s16x4 lo[3], hi[3];
+        bf16x8 a;
+        auto fetch = [&](int ks) {
+            a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s_p + n * PROW + ((ks * 4 + g) << 3)));
+            const int r_lo = 32 * ks + 4 * g, r_hi = r_lo + 16;
+            int rl, rh;
+            if (TR) {
+                rl = min(r_lo + (n >> 2), last_row);
+                rh = min(r_hi + (n >> 2), last_row);
+            } else {
+                rl = r_lo;
+                rh = r_hi;
+            }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int nt = wave + 8 * t;
-                if (nt < NT2) {
-                    const s16x4 lo = col4<TR>(smem, 32 * ks + 4 * g, 16 * nt, n);
-                    s16x4 hi = {0, 0, 0, 0};
-                    if (hi_on) hi = col4<TR>(smem, 32 * ks + 16 + 4 * g, 16 * nt, n);
-                    const s16x8 bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+                if (TR) {
+                    const unsigned char* pl = smem + (size_t)rl * ROWB + (size_t)(ft[t] + 4 * (n & 3)) * 2;
+                    const unsigned char* ph = smem + (size_t)rh * ROWB + (size_t)(ft[t] + 4 * (n & 3)) * 2;
+                    lo[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)pl);
+                    hi[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)ph);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[t][k] = *reinterpret_cast<const short*>(smem + (size_t)min(rl + k, last_row) * ROWB + (size_t)(ft[t] + n) * 2);
+                        hi[t][k] = *reinterpret_cast<const short*>(smem + (size_t)min(rh + k, last_row) * ROWB + (size_t)(ft[t] + n) * 2);
+                    }
                 }
             }
+        };
+        fetch(0);
+        for (int ks = 0; ks < nks; ++ks) {
+            const bf16x8 ac = a;
+            s16x8 bv[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bv[t] = s16x8{lo[t][0], lo[t][1], lo[t][2], lo[t][3], hi[t][0], hi[t][1], hi[t][2], hi[t][3]};
+            if (ks + 1 < nks) fetch(ks + 1);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac, __builtin_bit_cast(bf16x8, bv[t]), acc[t], 0, 0, 0);
         }
         MG_FSTAMP(7);
 #pragma unroll

@@ -952,9 +952,14 @@ def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3):
     return out, qh
 
 
-def mha_tail_c16(c, q, packed, eps, next_packed=None):
-    """The bf16 fused tail behind sq_mha_folded_bf16 (mgnns_mha_tail_c16_fwd): c bf16 [B, H*300]; packed["fc"] = the composed map
-    fc . blockdiag(W_v); next_packed = ((hi, lo), bias, H*300) of the next layer's composed query map or None."""
+TAIL_C16_KSPLIT = os.environ.get("MGNNS_TAIL_C16_KSPLIT", "1") == "1"
+
+
+def mha_tail_c16(c, q, packed, eps, next_packed=None, cluster=0, ksplit=None):
+    """The bf16 fused tail behind sq_mha_folded_bf16 (mgnns_mha_tail_c16_fwd): c bf16 [B, H*300 rounded up to 32];
+    packed["fc"] = the composed map fc . blockdiag(W_v); next_packed = ((hi, lo), bias, H*300) of the next layer's composed query
+    map or None.  cluster: workgroups per 16-sample tile (0 = the library's default); ksplit (default on): the ranks split the K of
+    the first product and exchange partial sums through scratch owned by `packed`, one per (capture epoch, launch stream)."""
     import ctypes
     _chk(c, "c", torch.bfloat16, 2)
     _chk(q, "q", ndim=2)
@@ -971,9 +976,23 @@ def mha_tail_c16(c, q, packed, eps, next_packed=None):
         un = torch.empty(B, hcn, device=c.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * 8)(*ptrs)
     L = _lib.lib()
+    scratch = counters = None
+    if (TAIL_C16_KSPLIT if ksplit is None else ksplit) and B > 0 and cluster != 1:
+        tiles = (B + 15) // 16
+        slot = packed.setdefault("_cluster_ws", {})
+        key = _scratch_key()                                     # per (capture epoch, launch stream), like the channel tail's
+        ws = slot.get(key)
+        if ws is None or ws[0] < tiles or ws[1].device != c.device:
+            if ws is not None:
+                packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
+            ws = (tiles, torch.empty(L.mgnns_mha_tail_c16_scratch_floats(16 * tiles, 8), device=c.device, dtype=torch.float32),
+                  torch.zeros(2 * tiles, device=c.device, dtype=torch.int32))
+            slot[key] = ws
+        scratch, counters = ws[1], ws[2]
     _launch("mgnns_mha_tail_c16_fwd", ("mgnns_mha_tail_c16_fwd",), L.mgnns_mha_tail_c16_fwd, _p(c), HC, _p(q), B, 300,
             arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
-            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hcn, _p(un), _stream())
+            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hcn, _p(un), int(cluster), _p(scratch), _p(counters),
+            _stream())
     return out, un
 
 

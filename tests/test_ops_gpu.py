@@ -784,6 +784,49 @@ def test_sq_mha_folded_bf16_ragged_lengths_and_masked_tiles():
         assert err < 8e-3, (L, err)
 
 
+@pytest.mark.parametrize("Hn,B", [(8, 256), (8, 37), (4, 16), (1, 5)])
+def test_mha_tail_c16_cluster_forms_agree_and_match_fp64(Hn, B):
+    """The tail behind the folded attention: one workgroup per tile, clusters of 2 / 4 / 8 that recompute the front, clusters that
+    split the K of the composed output map and exchange partial sums -- against fp64 on the bf16-rounded operands of the first
+    product (the later products round their own inputs: bf16-class bound), against each other (same value up to the summation
+    order of the first product) and launch after launch (bit-equal: the exchange sums in rank order)."""
+    g = torch.Generator(device=DEV).manual_seed(11 + Hn)
+    r = lambda *shape: torch.randn(*shape, device=DEV, generator=g) * 0.05
+    HD = Hn * 300
+    ldc = (HD + 31) // 32 * 32
+    c = torch.zeros(B, ldc, device=DEV, dtype=torch.bfloat16)
+    c[:, :HD] = torch.randn(B, HD, device=DEV, generator=g).to(torch.bfloat16)
+    q = torch.randn(B, 300, device=DEV, generator=g)
+    fc, w1, w2, wq = r(300, HD), r(300, 300), r(300, 300), r(HD, 300)
+    pk = {"fc_b": r(300), "g1": r(300) + 1, "be1": r(300), "b1": r(300), "b2": r(300), "g2": r(300) + 1, "be2": r(300),
+          "fc": ops.pack_weight_bf16_split(fc), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
+    bq = r(HD)
+    nx = (ops.pack_weight_bf16_split(wq), bq, HD)
+
+    def ln(x, gamma, beta):
+        mu = x.mean(-1, keepdim=True)
+        sd = (x - mu).pow(2).sum(-1, keepdim=True).div(x.shape[-1] - 1).sqrt()
+        return gamma.double() * (x - mu) / (sd + 1e-6) + beta.double()
+    bfr = lambda t: t.to(torch.bfloat16).double()
+    y = ln(c[:, :HD].double() @ bfr(fc).t() + pk["fc_b"].double() + q.double(), pk["g1"], pk["be1"])
+    h = torch.relu(bfr(y.float()) @ bfr(w1).t() + pk["b1"].double())
+    want = ln(bfr(h.float()) @ bfr(w2).t() + pk["b2"].double() + y, pk["g2"], pk["be2"])
+    want_u = bfr(want.float()) @ bfr(wq).t() + bq.double()
+    ref = None
+    for cluster, ksplit in ((1, False), (2, False), (4, False), (0, True), (2, True), (4, True), (8, True)):
+        out, u = ops.mha_tail_c16(c, q, pk, 1e-6, nx, cluster=cluster, ksplit=ksplit)
+        out2, u2 = ops.mha_tail_c16(c, q, pk, 1e-6, nx, cluster=cluster, ksplit=ksplit)
+        assert torch.equal(out, out2) and torch.equal(u, u2), (cluster, ksplit)
+        assert H.maxabs(out.cpu(), want.cpu()) < 2e-2 and H.relerr(u.cpu(), want_u.cpu()) < 2e-2, (cluster, ksplit)
+        if ref is None:
+            ref = (out, u)
+        else:
+            # (a different summation order of the first product can move an intermediate across a bf16 rounding boundary)
+            assert H.maxabs(out.cpu(), ref[0].cpu()) < 1.2e-2 and H.relerr(u.cpu(), ref[1].cpu()) < 1.2e-2, (cluster, ksplit)
+        last, none = ops.mha_tail_c16(c, q, pk, 1e-6, None, cluster=cluster, ksplit=ksplit)
+        assert none is None and torch.equal(last, out), (cluster, ksplit)
+
+
 @pytest.mark.parametrize("Hn", [1, 4, 8])
 def test_run_stack_folded_bf16_matches_golden_and_the_explicit_bf16_stack(Hn):
     """bf16 mode + folded attention through fusion.run_stack (composed query map, one-bank-read attention, tail with the

@@ -130,8 +130,10 @@ def tail_c16(B=256, H=8):
     pk = {"fc_b": r(300), "g1": r(300) + 1, "be1": r(300), "b1": r(300), "b2": r(300), "g2": r(300) + 1, "be2": r(300),
           "fc": ops.pack_weight_bf16_split(fc), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
     nx = (ops.pack_weight_bf16_split(wq), r(H * 300), H * 300)
-    print("mha_tail_c16 H=%d (+next composed query map): %.1f us" % (H, timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, nx)) * 1e3))
-    print("mha_tail_c16 H=%d (last layer): %.1f us" % (H, timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, None)) * 1e3))
+    for cluster, ksplit in ((0, True), (2, True), (4, True), (8, True), (2, False), (4, False)):
+        print("mha_tail_c16 B=%d H=%d cluster=%d ksplit=%s: %.1f us (+next composed query map)  %.1f us (last layer)" % (
+            B, H, cluster, ksplit, timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, nx, cluster=cluster, ksplit=ksplit)) * 1e3,
+            timeit(lambda: ops.mha_tail_c16(c, q, pk, 1e-6, None, cluster=cluster, ksplit=ksplit)) * 1e3))
 
 
 if __name__ == "__main__":
@@ -153,6 +155,7 @@ if __name__ == "__main__":
         mha("folded_c16", B=128)
         mha("folded_c16", B=512)
         tail_c16()
+        tail_c16(B=64)
     if "imgbank" in what:
         imgbank()
     if "tail" in what:

@@ -33,5 +33,5 @@ for B, L, masked in ((256, 196, False), (256, 100, True), (64, 196, False)):
     names = ["mask / live rows", "DMA issue", "U + P zero", "wait DMA + barrier", "GEMM 1", "softmax", "GEMM 2", "C store"]
     for w in range(2):
         t = list(buf)[16 * w:16 * w + 9]
-        print("B=%d L=%d masked=%s wg %d: total %d ticks (100 MHz): " % (B, L, masked, 129 * w, t[8] - t[0]) +
+        print("B=%d L=%d masked=%s wg %d: total %d cycles: " % (B, L, masked, 129 * w, t[8] - t[0]) +
               "  ".join("%s %d" % (names[i], t[i + 1] - t[i]) for i in range(8)))
