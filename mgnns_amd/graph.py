@@ -104,6 +104,8 @@ class GraphedForward:
                     self.static_out = post(self.static_out)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import ops as _ops
+        _ops.reserve_zeros(self.static_in[0].device)      # counters of the launches captured below: no fill nodes in the graphs
         if self.mode in ("single", "auto"):
             try:
                 self.graph = torch.cuda.CUDAGraph()

@@ -39,6 +39,47 @@ def _scratch_key():
     return (_SCRATCH_EPOCH, _stream())
 
 
+# Counters of the persistent / cluster launches start at zero and are left at zero by the kernels themselves (the last
+# workgroup re-arms them).  They come out of a pool that is zeroed OUTSIDE any capture: a torch.zeros inside a capture is a
+# fill node of the graph -- a 5-8 us launch in front of the kernel on every replay (13 of them per forward, most on the
+# bank -> tail -> stack chains).  Slices are handed out once and never reused.
+_ZERO_POOL = {}
+_ZERO_CHUNK = 64 << 20
+
+
+def _capturing():
+    return torch.cuda.is_current_stream_capturing()
+
+
+def reserve_zeros(device, nbytes=24 << 20):
+    """Make sure the zero pool of `device` has nbytes left (call outside a capture, e.g. right before one)."""
+    device = torch.device(device)
+    pool = _ZERO_POOL.get(device)
+    if (pool is None or pool[1] + nbytes > pool[0].numel()) and not _capturing():
+        buf = torch.zeros(max(_ZERO_CHUNK, nbytes), dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()           # zero before any stream uses a slice
+        _ZERO_POOL[device] = [buf, 0]
+
+
+def zeros_bytes(nbytes, device):
+    """nbytes of zeroed device memory (256-B aligned) that the caller's kernels keep zero between launches."""
+    device = torch.device(device)
+    n = (int(nbytes) + 255) // 256 * 256
+    pool = _ZERO_POOL.get(device)
+    if pool is None or pool[1] + n > pool[0].numel():
+        if _capturing():                                          # pool exhausted inside a capture: a fill node, still correct
+            return torch.zeros(n, dtype=torch.uint8, device=device)
+        reserve_zeros(device, max(n, 24 << 20))
+        pool = _ZERO_POOL[device]
+    t = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return t
+
+
+def zeros_i32(n, device):
+    return zeros_bytes(4 * n, device).view(torch.int32)[:n]
+
+
 class KernelTimer:
     """Opt-in per-launch HIP-event timing (bench.py's roofline leg).  Events are recorded on the stream
     the kernels are launched on (PyTorch's current stream), around the C-ABI call only."""
@@ -156,7 +197,7 @@ def classifier_head(feats, weight, bias):
 def classifier_head_state(B, NL, nparts, device):
     """Buffers of one forward's split classifier head (classifier_head_part): parts [nparts,B,NL], arrival counter (zero),
     logits [B,NL]."""
-    return (torch.empty(nparts, B, NL, device=device, dtype=torch.float32), torch.zeros(1, device=device, dtype=torch.int32),
+    return (torch.empty(nparts, B, NL, device=device, dtype=torch.float32), zeros_i32(1, device),
             torch.empty(B, NL, device=device, dtype=torch.float32))
 
 
@@ -251,7 +292,7 @@ def label_gcn(A, inp, packed, want_packed_g=False, query=None, grid=0):
     if ws is None or ws.numel() < need or ws.device != A.device:
         if ws is not None:
             packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
-        ws = torch.zeros(need, dtype=torch.uint8, device=A.device)        # counters (first 256 B) start at zero
+        ws = zeros_bytes(need, A.device)[:need]                           # counters (first 256 B) start at zero
         slot[key] = ws
     G = torch.empty(C, N2, device=A.device, dtype=torch.float32)
     gh = gl = None
@@ -712,7 +753,7 @@ def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3, cl
             if ws is not None:
                 packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(tiles * 4 * 6144, device=Q.device, dtype=torch.float32),
-                  torch.zeros(2 * tiles, device=Q.device, dtype=torch.int32))
+                  zeros_i32(2 * tiles, Q.device))
             slot[key] = ws
         scratch, counters = ws[1], ws[2]
     L = _lib.lib()
@@ -986,7 +1027,7 @@ def mha_tail_c16(c, q, packed, eps, next_packed=None, cluster=0, ksplit=None):
             if ws is not None:
                 packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(L.mgnns_mha_tail_c16_scratch_floats(16 * tiles, 8), device=c.device, dtype=torch.float32),
-                  torch.zeros(2 * tiles, device=c.device, dtype=torch.int32))
+                  zeros_i32(2 * tiles, c.device))
             slot[key] = ws
         scratch, counters = ws[1], ws[2]
     _launch("mgnns_mha_tail_c16_fwd", ("mgnns_mha_tail_c16_fwd",), L.mgnns_mha_tail_c16_fwd, _p(c), HC, _p(q), B, 300,
