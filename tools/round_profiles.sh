@@ -1,19 +1,19 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/round_profiles.sh <round-tag>   -- everything profiles/ is refreshed from:
-# kernel stats (bf16 graph replay / bf16 serial eager / f32 / folded), three PMC passes (bf16, eager), bench lines, stress json -> gpurun_out/
+# kernel stats (bf16 graph replay / bf16 serial eager / f32 / bf16 with the explicit attention), three PMC passes (bf16, eager), bench lines, stress json -> gpurun_out/
 tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/${tag}_bench_bf16.log 2>&1; tail -1 gpurun_out/${tag}_bench_bf16.log > gpurun_out/${tag}_bench_bf16.json
 timeout 400 python bench.py --steps 20 --warmup 5 --dtype f32 --no-variants > gpurun_out/${tag}_bench_f32.log 2>&1; tail -1 gpurun_out/${tag}_bench_f32.log > gpurun_out/${tag}_bench_f32.json
 timeout 300 python tools/bench_stress.py 2>/dev/null | tail -1 > gpurun_out/${tag}_stress_gcn.json
-timeout 300 python tools/bench_kernels.py textgcn tail lstm imgbank > gpurun_out/${tag}_bench_kernels.txt 2>&1
-MGNNS_BENCH_GRAPH=1 timeout 300 python tools/bench_kernels.py textgcn tail >> gpurun_out/${tag}_bench_kernels.txt 2>&1
+timeout 300 python tools/bench_kernels.py textgcn tail lstm imgbank folded_c16 mha_bf16 > gpurun_out/${tag}_bench_kernels.txt 2>&1
+MGNNS_BENCH_GRAPH=1 timeout 300 python tools/bench_kernels.py textgcn tail folded_c16 mha_bf16 >> gpurun_out/${tag}_bench_kernels.txt 2>&1
 timeout 200 python tools/graph_timeline.py > gpurun_out/${tag}_timeline.txt 2>&1
 timeout 400 tools/prof.sh ${tag}_bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-variants
 timeout 400 tools/prof.sh ${tag}_bf16_serial --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream
 timeout 400 tools/prof.sh ${tag}_f32 --steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32
-timeout 400 tools/prof.sh ${tag}_folded --steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded
+timeout 400 tools/prof.sh ${tag}_faithful --steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn faithful
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout 400 tools/pmc.sh ${tag}_$c $c --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-graph > /dev/null
 done

@@ -35,7 +35,7 @@ def kernel_stats(db):
         lines.append("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (short, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
     # the attention core runs on two problem sizes (image banks L=196 / text bank L=100) with one grid: split at the median
     split = {}
-    for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "folded_attn_kernel"):
+    for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "folded_attn_kernel", "folded_attn_bf16_kernel"):
         v = sorted(r[0] for r in cur.execute("select d.end - d.start from %s d join %s s on d.kernel_id = s.id where s.kernel_name like ?"
                                              % (disp, sym), ("%" + sub + "%",)))
         if len(v) >= 2:
@@ -58,7 +58,7 @@ def main():
     cmds = {"bf16": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants",
             "bf16_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream",
             "f32": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32",
-            "folded": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded"}
+            "faithful": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn faithful"}
     for m, args in cmds.items():
         db = os.path.join(GO, "prof_%s_%s" % (tag, m), "%s_%s_results.db" % (tag, m))
         if not os.path.exists(db):
@@ -89,6 +89,9 @@ def main():
     if all(os.path.exists(p) for p in dbs.values()):
         kern = [("sq_mha_core_bf16_kernel L=196 (image banks)", "sq_mha_core_bf16_kernel", True, "32.1 bank + 1.3 W + 1.0 q + 1.0 out"),
                 ("sq_mha_core_bf16_kernel L=100 (text bank, masked)", "sq_mha_core_bf16_kernel", False, "16.4 bank + 1.3 W + 1.0 q + 1.0 out"),
+                ("folded_attn_bf16_kernel L=196 (image banks)", "folded_attn_bf16_kernel", True, "32.1 bank + 2.5 u + 1.2 c"),
+                ("folded_attn_bf16_kernel L=100 (text bank, masked)", "folded_attn_bf16_kernel", False, "<= 16.4 bank (live row tiles only) + 2.5 u + 1.2 c"),
+                ("mha_tail_c16", "mha_tail_c16", None, "1.2 c + 3.3 W (L2) + exchange"),
                 ("imgbank_pool_bf16", "imgbank_pool_bf16", None, "411.0 map + 1.2 W + 32.1 bank"),
                 ("lstm_rec", "lstm_rec", None, "Gx + h"),
                 ("mha_tail_bf16", "mha_tail_bf16", None, "1.6 W per WG (L2)"),
@@ -107,6 +110,12 @@ def main():
                     "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre,
                     "kernel_source": "mgnns_amd/csrc/sq_mha_bf16.hip",
                     "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/sq_mha_bf16.hip"), "rb").read()).hexdigest()[:16]}
+            if label.startswith("folded_attn_bf16_kernel L=196"):
+                traffic["folded_attn_bf16@L196"] = {
+                    "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
+                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes)" % pre,
+                    "kernel_source": "mgnns_amd/csrc/sq_mha_folded_bf16.hip",
+                    "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/sq_mha_folded_bf16.hip"), "rb").read()).hexdigest()[:16]}
             if label == "imgbank_pool_bf16":
                 traffic["imgbank_pool_bf16@B256"] = {
                     "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
