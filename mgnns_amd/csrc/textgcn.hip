@@ -20,8 +20,9 @@
 
 namespace {
 
-constexpr int TG_THREADS = 1024;
 constexpr int TG_MAX_CHUNKS = 16;
+constexpr int TG_SHORT_THREADS = 256;
+constexpr int TG_SHORT_CAP = 24;      // tokens: 24 x 1200 B of node rows + band + chunk sums = 33 KB of LDS, four workgroups per CU
 constexpr int TG_WIN = 8;            // candidate window of a lookup: positions lo .. lo+8
 
 __device__ __forceinline__ float pmi_weight(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -49,20 +50,28 @@ __device__ __forceinline__ float pmi_weight(const int32_t* __restrict__ row_ptr,
     return edge_w[id];
 }
 
-template <int GT>      // compile-time ngram (window fully unrolled), 0 = runtime ngram
-__global__ __launch_bounds__(TG_THREADS) void textgcn_kernel(const int64_t* __restrict__ tok, int T, int Tm,
+// GT: compile-time ngram (window fully unrolled), 0 = runtime ngram.  NT: threads of the workgroup.
+// Two launch forms.  One launch of 1024-thread workgroups with LDS for Tm node rows (120 KB at T = 100): a whole CU per
+// document, although a document is a chain of ~5 dependent global round trips that a CU mostly waits for.  Or TWO launches
+// (batches from 64 documents on): 256-thread workgroups with LDS for `cap` node rows -- four of them share a CU -- take the
+// documents with at most `cap` distinct-position tokens (mode 1: longer ones leave after the token compaction), then the
+// 1024-thread form takes the longer ones (mode 2: the short ones leave).  Tn = rows of LDS (Tm or cap).
+template <int GT, int NT>
+__global__ __launch_bounds__(NT) void textgcn_kernel(const int64_t* __restrict__ tok, int T, int Tm,
                                const float* __restrict__ node_hidden, int V, int D,
                                const float* __restrict__ edge_w, int n_edge_w,
                                const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                               const int32_t* __restrict__ eid, int g_rt, float* __restrict__ out, int vec, int C) {
+                               const int32_t* __restrict__ eid, int g_rt, float* __restrict__ out, int vec, int C, int Tn,
+                               int mode, int cap) {
+    constexpr int TG_THREADS = NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = GT > 0 ? GT : g_rt;
     const int W = 2 * g + 1;
     const int D4 = (D + 3) >> 2, Dp = D4 << 2;
-    float* s_h = smem;                                   // [Tm][Dp]
-    float* s_part = s_h + (size_t)Tm * Dp;               // [C][Dp]
-    float* s_w = s_part + (size_t)C * Dp;                // [Tm][W]
-    int* s_tok = reinterpret_cast<int*>(s_w + (size_t)Tm * W);   // [Tm]
+    float* s_h = smem;                                   // [Tn][Dp]
+    float* s_part = s_h + (size_t)Tn * Dp;               // [C][Dp]
+    float* s_w = s_part + (size_t)C * Dp;                // [Tn][W]
+    int* s_tok = reinterpret_cast<int*>(s_w + (size_t)Tn * W);   // [Tm]
     int* s_next = s_tok + Tm;                            // [Tm] next position holding the same token, INT_MAX = none
     int* s_first = s_next + Tm;                          // [Tm] 1 if first occurrence of its token
     int* s_n = s_first + Tm;                             // [1]
@@ -88,6 +97,7 @@ __global__ __launch_bounds__(TG_THREADS) void textgcn_kernel(const int64_t* __re
     for (int j = tid; j < Tm; j += TG_THREADS) { s_first[j] = 1; s_next[j] = 0x7fffffff; }
     __syncthreads();
     const int n = *s_n;
+    if ((mode == 1 && n > cap) || (mode == 2 && n <= cap)) return;         // the other launch's document (uniform per workgroup)
 
     // -- 2a. stage node rows h[t_i] into LDS: batches of 4 independent 16-B loads per thread ---------------
     if (vec) {
@@ -177,20 +187,20 @@ __global__ __launch_bounds__(TG_THREADS) void textgcn_kernel(const int64_t* __re
         *reinterpret_cast<f32x4*>(s_part + (size_t)cidx * Dp + 4 * f) = sum;
     }
     __syncthreads();
-    if (tid < D) {
+    for (int d = tid; d < D; d += TG_THREADS) {
         float total = 0.f;
-        for (int c = 0; c < C; ++c) total += s_part[(size_t)c * Dp + tid];      // fixed order: deterministic
-        out[(size_t)b * D + tid] = fmaxf(total, 0.f);
+        for (int c = 0; c < C; ++c) total += s_part[(size_t)c * Dp + d];        // fixed order: deterministic
+        out[(size_t)b * D + d] = fmaxf(total, 0.f);
     }
 }
 
-template <int GT>
+template <int GT, int NT>
 int launch(const int64_t* tok, int B, int T, int Tm, const float* node_hidden, int V, int D, const float* edge_w, int n_edge_w,
-           const int32_t* rp, const int32_t* col, const int32_t* eid, int ngram, float* out, int vec, int C, size_t lds,
-           hipStream_t st) {
-    MG_DYN_LDS(textgcn_kernel<GT>, 160 * 1024);
-    hipLaunchKernelGGL(textgcn_kernel<GT>, dim3(B), dim3(TG_THREADS), lds, st, tok, T, Tm, node_hidden, V, D, edge_w, n_edge_w,
-                       rp, col, eid, ngram, out, vec, C);
+           const int32_t* rp, const int32_t* col, const int32_t* eid, int ngram, float* out, int vec, int C, int Tn, int mode, int cap,
+           size_t lds, hipStream_t st) {
+    MG_DYN_LDS((textgcn_kernel<GT, NT>), NT == 1024 ? 160 * 1024 : 40 * 1024);
+    hipLaunchKernelGGL((textgcn_kernel<GT, NT>), dim3(B), dim3(NT), lds, st, tok, T, Tm, node_hidden, V, D, edge_w, n_edge_w,
+                       rp, col, eid, ngram, out, vec, C, Tn, mode, cap);
     MG_CHECK_LAUNCH("mgnns_textgcn_fwd");
     return 0;
 }
@@ -210,19 +220,37 @@ extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* 
     const int Tm = T < max_length ? T : max_length;
     const int W = 2 * ngram + 1;
     const int D4 = (D + 3) / 4, Dp = 4 * D4;
-    int C = TG_THREADS / D4;
+    auto lds_of = [&](int Tn, int C) {
+        return ((size_t)Tn * Dp + (size_t)C * Dp + (size_t)Tn * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
+    };
+    int C = 1024 / D4;
     C = C > TG_MAX_CHUNKS ? TG_MAX_CHUNKS : C;
-    const size_t lds = ((size_t)Tm * Dp + (size_t)C * Dp + (size_t)Tm * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
+    const size_t lds = lds_of(Tm, C);
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_textgcn_fwd: min(T,max_length)=%d needs %zu B of LDS (> 160 KiB)", Tm, lds);
     const int vec = (D % 4 == 0) && mg_aligned16(node_hidden);
     hipStream_t st = (hipStream_t)stream;
-#define TG_ARGS tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec, C, lds, st
-    switch (ngram) {
-        case 1: return launch<1>(TG_ARGS);
-        case 2: return launch<2>(TG_ARGS);
-        case 3: return launch<3>(TG_ARGS);
-        case 4: return launch<4>(TG_ARGS);
-        default: return launch<0>(TG_ARGS);
+    // short documents four to a CU, then the long ones (see the kernel's comment); one launch for small batches, short rows or
+    // shapes whose 256-thread form does not fit (MGNNS_TEXTGCN_SPLIT=0: always one launch)
+    int Cs = TG_SHORT_THREADS / D4;
+    Cs = Cs > TG_MAX_CHUNKS ? TG_MAX_CHUNKS : Cs;
+    const size_t lds_s = lds_of(TG_SHORT_CAP, Cs);
+    const bool split = B >= 64 && Tm > TG_SHORT_CAP && Cs >= 1 && lds_s <= 40 * 1024 && mg_env_int("MGNNS_TEXTGCN_SPLIT", 1, 7) != 0;
+#define TG_ARGS(Tn_, C_, mode_, lds_) tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec, C_, Tn_, mode_, TG_SHORT_CAP, lds_, st
+#define TG_LAUNCH(GT_)                                                                                     \
+    {                                                                                                      \
+        if (split) {                                                                                       \
+            if (int rc = launch<GT_, TG_SHORT_THREADS>(TG_ARGS(TG_SHORT_CAP, Cs, 1, lds_s))) return rc;    \
+            return launch<GT_, 1024>(TG_ARGS(Tm, C, 2, lds));                                              \
+        }                                                                                                  \
+        return launch<GT_, 1024>(TG_ARGS(Tm, C, 0, lds));                                                  \
     }
+    switch (ngram) {
+        case 1: TG_LAUNCH(1)
+        case 2: TG_LAUNCH(2)
+        case 3: TG_LAUNCH(3)
+        case 4: TG_LAUNCH(4)
+        default: TG_LAUNCH(0)
+    }
+#undef TG_LAUNCH
 #undef TG_ARGS
 }

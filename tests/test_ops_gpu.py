@@ -418,6 +418,30 @@ def test_textgcn_vs_oracle_full_length_and_edge_cases():
         assert H.relerr(y.cpu(), ref) < 1e-5
 
 
+def test_textgcn_two_launch_form_short_and_long_documents():
+    """From 64 documents on the text GCN runs as two launches (documents of at most 24 tokens four to a CU, then the longer ones):
+    lengths on both sides of the cap incl. exactly 24 / 25, empty and full-length documents, against the oracle and against the
+    same documents run in batches below the threshold (one launch; same values up to the summation order of the chunk sums)."""
+    V, T, B = 5000, 100, 96
+    pmi, count = synth.synth_pmi(V, seed=6)
+    tok, lens, _ = synth.synth_tokens(B, T, V, pmi, seed=12)
+    rs = np.random.RandomState(3)
+    for b, n in ((2, 24), (3, 25), (4, 0), (5, 100), (6, 1), (7, 23), (8, 26)):
+        tok[b] = 0
+        tok[b, :n] = rs.randint(2, V, size=n)
+    tok[9, ::3] = 0                                             # PADs inside: the cap counts non-PAD tokens
+    p = H.params_for({"text_features.node_hidden.weight": (V, 300), "text_features.seq_edge_w.weight": (count, 1)})
+    nh, ew = dev(p["text_features.node_hidden.weight"]), dev(p["text_features.seq_edge_w.weight"])
+    for ngram in (4, 0, 6):
+        ref = R.text_gcn(tok, p["text_features.node_hidden.weight"], p["text_features.seq_edge_w.weight"], pmi, ngram)
+        y = ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram)
+        assert H.relerr(y.cpu(), ref) < 1e-5, ngram
+        assert float(y[4].abs().max()) == 0.0
+        parts = torch.cat([ops.textgcn(dev(tok[i:i + 32]), nh, ew, pmi.device_arrays(DEV), ngram) for i in range(0, B, 32)])
+        assert H.relerr(y.cpu(), parts.cpu()) < 1e-6, ngram
+        assert torch.equal(y, ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram))
+
+
 def test_textgcn_explicit_ids_long_rows_and_odd_width():
     """(a) a PMI map whose ids are NOT positional (shuffled ids: the kernel must read `eid`), (b) rows far longer than the
     lookup's 9-candidate window (bisection first), hit and miss, first / last column, (c) hidden width not a multiple of 4
