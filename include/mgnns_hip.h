@@ -361,10 +361,11 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
  * fc . blockdiag(Wv) [d_model, n_head * d_model], fc_b = fc bv + b_fc; packed[6] / bq_next = the NEXT layer's composed query map
  * [HC_next, d_model] and its bias (NULL: none); only the hi buffers (even entries of `packed`) are read.
  * cluster: workgroups per 16-sample tile (0 = default: 4 with the exchange buffers; 1..8).  With cluster_scratch
- * (mgnns_mha_tail_c16_scratch_floats(B, 8) floats, 16-byte aligned) and cluster_counters (2 * ceil(B/16) int32, ZERO before the
- * first launch; the kernel leaves them zero) the ranks split the K of the first product and exchange partial sums through the
- * scratch (bounded wait + status word as mgnns_label_tail_bf16_fwd; one pair of buffers per concurrently running launch);
- * without them every rank streams the whole composed map.  Everything else as mgnns_mha_tail_bf16_fwd.
+ * (mgnns_mha_tail_c16_scratch_floats(B, 8) floats, 16-byte aligned) and cluster_counters (ceil(B/16) int32, ZERO before the
+ * first launch; the kernel leaves them zero; one pair of buffers per concurrently running launch) the ranks split the K of the
+ * first product, the rank that arrives LAST adds the partial sums and finishes the tile (nobody waits), and the next layer's
+ * query map runs as a second launch behind it; without them every rank streams the whole composed map and takes a share of the
+ * next one.  Everything else as mgnns_mha_tail_bf16_fwd.
  */
 size_t mgnns_mha_tail_c16_scratch_floats(int B, int cluster);
 int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q, int B, int d_model, const void* const* packed,

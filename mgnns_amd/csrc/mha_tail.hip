@@ -296,11 +296,75 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
 __global__ __launch_bounds__(NTHR) void mha_tail_c16_kernel(const unsigned short* __restrict__ c, int HC, const float* __restrict__ q,
                                                             int B, TailW w, float eps, float* __restrict__ out, int HCn,
                                                             float* __restrict__ u_next, int cl, float* __restrict__ xpart,
-                                                            int* __restrict__ xcnt, int* __restrict__ status) {
+                                                            int* __restrict__ xcnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    // the ranks of a tile are adjacent in dispatch order (see the exchange in tail_bf16_body)
     mg_tail::tail_bf16_body<1, false, true>(smem_b, reinterpret_cast<const float*>(c), HC, q, B, w, eps, out, HCn, u_next,
-                                            (int)blockIdx.x / cl, (int)blockIdx.x % cl, cl, xpart, xcnt, status);
+                                            (int)blockIdx.x / cl, (int)blockIdx.x % cl, cl, xpart, xcnt);
+}
+
+// u = M x + c for a 16-sample tile x (fp32 [B, 300], a layer's output) and the next layer's composed query map M (packed bf16,
+// [HCn, 300]): a launch of its own behind the last-arriver form of the tail above.  `cl` workgroups per tile share M's column
+// tiles; each wave streams its tiles' fragments as ONE stream (k-step d of the next tile is requested when k-step d of the
+// current one is consumed).  11 KB of LDS, ~100 registers: shares a CU with anything.
+__global__ __launch_bounds__(NTHR) void mha_proj_c16_kernel(const float* __restrict__ x, int B, const unsigned short* __restrict__ wq_h,
+                                                            const float* __restrict__ bq, int HCn, float* __restrict__ u_next, int cl) {
+    __shared__ __attribute__((aligned(16))) uint4 s_a[ROWS * SCD];
+    constexpr int KSd = (D + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = (int)blockIdx.x / cl, rank = (int)blockIdx.x % cl, r0 = tile * ROWS;
+    const int NTq = (HCn + 15) / 16;
+    const int slots = (NTq + 7) / 8;
+    const int per = (slots + cl - 1) / cl;
+    const int s_lo = rank * per, s_hi = min(slots, s_lo + per);
+    if (s_lo >= s_hi) return;
+    const uint4* Wq = reinterpret_cast<const uint4*>(wq_h);
+    auto wq_off = [&](int slot) {
+        const int nt = wave + 8 * slot;
+        return ((size_t)(nt < NTq ? nt : 0) * KSd) * 64 + lane;
+    };
+    uint4 rq[KSd];
+    {
+        const size_t o0 = wq_off(s_lo);
+#pragma unroll
+        for (int d = 0; d < KSd; ++d) rq[d] = Wq[o0 + (size_t)d * 64];
+    }
+    // x tile -> bf16 A image [16][SCD chunks of 8] (zero padded)
+    for (int i = tid; i < ROWS * SCD; i += NTHR) {
+        const int r = i / SCD, c8 = (i - r * SCD) * 8;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < B) {
+            const float* xr = x + (size_t)(r0 + r) * D + c8;
+            if (c8 + 4 <= D) a = *reinterpret_cast<const f32x4*>(xr);
+            if (c8 + 8 <= D) b = *reinterpret_cast<const f32x4*>(xr + 4);
+        }
+        s_a[i] = make_uint4(f2bf2_t(a[0], a[1]), f2bf2_t(a[2], a[3]), f2bf2_t(b[0], b[1]), f2bf2_t(b[2], b[3]));
+    }
+    __syncthreads();
+    bf16x8 aq[KSd];
+#pragma unroll
+    for (int d = 0; d < KSd; ++d) aq[d] = __builtin_bit_cast(bf16x8, s_a[(lane & 15) * SCD + (lane >> 4) + 4 * d]);
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    for (int slot = s_lo; slot < s_hi; ++slot) {
+        const int nt = wave + 8 * slot, n = nt * 16 + ccol;
+        const bool live = nt < NTq && n < HCn;
+        const float bv = (live && bq) ? bq[n] : 0.f;
+        const bool more = slot + 1 < s_hi;
+        const size_t nx = wq_off(more ? slot + 1 : slot);
+        f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < KSd; ++d) {
+            const uint4 c = rq[d];
+            if (more) rq[d] = Wq[nx + (size_t)d * 64];
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[d], __builtin_bit_cast(bf16x8, c), a2, 0, 0, 0);
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = r0 + crow + r;
+                if (gr < B) u_next[(size_t)gr * HCn + n] = a2[r] + bv;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -388,8 +452,6 @@ extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q
     MG_REQUIRE((cluster_scratch != nullptr) == (cluster_counters != nullptr), "mgnns_mha_tail_c16_fwd: cluster scratch and counters go together");
     MG_REQUIRE(!cluster_scratch || mg_aligned16(cluster_scratch), "mgnns_mha_tail_c16_fwd: cluster scratch must be 16-byte aligned");
     if (B <= 0) return 0;
-    if (cluster_scratch)
-        if (int rc = mg_check_status("mgnns_mha_tail_c16_fwd")) return rc;     // a bounded wait of an earlier launch ran out
     TailW w;
     w.fc_h = (const unsigned short*)packed[0]; w.fc_l = nullptr;
     w.w1_h = (const unsigned short*)packed[2]; w.w1_l = nullptr;
@@ -401,8 +463,8 @@ extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q
     MG_REQUIRE(lds <= 160 * 1024, "mgnns_mha_tail_c16_fwd: needs %zu B of LDS", lds);
     MG_DYN_LDS(mha_tail_c16_kernel, 160 * 1024);
     // A cluster of workgroups per 16-sample tile.  With exchange buffers the ranks split the K of the first product (the composed
-    // output map) and exchange partial sums, then each repeats the short LayerNorm / FFN chain and takes a share of the next
-    // composed query map's columns; without buffers (or without a next map and cluster == 0) one workgroup per tile.
+    // output map); without buffers every rank repeats the front part and takes a share of the next composed query map's columns
+    // (or, without a next map and cluster == 0, one workgroup per tile).
     // (measured at B = 256, two forwards in flight: 442 k samples/s with four ranks, 435 k with two; one at a time 0.624 / 0.643 ms)
     int cl = cluster ? cluster : (cluster_scratch ? 4 : (packed[6] ? (B >= 256 ? 2 : 4) : 1));
     if (!cluster) {
@@ -411,10 +473,21 @@ extern "C" int mgnns_mha_tail_c16_fwd(const void* c_bf16, int HC, const float* q
     if (cl < 1) cl = 1;
     if (cl > 8) cl = 8;
     if (!packed[6] && !cluster_scratch) cl = 1;            // nothing to share
-    dim3 grid((unsigned)((B + ROWS - 1) / ROWS) * cl);
-    hipLaunchKernelGGL(mha_tail_c16_kernel, grid, dim3(NTHR), lds, (hipStream_t)stream, static_cast<const unsigned short*>(c_bf16), HC,
-                       q, B, w, eps, out, HC_next, u_next, cl, cluster_scratch, cluster_counters,
-                       cluster_scratch ? mg_status_word() : (int*)nullptr);
+    const unsigned tiles = (unsigned)((B + ROWS - 1) / ROWS);
+    // With exchange buffers and more than one rank: the LAST rank of a tile to arrive adds the partial sums and runs the rest of
+    // the tail alone (nobody waits; the LayerNorm / FFN chain runs once per tile), and the next layer's composed query map is a
+    // launch of its own on 8 workgroups per tile.
+    const bool last_arriver = cluster_scratch && cl > 1;
+    if (last_arriver) w.wq_h = nullptr;
+    hipLaunchKernelGGL(mha_tail_c16_kernel, dim3(tiles * cl), dim3(NTHR), lds, (hipStream_t)stream,
+                       static_cast<const unsigned short*>(c_bf16), HC, q, B, w, eps, out, HC_next, u_next, cl,
+                       last_arriver ? cluster_scratch : (float*)nullptr, last_arriver ? cluster_counters : (int*)nullptr);
     MG_CHECK_LAUNCH("mgnns_mha_tail_c16_fwd");
+    if (last_arriver && packed[6]) {
+        const int pcl = 8;
+        hipLaunchKernelGGL(mha_proj_c16_kernel, dim3(tiles * pcl), dim3(NTHR), 0, (hipStream_t)stream, (const float*)out, B,
+                           (const unsigned short*)packed[6], bq_next, HC_next, u_next, pcl);
+        MG_CHECK_LAUNCH("mgnns_mha_tail_c16_fwd(projection)");
+    }
     return 0;
 }

@@ -115,12 +115,11 @@ template <int TERMS, bool O_COHERENT, bool O_BF16 = false>
 __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const float* __restrict__ o, int HK, const float* __restrict__ q,
                                                int B, const TailW& w, float eps, float* __restrict__ out, int HKn,
                                                float* __restrict__ qh_next, int tile, int crank, int csize,
-                                               float* __restrict__ xpart = nullptr, int* __restrict__ xcnt = nullptr,
-                                               int* __restrict__ status = nullptr) {
+                                               float* __restrict__ xpart = nullptr, int* __restrict__ xcnt = nullptr) {
     static_assert(!O_BF16 || TERMS == 1, "a bf16 o has no lo part");
     // K-split (O_BF16 with exchange buffers): the ranks of a tile's cluster each contract a slice of the first product's K
-    // (1.44 MB of composed weights behind the folded attention) and exchange the partial sums (the channel tail's scheme,
-    // label_tail.hip) instead of every rank streaming all of it.
+    // (1.44 MB of composed weights behind the folded attention) instead of every rank streaming all of it; the last rank to
+    // arrive adds the partial sums and finishes the tile (below).
     const bool ksplit = O_BF16 && xpart != nullptr && csize > 1;
     const int KSo_all = (HK + 31) / 32;
     const int ks_lo = ksplit ? crank * KSo_all / csize : 0;
@@ -248,10 +247,10 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     MG_TSTAMP(2);
     if (ksplit) {
         // partial [tile][rank][wave][t][lane] x 16 B: a lane writes and reads exactly the accumulator slots it owns (write-through
-        // stores, loads that bypass the non-coherent caches, one relaxed agent-scope arrival per rank).  The ranks of a tile are
-        // ADJACENT in dispatch order (blockIdx = tile * csize + rank): at most one cluster of a launch straddles the edge of what
-        // is resident and everything in front of it retires without waiting for anybody.  The wait is bounded all the same; when
-        // it runs out the rank goes on with what has arrived and raises the library's status word.
+        // stores acknowledged by vmcnt(0), ONE relaxed agent-scope arrival per rank, loads that bypass the non-coherent caches).
+        // Nobody waits: the rank that arrives LAST adds the partials in rank order and runs the rest of the tail for the tile
+        // alone, the others are done -- the LayerNorm / FFN chain runs once per tile, and there is no co-residency assumption
+        // (the first form had every rank wait for the partials and repeat the chain: same speed, 4x the chain's CU time).
         typedef int tl_i32x4 __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t xp = __builtin_amdgcn_make_buffer_rsrc(xpart + (size_t)tile * csize * (8 * 3 * 64 * 4), 0,
                                                                             csize * 8 * 3 * 64 * 16, 0x00027000);
@@ -262,18 +261,16 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tl_i32x4, acc[t]), xp, slot + t * 64 * 16, crank * (8 * 3 * 64 * 16), 17);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores are acknowledged
         __syncthreads();
+        int* s_flag = reinterpret_cast<int*>(s_t);
         if (tid == 0) {
-            __hip_atomic_fetch_add(&xcnt[2 * tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            while (__hip_atomic_load(&xcnt[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < csize) {
-                if (++spins > (1 << 24)) {
-                    if (status) __hip_atomic_store(status, MGNNS_STATUS_CLUSTER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
+            const int old = __hip_atomic_fetch_add(&xcnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == csize - 1;
+            if (last) __hip_atomic_store(&xcnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            *s_flag = last;
         }
         __syncthreads();
+        if (!*s_flag) return;
+        __syncthreads();                                       // (s_t is written again below)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -284,20 +281,13 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
                     pr[rk] = rk < csize ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xp, slot + t * 64 * 16, rk * (8 * 3 * 64 * 16), 17))
                                         : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int rk = 0; rk < 8; ++rk) sum += pr[rk];          // rank order: every rank forms the same sum
+                for (int rk = 0; rk < 8; ++rk) sum += pr[rk];          // rank order, whichever rank arrived last
             }
             acc[t] = sum;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials are in registers
-        __syncthreads();
-        if (tid == 0) {        // every thread of this rank has consumed the partials: the last rank to get here re-arms the counters
-            const int old = __hip_atomic_fetch_add(&xcnt[2 * tile + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == csize - 1) {
-                __hip_atomic_store(&xcnt[2 * tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&xcnt[2 * tile + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
     }
+    const int prank = ksplit ? 0 : crank;                              // who stores `out` / how the projection is shared from here on
+    const int psize = ksplit ? 1 : csize;
     ring_prime(ring, KSd, w.w1_h, w.w1_l, DT, wave, lane, 0);          // w_1 flies through LayerNorm 1
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -337,8 +327,8 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
     // the projection's first column-tile pair flies through LayerNorm 2
     const int NTq = (HKn + 15) / 16;
     const int slots = (NTq + 7) / 8;                                       // column-tile slots per wave over the whole N
-    const int per = (slots + csize - 1) / csize;
-    const int s_lo = crank * per, s_hi = min(slots, s_lo + per);
+    const int per = (slots + psize - 1) / psize;
+    const int s_lo = prank * per, s_hi = min(slots, s_lo + per);
     // TERMS == 1: the projection's weights as ONE stream per wave -- k-step d of the wave's next column tile is requested the
     // moment k-step d of the current one is consumed (a ring of KSd fragments), so the stream never restarts cold (with a ring
     // primed per pair of column tiles every pair paid an L2 round trip: 21 us for the 1.44 MB composed query map split over
@@ -369,7 +359,7 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
         }
     }
     mg_lds_barrier();
-    ln_rows_emit<TERMS>(s_t, lg2, lb2, eps, wave, lane, ah16, al16, w.wq_h != nullptr, crank == 0 ? out + (size_t)r0 * D : nullptr,
+    ln_rows_emit<TERMS>(s_t, lg2, lb2, eps, wave, lane, ah16, al16, w.wq_h != nullptr, prank == 0 ? out + (size_t)r0 * D : nullptr,
                         B - r0);
     MG_TSTAMP(7);
     // ---- 4. next layer's query projection -------------------------------------------------------------------------------------
