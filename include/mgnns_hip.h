@@ -301,8 +301,8 @@ int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const flo
  * Same inputs and outputs as mgnns_sq_mha_core_fwd (submodules.py:55-119, len_q == 1) computed as
  *   U_h = Wk_h^T qh_h;   p = softmax_l(U_h . bank[b,l,:] / sqrt(dk)) (masked);   o_h = Wv_h (sum_l p_l bank[b,l,:]) + bv_h
  * which is algebraically the reference's result (q.bk is constant over l and drops out of the softmax; sum_l p_l = 1
- * carries bv through) at 1/100 of the FLOPs, all in fp32 (f32 MFMA).  Selected explicitly; the faithful kernels
- * above are what the MFMA-utilisation target is measured on.
+ * carries bv through) at 1/100 of the FLOPs, all in fp32 (f32 MFMA): the folded attention of the fp32 / bf16x3 modes (the
+ * faithful kernels above are what the MFMA-utilisation target is measured on; bf16 mode: mgnns_sq_mha_folded_bf16_fwd below).
  * bank: fp32 [B, L, D] (bank_is_bf16 == 0, ld_bank == D) or bf16 [B, L, ld_bank] zero padded (bank_is_bf16 == 1).
  * workspace: mgnns_sq_mha_folded_workspace_bytes(B, D, H) bytes.  D <= 320, D % 4 == 0, H <= 8, dk % 4 == 0, L <= 208.
  */

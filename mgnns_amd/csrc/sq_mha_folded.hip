@@ -5,8 +5,9 @@
 //   o[b,h]   = sum_l p_l (W_v,h x_l + b_v,h)      = W_v,h (sum_l p_l x_l) + b_v,h           (sum_l p_l == 1)
 // so one layer is  U = qh . W_k (batched over heads),  C = softmax(U X^T / T) X,  o = C . W_v^T + b_v:
 // 0.55 GFLOP instead of 61.9 GFLOP at B=256, L=196, all in exact fp32 (MFMA f32 16x16x4), bound by one read of
-// the bank.  It is NOT the formulation the north-star's MFMA-utilisation metric is quoted on; the faithful
-// kernels (sq_mha.hip, sq_mha_bf16.hip) stay the default and this one is selected explicitly.
+// the bank.  It is NOT the formulation the north-star's MFMA-utilisation metric is quoted on (sq_mha.hip / sq_mha_bf16.hip are).
+// This exact-fp32 form is the folded attention of the fp32 and bf16x3 modes (model.set_attention('folded'); the default of
+// bf16x3); bf16 mode runs the composed-map form of sq_mha_folded_bf16.hip by default.
 //
 // folded_attn_kernel: one workgroup (8 waves) per sample; wave w owns the 16-row bank tiles w, w+8, ... and reads
 // each of them from memory exactly once:
