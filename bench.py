@@ -50,11 +50,11 @@ def parse_args(argv=None):
                     help="which figure is the headline `value` at N>1 (both are always measured)")
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
-    ap.add_argument("--attn", default="auto", choices=["auto", "faithful", "folded"],
-                    help="fusion attention: folded = the projections folded away algebraically (one read of the memory bank); "
-                         "faithful = K/V projected from the memory bank as the reference does (the kernels the north-star's MFMA "
-                         "figure is quoted on; always reported next to the headline as a variant and in roofline_all); "
-                         "auto = the model's default: folded in bf16 mode, faithful in fp32 mode")
+    ap.add_argument("--attn", default="faithful", choices=["auto", "faithful", "folded"],
+                    help="fusion attention: faithful = K/V projected from the memory bank as the reference does (the headline: the "
+                         "formulation the north-star's MFMA figure is quoted on); folded = the projections folded away algebraically "
+                         "(one read of the memory bank; always reported next to the headline as a variant and in roofline_all); "
+                         "auto = folded in bf16 mode, faithful in fp32 mode")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra legs (fp32 parity mode, folded attention, "
                                                                "configs[4] stress, CNN trunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -860,8 +860,9 @@ def run_rank(args):
         for _ in range(3):          # the label GCN as separate operators (gen_adj / GEMM / CSR SpMM): their own roofline rows
             model._label_gcn(model.object_A, call[5])
             model._label_gcn(model.place_A, call[6])
-        if attn == "folded":        # the reference's own formulation too: the MFMA rows of roofline_all are measured on it
-            model.set_attention("faithful")
+        other = "faithful" if attn == "folded" else "folded"       # the other formulation's kernels too: their rows of roofline_all
+        if args.dtype == "bf16":
+            model.set_attention(other)
             for _ in range(min(args.steps, 5)):
                 model(*call)
             model.set_attention(args.attn)
@@ -878,9 +879,15 @@ def run_rank(args):
                 model.set_attention("folded")
                 variants["attention=folded"] = graphed_variant(
                     model, call, B, args.steps, args.warmup,
-                    "same step, fusion attention with the projections folded away algebraically (bf16 mode: "
-                    "csrc/sq_mha_folded_bf16.hip + the c16 tail; fp32 mode: csrc/sq_mha_folded.hip): one read of the memory bank "
-                    "instead of the K/V projection GEMMs", in_flight=max(1, args.in_flight))
+                    "same step, fusion attention with the projections folded away algebraically (model.set_attention('folded'); bf16 "
+                    "mode: csrc/sq_mha_folded_bf16.hip + the c16 tail; fp32 mode: csrc/sq_mha_folded.hip): one read of the memory "
+                    "bank per layer instead of the K/V projection GEMMs, same results to rounding (tests/: the reference's goldens); "
+                    "not the formulation the MFMA target is quoted on, hence a variant", in_flight=max(1, args.in_flight))
+                sb = {}
+                for bs in (128, 64, 32):       # the per-GPU shards of a strong-scaling run with this attention (one forward at a time)
+                    sub = {k: (v[:bs] if k != "label_query" else v) for k, v in inp.items()}
+                    sb["B=%d" % bs] = graphed_variant(model, harness.call_args(sub, dev), bs, args.steps, args.warmup, "")["ms_per_step"]
+                variants["attention=folded"]["small_batch_ms_per_step"] = sb
             else:
                 model.set_attention("faithful")
                 variants["attention=faithful (the north-star's MFMA formulation)"] = graphed_variant(

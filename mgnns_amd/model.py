@@ -216,10 +216,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self.fused_label_gcn = os.environ.get('MGNNS_FUSED_LABEL_GCN', '1') == '1'      # label GCN as one persistent launch
         self.label_tail_terms = int(os.environ.get('MGNNS_LABEL_TAIL_TERMS', '3'))
         self.precision = 'fp32'
-        self.attention_choice = 'auto'
+        self.attention_choice = 'faithful'
         self.attention = 'faithful'
         self.set_precision(opt.get('precision', 'fp32'))
-        self.set_attention(opt.get('attention', 'auto'))
+        self.set_attention(opt.get('attention', 'faithful'))
 
     def set_precision(self, precision):
         """'fp32': every contraction on the exact-f32 MFMA (the parity path, <=1e-4 on logits).
@@ -246,14 +246,14 @@ class Multi_GCN_Multihead_Att(nn.Module):
         return self.set_attention(self.attention_choice)
 
     def set_attention(self, attention):
-        """'faithful': the fusion attention projects K and V from the memory bank as the reference does (submodules.py:64-72;
-        the MFMA kernels the north-star's utilisation figure is quoted on).  'folded': the same attention with the projections
-        folded away algebraically (len_q == 1: q.(W_k x_l) = (W_k^T q).x_l and sum_l p_l W_v x_l = W_v sum_l p_l x_l) -- one read
-        of the memory bank instead of 242 MFLOP per sample and layer, same results to rounding (tests: the reference's goldens).
-        In bf16 mode the query / output projections are composed with them too (csrc/sq_mha_folded_bf16.hip + the c16 tail); in
-        fp32 / bf16x3 mode it is the exact-fp32 kernel of csrc/sq_mha_folded.hip.
-        'auto' (default): 'folded' in the bf16 modes, 'faithful' in fp32 mode (the parity path keeps the reference's own
-        formulation)."""
+        """'faithful' (default): the fusion attention projects K and V from the memory bank as the reference does
+        (submodules.py:64-72; the MFMA kernels the north-star's utilisation figure is quoted on, and what bench.py's headline runs).
+        'folded': the same attention with the projections folded away algebraically (len_q == 1: q.(W_k x_l) = (W_k^T q).x_l and
+        sum_l p_l W_v x_l = W_v sum_l p_l x_l) -- one read of the memory bank instead of 242 MFLOP per sample and layer, same results
+        to rounding (tests: the reference's goldens); bench.py reports it as a variant.  In bf16 mode the query / output projections
+        are composed with them too (csrc/sq_mha_folded_bf16.hip + the c16 tail): the fastest forward of this library (457 k against
+        371 k samples/s at B=256).  In fp32 / bf16x3 mode it is the exact-fp32 kernel of csrc/sq_mha_folded.hip.
+        'auto': 'folded' in the bf16 modes, 'faithful' in fp32 mode."""
         if attention not in ('auto', 'faithful', 'folded'):
             raise ValueError("attention must be 'auto', 'faithful' or 'folded'")
         self.attention_choice = attention

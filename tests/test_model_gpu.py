@@ -135,9 +135,9 @@ def test_module_surface_on_gpu():
 
 @pytest.mark.parametrize("attention", ["auto", "faithful"])
 def test_bf16_precision_mode_is_close_and_reports_error(attention):
-    """bf16 mode (BASELINE config 3), with the default attention of the mode (the folded bf16 kernels) and with the reference's
-    own formulation (K / V projected on the bf16 MFMA): logits stay within bf16-class error of the fp32 reference golden and
-    the predicted class does not change."""
+    """bf16 mode (BASELINE config 3), with the reference's own formulation (K / V projected on the bf16 MFMA: the default) and
+    with 'auto' (the folded bf16 kernels): logits stay within bf16-class error of the fp32 reference golden and the predicted
+    class does not change."""
     cfg_name = "mvsa_multiple_b256"
     g = H.load_golden("full_%s.npz" % cfg_name)
     adj = H.load_golden("adjacency.npz")

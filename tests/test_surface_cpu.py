@@ -71,24 +71,26 @@ def test_pmi_csr_matches_dense_lookup():
     assert np.array_equal(m2.col, m.col) and np.array_equal(m2.eid, m.eid)
 
 
-def test_attention_choice_follows_the_precision_mode():
-    """'auto' (the default): the folded attention in the bf16 modes, the reference's explicit formulation in fp32 mode; an explicit
-    choice survives a change of the precision mode; every fusion layer carries the resolved choice; unknown names raise."""
+def test_attention_choice_and_the_precision_mode():
+    """The default is the reference's explicit formulation in every precision mode; 'folded' is an explicit choice that survives a
+    change of the precision mode; 'auto' = the folded attention in the bf16 modes and the explicit one in fp32 mode; every fusion
+    layer carries the resolved choice; unknown names raise."""
     from mgnns_amd.fusion import MultiHeadAttention
     cfg = synth.CONFIGS["mvsa_single_b8"]
     pmi, count = synth.synth_pmi(cfg.V, seed=3)
     adj = H.load_golden("adjacency.npz")
     m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], np.zeros((7, 300), np.float32))
     layers = [x for x in m.modules() if isinstance(x, MultiHeadAttention)]
-    assert layers and m.attention_choice == "auto" and m.precision == "fp32" and m.attention == "faithful"
+    assert layers and m.attention_choice == "faithful" and m.precision == "fp32" and m.attention == "faithful"
+    for prec in ("bf16", "bf16x3", "fp32"):
+        m.set_precision(prec)
+        assert m.attention == "faithful" and all(x.attention == "faithful" and x.precision == prec for x in layers), prec
+    m.set_attention("auto")
     for prec, want in (("bf16", "folded"), ("bf16x3", "folded"), ("fp32", "faithful")):
         m.set_precision(prec)
-        assert m.attention == want and all(x.attention == want and x.precision == prec for x in layers), prec
-    m.set_attention("faithful").set_precision("bf16")
-    assert m.attention == "faithful" and all(x.attention == "faithful" for x in layers)
+        assert m.attention == want and all(x.attention == want for x in layers), prec
     m.set_attention("folded").set_precision("fp32")
-    assert m.attention == "folded"
-    assert m.set_attention("auto").attention == "faithful"
+    assert m.attention == "folded" and all(x.attention == "folded" for x in layers)
     with pytest.raises(ValueError):
         m.set_attention("flash")
 
