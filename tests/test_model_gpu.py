@@ -165,8 +165,8 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
     a1 = call_args(synth.make_inputs(cfg, B=16, seed=1, pmi=pmi), DEV)
     a2 = call_args(synth.make_inputs(cfg, B=16, seed=2, pmi=pmi), DEV)
-    for prec in ("fp32", "bf16"):
-        model.set_precision(prec)
+    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded")):
+        model.set_precision(prec).set_attention(att)
         model.use_streams = False
         ref1, ref2 = model(*a1).clone(), model(*a2).clone()
         model.use_streams = True
@@ -189,8 +189,9 @@ def test_pipelined_replays_two_forwards_in_flight_equal_serial_ones():
     pmi, count = synth.synth_pmi(cfg.V, seed=91)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
     sets = [call_args(synth.make_inputs(cfg, B=16, seed=s, pmi=pmi), DEV) for s in (1, 2, 3, 4, 5)]
-    for prec in ("fp32", "bf16"):
-        model.set_precision(prec)
+    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded")):
+        # (folded: the layer tails' partial sums are added in rank order by whichever workgroup arrives last -- the same bits)
+        model.set_precision(prec).set_attention(att)
         refs = [model(*a).clone() for a in sets]
         for depth in (2, 3):
             pipe = GraphedPipeline(model, sets[0], depth=depth)
@@ -202,7 +203,7 @@ def test_pipelined_replays_two_forwards_in_flight_equal_serial_ones():
                     if len(outs) >= depth:                       # the instance about to be reused: read its result first
                         old, k = outs[len(outs) - depth]
                         old.wait()
-                        assert torch.equal(old.static_out, refs[k]), (prec, depth, rep, k)
+                        assert torch.equal(old.static_out, refs[k]), (prec, att, depth, rep, k)
             pipe.wait()
             torch.cuda.synchronize()
             for old, k in outs[-depth:]:
