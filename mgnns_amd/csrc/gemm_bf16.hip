@@ -62,6 +62,7 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
                                                                int act, int nrb, int nct, int rps, int jmax,
                                                                const int32_t* __restrict__ m_dev, int c_bf16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nrb_host = nrb;                                      // (the column-split map is laid out for the host's row-block count)
     if (m_dev) {                                                   // row count produced on the device (ragged batches): M is its bound
         const int md = *m_dev;
         M = md < M ? (md < 0 ? 0 : md) : M;
@@ -73,7 +74,17 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
     const int per = rps * nct;
     const int nk = Kp / BK;
     // virtual tile j of this XCD -> (m0, n0); false beyond the last row block
+    // (rps == 0: fewer super rows than XCDs -- e.g. a 512-row read-out against 10 000 columns -- so the XCDs split the COLUMN
+    //  tiles instead: XCD x takes column tiles x * cpx .. + cpx - 1 with every row block, the row blocks of a column tile next to
+    //  each other; with the row-block map only `supers` of the eight XCDs had work: 88 us instead of 35 for that read-out)
     auto decode = [&](int j, int& m0, int& n0) {
+        if (rps == 0) {
+            const int cpx = jmax / nrb_host;
+            const int ct = xcd * cpx + j / nrb_host, rb = j % nrb_host;
+            m0 = rb * TM;
+            n0 = ct * TN;
+            return j < jmax && ct < nct && rb < nrb;
+        }
         const int sl = j / per, within = j - sl * per;
         const int rb = (sl * 8 + xcd) * rps + within / nct, ct = within % nct;
         m0 = rb * TM;
@@ -260,7 +271,11 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     if (rps < 1) rps = 1;
     if (rps > nrb) rps = nrb;
     const int supers = (nrb + rps - 1) / rps;
-    const int jmax = ((supers + 7) / 8) * rps * nct;               // virtual tiles per XCD
+    int jmax = ((supers + 7) / 8) * rps * nct;                     // virtual tiles per XCD
+    if (supers < 8 && nct >= 8) {                                  // fewer super rows than XCDs: split the column tiles over the XCDs
+        rps = 0;
+        jmax = nrb * ((nct + 7) / 8);
+    }
     const int n_cu = mg_cu_count();
     if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU

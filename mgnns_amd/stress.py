@@ -189,6 +189,37 @@ class StressWorkload:
         """-> {(channel, b0, b1): read-out [b1 - b0, N] fp32}"""
         return {(c, b0, b1): self.channels[c].forward(self.pooled[c][b0:b1].contiguous()) for c, b0, b1 in self.shards}
 
+    def capture(self):
+        """One hipGraph per shard (a channel's five launches), replayed side by side on a stream per shard: the channels are
+        independent (MODEL:460-506), so nothing orders them but the join at the end.  -> replay() returning the same dict as
+        forward() (static output buffers)."""
+        shards = list(self.shards)
+        ins = {k: self.pooled[k[0]][k[1]:k[2]].contiguous() for k in shards}
+        for _ in range(2):                                   # weight packs / workspaces exist before any capture
+            for k in shards:
+                self.channels[k[0]].forward(ins[k])
+        torch.cuda.synchronize()
+        graphs, outs, streams = {}, {}, {}
+        for k in shards:
+            streams[k] = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=streams[k]):
+                outs[k] = self.channels[k[0]].forward(ins[k])
+            graphs[k] = g
+        torch.cuda.synchronize()
+
+        def replay():
+            main = torch.cuda.current_stream()
+            for k in shards:
+                streams[k].wait_stream(main)
+                with torch.cuda.stream(streams[k]):
+                    graphs[k].replay()
+            for k in shards:
+                main.wait_stream(streams[k])
+            return outs
+        self._captured = (graphs, outs, streams, ins)            # (keeps the static buffers alive)
+        return replay
+
 
 def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
     """Cache-cold per-kernel figures of configs[4] on one GPU -> dict (bench.py `stress`).  HBM fractions are against
@@ -254,6 +285,13 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
                                         "ms_gcn_of_one_channel": round(ms1, 4),
                                         "what": "3 channels one after the other on one stream, eager launches, bf16 operands / fp32 "
                                                 "accumulation end to end (5 launches per channel)"}
+        try:                                                  # the same three channels as one hipGraph each, side by side on three streams
+            replay = wl.capture()
+            msg = time_warm(replay, (), reps=10)
+            out["workload_bf16_" + name].update({"ms_per_3_channel_forward_graphs_on_3_streams": round(msg, 4),
+                                                 "samples_per_s_graphs_on_3_streams": round(batch / msg * 1e3, 1)})
+        except Exception as e:                                # capture refused: the eager figure stands
+            out["workload_bf16_" + name]["graphs_on_3_streams_error"] = "%s: %s" % (type(e).__name__, e)
         del wl, ch
     pooled = torch.relu(torch.randn(batch, 2048, device=dev, generator=g))
     ch = StressChannel(n=n, dev=dev, density=DENSITIES[0], dtype="f32")

@@ -1019,11 +1019,13 @@ def test_metrics_tail_softmax_argmax_confusion():
         assert np.array_equal(pred_only.cpu().numpy(), ps[-1])
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 132, 1000), (37, 4, 64), (1030, 520, 333)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 132, 1000), (37, 4, 64), (1030, 520, 333), (512, 1100, 256),
+                                   (37, 1028, 64), (1030, 1540, 128)])
 def test_gemm_bf16_nt_vs_fp64_on_rounded_operands(M, N, K):
     """Dense bf16 GEMM (LDS-DMA ring, XCD-aware tile map) vs an fp64 product of the SAME bf16-rounded operands: ragged
     M / N / K (rows beyond M and N are clamped loads, K is zero padded to 64), bias + LeakyReLU epilogue, and the
-    adjacency helper built from cast_pad_bf16 + transpose_cast_bf16."""
+    adjacency helper built from cast_pad_bf16 + transpose_cast_bf16.  The last three shapes have fewer row blocks than XCDs
+    and at least eight column tiles: the XCDs split the column tiles (the read-out of configs[4])."""
     rs = np.random.RandomState(M + N + K)
     a = rs.standard_normal((M, K)).astype(np.float32)
     b = rs.standard_normal((K, N)).astype(np.float32)
