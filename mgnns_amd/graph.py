@@ -82,11 +82,14 @@ class GraphedForward:
             _ops.set_scratch_epoch(prev_epoch)
 
     def __del__(self):
-        m = getattr(self, "model", None)
-        if m is not None and getattr(m, "_live_graphs", 0) > 0:
-            m._live_graphs -= 1
-            if m._live_graphs == 0 and hasattr(m, "_wt_retired"):
-                m._wt_retired.clear()
+        try:
+            m = getattr(self, "model", None)
+            if m is not None and getattr(m, "_live_graphs", 0) > 0:
+                m._live_graphs -= 1
+                if m._live_graphs == 0 and hasattr(m, "_wt_retired"):
+                    m._wt_retired.clear()
+        except Exception:          # interpreter shutdown: torch's module machinery may already be torn down
+            pass
 
     def _build(self, model, example_args, warmup, post, settle):
         self.static_in = [a.clone() if torch.is_tensor(a) else a for a in example_args]
