@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/round_profiles.sh <round-tag>   -- everything profiles/ is refreshed from:
-# kernel stats (bf16 graph replay / bf16 serial eager / f32 / bf16 with the explicit attention), three PMC passes (bf16, eager), bench lines, stress json -> gpurun_out/
+# kernel stats (bf16 graph replay / bf16 serial eager / f32 / bf16 with the folded attention), three PMC passes (bf16, eager), bench lines, stress json -> gpurun_out/
 tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
@@ -13,7 +13,7 @@ timeout 200 python tools/graph_timeline.py > gpurun_out/${tag}_timeline.txt 2>&1
 timeout 400 tools/prof.sh ${tag}_bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-variants
 timeout 400 tools/prof.sh ${tag}_bf16_serial --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream
 timeout 400 tools/prof.sh ${tag}_f32 --steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32
-timeout 400 tools/prof.sh ${tag}_faithful --steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn faithful
+timeout 400 tools/prof.sh ${tag}_folded --steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout 400 tools/pmc.sh ${tag}_$c $c --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-graph > /dev/null
 done

@@ -58,7 +58,7 @@ def main():
     cmds = {"bf16": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants",
             "bf16_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream",
             "f32": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32",
-            "faithful": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn faithful"}
+            "folded": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded"}
     for m, args in cmds.items():
         db = os.path.join(GO, "prof_%s_%s" % (tag, m), "%s_%s_results.db" % (tag, m))
         if not os.path.exists(db):
