@@ -601,6 +601,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "banks_serial": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                          ("bank_place+bank_obj", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                          ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # 'channels' with the place channel's memory bank in FRONT of its label GCN (the longer one, C = 365: 105-123 us): the bank
+        # starts at t = 0 instead of behind it
+        "place_bank_first": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("bank_place", "s2"),
+                             ("lgcn_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+                             ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # the same with the place label GCN on the text-GCN stream (idle until the place bank is done)
+        "place_bank_first_lgcn_s3": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("bank_place", "s2"),
+                                     ("lgcn_place", "s3"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
+                                     ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
         "tails_first_obj": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
                             ("bank_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio+tail_obj", "main"), ("tip", "s3"),
                             ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
