@@ -211,6 +211,21 @@ def test_stress_workload_shards_equal_the_single_rank_result():
         assert all(m.all() for m in seen.values())
 
 
+def test_stress_workload_graphs_on_three_streams_equal_the_eager_forward():
+    """StressWorkload.capture(): one hipGraph per channel replayed side by side on three streams == the eager forward, bit for
+    bit, replay after replay (sparse and dense adjacency)."""
+    for kw in (dict(density=stress.DENSITIES[0]), dict(dense=True)):
+        wl = stress.StressWorkload(0, 1, n=1500, batch=64, dev=DEV, **kw)
+        ref = {k: v.clone() for k, v in wl.forward().items()}
+        replay = wl.capture()
+        for _ in range(3):
+            got = replay()
+            torch.cuda.synchronize()
+            assert set(got) == set(ref)
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (kw, k)
+
+
 def test_stress_measure_reports_cold_figures():
     r = stress.measure(DEV, n=4000, batch=64)
     for k in ("spmm_bf16_d0.0004_F1024", "spmm_bf16_d0.01_F2048", "spmm_f32_d0.0004_F1024", "dense_adj_bf16_F1024",
