@@ -44,6 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each (one warm-up, then the regions back to back, each bracketed by "
+                         "barrier + synchronize): ms_per_step / value are the MEDIAN region, min / max are reported next to it")
     ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="samples per GPU (weak scaling)")
     ap.add_argument("--config", default="mvsa_multiple_b256")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -574,34 +577,39 @@ def text_pipeline_leg(dev):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def graphed_variant(model, call, B, steps, warmup, what, in_flight=1):
+def graphed_variant(model, call, B, steps, warmup, what, in_flight=1, regions=3):
+    """One more captured form of the step, timed like the headline: `regions` regions of `steps` replays, the median reported."""
     import torch
+    from mgnns_amd import _lib
     from mgnns_amd.graph import GraphedForward, GraphedPipeline
+
+    def timed(fn, end):
+        for _ in range(warmup):
+            fn()
+        ds = []
+        for _ in range(max(1, regions)):
+            end()
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            end()
+            torch.cuda.synchronize()
+            ds.append((time.perf_counter() - tv) / steps)
+        _lib.take_status()
+        return sorted(ds)[(len(ds) - 1) // 2], ds
+
     gv = GraphedForward(model, call, mode="segments" if in_flight > 1 else None)
-    for _ in range(warmup):
-        vout = gv.replay()
-    torch.cuda.synchronize()
-    tv = time.perf_counter()
-    for _ in range(steps):
-        vout = gv.replay()
-    torch.cuda.synchronize()
-    dv = (time.perf_counter() - tv) / steps
+    dv, dvs = timed(gv.replay, lambda: None)
+    vout = gv.static_out
     r = {"value": round(B / dv, 1), "unit": "samples/s", "ms_per_step": round(dv * 1e3, 4), "forwards_in_flight": 1, "what": what,
-         "_out": vout[:B].float().cpu()}
+         "regions_ms_per_step": [round(d * 1e3, 4) for d in dvs], "_out": vout[:B].float().cpu()}
     if in_flight > 1:       # the same measurement as the headline: captures with buffers of their own, replayed without a join
         pipe = GraphedPipeline.of([gv] + [GraphedForward(model, call, mode="segments") for _ in range(in_flight - 1)])
-        for _ in range(warmup):
-            pipe.replay()
-        pipe.wait()
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(steps):
-            pipe.replay()
-        pipe.wait()
-        torch.cuda.synchronize()
-        dp = (time.perf_counter() - tv) / steps
-        r["serial_replay"] = {"value": r["value"], "ms_per_step": r["ms_per_step"]}
-        r.update({"value": round(B / dp, 1), "ms_per_step": round(dp * 1e3, 4), "forwards_in_flight": in_flight})
+        dp, dps = timed(pipe.replay, pipe.wait)
+        r["serial_replay"] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "regions_ms_per_step": r["regions_ms_per_step"]}
+        r.update({"value": round(B / dp, 1), "ms_per_step": round(dp * 1e3, 4), "forwards_in_flight": in_flight,
+                  "regions_ms_per_step": [round(d * 1e3, 4) for d in dps]})
     return r
 
 
@@ -714,7 +722,7 @@ def run_rank(args):
 
     import numpy as np
     import torch
-    from mgnns_amd import harness, ops, synth
+    from mgnns_amd import _lib, harness, ops, synth
     from mgnns_amd.graph import GraphedForward, GraphedPipeline
     from mgnns_amd.sharded import ShardedForward, shard_bounds
 
@@ -824,21 +832,33 @@ def run_rank(args):
                 return step_serial()
             out["logits"] = pipe.replay().static_out
 
+        def regions(fn, after_warmup=None):
+            """args.regions timed regions of EXACTLY args.steps steps (each bracketed by barrier + synchronize, max over ranks),
+            one warm-up in front of the first -> (median region, its per-rank times, every region's ms per step)"""
+            rs = []
+            for r in range(max(1, args.regions)):
+                d = timed_steps(fn, args.steps, args.warmup if r == 0 else 0, barrier, after_warmup if r == 0 else None)
+                rs.append(max_over_ranks(d, dist, dev))
+            order = sorted(range(len(rs)), key=lambda i: rs[i][0])
+            med = rs[order[(len(rs) - 1) // 2]]                   # (lower) median: a region that was actually measured
+            return med[0], med[1], [round(d / args.steps * 1e3, 4) for d, _ in rs]
+
         serial = None
+        total = world * b_local
         with torch.no_grad():
             if pipe is not None:
                 # the same forward one at a time (every replay joins the four streams before the next starts): reported next
                 # to the headline as `serial_replay`
-                ds = timed_steps(step_serial, args.steps, args.warmup, barrier)
-                ds, _ = max_over_ranks(ds, dist, dev)
-                serial = {"ms_per_step": round(ds / args.steps * 1e3, 4), "value": round(world * b_local / (ds / args.steps), 1),
-                          "unit": "samples/s", "what": "one forward in flight: a join of the four streams between replays"}
+                ds, _, sreg = regions(step_serial)
+                serial = {"ms_per_step": round(ds / args.steps * 1e3, 4), "value": round(total / (ds / args.steps), 1),
+                          "unit": "samples/s", "what": "one forward in flight: a join of the four streams between replays",
+                          "regions_ms_per_step": sreg}
             # after the warm-up: RCCL's banner out of every rank's C stdio buffer, long before the JSON line
-            dt = timed_steps(step, args.steps, args.warmup, barrier, flush_c_stdio if dist is not None else None)
-        dt, dts = max_over_ranks(dt, dist, dev)
-        total = world * b_local
+            dt, dts, reg = regions(step, flush_c_stdio if dist is not None else None)
+        torch.cuda.synchronize()
+        _lib.take_status()                  # a persistent launch inside a replayed graph that gave up a bounded wait: no number then
         return {"inp": inp, "call": call, "b_local": b_local, "dt": dt, "dt_ranks": dts, "launch": launch,
-                "value": total / (dt / args.steps), "ms": dt / args.steps * 1e3, "global_batch": total,
+                "value": total / (dt / args.steps), "ms": dt / args.steps * 1e3, "global_batch": total, "regions_ms": reg,
                 "logits": out["logits"], "serial": serial, "in_flight": 1 if pipe is None else len(pipe.items)}
 
     if os.environ.get("MGNNS_BENCH_ORDER") == "strong_first" and world > 1:      # test hook: order effects
@@ -1020,6 +1040,13 @@ def run_rank(args):
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
+    # `steps` steps per region; ms_per_step / value = the median of these regions (one warm-up in front of the first)
+    line["timing"] = {"regions": len(head["regions_ms"]), "steps_per_region": args.steps, "statistic": "median region",
+                      "regions_ms_per_step": head["regions_ms"], "min_ms_per_step": min(head["regions_ms"]),
+                      "max_ms_per_step": max(head["regions_ms"]),
+                      "value_is": ("throughput with %d forwards in flight (captures with buffers of their own, no join between "
+                                   "replays); one forward at a time = serial_replay" % head.get("in_flight", 1))
+                      if head.get("in_flight", 1) > 1 else "one forward at a time"}
     if head.get("serial"):
         line["serial_replay"] = head["serial"]
     if strong is not None:

@@ -8,6 +8,8 @@ kernel builds the n-gram graphs from the token ids on the device."""
 import numpy as np
 import torch
 
+from . import _lib
+
 from .vocab import Word2Id
 
 
@@ -208,7 +210,15 @@ class PipelinedForward:
             self.gf.static_in[2].copy_(mask, non_blocking=True)
             out = self.gf.replay()
             torch.cuda.current_stream().synchronize()
+            _lib.take_status()                       # a persistent launch of THIS replay that gave up a bounded wait raises here
             if on_logits is not None:
                 on_logits(i, out)
             i += 1
         return i
+
+    def finish(self):
+        """Host-side end of a run() / run_in_flight(): wait for everything enqueued, then check the persistent launches' status
+        word.  Every replay reports a bounded wait that ran out in an EARLIER replay (graph.GraphedForward.replay); this
+        covers the last ones -- call it before results accumulated by on_logits (metrics, logits copies) are read on the host."""
+        torch.cuda.synchronize()
+        _lib.take_status()

@@ -133,6 +133,7 @@ class MultiHeadAttention(nn.Module):
         wk, wv = self.w_ks.weight, self.w_vs.weight
         key = (wk.data_ptr(), wk._version, wv.data_ptr(), wv._version, str(wk.device))
         if self._wp is None or self._wp[0] != key:
+            ops.retire(self._wp)                # a live capture may hold the old pack's address
             self._wp = (key, ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k))
         return self._wp[1]
 
@@ -201,6 +202,7 @@ def _tail_pack(layer):
              "w2_wp": ops.pack_weight_f32(f.w_2.weight.detach().view(f.w_2.out_channels, f.w_2.in_channels)),
              "b2": f.w_2.bias.detach(), "g2": f.layer_norm.gamma.detach(), "be2": f.layer_norm.beta.detach()}
         hit = (key, d)
+        ops.retire(getattr(layer, "_tail_cache", None))      # a live capture may hold the old pack's addresses
         layer._tail_cache = hit
     return hit[1]
 
@@ -219,6 +221,7 @@ def _tail_pack_bf16(layer):
              "w2": ops.pack_weight_bf16_split(f.w_2.weight.detach().view(f.w_2.out_channels, f.w_2.in_channels)),
              "b2": f.w_2.bias.detach(), "g2": f.layer_norm.gamma.detach(), "be2": f.layer_norm.beta.detach()}
         hit = (key, d)
+        ops.retire(getattr(layer, "_tail_cache_bf16", None))      # a live capture may hold the old pack's addresses
         layer._tail_cache_bf16 = hit
     return hit[1]
 
@@ -229,6 +232,7 @@ def _wq_pack_bf16(layer):
     hit = getattr(layer, "_wq_cache_bf16", None)
     if hit is None or hit[0] != key:
         hit = (key, (ops.pack_weight_bf16_split(a.w_qs.weight.detach()), a.w_qs.bias.detach(), a.w_qs.out_features))
+        ops.retire(getattr(layer, "_wq_cache_bf16", None))      # a live capture may hold the old pack's addresses
         layer._wq_cache_bf16 = hit
     return hit[1]
 
@@ -255,6 +259,7 @@ def composed_query_map(layer):
             bias.append(ops.matmul(wkt, bq[h * dk:(h + 1) * dk].reshape(dk, 1).contiguous()).reshape(-1))
         m = torch.cat(rows, 0).contiguous()
         hit = (key, (ops.pack_weight_bf16_split(m), torch.cat(bias).contiguous(), m.shape[0]), m)
+        ops.retire(getattr(layer, "_uq_cache", None))      # a live capture may hold the old pack's addresses
         layer._uq_cache = hit
     return hit[1]
 
@@ -282,6 +287,7 @@ def _tail_pack_folded(layer):
         d["fc"] = ops.pack_weight_bf16_split(n)
         d["fc_b"] = nb
         hit = (key, d)
+        ops.retire(getattr(layer, "_tail_cache_folded", None))      # a live capture may hold the old pack's addresses
         layer._tail_cache_folded = hit
     return hit[1]
 
@@ -292,6 +298,7 @@ def _tile_counters(layer, B, device):
     c = getattr(layer, "_tile_counters", None)
     if c is None or c.shape[0] < n or c.device != device:
         c = torch.zeros(max(n, 64), dtype=torch.int32, device=device)
+        ops.retire(getattr(layer, "_tile_counters", None))
         layer._tile_counters = c
     return c
 
@@ -302,6 +309,7 @@ def _wq_pack(layer):
     hit = getattr(layer, "_wq_cache", None)
     if hit is None or hit[0] != key:
         hit = (key, (ops.pack_weight_f32(a.w_qs.weight.detach()), a.w_qs.bias.detach(), a.w_qs.out_features))
+        ops.retire(getattr(layer, "_wq_cache", None))
         layer._wq_cache = hit
     return hit[1]
 

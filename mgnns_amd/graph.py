@@ -24,6 +24,8 @@ import warnings
 
 import torch
 
+from . import _lib
+
 _PROBED = {}
 
 
@@ -76,6 +78,7 @@ class GraphedForward:
         self._epoch = _ops.new_scratch_epoch()
         prev_epoch = _ops.set_scratch_epoch(self._epoch)
         model._live_graphs = getattr(model, "_live_graphs", 0) + 1
+        _ops.capture_born()                         # layer-level packs (fusion.py) park instead of freeing while this lives
         try:
             self._build(model, example_args, warmup, post, settle)
         finally:
@@ -83,6 +86,11 @@ class GraphedForward:
 
     def __del__(self):
         try:
+            if getattr(self, "_epoch", None) is not None:
+                from . import ops as _ops
+                _ops.release_scratch_epoch(self._epoch)     # the persistent launches' scratch slots created for this capture
+                _ops.capture_gone()
+                self._epoch = None
             m = getattr(self, "model", None)
             if m is not None and getattr(m, "_live_graphs", 0) > 0:
                 m._live_graphs -= 1
@@ -217,6 +225,10 @@ class GraphedForward:
 
     def replay(self):
         """Run the captured forward on the static inputs; returns the static logits tensor."""
+        # A replay runs no C-ABI launcher, so nothing else would ever look at the persistent launches' status word: a bounded
+        # wait that ran out inside an EARLIER replay is reported here (host read of a pinned word, no synchronisation);
+        # result() is the form that covers the replay it returns.
+        _lib.take_status()
         if self.mode == "single":
             self.graph.replay()
             return self._single_out
@@ -238,6 +250,9 @@ class GraphedForward:
                     done[name] = (ev, st)
         for st in self._side.values():
             main.wait_stream(st)
+        if hasattr(self, "_end"):                   # a later replay_async() orders its streams behind THIS replay as well
+            for skey, st in streams.items():
+                self._end[skey].record(main)
         return self._seg_out
 
     def replay_async(self, inputs_ready=None):
@@ -248,6 +263,7 @@ class GraphedForward:
         copy_inputs; None: the static inputs are unchanged).  Returns the static logits; wait() before reading them."""
         if self.mode == "single":
             raise RuntimeError("replay_async needs one graph per segment (mode 'segments')")
+        _lib.take_status()                          # an earlier replay's bounded wait that ran out (see replay())
         main = torch.cuda.current_stream()
         streams = dict(self._side, main=main)
         if not hasattr(self, "_end"):
@@ -278,6 +294,15 @@ class GraphedForward:
         main = torch.cuda.current_stream()
         for ev in getattr(self, "_end", {}).values():
             main.wait_event(ev)
+
+    def result(self):
+        """The logits of the last replay()/replay_async() for the HOST: waits for it, then checks the persistent launches'
+        status word -- a launch inside the replayed graphs that gave up a bounded wait raises here instead of handing back
+        invalid logits."""
+        self.wait()
+        torch.cuda.current_stream().synchronize()
+        _lib.take_status()
+        return self.static_out
 
     def __call__(self, *args):
         self.copy_inputs(*args)

@@ -39,6 +39,50 @@ def _scratch_key():
     return (_SCRATCH_EPOCH, _stream())
 
 
+# Every scratch slot created under a capture epoch is remembered, so that the capture's owner (graph.GraphedForward) can drop
+# them when it goes: slot dicts would otherwise pin a slice of the zero pool per (capture, launch) for the life of the process.
+_EPOCH_SLOTS = {}
+
+
+def _scratch_slot_put(slot, key, ws):
+    slot[key] = ws
+    if key[0]:
+        _EPOCH_SLOTS.setdefault(key[0], []).append((slot, key))
+
+
+def release_scratch_epoch(epoch):
+    """Forget the scratch buffers created under `epoch` (its graphs are gone: nothing holds their addresses any more)."""
+    for slot, key in _EPOCH_SLOTS.pop(int(epoch), []):
+        slot.pop(key, None)
+
+
+# Derived weight packs / scratch that a captured hipGraph may hold by raw address: while any capture is alive, a superseded
+# pack is parked here instead of being freed (load_state_dict / set_precision with a live GraphedForward must not let a replay
+# read recycled memory); the park empties when the last capture goes.  model._cache_put keeps its own per-model list; the
+# layer-level caches of fusion.py (no back-pointer to the model) use this one.
+_LIVE_CAPTURES = 0
+_RETIRED = []
+
+
+def capture_born():
+    global _LIVE_CAPTURES
+    _LIVE_CAPTURES += 1
+
+
+def capture_gone():
+    global _LIVE_CAPTURES
+    if _LIVE_CAPTURES > 0:
+        _LIVE_CAPTURES -= 1
+    if _LIVE_CAPTURES == 0:
+        _RETIRED.clear()
+
+
+def retire(obj):
+    """Park a superseded cache entry while a capture that may hold its addresses is alive."""
+    if obj is not None and _LIVE_CAPTURES > 0:
+        _RETIRED.append(obj)
+
+
 # Counters of the persistent / cluster launches start at zero and are left at zero by the kernels themselves (the last
 # workgroup re-arms them).  They come out of a pool that is zeroed OUTSIDE any capture: a torch.zeros inside a capture is a
 # fill node of the graph -- a 5-8 us launch in front of the kernel on every replay (13 of them per forward, most on the
@@ -293,7 +337,7 @@ def label_gcn(A, inp, packed, want_packed_g=False, query=None, grid=0):
         if ws is not None:
             packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
         ws = zeros_bytes(need, A.device)[:need]                           # counters (first 256 B) start at zero
-        slot[key] = ws
+        _scratch_slot_put(slot, key, ws)
     G = torch.empty(C, N2, device=A.device, dtype=torch.float32)
     gh = gl = None
     if want_packed_g:
@@ -754,7 +798,7 @@ def label_tail_bf16(pooled, g_pair, Q, n_heads, packed, next_q=None, terms=3, cl
                 packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(tiles * 4 * 6144, device=Q.device, dtype=torch.float32),
                   zeros_i32(2 * tiles, Q.device))
-            slot[key] = ws
+            _scratch_slot_put(slot, key, ws)
         scratch, counters = ws[1], ws[2]
     L = _lib.lib()
     _launch("mgnns_label_tail_bf16_fwd", ("mgnns_label_tail_bf16_fwd", packed["C"]), L.mgnns_label_tail_bf16_fwd, _p(pooled), B,
@@ -1028,7 +1072,7 @@ def mha_tail_c16(c, q, packed, eps, next_packed=None, cluster=0, ksplit=None):
                 packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
             ws = (tiles, torch.empty(L.mgnns_mha_tail_c16_scratch_floats(16 * tiles, 8), device=c.device, dtype=torch.float32),
                   zeros_i32(2 * tiles, c.device))
-            slot[key] = ws
+            _scratch_slot_put(slot, key, ws)
         scratch, counters = ws[1], ws[2]
     _launch("mgnns_mha_tail_c16_fwd", ("mgnns_mha_tail_c16_fwd",), L.mgnns_mha_tail_c16_fwd, _p(c), HC, _p(q), B, 300,
             arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),

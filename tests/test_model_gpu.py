@@ -605,3 +605,59 @@ def test_status_word_reports_a_raised_flag_once():
     model(*a)                                                                  # ... once
     torch.cuda.synchronize()
     assert L.mgnns_take_status() == 0
+
+
+def test_status_word_raised_during_graph_replays_is_reported():
+    """A replayed hipGraph runs no C-ABI launcher, so the replay paths look at the persistent launches' status word themselves
+    (ADVICE r3): GraphedForward.replay / replay_async report a word raised by an EARLIER replay, result() covers the replay it
+    returns, PipelinedForward.finish() the tail of a run; and a weight pack superseded at LAYER level (fusion.py caches) while a
+    capture is alive is parked, not freed."""
+    import gc
+    from mgnns_amd import _lib, ops
+    from mgnns_amd.graph import GraphedForward, GraphedPipeline
+    cfg = synth.CONFIGS["tumemo_b64"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    from mgnns_amd import harness
+    A_obj, A_place = harness.synthetic_adjacencies(cfg)
+    inp = synth.make_inputs(cfg, B=8, seed=5, pmi=pmi)
+    model = build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], DEV)
+    model.set_precision("bf16")
+    args = list(call_args(inp, DEV))
+    args[1] = args[1].to(DEV)
+    gf = GraphedForward(model, args, mode="segments")
+    ref = gf.result().clone()
+    _lib._status_word[0] = 2                      # what a cluster exchange inside a replayed graph writes when it gives up
+    with pytest.raises(RuntimeError, match="bounded wait"):
+        gf.replay()
+    assert torch.equal(gf.result(), ref)           # cleared: the next replay runs, same logits
+    gf.replay()
+    _lib._status_word[0] = 1
+    with pytest.raises(RuntimeError, match="bounded wait"):
+        gf.result()                               # the host-side read of THIS replay's logits checks after the wait
+    assert torch.equal(gf.result(), ref)
+    pipe = GraphedPipeline.of([gf, GraphedForward(model, args, mode="segments")])
+    pipe.replay()
+    _lib._status_word[0] = 2
+    with pytest.raises(RuntimeError, match="bounded wait"):
+        pipe.replay()                             # replay_async reports it too
+    pipe.wait()
+    torch.cuda.synchronize()
+    # layer-level packs: an in-place weight update with captures alive parks the old pack ...
+    n0 = len(ops._RETIRED)
+    assert ops._LIVE_CAPTURES >= 2
+    with torch.no_grad():
+        model.text_img_object_multi_head_att[0].slf_attn.w_ks.weight.mul_(1.0)      # bumps the version: every derived pack is rebuilt
+        model.text_img_object_multi_head_att[0].slf_attn.fc.weight.mul_(1.0)
+    model(*args)
+    torch.cuda.synchronize()
+    assert len(ops._RETIRED) > n0
+    # ... and the scratch slots / the park go when the last capture does
+    ep = [gf._epoch, pipe.items[1]._epoch]
+    assert all(e in ops._EPOCH_SLOTS for e in ep)
+    live = ops._LIVE_CAPTURES
+    del pipe, gf
+    gc.collect()
+    assert ops._LIVE_CAPTURES == live - 2 and not any(e in ops._EPOCH_SLOTS for e in ep)
+    if ops._LIVE_CAPTURES == 0:
+        assert not ops._RETIRED
+    _lib.take_status()

@@ -235,3 +235,69 @@ def test_stress_measure_reports_cold_figures():
     assert s["sets"] >= 4 and s["sets"] * 2 * 4000 * 2048 * 2 >= stress.COLD_BYTES and s["cold_ms"] > 0 and 0 < s["frac_of_copy"] < 1.5
     assert s["algorithmic_MB"] == pytest.approx((s["nnz"] * 6 + 2 * 4000 * 2048 * 2) / 1e6, abs=0.01)
     assert r["spmm_bf16_d0.01_F1024"]["path"].startswith("tiled") and s["path"].startswith("direct")
+
+
+def _channel_ref_fp64_device(ch, pooled_bf16):
+    """fp64 on the device (torch / rocBLAS, nothing of ours) of one configs[4] channel at FULL size, twice: `exact` keeps
+    fp64 between the products; `chain` rounds every intermediate to bf16 where the bf16 workload stores one (S1, X1, S2, G),
+    so only the fp32 accumulation order separates it from the kernels."""
+    bf, f64 = torch.bfloat16, torch.float64
+    n = ch.n
+    if ch.dense:
+        A = ch.adj_bf16[:, :n].to(f64)
+    else:
+        rp, col, val = ch.csr
+        rows = torch.repeat_interleave(torch.arange(n, device=rp.device), (rp[1:] - rp[:-1]).long())
+        A = torch.zeros(n, n, device=rp.device, dtype=f64)
+        A.index_put_((rows, col.long()), val.to(bf).to(f64), accumulate=True)      # (the bf16 SpMM holds bf16 values)
+    X, W1, W2 = ch.Xb[:, :300].to(f64), ch.W1t[:, :300].to(f64).t(), ch.W2t.to(f64).t()
+    P = pooled_bf16.to(f64)
+    lrelu = lambda t: torch.where(t > 0, t, 0.2 * t)
+    exact = P @ (A @ (lrelu(A @ (X @ W1)) @ W2)).t()
+    r = lambda t: t.to(torch.float32).to(bf).to(f64)
+    chain = P @ r(A @ r(r(lrelu(A @ r(X @ W1))) @ W2)).t()
+    return exact, chain
+
+
+@pytest.mark.parametrize("kind", ["csr_d4e-4", "csr_d1e-2", "dense"])
+def test_stress_workload_full_size(kind):
+    """BASELINE.json configs[4] AS A WORKLOAD at its stated size -- N = 10 000 nodes, 3 channels, batch 512, bf16 -- the forward
+    bench.py's `stress` leg times (MODEL:52-58, 460-474 at stress size): every one of the 3 x 512 x 10 000 outputs against fp64
+    (not a sample), and -- for the PMI-like density -- the 3- and 8-rank shard plans against the one-rank result at that size."""
+    kw = {"csr_d4e-4": dict(density=stress.DENSITIES[0]), "csr_d1e-2": dict(density=stress.DENSITIES[1]), "dense": dict(dense=True)}[kind]
+    wl = stress.StressWorkload(0, 1, dev=DEV, **kw)
+    assert [s for s in wl.shards] == [(0, 0, stress.BATCH), (1, 0, stress.BATCH), (2, 0, stress.BATCH)]
+    out = wl.forward()
+    torch.cuda.synchronize()
+    full = {}
+    for (c, b0, b1), v in out.items():
+        assert v.dtype == torch.float32 and tuple(v.shape) == (stress.BATCH, N) and bool(torch.isfinite(v).all())
+        exact, chain = _channel_ref_fp64_device(wl.channels[c], wl.pooled[c])
+        scale = float(exact.abs().max())
+        assert scale > 0
+        e_chain = float((v.double() - chain).abs().max()) / scale
+        e_exact = float((v.double() - exact).abs().max()) / scale
+        # same roundings as the kernels' chain: what is left is fp32 accumulation order and the odd 1-ulp bf16 flip of an
+        # intermediate it causes; against unrounded fp64: four bf16 roundings of intermediates
+        assert e_chain < 4e-3, (kind, c, e_chain)
+        assert e_exact < 2e-2, (kind, c, e_exact)
+        # >= 64 sampled (sample, node) entries per channel, relative to each entry's own magnitude where it is not tiny
+        g = torch.Generator(device="cpu").manual_seed(100 + c)
+        bi = torch.randint(0, stress.BATCH, (256,), generator=g).to(v.device)
+        ni = torch.randint(0, N, (256,), generator=g).to(v.device)
+        got, want = v[bi, ni].double(), chain[bi, ni]
+        big = want.abs() > 0.05 * scale
+        assert int(big.sum()) >= 64, (kind, c, int(big.sum()))
+        assert float(((got - want).abs() / want.abs())[big].max()) < 3e-2, (kind, c)
+        full[c] = v
+        del exact, chain
+    if kind != "csr_d4e-4":
+        return
+    for world in (3, 8):
+        seen = {c: torch.zeros(stress.BATCH, dtype=torch.bool) for c in full}
+        for rank in range(world):
+            for (c, b0, b1), v in stress.StressWorkload(rank, world, dev=DEV, **kw).forward().items():
+                assert torch.equal(v, full[c][b0:b1]), (world, rank, c)
+                assert not seen[c][b0:b1].any()
+                seen[c][b0:b1] = True
+        assert all(m.all() for m in seen.values())

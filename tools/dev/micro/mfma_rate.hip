@@ -4,6 +4,27 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MODE 2: v_mfma_f32_32x32x16_bf16, 4 independent accumulators (64 registers)
+__global__ __launch_bounds__(512) void k32(float* out, unsigned long long* cyc, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 a8, b8;
+    for (int j = 0; j < 8; ++j) { a8[j] = (__bf16)(float)(threadIdx.x + j); b8[j] = (__bf16)(float)(j + 1); }
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[i], 0, 0, 0);
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
@@ -46,6 +67,15 @@ int main() {
             printf("%s waves/SIMD=%d: %.2f ticks per MFMA per wave (wave 0), %.2f per SIMD-MFMA\n", mode ? "16x16x16" : "16x16x32", threads / 256,
                    (double)h[0] / (iters * 8), (double)h[0] / (iters * 8) / (threads / 256));
         }
+    }
+    for (int threads : {256, 512}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k32, dim3(1), dim3(threads), 0, 0, out, cyc, iters);
+            hipDeviceSynchronize();
+        }
+        hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+        printf("32x32x16 waves/SIMD=%d: %.2f ticks per MFMA per wave (wave 0), %.2f per SIMD-MFMA = %.2f per 16x16x32-equivalent\n", threads / 256,
+               (double)h[0] / (iters * 4), (double)h[0] / (iters * 4) / (threads / 256), (double)h[0] / (iters * 4) / (threads / 256) / 2);
     }
     return 0;
 }
