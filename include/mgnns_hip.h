@@ -297,6 +297,27 @@ int mgnns_sq_mha_core_bf16_fwd(const float* qh, const void* bank_bf16, const flo
                                const void* Wp, const float* bk, const float* bv,
                                float* o, float* attn, mgnns_stream_t stream);
 
+/* ---- a8, bf16 operands on v_mfma_f32_32x32x16_bf16 (round 4) -----------------------------------------------
+ * Same contract and inputs as mgnns_sq_mha_core_bf16_fwd (submodules.py:55-119, len_q == 1; moudles.py:207-230 calls it);
+ * bank rows in tiles of 32, the model dim in 19 k-steps of 16 (300 -> 304), L <= 224.  The K/V weights are packed by
+ * mgnns_sq_mha32_pack_weights_bf16 into mgnns_sq_mha32_packed_weight_bytes(H) bytes (a different fragment order from the
+ * 16x16x32 form's).
+ * `plan` (optional, needs a mask and L <= 128): the packing plan of the batch's mask -- mgnns_sq_mha32_plan_ints(B) int32 built
+ * by mgnns_sq_mha32_plan(mask, B, L, plan) once per batch and shared by every launch on that mask (Multi_GCN_Multihead_att.py:
+ * 509-527: both image->text stacks, every layer).  With a plan the live rows of several short samples share a workgroup
+ * (8-row aligned, <= 128 rows and <= 16 samples per group): the weight stream is read once per group instead of once per
+ * sample.  Same results as without a plan up to fp32 summation order.  plan == NULL: one workgroup per sample.
+ */
+size_t mgnns_sq_mha32_packed_weight_bytes(int H);
+int mgnns_sq_mha32_pack_weights_bf16(const float* Wk, const float* Wv, int H, int dk, int D, void* Wp,
+                                     mgnns_stream_t stream);
+size_t mgnns_sq_mha32_plan_ints(int B);
+int mgnns_sq_mha32_plan(const float* mask, int B, int L, int32_t* plan, mgnns_stream_t stream);
+int mgnns_sq_mha32_core_bf16_fwd(const float* qh, const void* bank_bf16, const float* mask,
+                                 int B, int L, int ld, int H, int dk,
+                                 const void* Wp, const float* bk, const float* bv,
+                                 float* o, float* attn, const int32_t* plan, mgnns_stream_t stream);
+
 /* ---- a8, folded variant: the K/V projections folded into the query side ---------------------------------
  * Same inputs and outputs as mgnns_sq_mha_core_fwd (submodules.py:55-119, len_q == 1) computed as
  *   U_h = Wk_h^T qh_h;   p = softmax_l(U_h . bank[b,l,:] / sqrt(dk)) (masked);   o_h = Wv_h (sum_l p_l bank[b,l,:]) + bv_h

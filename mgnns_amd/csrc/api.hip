@@ -102,7 +102,7 @@ int mg_env_int(const char* name, int fallback, int slot) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 12; }
+extern "C" int mgnns_abi_version(void) { return 13; }
 
 namespace {
 __global__ void stamp_kernel(unsigned long long* slots, int idx) { slots[idx] = __builtin_amdgcn_s_memrealtime(); }

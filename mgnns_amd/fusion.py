@@ -57,6 +57,16 @@ class MemoryBank:
         return t.shape
 
 
+def make_mask_plan(mask, precision='bf16', attention='faithful'):
+    """The packing plan of a [B, L] attention mask for the bf16 core (ops.sq_mha_plan: the live rows of short samples share a
+    workgroup), or None where it does not apply.  Depends on the mask's VALUES only; whoever passes it to run_stack(plan=...)
+    orders the launch that built it in front of the stack (an event if it ran on another stream)."""
+    if (precision == 'bf16' and attention == 'faithful' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask is not None
+            and mask.shape[-1] <= ops.PLAN_MAX_L and not FUSED_LAYER):
+        return ops.sq_mha_plan(mask.reshape(mask.shape[0], -1).float().contiguous())
+    return None
+
+
 class LayerNorm(nn.Module):
     """gamma * (x - mean) / (std_unbiased + eps) + beta  (submodules.py:153-156)."""
 
@@ -106,7 +116,7 @@ class MultiHeadAttention(nn.Module):
         if self.attention == 'folded':
             o, attn = self._folded(qh, bank, m2, True)
         elif self.precision == 'bf16':
-            o, attn = ops.sq_mha_core_bf16(qh, bank.bf16, m2, self.n_head, self.d_k, self._packed_kv(),
+            o, attn = ops.sq_mha_core_bf16(qh, bank.bf16, m2, self.n_head, self.d_k, self._packed_kv(ops.MHA_CORE_PLAIN),
                                            self.w_ks.bias.detach(), self.w_vs.bias.detach())
         else:
             if bank.f32 is None:
@@ -128,14 +138,19 @@ class MultiHeadAttention(nn.Module):
         return ops.sq_mha_folded(qh, x, m2, self.n_head, self.d_k, self.w_ks.weight.detach(),
                                  self.w_vs.weight.detach(), self.w_vs.bias.detach(), want_attn=want_attn)
 
-    def _packed_kv(self):
-        """w_ks / w_vs in the MFMA-fragment-major bf16 layout, rebuilt when either weight changes."""
+    def _packed_kv(self, form=None):
+        """w_ks / w_vs in the MFMA-fragment-major bf16 layout of the attention core's build `form` (ops.MHA_CORE; the fused
+        layer kernel takes 16), rebuilt when either weight changes."""
+        form = ops.MHA_CORE if form is None else form
         wk, wv = self.w_ks.weight, self.w_vs.weight
         key = (wk.data_ptr(), wk._version, wv.data_ptr(), wv._version, str(wk.device))
         if self._wp is None or self._wp[0] != key:
-            ops.retire(self._wp)                # a live capture may hold the old pack's address
-            self._wp = (key, ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k))
-        return self._wp[1]
+            ops.retire(self._wp)                # a live capture may hold the old packs' addresses
+            self._wp = (key, {})
+        packs = self._wp[1]
+        if form not in packs:
+            packs[form] = ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k, form=form)
+        return packs[form]
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -340,11 +355,12 @@ def first_query(layers, q):
     return ops.linear(q, a0.w_qs.weight.detach(), a0.w_qs.bias.detach())
 
 
-def run_stack(layers, q, bank, mask=None, qh=None):
+def run_stack(layers, q, bank, mask=None, qh=None, plan=None):
     """A stack of MyMultiHeadAttention layers sharing one memory bank (MODEL:509-546): per layer TWO launches --
     the fused attention core and the fused tail (which also emits the next layer's projected query) -- instead
     of the reference's ~12 small kernels.  Numerically the same chain as calling the layers one by one.
-    qh: the first layer's projected query w_qs(q) + b when the producer of q already computed it."""
+    qh: the first layer's projected query w_qs(q) + b when the producer of q already computed it.
+    plan: make_mask_plan(mask) when the caller already built it (both masked stacks of the model share one)."""
     layers = list(layers)
     if not layers:
         return q
@@ -373,6 +389,11 @@ def run_stack(layers, q, bank, mask=None, qh=None):
         return q
     if qh is None:
         qh = first_query(layers, q)
+    # masked bank, bf16 core: the caller's packing plan of this mask (model.py builds it once per batch), else one for this stack
+    if plan is None and m2 is not None:
+        plan = make_mask_plan(m2, a0.precision, a0.attention)
+    elif plan is not None and (m2 is None or a0.precision != 'bf16' or a0.attention != 'faithful'):
+        plan = None
     for i, layer in enumerate(layers):
         a = layer.slf_attn
         if a.attention == 'folded':
@@ -380,13 +401,15 @@ def run_stack(layers, q, bank, mask=None, qh=None):
         elif a.precision == 'bf16' and FUSED_LAYER and TAIL_TERMS == 1 and a.n_head * a.d_v % 32 == 0:
             # the whole layer in one launch: the tile's last attention-core workgroup runs the tile's tail
             nxt = _wq_pack_bf16(layers[i + 1]) if i + 1 < len(layers) else None
-            q, qh = ops.sq_mha_layer_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
+            q, qh = ops.sq_mha_layer_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(16), a.w_ks.bias.detach(),
                                           a.w_vs.bias.detach(), q, _tail_pack_bf16(layer), a.layer_norm.eps,
                                           _tile_counters(layer, B, q.device), nxt)
             continue
         elif a.precision == 'bf16':
-            o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k, a._packed_kv(), a.w_ks.bias.detach(),
-                                        a.w_vs.bias.detach(), want_attn=False)
+            # packed masked banks: the 32x32x16 form; one workgroup per sample: whichever form is the faster (ops.MHA_CORE_PLAIN)
+            o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k,
+                                        a._packed_kv(32 if plan is not None else ops.MHA_CORE_PLAIN), a.w_ks.bias.detach(),
+                                        a.w_vs.bias.detach(), want_attn=False, plan=plan)
         else:
             o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
                                    a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)

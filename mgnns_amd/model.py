@@ -17,7 +17,7 @@ from torch.nn import Parameter
 
 from . import _lib, ops
 from .adjacency import gen_A, gen_adj_csr
-from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query,
+from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query, make_mask_plan,
                      first_query_pack, first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
@@ -707,6 +707,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
 
         def tail(tag, attention, linear_5, x_linear, next_stack, next_name):
             def run():
+                # the packing plan of the text mask for the image->text stack this tail feeds (which samples share a workgroup of
+                # its masked attention launches, MODEL:509-527): one small launch per channel, HERE -- on the stack's own stream,
+                # which has slack; on the BiLSTM's stream (the longest chain) it cost the pipelined forward 3 %, and one plan for
+                # both stacks means a cross-stream dependency the runtime's one-graph capture of the schedule does not survive
+                ctx['mha_plan_' + next_name] = make_mask_plan(text_mask, self.precision, self.attention)
                 ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
                     ctx['pooled_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag), ctx['Q_' + tag], attention, linear_5, x_linear,
                     next_stack)
@@ -733,7 +738,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             def run():
                 ops.stamp("%s stack start" % name)
                 ctx[name] = run_stack(layers, ctx[q_key], ctx[bank_key], ctx['text_mask'] if masked else None,
-                                      qh=ctx.get('qh_' + name))
+                                      qh=ctx.get('qh_' + name), plan=ctx.get('mha_plan_' + name) if masked else None)
                 if split_head:
                     wc, bc, hstate = ctx['_head']
                     ops.classifier_head_part(ctx[name], part_of[name], 4, wc, bc, hstate)

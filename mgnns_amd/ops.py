@@ -832,15 +832,44 @@ def sq_mha_core(qh, bank, mask, n_head, d_kv, wk, bk, wv, bv, want_attn=True):
     return o, attn
 
 
-def pack_kv_weights_bf16(wk, wv, n_head, d_kv):
+# The bf16 attention core has two builds: 32 = v_mfma_f32_32x32x16_bf16 (csrc/sq_mha32_bf16.hip; packed masked banks), 16 = the
+# 16x16x32 form of rounds 1-3 (csrc/sq_mha_bf16.hip; also what the fused layer kernel runs).  The packed weights differ: a pack
+# carries its form as an attribute and sq_mha_core_bf16 dispatches on it.
+MHA_CORE = int(os.environ.get("MGNNS_MHA_CORE", "32"))
+MHA_CORE_PLAIN = int(os.environ.get("MGNNS_MHA_CORE_PLAIN", "16"))      # one workgroup per sample (no plan): the faster build
+MHA_PACKED = os.environ.get("MGNNS_MHA_PACKED", "1") == "1"      # masked banks: pack the live rows of short samples (a plan)
+
+
+def pack_kv_weights_bf16(wk, wv, n_head, d_kv, form=None):
     """w_ks / w_vs [H*dk, D] fp32 -> MFMA-fragment-major bf16 buffer for sq_mha_core_bf16."""
     _chk(wk, "w_ks.weight", ndim=2)
     _chk(wv, "w_vs.weight", ndim=2)
+    form = MHA_CORE if form is None else int(form)
     L = _lib.lib()
-    buf = torch.empty(L.mgnns_sq_mha_packed_weight_bytes(n_head), dtype=torch.uint8, device=wk.device)
-    _lib.check(L.mgnns_sq_mha_pack_weights_bf16(_p(wk), _p(wv), n_head, d_kv, wk.shape[1], _p(buf), _stream()),
-               "mgnns_sq_mha_pack_weights_bf16")
+    if form == 32:
+        buf = torch.empty(L.mgnns_sq_mha32_packed_weight_bytes(n_head), dtype=torch.uint8, device=wk.device)
+        _lib.check(L.mgnns_sq_mha32_pack_weights_bf16(_p(wk), _p(wv), n_head, d_kv, wk.shape[1], _p(buf), _stream()),
+                   "mgnns_sq_mha32_pack_weights_bf16")
+    else:
+        buf = torch.empty(L.mgnns_sq_mha_packed_weight_bytes(n_head), dtype=torch.uint8, device=wk.device)
+        _lib.check(L.mgnns_sq_mha_pack_weights_bf16(_p(wk), _p(wv), n_head, d_kv, wk.shape[1], _p(buf), _stream()),
+                   "mgnns_sq_mha_pack_weights_bf16")
+    buf._mg_form = form
     return buf
+
+
+def sq_mha_plan(mask):
+    """Packing plan of a [B, L] mask (L <= 128) for sq_mha_core_bf16(plan=...): which samples share a workgroup.  One launch;
+    build it once per batch, every attention launch on that mask takes it."""
+    _chk(mask, "mask", ndim=2)
+    B, L_ = mask.shape
+    L = _lib.lib()
+    plan = torch.empty(L.mgnns_sq_mha32_plan_ints(B), dtype=torch.int32, device=mask.device)
+    _lib.check(L.mgnns_sq_mha32_plan(_p(mask), B, L_, _p(plan), _stream()), "mgnns_sq_mha32_plan")
+    return plan
+
+
+PLAN_MAX_L = 128
 
 
 def cast_pad_bf16(x, ld=BANK_LD):
@@ -853,7 +882,8 @@ def cast_pad_bf16(x, ld=BANK_LD):
     return y.view(*x.shape[:-1], ld)
 
 
-def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=True):
+def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=True, plan=None):
+    """plan: sq_mha_plan(mask) (32x32x16 form, L <= 128) -- the live rows of short samples packed into shared workgroups."""
     _chk(qh, "qh", ndim=2)
     _chk(bank_bf16, "memory bank (bf16)", torch.bfloat16, 3)
     _chk(wp, "packed K/V weights", torch.uint8, 1)
@@ -867,6 +897,18 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
     attn = torch.empty(n_head * B, 1, L_, device=qh.device, dtype=torch.float32) if want_attn else None
     L = _lib.lib()
+    form = getattr(wp, "_mg_form", 16)
+    if form == 32:
+        if plan is not None:
+            _chk(plan, "plan", torch.int32, 1)
+            if mask is None or L_ > PLAN_MAX_L or plan.numel() < L.mgnns_sq_mha32_plan_ints(B):
+                raise ValueError("a packing plan needs a mask, L <= %d and %d ints" % (PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
+        _launch("mgnns_sq_mha_core_bf16_fwd", ("mgnns_sq_mha_core_bf16_fwd", L_, mask is not None),
+                L.mgnns_sq_mha32_core_bf16_fwd, _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk),
+                _p(bv), _p(o), _p(attn), _p(plan), _stream())
+        return o, attn
+    if plan is not None:
+        raise ValueError("a packing plan needs the 32x32x16 form of the packed weights")
     _launch("mgnns_sq_mha_core_bf16_fwd", ("mgnns_sq_mha_core_bf16_fwd", L_, mask is not None),
             L.mgnns_sq_mha_core_bf16_fwd, _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk),
             _p(bv), _p(o), _p(attn), _stream())
@@ -881,6 +923,8 @@ def sq_mha_layer_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, q, packed, 
     _chk(qh, "qh", ndim=2)
     _chk(bank_bf16, "memory bank (bf16)", torch.bfloat16, 3)
     _chk(wp, "packed K/V weights", torch.uint8, 1)
+    if getattr(wp, "_mg_form", 16) != 16:
+        raise ValueError("the fused layer kernel takes the 16x16x32 form of the packed K/V weights (pack_kv_weights_bf16(form=16))")
     _chk(q, "q", ndim=2)
     _chk(counters, "tile counters", torch.int32, 1)
     B, L_, ld = bank_bf16.shape

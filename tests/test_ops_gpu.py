@@ -537,11 +537,17 @@ def _bf16_round(x):
     return torch.as_tensor(x).to(torch.bfloat16).float()
 
 
+@pytest.mark.parametrize("form", [32, 16, "packed"])
 @pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
-def test_sq_mha_core_bf16(Hn, tag, L, masked):
-    """bf16-operand kernel: (i) exact-logic check against the oracle fed the SAME bf16-rounded bank and
-    K/V weights (only fp32 summation order differs -> tight), (ii) error vs the fp32 reference golden is
-    reported and bounded loosely (bf16 operands: ~3 significant digits)."""
+def test_sq_mha_core_bf16(Hn, tag, L, masked, form):
+    """bf16-operand kernels (32: v_mfma_f32_32x32x16_bf16, one workgroup per sample; "packed": the same with the masked
+    bank's live rows packed by a plan; 16: the 16x16x32 form): (i) exact-logic check against the oracle fed the SAME
+    bf16-rounded bank and K/V weights (only fp32 summation order differs -> tight), (ii) error vs the fp32 reference golden
+    is reported and bounded loosely (bf16 operands: ~3 significant digits)."""
+    packed = form == "packed"
+    if packed and not masked:
+        pytest.skip("a packing plan is for masked banks")
+    form = 32 if packed else form
     g = H.load_golden("mha.npz")
     name = "h%d_%s" % (Hn, tag)
     pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
@@ -553,9 +559,10 @@ def test_sq_mha_core_bf16(Hn, tag, L, masked):
     assert bank_bf.shape == (bank.shape[0], L, ops.BANK_LD)
     assert torch.equal(bank_bf[..., :300].float().cpu(), _bf16_round(bank))      # RNE like torch
     assert float(bank_bf[..., 300:].float().abs().max()) == 0.0
-    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128)
-    o, attn = ops.sq_mha_core_bf16(qh, bank_bf, None if mask is None else dev(mask), Hn, 128, wp,
-                                   p[a + "w_ks.bias"], p[a + "w_vs.bias"])
+    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128, form=form)
+    dmask = None if mask is None else dev(mask)
+    o, attn = ops.sq_mha_core_bf16(qh, bank_bf, dmask, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"],
+                                   plan=ops.sq_mha_plan(dmask) if packed else None)
     # (i) oracle on bf16-rounded operands
     pr = dict(pc)
     pr[a + "w_ks.weight"] = _bf16_round(pc[a + "w_ks.weight"])
@@ -630,6 +637,79 @@ def test_sq_mha_core_bf16_more_heads_than_probability_rows(Hn):
         assert torch.isfinite(attn).all() and torch.isfinite(o).all()
         assert H.maxabs(attn.cpu(), attn32.cpu()) < 5e-3, (B, L)
         assert H.maxabs(o.cpu(), o32.cpu()) < 2e-2, (B, L)
+
+
+def _decode_plan(plan, B):
+    pl = plan.cpu().numpy()
+    ng = int(pl[0])
+    groups = [tuple(int(x) for x in pl[4 + 4 * g: 4 + 4 * g + 3]) for g in range(ng)]
+    off = pl[4 + 4 * B: 4 + 6 * B: 2].astype(int)
+    lv = pl[4 + 4 * B + 1: 4 + 6 * B: 2].astype(int)
+    return groups, off, lv
+
+
+@pytest.mark.parametrize("Hn,B,L", [(8, 256, 100), (8, 300, 128), (4, 64, 100), (1, 5, 37), (3, 33, 64), (8, 1, 100), (8, 256, 9)])
+def test_sq_mha_core_bf16_packed_plan_equals_one_workgroup_per_sample(Hn, B, L):
+    """Masked banks with a packing plan (csrc/sq_mha32_bf16.hip: several short samples per workgroup, 8-row aligned, segmented
+    softmax, block-wise weighted sums) against the same kernel family with one workgroup per sample, and against the exact-fp32
+    core: MVSA-like ragged lengths, a full-length row, lengths 1 / 8 / 9, masks with HOLES (any 0/1 pattern is legal at the
+    operator), a fully masked sample (NaN row, like the reference's softmax of -inf), odd head counts, batches beyond the grid;
+    the plan itself: every sample exactly once, groups of <= 128 rows and <= 16 samples, 8-aligned offsets."""
+    rs = np.random.RandomState(Hn * 1000 + B + L)
+    wq, wk, wv = (dev((0.05 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
+    bq, bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(3))
+    wp = ops.pack_kv_weights_bf16(wk, wv, Hn, 128, form=32)
+    lens = np.clip(np.round(np.exp(rs.normal(2.4, 0.75, B))), 1, L).astype(int)
+    lens[0] = L
+    for i, v in enumerate((1, 8, 9, 16, 17)):
+        if i + 1 < B:
+            lens[i + 1] = min(v, L)
+    m = np.zeros((B, L), np.float32)
+    for b in range(B):
+        m[b, :lens[b]] = 1
+        if lens[b] > 3 and b % 3 == 0:                       # holes (the last live position stays)
+            m[b, rs.randint(0, lens[b] - 1, size=max(1, lens[b] // 4))] = 0
+    dead = B - 1 if B > 7 else None
+    if dead is not None:
+        m[dead] = 0
+    mask = dev(m)
+    q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+    bank32 = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+    qh = ops.linear(q, wq, bq)
+    bb = ops.cast_pad_bf16(bank32)
+    plan = ops.sq_mha_plan(mask)
+    groups, off, lv = _decode_plan(plan, B)
+    want_lv = np.array([0 if not m[b].any() else int(np.nonzero(m[b])[0][-1]) + 1 for b in range(B)])
+    assert np.array_equal(lv, want_lv)
+    seen = np.zeros(B, int)
+    for first, cnt, rows in groups:
+        assert 1 <= cnt <= 16 and rows <= 128
+        r = 0
+        for b in range(first, first + cnt):
+            seen[b] += 1
+            assert off[b] == r and r % 8 == 0
+            r += max(8, (lv[b] + 7) // 8 * 8)
+        assert r == rows
+    assert (seen == 1).all()
+    o, attn = ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp, bk, bv, plan=plan)
+    o2, attn2 = ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp, bk, bv, plan=plan)
+    o1, attn1 = ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp, bk, bv)                     # one workgroup per sample
+    o32, attn32 = ops.sq_mha_core(qh, bank32, mask, Hn, 128, wk, bk, wv, bv)
+    live = np.ones(B, bool)
+    if dead is not None:
+        live[dead] = False
+        for t in (o, o1):
+            assert torch.isnan(t[dead]).all()
+        for t in (attn, attn1):
+            assert torch.isnan(t.view(Hn, B, L)[:, dead]).all()
+    lv_t = torch.from_numpy(live).to(o.device)
+    assert torch.equal(o[lv_t], o2[lv_t]) and torch.equal(attn.view(Hn, B, L)[:, lv_t], attn2.view(Hn, B, L)[:, lv_t])
+    assert torch.isfinite(o[lv_t]).all() and torch.isfinite(attn.view(Hn, B, L)[:, lv_t]).all()
+    assert H.maxabs(attn.view(Hn, B, L)[:, lv_t].cpu(), attn1.view(Hn, B, L)[:, lv_t].cpu()) < 2e-6
+    assert H.maxabs(o[lv_t].cpu(), o1[lv_t].cpu()) < 2e-5
+    assert float(attn.view(Hn, B, L)[:, lv_t].cpu()[:, torch.from_numpy(m[live] == 0)].abs().max()) == 0.0    # masked positions: exactly 0
+    assert H.maxabs(attn.view(Hn, B, L)[:, lv_t].cpu(), attn32.view(Hn, B, L)[:, lv_t].cpu()) < 5e-3
+    assert H.maxabs(o[lv_t].cpu(), o32[lv_t].cpu()) < 2e-2
 
 
 @pytest.mark.parametrize("form,B,P,K", [(1, 1, 196, 2048), (1, 3, 196, 2048), (2, 1, 196, 2048), (2, 3, 196, 2048),
@@ -962,7 +1042,7 @@ def test_fused_layer_bf16_equals_core_plus_tail(Hn, L, masked):
           "b2": p[f + "w_2.bias"], "g2": p[f + "layer_norm.gamma"], "be2": p[f + "layer_norm.beta"],
           "fc": ops.pack_weight_bf16_split(p[a + "fc.weight"]), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
     nx = (ops.pack_weight_bf16_split(p[a + "w_qs.weight"]), p[a + "w_qs.bias"], Hn * 128)
-    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128)
+    wp = ops.pack_kv_weights_bf16(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128, form=16)      # (the fused layer runs the 16x16x32 core)
     counters = torch.zeros(64, dtype=torch.int32, device=DEV)
     rs = np.random.RandomState(Hn + L)
     for B in (256, 37, 16, 1, 300):

@@ -66,7 +66,12 @@ def mha(kind, B=256, L=196, H=8, masked=False):
     if kind == "bf16":
         bb = ops.cast_pad_bf16(bank)
         wp = ops.pack_kv_weights_bf16(wk, wv, H, 128)
-        ms = timeit(lambda: ops.sq_mha_core_bf16(qh, bb, mask, H, 128, wp, bk, bv))
+        plan = ops.sq_mha_plan(mask) if (masked and ops.MHA_CORE == 32 and ops.MHA_PACKED) else None
+        if plan is not None:
+            print("  plan: %d groups for %d samples, %d live rows" % (int(plan[0]), B, int(mask.sum())))
+            print("  sq_mha_plan: %.1f us" % (timeit(lambda: ops.sq_mha_plan(mask)) * 1e3))
+        ms = timeit(lambda: ops.sq_mha_core_bf16(qh, bb, mask, H, 128, wp, bk, bv, want_attn=False, plan=plan))
+        print("  [core form %d%s]" % (ops.MHA_CORE, ", packed" if plan is not None else ""))
     elif kind == "folded_c16":
         bb = ops.cast_pad_bf16(bank)
         u = torch.randn(B, H * 300, device=DEV, generator=g) * 0.3
