@@ -147,6 +147,9 @@ int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* 
  *   PMI-like graphs (a few non-zeros per row).  F % 8 == 0; nnz = row_ptr[n_rows]; val_bf16 must be readable up to an
  *   even number of elements (the values travel as aligned dwords).  variant = 0 (default: the pipelined ring form) or a
  *   sweep code selecting one of the three kernel forms and its launch geometry (csrc/spmm_bf16.hip, tools/dev).
+ *   row_map (optional, int32 [n_rows]): the CSR's row r is row row_map[r] of Y -- a static adjacency is handed over with its
+ *   rows SORTED BY LENGTH (four rows share a wave instruction: with equal lengths nobody idles; ops.SparseAdjBf16 does it),
+ *   the values of every row of Y are the same bits either way.  NULL: the CSR's row r is row r of Y.
  * mgnns_spmm_tiled_bf16_fwd: dense-ish graphs (tens of non-zeros per row): X staged through LDS tiles of `tile_cols`
  *   columns by LDS-DMA, a workgroup of 16 waves owns 16 * rows_per_wave rows x 32 * lane_bytes features of Y in
  *   registers.  The adjacency comes as the one-off re-ordered stream of mgnns_amd/spmm_plan.py (format documented
@@ -158,7 +161,7 @@ int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* 
 int mgnns_cast_bf16(const float* src, long long n, void* dst_bf16, mgnns_stream_t stream);
 int mgnns_spmm_csr_bf16_fwd(const int32_t* row_ptr, const int32_t* col, const void* val_bf16, int n_rows, int nnz,
                             const void* X_bf16, int F, void* Y, int y_bf16, int act, int variant,
-                            mgnns_stream_t stream);
+                            const int32_t* row_map, mgnns_stream_t stream);
 int mgnns_spmm_tiled_bf16_fwd(const uint32_t* wave_off, const uint32_t* ent, int lane_bytes, int rows_per_wave,
                               int tile_cols, int n_rows, int n_cols, const void* X_bf16, int F, void* Y, int y_bf16,
                               int act, mgnns_stream_t stream);

@@ -30,7 +30,7 @@ SIGNATURES = {
     "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P, _SZ, _P],
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
     "mgnns_cast_bf16": [_P, _c.c_longlong, _P, _P],
-    "mgnns_spmm_csr_bf16_fwd": [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
+    "mgnns_spmm_csr_bf16_fwd": [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P],
     "mgnns_spmm_tiled_bf16_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     "mgnns_linear_fwd": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _SZ, _P],
     "mgnns_imgbank_pool_fwd": [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P],

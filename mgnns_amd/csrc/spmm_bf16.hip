@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void spmm_bf16_slab_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ col,
                                                              const uint16_t* __restrict__ val,
                                                              const uint16_t* __restrict__ X, int n_rows, int F,
-                                                             void* __restrict__ Yv, int y_bf16, int act) {
+                                                             void* __restrict__ Yv, int y_bf16, int act,
+                                                             const int32_t* __restrict__ row_map) {
     constexpr int SW = 128;                     // slab width in features (16 lanes x 8 bf16)
     const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3, nb = gridDim.x >> 3;
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
@@ -54,11 +55,12 @@ __global__ __launch_bounds__(256) void spmm_bf16_slab_kernel(const int32_t* __re
             fon[q] = sl < nslabs && sl < (xcd + 1) * spx && f[q] < F;
         }
         for (int r0 = wave * 4 * RU; r0 < n_rows; r0 += nwaves * 4 * RU) {
-            int p[RU], hi[RU], row[RU];
+            int p[RU], hi[RU], row[RU], orow[RU];      // row: position in the (possibly length-sorted) CSR, orow: the row of Y it is
             float acc[RU][NS][8];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 row[u] = r0 + 4 * u + g;
+                orow[u] = row[u];
                 p[u] = hi[u] = 0;
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void spmm_bf16_slab_kernel(const int32_t* __re
                 if (row[u] < n_rows) {
                     p[u] = row_ptr[row[u]];
                     hi[u] = row_ptr[row[u] + 1];
+                    if (row_map) orow[u] = row_map[row[u]];
                 }
             }
             bool more = false;
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(256) void spmm_bf16_slab_kernel(const int32_t* __re
                         if (y_bf16) {
                             const u32x4 ov = {sb_pack_bf16(o[0], o[1]), sb_pack_bf16(o[2], o[3]), sb_pack_bf16(o[4], o[5]),
                                               sb_pack_bf16(o[6], o[7])};
-                            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(Yv) + (size_t)row[u] * F + f[q]));
+                            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(Yv) + (size_t)orow[u] * F + f[q]));
                         } else {
-                            float* yp = static_cast<float*>(Yv) + (size_t)row[u] * F + f[q];
+                            float* yp = static_cast<float*>(Yv) + (size_t)orow[u] * F + f[q];
                             __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(yp));
                             __builtin_nontemporal_store(f32x4{o[4], o[5], o[6], o[7]}, reinterpret_cast<f32x4*>(yp + 4));
                         }
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(256) void spmm_bf16_ring_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ col,
                                                              const uint16_t* __restrict__ val,
                                                              const uint16_t* __restrict__ X, int n_rows, int F,
-                                                             void* __restrict__ Yv, int y_bf16, int act, int nnz) {
+                                                             void* __restrict__ Yv, int y_bf16, int act, int nnz,
+                                                             const int32_t* __restrict__ row_map) {
     constexpr int SB = NSL * 256, LPS = SB / 16, EPI = 64 / LPS, RING_E = RI * EPI;
     constexpr int WAVE_LDS = RI * 1024 + 1024 + 512;               // gather ring + col ring (256 x 4 B) + val ring (256 x 2 B)
     static_assert(RING_E <= 64, "the gather ring must not outrun the four 64-entry metadata windows");
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(256) void spmm_bf16_ring_kernel(const int32_t* __re
         }
         int rwin = r_begin;                                        // first row of the row-pointer window
         int rpv = row_ptr[min(rwin + lane, n_rows)], rpe = row_ptr[min(rwin + lane + 1, n_rows)];
-        asm volatile("" : "+v"(rpv), "+v"(rpe));                   // landed here (nothing else is in flight yet)
+        int rmv = row_map ? row_map[min(rwin + lane, n_rows - 1)] : rwin + lane;      // the row of Y behind CSR position rwin + lane
+        asm volatile("" : "+v"(rpv), "+v"(rpe), "+v"(rmv));        // landed here (nothing else is in flight yet)
         request_window(0);
         request_window(1);
         int wreq = 1;                                              // highest window requested
@@ -231,9 +236,11 @@ __global__ __launch_bounds__(256) void spmm_bf16_ring_kernel(const int32_t* __re
                 rwin = r;
                 rpv = row_ptr[min(rwin + lane, n_rows)];
                 rpe = row_ptr[min(rwin + lane + 1, n_rows)];
-                asm volatile("" : "+v"(rpv), "+v"(rpe));
+                rmv = row_map ? row_map[min(rwin + lane, n_rows - 1)] : rwin + lane;
+                asm volatile("" : "+v"(rpv), "+v"(rpe), "+v"(rmv));
             }
             const int rr = r + g;
+            const int ro = __shfl(rmv, min(r - rwin + g, 63), 64);  // where this lane group's row goes
             const int rs = __shfl(rpv, r - rwin + g, 64) - e0, re = __shfl(rpe, r - rwin + g, 64) - e0;   // this lane group's row
             const int chunk_end = __builtin_amdgcn_readlane(rpe, min(r + 3, r_end - 1) - rwin) - e0;
             float acc[NSL][8];
@@ -323,9 +330,9 @@ __global__ __launch_bounds__(256) void spmm_bf16_ring_kernel(const int32_t* __re
                         if (y_bf16) {
                             const u32x4 ov = {sb_pack_bf16(o[0], o[1]), sb_pack_bf16(o[2], o[3]), sb_pack_bf16(o[4], o[5]),
                                               sb_pack_bf16(o[6], o[7])};
-                            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(Yv) + (size_t)rr * F + f[q]));
+                            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(Yv) + (size_t)ro * F + f[q]));
                         } else {
-                            float* yp = static_cast<float*>(Yv) + (size_t)rr * F + f[q];
+                            float* yp = static_cast<float*>(Yv) + (size_t)ro * F + f[q];
                             __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(yp));
                             __builtin_nontemporal_store(f32x4{o[4], o[5], o[6], o[7]}, reinterpret_cast<f32x4*>(yp + 4));
                         }
@@ -661,7 +668,7 @@ extern "C" int mgnns_cast_bf16(const float* src, long long n, void* dst, mgnns_s
 
 extern "C" int mgnns_spmm_csr_bf16_fwd(const int32_t* row_ptr, const int32_t* col, const void* val_bf16, int n_rows, int nnz,
                                        const void* X, int F, void* Y, int y_bf16, int act, int variant,
-                                       mgnns_stream_t stream) {
+                                       const int32_t* row_map, mgnns_stream_t stream) {
     MG_REQUIRE(row_ptr && X && Y && (nnz == 0 || (col && val_bf16)), "mgnns_spmm_csr_bf16_fwd: null pointer");
     MG_REQUIRE(n_rows >= 0 && nnz >= 0 && F > 0 && F % 8 == 0, "mgnns_spmm_csr_bf16_fwd: F=%d must be a positive multiple of 8", F);
     MG_REQUIRE(mg_aligned16(X) && mg_aligned16(Y), "mgnns_spmm_csr_bf16_fwd: X/Y must be 16-byte aligned");
@@ -682,13 +689,13 @@ extern "C" int mgnns_spmm_csr_bf16_fwd(const int32_t* row_ptr, const int32_t* co
         MG_REQUIRE(wgx > 0 && wgx <= 4096 && ns <= 2 && ru <= 2, "mgnns_spmm_csr_bf16_fwd: bad variant %d", variant);
         const dim3 grid(8 * wgx), blk(256);
         if (ns == 1 && ru == 1)
-            hipLaunchKernelGGL((spmm_bf16_slab_kernel<1, 1>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act);
+            hipLaunchKernelGGL((spmm_bf16_slab_kernel<1, 1>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, row_map);
         else if (ns == 1)
-            hipLaunchKernelGGL((spmm_bf16_slab_kernel<1, 2>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act);
+            hipLaunchKernelGGL((spmm_bf16_slab_kernel<1, 2>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, row_map);
         else if (ru == 1)
-            hipLaunchKernelGGL((spmm_bf16_slab_kernel<2, 1>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act);
+            hipLaunchKernelGGL((spmm_bf16_slab_kernel<2, 1>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, row_map);
         else
-            hipLaunchKernelGGL((spmm_bf16_slab_kernel<2, 2>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act);
+            hipLaunchKernelGGL((spmm_bf16_slab_kernel<2, 2>), grid, blk, 0, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, row_map);
     } else {
         MG_REQUIRE(variant & (1 << 29), "mgnns_spmm_csr_bf16_fwd: bad variant %d", variant);
         variant &= ~(1 << 29);
@@ -700,7 +707,7 @@ extern "C" int mgnns_spmm_csr_bf16_fwd(const int32_t* row_ptr, const int32_t* co
         auto kfn = spmm_bf16_ring_kernel<NSL_, RI_>;                                                              \
         const int lds = 4 * (RI_ * 1024 + 1536);                                                                  \
         MG_DYN_LDS(kfn, lds);                                                                                     \
-        hipLaunchKernelGGL(kfn, grid, blk, lds, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, nnz);          \
+        hipLaunchKernelGGL(kfn, grid, blk, lds, st, row_ptr, col, v, x, n_rows, F, Y, y_bf16, act, nnz, row_map); \
     }
         MG_RING(1, 16) MG_RING(1, 8) MG_RING(2, 16) MG_RING(2, 8)
 #undef MG_RING

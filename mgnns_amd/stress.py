@@ -185,9 +185,35 @@ class StressWorkload:
                 self.pooled[c] = ops.cast_pad_bf16(full, ld=2048) if dtype == "bf16" else full
         del g
 
-    def forward(self):
-        """-> {(channel, b0, b1): read-out [b1 - b0, N] fp32}"""
-        return {(c, b0, b1): self.channels[c].forward(self.pooled[c][b0:b1].contiguous()) for c, b0, b1 in self.shards}
+    def forward(self, union=None):
+        """-> {(channel, b0, b1): read-out [b1 - b0, N] fp32}.  union (default: whenever it applies -- bf16, gather-path sparse
+        adjacency, more than one channel on this rank): the channels' sparse propagations as ONE launch per layer on the
+        block-diagonal union of their adjacencies (ops.SparseAdjBf16.block_diagonal); same bits as channel by channel."""
+        chans = sorted(self.channels)
+        ch0 = self.channels[chans[0]]
+        can = (len(chans) > 1 and ch0.dtype == "bf16" and not ch0.dense
+               and ch0.sadj.avg_nnz < ops.SparseAdjBf16.TILED_MIN_AVG_NNZ)
+        if union is None:
+            union = can
+        if not union:
+            return {(c, b0, b1): self.channels[c].forward(self.pooled[c][b0:b1].contiguous()) for c, b0, b1 in self.shards}
+        if not can:
+            raise ValueError("the union form needs bf16 channels with a gather-path sparse adjacency, more than one of them")
+        n, bf = ch0.n, torch.bfloat16
+        if getattr(self, "_union", None) is None:
+            dev = ch0.Xb.device
+            self._union = (ops.SparseAdjBf16.block_diagonal([self.channels[c].sadj for c in chans]),
+                           torch.empty(len(chans) * n, 1024, device=dev, dtype=bf), torch.empty(len(chans) * n, 2048, device=dev, dtype=bf))
+        adj, S1, S2 = self._union
+        for i, c in enumerate(chans):
+            ops.gemm_bf16_nt(self.channels[c].Xb, self.channels[c].W1t, out=S1[i * n:(i + 1) * n])
+        X1 = ops.spmm_bf16(adj, S1, act=ops.ACT_LRELU2)
+        for i, c in enumerate(chans):
+            ops.gemm_bf16_nt(X1[i * n:(i + 1) * n], self.channels[c].W2t, out=S2[i * n:(i + 1) * n])
+        G = ops.spmm_bf16(adj, S2)
+        pos = {c: i for i, c in enumerate(chans)}
+        return {(c, b0, b1): ops.gemm_bf16_nt(self.pooled[c][b0:b1].contiguous(), G[pos[c] * n:(pos[c] + 1) * n])
+                for c, b0, b1 in self.shards}
 
     def capture(self):
         """One hipGraph per shard (a channel's five launches), replayed side by side on a stream per shard: the channels are
@@ -252,6 +278,25 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
                 "copy_cold_ms": round(ms_c, 5), "copy_cold_GBps": round(2.0 * n * F * 2 / ms_c / 1e6, 1),
                 "frac_of_copy": round(ms_c / ms * by / (2.0 * n * F * 2), 4)}
             del xs, ys
+        # configs[4]'s THREE channels as one launch: the block-diagonal union of three such graphs on the stacked features
+        if adj.avg_nnz < ops.SparseAdjBf16.TILED_MIN_AVG_NNZ:
+            adjs = [adj] + [ops.SparseAdjBf16(csr_to_device(random_csr(n, dens, 1 + 10 * c), dev)) for c in (1, 2)]
+            big = ops.SparseAdjBf16.block_diagonal(adjs)
+            for F in (1024, 2048):
+                by = big.nnz * 6.0 + 2.0 * 3 * n * F * 2
+                k = _sets_for(2.0 * 3 * n * F * 2)
+                xs = [torch.randn(3 * n, F, device=dev, generator=g).bfloat16() for _ in range(k)]
+                ys = [torch.empty_like(x) for x in xs]
+                ms = time_cold(lambda x, y: ops.spmm_bf16(big, x, act=ops.ACT_LRELU2, out=y), list(zip(xs, ys)))
+                ms_c = time_cold(lambda d, s_: d.copy_(s_), list(zip(ys, xs)))
+                out["spmm_bf16_3ch_d%g_F%d" % (dens, F)] = {
+                    "what": "three channels' propagations as ONE launch (block-diagonal union, rows in order of length)",
+                    "nnz": big.nnz, "sets": k, "cold_ms": round(ms, 5), "cold_ms_per_channel": round(ms / 3, 5),
+                    "algorithmic_MB": round(by / 1e6, 2), "cold_GBps": round(by / ms / 1e6, 1),
+                    "frac_of_8TBps": round(by / ms / 1e6 / 8000.0, 4), "copy_cold_ms": round(ms_c, 5),
+                    "frac_of_copy": round(ms_c / ms * by / (2.0 * 3 * n * F * 2), 4)}
+                del xs, ys
+            del big, adjs
         # the fp32-feature kernel of the model's own label GCN (mgnns_spmm_csr_fwd) on the same graph, for reference
         F = 1024
         by = nnz * 8.0 + 2.0 * n * F * 4
@@ -279,9 +324,11 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
     for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("csr_d0.01", dict(density=DENSITIES[1])), ("dense", dict(dense=True))):
         wl = StressWorkload(n=n, batch=batch, dev=dev, **kw)
         ms = time_warm(wl.forward, (), reps=5)
+        ms_sep = time_warm(lambda: wl.forward(union=False), (), reps=5)
         ch = next(iter(wl.channels.values()))
         ms1 = time_warm(ch.gcn, (), reps=5)
         out["workload_bf16_" + name] = {"ms_per_3_channel_forward": round(ms, 4), "samples_per_s": round(batch / ms * 1e3, 1),
+                                        "ms_per_3_channel_forward_channel_by_channel": round(ms_sep, 4),
                                         "ms_gcn_of_one_channel": round(ms1, 4),
                                         "what": "3 channels one after the other on one stream, eager launches, bf16 operands / fp32 "
                                                 "accumulation end to end (5 launches per channel)"}

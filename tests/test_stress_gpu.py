@@ -301,3 +301,45 @@ def test_stress_workload_full_size(kind):
                 assert not seen[c][b0:b1].any()
                 seen[c][b0:b1] = True
         assert all(m.all() for m in seen.values())
+
+
+def test_bf16_spmm_rows_in_order_of_length_and_block_diagonal_union():
+    """The gather kernels take a static adjacency with its rows SORTED BY LENGTH (+ the map back to the rows of Y; the ring
+    form in strided quads) and the three channels of configs[4] as ONE launch on the block-diagonal union: every row of Y is
+    the same fmaf chain either way -- bit-identical to the rows-in-graph-order launch, both kernel forms (F = 1024: ring,
+    F = 2048: register), bf16 and fp32 outputs, empty rows and one very long row included."""
+    n = 3000
+    rs = np.random.RandomState(5)
+    csrs = []
+    for c in range(3):
+        rp, col, val = stress.random_csr(n, 2e-3, 40 + c)
+        csrs.append((rp, col, val))
+    # an adjacency with empty rows and one row of 500 entries
+    per = rs.poisson(3.0, size=n)
+    per[7] = 0
+    per[8] = 500
+    rows = np.repeat(np.arange(n), per)
+    cols = rs.randint(0, n, size=rows.size)
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    rows, cols = key // n, key % n
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, rows + 1, 1)
+    csrs[1] = (np.cumsum(rp).astype(np.int32), cols.astype(np.int32), rs.uniform(0, 1, cols.size).astype(np.float32))
+    dev_csrs = [stress.csr_to_device(c, DEV) for c in csrs]
+    plain = [ops.SparseAdjBf16(c, sort_rows=False) for c in dev_csrs]
+    srt = [ops.SparseAdjBf16(c) for c in dev_csrs]
+    big = ops.SparseAdjBf16.block_diagonal(srt)
+    assert big.n_rows == 3 * n and big.n_cols == 3 * n and big.nnz == sum(a.nnz for a in srt)
+    for F in (1024, 2048, 136):
+        x = torch.randn(3 * n, F, device=DEV).bfloat16()
+        for dt in (torch.bfloat16, torch.float32):
+            ref = torch.cat([ops.spmm_bf16(plain[c], x[c * n:(c + 1) * n].contiguous(), act=ops.ACT_LRELU2, out_dtype=dt) for c in range(3)])
+            assert srt[0].sorted_for(F) is not None
+            got = torch.cat([ops.spmm_bf16(srt[c], x[c * n:(c + 1) * n].contiguous(), act=ops.ACT_LRELU2, out_dtype=dt) for c in range(3)])
+            assert torch.equal(got, ref), (F, dt)
+            one = ops.spmm_bf16(big, x, act=ops.ACT_LRELU2, out_dtype=dt)
+            assert torch.equal(one, ref), (F, dt)
+    # and the workload: the union forward == channel by channel, bit for bit
+    wl = stress.StressWorkload(0, 1, n=1500, batch=32, dev=DEV)
+    a, b = wl.forward(union=True), wl.forward(union=False)
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
