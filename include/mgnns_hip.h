@@ -378,7 +378,11 @@ int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, int B, int d
                             const void* const* packed,
                             const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
                             const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
-                            const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream);
+                            const float* bq_next, int HK_next, float* qh_next, int cluster, float* cluster_scratch,
+                            int* cluster_counters, mgnns_stream_t stream);
+/* cluster / cluster_scratch / cluster_counters as in mgnns_mha_tail_c16_fwd below (terms = 1 only; NULL buffers: every workgroup
+ * of a tile's cluster streams all of fc and the ranks share the next layer's w_qs columns): with the buffers the ranks split the K
+ * of fc (submodules.py:88), the last arriver finishes the tile and the next layer's w_qs runs as a second launch. */
 
 /* The bf16 tail (terms = 1) behind mgnns_sq_mha_folded_bf16_fwd: `c` = bf16 [B, HC] (HC = n_head * d_model rounded up to a
  * multiple of 32, <= 2560; zeros behind n_head * d_model) instead of the fp32 head outputs; packed[0] = the composed map

@@ -60,7 +60,7 @@ SIGNATURES = {
     "mgnns_pack_weight_f32": [_P, _I, _I, _P, _P],
     "mgnns_mha_tail_fwd": [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P],
     "mgnns_pack_weight_bf16_split": [_P, _I, _I, _P, _P, _P],
-    "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P],
+    "mgnns_mha_tail_bf16_fwd": [_P, _I, _P, _I, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_mha_tail_c16_fwd": [_P, _I, _P, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_sq_mha_folded_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P],
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],

@@ -291,6 +291,18 @@ __global__ __launch_bounds__(NTHR) void mha_tail_bf16_kernel(const float* __rest
     mg_tail::tail_bf16_body<TERMS, false>(smem_b, o, HK, q, B, w, eps, out, HKn, qh_next, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
+// the same with the K of `fc` split over the cluster (round 4; as mha_tail_c16_kernel): ranks of a tile are ADJACENT workgroups,
+// each contracts a slice of K, the rank that arrives last adds the partial sums and finishes the tile; the next layer's w_qs is a
+// launch of its own behind it (mha_proj_c16_kernel)
+template <int TERMS>
+__global__ __launch_bounds__(NTHR) void mha_tail_bf16_ks_kernel(const float* __restrict__ o, int HK, const float* __restrict__ q, int B,
+                                                                TailW w, float eps, float* __restrict__ out, int cl,
+                                                                float* __restrict__ xpart, int* __restrict__ xcnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    mg_tail::tail_bf16_body<TERMS, false>(smem_b, o, HK, q, B, w, eps, out, 0, nullptr, (int)blockIdx.x / cl, (int)blockIdx.x % cl, cl,
+                                          xpart, xcnt);
+}
+
 // the same tail behind the folded attention (sq_mha_folded_bf16.hip): `c` = bf16 [B, HC] weighted bank rows per head, `fc` = the
 // composed map fc . blockdiag(W_v) [300, HC], the next projection = the composed W_k^T W_q rows [HCn, 300]
 __global__ __launch_bounds__(NTHR) void mha_tail_c16_kernel(const unsigned short* __restrict__ c, int HC, const float* __restrict__ q,
@@ -394,9 +406,13 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
                                        const void* const* packed /* fc_h,fc_l,w1_h,w1_l,w2_h,w2_l,wq_h,wq_l */,
                                        const float* fc_b, const float* ln1_gamma, const float* ln1_beta, const float* b1,
                                        const float* b2, const float* ln2_gamma, const float* ln2_beta, float eps, float* out,
-                                       const float* bq_next, int HK_next, float* qh_next, mgnns_stream_t stream) {
+                                       const float* bq_next, int HK_next, float* qh_next, int cluster, float* cluster_scratch,
+                                       int* cluster_counters, mgnns_stream_t stream) {
     MG_REQUIRE(o && q && packed && fc_b && ln1_gamma && ln1_beta && b1 && b2 && ln2_gamma && ln2_beta && out,
                "mgnns_mha_tail_bf16_fwd: null pointer");
+    MG_REQUIRE(cluster >= 0 && cluster <= 8, "mgnns_mha_tail_bf16_fwd: cluster=%d (0 = default, 1..8)", cluster);
+    MG_REQUIRE((cluster_scratch != nullptr) == (cluster_counters != nullptr), "mgnns_mha_tail_bf16_fwd: cluster scratch and counters go together");
+    MG_REQUIRE(!cluster_scratch || mg_aligned16(cluster_scratch), "mgnns_mha_tail_bf16_fwd: cluster scratch must be 16-byte aligned");
     MG_REQUIRE(d_model == D, "mgnns_mha_tail_bf16_fwd: d_model=%d unsupported (300 only)", d_model);
     MG_REQUIRE(terms == 1 || terms == 3, "mgnns_mha_tail_bf16_fwd: terms must be 1 (bf16) or 3 (split-bf16)");
     MG_REQUIRE(HK > 0 && HK % 32 == 0 && HK <= 2048, "mgnns_mha_tail_bf16_fwd: n_head*d_v=%d unsupported (multiple of 32, <= 2048)", HK);
@@ -418,8 +434,30 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     // share of the projection (MGNNS_TAIL_CLUSTER overrides: 1 = none).  Four while the chip has CUs to spare; TWO from 256
     // samples on, where the forward is bound by CU time and 64 workgroups x 21 us cost more than the shorter chain returns
     // (B=256: 0.811-0.820 ms per forward with 2, 0.830 with 4; B=128: equal; B=64: 0.453-0.458 with 4, 0.464-0.467 with 2)
+    if (cluster_scratch && terms == 1 && cluster != 1) {
+        // K-split form (round 4): the ranks of a tile split fc's K = n_head * d_v, the last arriver finishes the tile; the next
+        // layer's w_qs as a launch of its own on 8 workgroups per tile (csrc: mha_proj_c16_kernel -- x -> bf16, one MFMA chain
+        // per column tile, exactly what the tail's own projection phase does)
+        int cl = cluster ? cluster : 4;
+        if (cl > HK / 32) cl = HK / 32;                  // every rank needs a k-step of its own
+        const unsigned tiles = (unsigned)((B + ROWS - 1) / ROWS);
+        MG_DYN_LDS(mha_tail_bf16_ks_kernel<1>, 160 * 1024);
+        TailW w2 = w;
+        w2.wq_h = w2.wq_l = nullptr;
+        hipLaunchKernelGGL(mha_tail_bf16_ks_kernel<1>, dim3(tiles * cl), dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w2, eps,
+                           out, cl, cluster_scratch, cluster_counters);
+        MG_CHECK_LAUNCH("mgnns_mha_tail_bf16_fwd(K split)");
+        if (packed[6]) {
+            const int pcl = 8;
+            hipLaunchKernelGGL(mha_proj_c16_kernel, dim3(tiles * pcl), dim3(NTHR), 0, (hipStream_t)stream, (const float*)out, B,
+                               (const unsigned short*)packed[6], bq_next, HK_next, qh_next, pcl);
+            MG_CHECK_LAUNCH("mgnns_mha_tail_bf16_fwd(projection)");
+        }
+        return 0;
+    }
     int cl = packed[6] ? (B >= 256 ? 2 : 4) : 1;
     if (const int e = mg_env_int("MGNNS_TAIL_CLUSTER", 0, 1)) cl = packed[6] ? e : 1;
+    if (cluster) cl = packed[6] ? cluster : 1;
     if (cl < 1) cl = 1;
     if (cl > 8) cl = 8;
     dim3 grid((B + ROWS - 1) / ROWS, cl);

@@ -117,10 +117,10 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
                                                float* __restrict__ qh_next, int tile, int crank, int csize,
                                                float* __restrict__ xpart = nullptr, int* __restrict__ xcnt = nullptr) {
     static_assert(!O_BF16 || TERMS == 1, "a bf16 o has no lo part");
-    // K-split (O_BF16 with exchange buffers): the ranks of a tile's cluster each contract a slice of the first product's K
-    // (1.44 MB of composed weights behind the folded attention) instead of every rank streaming all of it; the last rank to
-    // arrive adds the partial sums and finishes the tile (below).
-    const bool ksplit = O_BF16 && xpart != nullptr && csize > 1;
+    // K-split (with exchange buffers): the ranks of a tile's cluster each contract a slice of the first product's K (1.44 MB of
+    // composed weights behind the folded attention, 0.6 MB of fc behind the explicit one) instead of every rank streaming all
+    // of it; the last rank to arrive adds the partial sums and finishes the tile (below).
+    const bool ksplit = xpart != nullptr && csize > 1;
     const int KSo_all = (HK + 31) / 32;
     const int ks_lo = ksplit ? crank * KSo_all / csize : 0;
     const int ks_hi = ksplit ? (crank + 1) * KSo_all / csize : KSo_all;
@@ -190,13 +190,14 @@ __device__ __forceinline__ void tail_bf16_body(unsigned char* smem_b, const floa
             const int i = tid + it * NTHR;
             const int r = i / so, c = i - r * so;
             v[it][0] = v[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < ROWS * so && r0 + r < B && c * 8 < HK) {
+            const int cg = c + 4 * ks_lo;                     // this rank's K slice (all of K without a split)
+            if (i < ROWS * so && r0 + r < B && c < 4 * KSo && cg * 8 < HK) {
                 if (O_COHERENT) {
-                    const int off = (int)(((size_t)r * HK + c * 8) * sizeof(float));
+                    const int off = (int)(((size_t)r * HK + cg * 8) * sizeof(float));
                     v[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, off, 0, 17));
                     v[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, off + 16, 0, 17));
                 } else {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(o + (size_t)(r0 + r) * HK + c * 8);
+                    const f32x4* src = reinterpret_cast<const f32x4*>(o + (size_t)(r0 + r) * HK + cg * 8);
                     v[it][0] = src[0];
                     v[it][1] = src[1];
                 }

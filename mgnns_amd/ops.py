@@ -1108,9 +1108,14 @@ def pack_weight_bf16_split(w):
     return hi, lo
 
 
-def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3):
+TAIL_BF16_KSPLIT = os.environ.get("MGNNS_TAIL_BF16_KSPLIT", "1") == "1"
+
+
+def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3, cluster=0, ksplit=None):
     """bf16-MFMA fused tail.  packed: dict with fc, w1, w2 = (hi, lo) buffers and fc_b, g1, be1, b1, b2, g2, be2;
-    next_packed = ((hi, lo), bq, HK_next) or None."""
+    next_packed = ((hi, lo), bq, HK_next) or None.  ksplit (terms == 1, default on): a tile's cluster of workgroups splits the K
+    of fc and exchanges partial sums through scratch owned by `packed` (one per capture epoch and launch stream), the next
+    layer's w_qs runs as a second launch; cluster: workgroups per 16-sample tile (0 = the library's default)."""
     import ctypes
     _chk(o, "o", ndim=2)
     _chk(q, "q", ndim=2)
@@ -1128,9 +1133,23 @@ def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3):
         qh = torch.empty(B, hkn, device=o.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * 8)(*ptrs)
     L = _lib.lib()
+    scratch = counters = None
+    if (TAIL_BF16_KSPLIT if ksplit is None else ksplit) and int(terms) == 1 and B > 0 and cluster != 1:
+        tiles = (B + 15) // 16
+        slot = packed.setdefault("_cluster_ws_ks", {})
+        key = _scratch_key()                                     # per (capture epoch, launch stream), like the c16 tail's
+        ws = slot.get(key)
+        if ws is None or ws[0] < tiles or ws[1].device != o.device:
+            if ws is not None:
+                packed.setdefault("_retired", []).append(ws)     # a captured hipGraph may still hold its address: never freed
+            ws = (tiles, torch.empty(L.mgnns_mha_tail_c16_scratch_floats(16 * tiles, 8), device=o.device, dtype=torch.float32),
+                  zeros_i32(2 * tiles, o.device))
+            _scratch_slot_put(slot, key, ws)
+        scratch, counters = ws[1], ws[2]
     _launch("mgnns_mha_tail_bf16_fwd", ("mgnns_mha_tail_bf16_fwd",), L.mgnns_mha_tail_bf16_fwd, _p(o), HK, _p(q), B, 300,
             int(terms), arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
-            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qh), _stream())
+            _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qh), int(cluster), _p(scratch), _p(counters),
+            _stream())
     return out, qh
 
 

@@ -1026,6 +1026,41 @@ def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
     assert 1e-4 < e1 < 5e-2
 
 
+@pytest.mark.parametrize("Hn", [1, 4, 8])
+def test_mha_tail_bf16_k_split_over_the_cluster(Hn):
+    """The explicit bf16 tail with fc's K = n_head * d_v split over a tile's cluster of workgroups (the last arriver adds the
+    partial sums and finishes the tile, the next layer's w_qs as a second launch: mgnns_mha_tail_bf16_fwd with exchange buffers)
+    against the one-workgroup-streams-all form: same chain, partial sums in another order -- an fp32 rounding difference that the
+    chain's bf16 operand roundings (LayerNorm 1's output feeds w_1 as bf16) can turn into one bf16 ulp of an intermediate; batches
+    that are not a multiple of the tile, every cluster size, repeated launches on the same scratch (the counters re-arm
+    themselves), and the exact-logic check: with ONE rank nothing is split and the bits are the reference's."""
+    name = "h%d_img" % Hn
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    a, f = name + ".slf_attn.", name + ".pos_ffn."
+    w1 = p[f + "w_1.weight"].squeeze(-1).contiguous()
+    w2 = p[f + "w_2.weight"].squeeze(-1).contiguous()
+    pk = {"fc_b": p[a + "fc.bias"], "g1": p[a + "layer_norm.gamma"], "be1": p[a + "layer_norm.beta"], "b1": p[f + "w_1.bias"],
+          "b2": p[f + "w_2.bias"], "g2": p[f + "layer_norm.gamma"], "be2": p[f + "layer_norm.beta"],
+          "fc": ops.pack_weight_bf16_split(p[a + "fc.weight"]), "w1": ops.pack_weight_bf16_split(w1), "w2": ops.pack_weight_bf16_split(w2)}
+    nx = (ops.pack_weight_bf16_split(p[a + "w_qs.weight"]), p[a + "w_qs.bias"], Hn * 128)
+    rs = np.random.RandomState(Hn)
+    for B in (256, 37, 1, 300):
+        o = dev(rs.standard_normal((B, Hn * 128)).astype(np.float32))
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        for nxt in (nx, None):
+            ref_out, ref_qh = ops.mha_tail_bf16(o, q, pk, 1e-6, nxt, terms=1, ksplit=False)
+            for cl in (0, 2, 3, 8):
+                for rep in range(2):
+                    out, qh = ops.mha_tail_bf16(o, q, pk, 1e-6, nxt, terms=1, ksplit=True, cluster=cl)
+                    assert H.maxabs(out.cpu(), ref_out.cpu()) < 1e-2 and H.relerr(out.cpu(), ref_out.cpu()) < 1e-3, (B, cl, rep)
+                    assert (qh is None) == (nxt is None)
+                    if qh is not None:                       # (the projection rounds `out` to bf16 first: a 1e-6 change can flip a rounding)
+                        assert H.maxabs(qh.cpu(), ref_qh.cpu()) < 1e-2 and H.relerr(qh.cpu(), ref_qh.cpu()) < 2e-3, (B, cl, rep)
+    ws = pk["_cluster_ws_ks"]
+    assert all(int(v[2].abs().sum()) == 0 for v in ws.values())               # the arrival counters are back at zero
+
+
 @pytest.mark.parametrize("Hn,L,masked", [(8, 196, False), (8, 100, True), (4, 196, False), (1, 50, True)])
 def test_fused_layer_bf16_equals_core_plus_tail(Hn, L, masked):
     """mgnns_sq_mha_layer_bf16_fwd (attention core + the tile's tail run by its last-finishing core workgroup, hand-over of
@@ -1057,7 +1092,7 @@ def test_fused_layer_bf16_equals_core_plus_tail(Hn, L, masked):
             mask = dev(m)
         o, _ = ops.sq_mha_core_bf16(qh, bank, mask, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"], want_attn=False)
         for nxt in (nx, None):
-            ref_out, ref_qh = ops.mha_tail_bf16(o, q, pk, 1e-6, nxt, terms=1)
+            ref_out, ref_qh = ops.mha_tail_bf16(o, q, pk, 1e-6, nxt, terms=1, ksplit=False)      # (the fused layer runs the unsplit chain)
             for rep in range(3):
                 out, qhn = ops.sq_mha_layer_bf16(qh, bank, mask, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"], q, pk, 1e-6,
                                                  counters, nxt)

@@ -123,8 +123,12 @@ def tail(B=256, H=8):
     pkbf = dict(common, fc=ops.pack_weight_bf16_split(fc), w1=ops.pack_weight_bf16_split(w1), w2=ops.pack_weight_bf16_split(w2))
     nxbf = (ops.pack_weight_bf16_split(wq), bq, H * 128)
     for terms in (1, 3):
-        print("mha_tail bf16 terms=%d (+next wq): %.1f us" % (terms, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=terms)) * 1e3))
-        print("mha_tail bf16 terms=%d (last layer): %.1f us" % (terms, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, None, terms=terms)) * 1e3))
+        for ks in ((True, False) if terms == 1 else (False,)):
+            tag = "terms=%d%s" % (terms, ", K of fc split over the cluster" if ks else "")
+            print("mha_tail bf16 %s (+next wq): %.1f us" % (tag, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=terms, ksplit=ks)) * 1e3))
+            print("mha_tail bf16 %s (last layer): %.1f us" % (tag, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, None, terms=terms, ksplit=ks)) * 1e3))
+    for cl in (2, 8):
+        print("mha_tail bf16 terms=1, K split, cluster %d (+next wq): %.1f us" % (cl, timeit(lambda: ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=1, cluster=cl)) * 1e3))
 
 
 def tail_c16(B=256, H=8):
