@@ -64,7 +64,7 @@ SIGNATURES = {
     "mgnns_mha_tail_c16_fwd": [_P, _I, _P, _I, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_sq_mha_folded_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P],
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
-    "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
+    "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _SZ, _P],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "mgnns_conv_fold_bn_bf16": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P],
     "mgnns_stem_conv7_fwd": [_P, _I, _I, _I, _P, _P, _P, _P],
@@ -94,6 +94,7 @@ SIZE_GETTERS = {
     "mgnns_packed_bf16_weight_bytes": [_I, _I],
     "mgnns_packed_f32_weight_bytes": [_I, _I],
     "mgnns_gemm_workspace_bytes": [],
+    "mgnns_gemm_bf16_workspace_bytes": [],
     "mgnns_imgbank_packed_weight_bytes": [_I],
     "mgnns_sq_mha_packed_weight_bytes": [_I],
     "mgnns_sq_mha32_packed_weight_bytes": [_I],

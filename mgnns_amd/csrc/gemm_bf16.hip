@@ -56,11 +56,36 @@ constexpr int APP = A_PIECES / NPROD, BPP = B_PIECES / NPROD, PPP = APP + BPP;  
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
+// (T, full, rem, f) of an XCD: shared by the GEMM kernel, the fix-up kernel and the host launcher
+__host__ __device__ inline void mg_gemm_split(int xcd, int nrb, int nct, int rps, int jmax, int W, int nk, int& T, int& full, int& rem, int& f) {
+    if (rps == 0) {
+        const int cpx = jmax / nrb;
+        int cts = nct - xcd * cpx;
+        cts = cts < 0 ? 0 : (cts > cpx ? cpx : cts);
+        T = cts * nrb;
+    } else {
+        T = ((xcd + 1) * nrb / 8 - xcd * nrb / 8) * nct;
+    }
+    full = T / W;
+    rem = T - full * W;
+    f = 0;
+    // only a last round that is at most a QUARTER full is split: the tile stream of a full chip is bound by the L2 -> LDS DMA
+    // traffic (a round of 256 CUs takes ~200 us, the 64-tile remainder of 10 000 x 1024 alone on 64 CUs ~95), so halves gain
+    // nothing (measured: 10 000 x 2048, f = 2: 473 us split, 451 whole; 10 000 x 1024, f = 4: 275 split, 295 whole)
+    if (rem > 0 && 4 * rem <= W) {
+        f = W / rem;
+        if (f > 8) f = 8;
+        if (f > nk) f = nk;
+        if (f < 2) f = 0;
+    }
+}
+
 __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ A,
                                                                const unsigned short* __restrict__ Bt, int M, int N, int Kp,
                                                                const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                                int act, int nrb, int nct, int rps, int jmax,
-                                                               const int32_t* __restrict__ m_dev, int c_bf16) {
+                                                               const int32_t* __restrict__ m_dev, int c_bf16,
+                                                               float* __restrict__ ws_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nrb_host = nrb;                                      // (the column-split map is laid out for the host's row-block count)
     if (m_dev) {                                                   // row count produced on the device (ragged batches): M is its bound
@@ -71,12 +96,16 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, jstep = gridDim.x >> 3;
-    const int per = rps * nct;
     const int nk = Kp / BK;
-    // virtual tile j of this XCD -> (m0, n0); false beyond the last row block
-    // (rps == 0: fewer super rows than XCDs -- e.g. a 512-row read-out against 10 000 columns -- so the XCDs split the COLUMN
-    //  tiles instead: XCD x takes column tiles x * cpx .. + cpx - 1 with every row block, the row blocks of a column tile next to
-    //  each other; with the row-block map only `supers` of the eight XCDs had work: 88 us instead of 35 for that read-out)
+    // virtual tile j of this XCD -> (m0, n0); false beyond its last tile.
+    // rps != 0: XCD x owns the row blocks [x nrb / 8, (x + 1) nrb / 8) -- a balanced split (rounds 1-3 dealt out whole "super rows"
+    //   of 32 / nct row blocks: 40 row blocks = 10 super rows = TWO for XCDs 0 and 1, one for the others, i.e. the chip waited for
+    //   two XCDs to run a second round) -- tile j = (row block j / nct of the range, column tile j % nct): the workgroups of a
+    //   round share a few row blocks of A and all of Bt's column tiles in the XCD's L2.
+    // rps == 0: fewer row blocks than XCDs -- e.g. a 512-row read-out against 10 000 columns -- so the XCDs split the COLUMN
+    //   tiles instead: XCD x takes column tiles x * cpx .. + cpx - 1 with every row block, the row blocks of a column tile next to
+    //   each other (with a row-block map only two of the eight XCDs had work: 88 us instead of 35 for that read-out)
+    const int rb0 = xcd * nrb / 8, rbn = (xcd + 1) * nrb / 8 - rb0;
     auto decode = [&](int j, int& m0, int& n0) {
         if (rps == 0) {
             const int cpx = jmax / nrb_host;
@@ -85,23 +114,70 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
             n0 = ct * TN;
             return j < jmax && ct < nct && rb < nrb;
         }
-        const int sl = j / per, within = j - sl * per;
-        const int rb = (sl * 8 + xcd) * rps + within / nct, ct = within % nct;
-        m0 = rb * TM;
-        n0 = ct * TN;
-        return j < jmax && rb < nrb;
+        m0 = (rb0 + j / nct) * TM;
+        n0 = (j % nct) * TN;
+        return j < rbn * nct;
     };
     auto next_valid = [&](int j, int& m0, int& n0) {
         while (j < jmax && !decode(j, m0, n0)) j += jstep;
         return j;
     };
-    int ntiles = 0;
-    {
-        int m0, n0;
-        for (int j = jj0; j < jmax; j += jstep) ntiles += decode(j, m0, n0) ? 1 : 0;
+    // ---- this workgroup's work list.  The XCD's valid tiles are j = 0 .. T - 1 (a prefix of the virtual tiles when the row count
+    //      is the host's); its W workgroups take them round robin: `full` whole rounds, then `rem` tiles are left over.  With a
+    //      workspace and rem <= W / 2 the LAST, partial round is not run as `rem` whole tiles on `rem` of the W compute units
+    //      (10 000 x 1024 on 256 CUs: 320 tiles = 1.25 rounds cost two rounds of time, 38 %): each left-over tile's K range is cut
+    //      into f = W / rem parts for f workgroups, partial sums go to the workspace and a small second launch adds them in part
+    //      order and runs the epilogue (gemm_bf16_fixup_kernel; deterministic, no counters, nobody waits).
+    const int W = jstep;
+    int T, full, rem, f;
+    mg_gemm_split(xcd, nrb, nct, rps, jmax, W, nk, T, full, rem, f);
+    if (m_dev) {                                                   // device row count: the column-split map can have holes -- the
+        full = 0;                                                  // plain round robin over the valid tiles, no K split
+        rem = 0;
+        f = 0;
+    } else if (!ws_part) {
+        f = 0;
     }
-    if (ntiles == 0) return;
-    const int S = ntiles * nk;                                     // slices in this workgroup's stream
+    // item i of this workgroup: i < full: tile jj0 + i W, all of K; then at most one more: a left-over tile (whole, f == 0) or
+    // one K part of it
+    const bool part_on = f > 0 && jj0 < rem * f;
+    const int part_id = part_on ? jj0 % f : 0, part_tile = full * W + (part_on ? jj0 / f : 0);
+    const int part_k0 = part_on ? part_id * nk / f : 0, part_k1 = part_on ? (part_id + 1) * nk / f : nk;
+    int nitems, S;
+    if (m_dev) {
+        int m0, n0;
+        nitems = 0;
+        for (int j = jj0; j < jmax; j += jstep) nitems += decode(j, m0, n0) ? 1 : 0;
+        S = nitems * nk;
+    } else {
+        const bool whole_rem = f == 0 && jj0 < rem;
+        nitems = full + ((whole_rem || part_on) ? 1 : 0);
+        S = full * nk + (whole_rem ? nk : 0) + (part_on ? part_k1 - part_k0 : 0);
+    }
+    if (nitems == 0) return;
+    // item -> (tile, first k slice, slices)
+    auto item = [&](int i, int& jcur, int& m0, int& n0, int& k0, int& kn) {
+        if (m_dev) {                                               // walk the valid tiles of jj0, jj0 + W, ...
+            jcur = next_valid(i == 0 ? jj0 : jcur + jstep, m0, n0);
+            k0 = 0;
+            kn = nk;
+            return;
+        }
+        if (i < full) {
+            jcur = jj0 + i * W;
+            k0 = 0;
+            kn = nk;
+        } else if (part_on) {
+            jcur = part_tile;
+            k0 = part_k0;
+            kn = part_k1 - part_k0;
+        } else {
+            jcur = full * W + jj0;
+            k0 = 0;
+            kn = nk;
+        }
+        decode(jcur, m0, n0);
+    };
 
     if (wave >= 8) {
         // ---- producer q: A pieces q + 4 i, Bt pieces 32 + q + 4 i of every slice.  Piece p covers 8 rows x 128 B; lane
@@ -110,13 +186,13 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
         const int q = wave - 8;
         const int row_in = lane >> 3, slot = lane & 7;
         const int chunk = slot ^ (4 * (q & 1) + (row_in >> 1));
-        int im0 = 0, in0 = 0, ikt = 0, ig = 0;
-        int ij = next_valid(jj0, im0, in0);
+        int im0 = 0, in0 = 0, ik0 = 0, ikn = 0, ikt = 0, ig = 0, ii = 0, ij = 0;
+        item(0, ij, im0, in0, ik0, ikn);
         const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
         auto issue = [&]() {                                       // slice ig of the stream -> stage ig % NSTAGE; then advance
             unsigned char* sb = smem + (size_t)(ig % NSTAGE) * STAGE_BYTES;
             const bool live = ig < S;                              // past the end: dummy pieces keep the operation count fixed
-            const size_t koff = (size_t)ikt * BK + chunk * 8;
+            const size_t koff = (size_t)(ik0 + ikt) * BK + chunk * 8;
             auto dma = [&](const unsigned short* src, int p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, 0, 0);
@@ -134,9 +210,9 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
                 dma(live ? Bt + (size_t)row * Kp + koff : zsrc, A_PIECES + q + NPROD * i);
             }
             ++ig;
-            if (++ikt == nk && ig < S) {
+            if (++ikt == ikn && ig < S) {
                 ikt = 0;
-                ij = next_valid(ij + jstep, im0, in0);
+                item(++ii, ij, im0, in0, ik0, ikn);
             }
         };
         // bare s_waitcnt + s_barrier: __syncthreads() carries vmcnt(0) and would wait for the slices just requested
@@ -192,8 +268,8 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
                                                                     __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
     };
-    int cm0 = 0, cn0 = 0, ckt = 0;
-    int cj = next_valid(jj0, cm0, cn0);
+    int cm0 = 0, cn0 = 0, ck0 = 0, ckn = 0, ckt = 0, ci = 0, cj = 0;
+    item(0, cj, cm0, cn0, ck0, ckn);
     asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
     reads(0, 0, 0);
     // software pipeline: the reads of k-step 1 are issued before the MFMAs of k-step 0 and -- behind the slice barrier in the
@@ -210,8 +286,20 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
         __builtin_amdgcn_sched_barrier(0);
         mmas(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (++ckt < nk) continue;
+        if (++ckt < ckn) continue;
         ckt = 0;
+        if (part_on && ci == full) {
+            // ---- a K part of a left-over tile: the partial sums go to this workgroup's slot of the workspace
+            //      ([slot][wave][i][jj][lane] x 16 B); gemm_bf16_fixup_kernel, the next launch on the stream, adds a tile's f
+            //      partials in part order and runs the epilogue
+            float* wp = ws_part + (size_t)(xcd * W + jj0) * (TM * TN) + ((size_t)(wave * 16) * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    __builtin_nontemporal_store(acc[i][jj], reinterpret_cast<f32x4*>(wp + (size_t)(i * 4 + jj) * 64 * 4));
+            return;
+        }
         // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*64 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -238,7 +326,59 @@ __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned sh
                 }
             }
         }
-        cj = next_valid(cj + jstep, cm0, cn0);
+        if (g + 1 < S) item(++ci, cj, cm0, cn0, ck0, ckn);
+    }
+}
+
+// The left-over tiles of gemm_bf16_nt_kernel's last round: workgroup (xcd, r) adds the f partial sums of left-over tile r of XCD
+// xcd in part order and runs that kernel's epilogue.  512 threads; thread t owns the accumulator slots of compute wave t >> 6
+// exactly as that wave wrote them.
+__global__ __launch_bounds__(512) void gemm_bf16_fixup_kernel(const float* __restrict__ ws_part, int M, int N, const float* __restrict__ bias,
+                                                              float* __restrict__ C, int ldc, int act, int nrb, int nct, int rps,
+                                                              int jmax, int W, int nk, int c_bf16) {
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    int T, full, rem, f;
+    mg_gemm_split(xcd, nrb, nct, rps, jmax, W, nk, T, full, rem, f);
+    if (f == 0 || r >= rem) return;
+    const int j = full * W + r;
+    int m0, n0;
+    if (rps == 0) {
+        const int cpx = jmax / nrb;
+        m0 = (j % nrb) * TM;
+        n0 = (xcd * cpx + j / nrb) * TN;
+    } else {
+        m0 = (xcd * nrb / 8 + j / nct) * TM;
+        n0 = (j % nct) * TN;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;        // the compute wave whose slots this thread sums
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fg = lane >> 4;
+    const float* base = ws_part + (size_t)(xcd * W + r * f) * (TM * TN) + ((size_t)(wave * 16) * 64 + lane) * 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int n = n0 + wc * 64 + jj * 16 + fg * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + fr;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (int pt = 0; pt < f; ++pt)
+                sum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)pt * (TM * TN) + (size_t)(i * 4 + jj) * 64 * 4));
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = mg_act(sum[q] + bv[q], act);
+            if (m < M && n < N) {
+                if (c_bf16) {
+                    unsigned lo, hi;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                } else {
+                    *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+                }
+            }
+        }
     }
 }
 
@@ -257,7 +397,7 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
 // internal launcher (also used by the bf16-mode LSTM input projections): m_dev != nullptr -> the row count is read on the
 // device and M is only its upper bound
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
-                        const int32_t* m_dev, hipStream_t stream, int c_bf16) {
+                        const int32_t* m_dev, hipStream_t stream, int c_bf16, void* workspace, size_t workspace_bytes) {
     MG_REQUIRE(A && Bt && C, "mgnns_gemm_bf16_nt_fwd: null pointer");
     MG_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && Kp > 0 && Kp % BK == 0 && ldc >= N && ldc % 4 == 0,
                "mgnns_gemm_bf16_nt_fwd: need N %% 4 == 0, Kp %% %d == 0, ldc %% 4 == 0 (M=%d N=%d Kp=%d ldc=%d)", BK, M, N, Kp, ldc);
@@ -267,12 +407,9 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     if (M == 0) return 0;
     MG_DYN_LDS(gemm_bf16_nt_kernel, SMEM_BYTES);
     const int nrb = (M + TM - 1) / TM, nct = (N + TN - 1) / TN;
-    int rps = 32 / nct;
-    if (rps < 1) rps = 1;
-    if (rps > nrb) rps = nrb;
-    const int supers = (nrb + rps - 1) / rps;
-    int jmax = ((supers + 7) / 8) * rps * nct;                     // virtual tiles per XCD
-    if (supers < 8 && nct >= 8) {                                  // fewer super rows than XCDs: split the column tiles over the XCDs
+    int rps = 1;                                                   // row-block ranges per XCD (see the kernel)
+    int jmax = ((nrb + 7) / 8) * nct;                              // virtual tiles per XCD
+    if (nrb < 8 && nct >= 8) {                                     // fewer row blocks than XCDs: split the column tiles over the XCDs
         rps = 0;
         jmax = nrb * ((nct + 7) / 8);
     }
@@ -281,14 +418,37 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     int per_xcd = n_cu / 8;                                        // one persistent workgroup per CU
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > jmax) per_xcd = jmax;
+    // workspace (optional): 8 W slots of 256 x 128 fp32 partial sums for the K split of a last, partial round of tiles (see the
+    // kernel; mg_gemm_split decides here, too, whether there is anything to fix up)
+    float* ws_part = nullptr;
+    if (workspace && !m_dev && workspace_bytes >= (size_t)8 * per_xcd * TM * TN * sizeof(float) && mg_aligned16(workspace))
+        ws_part = static_cast<float*>(workspace);
+    const int W = per_xcd, nk = Kp / BK;
+    int max_rem = 0;
+    if (ws_part) {
+        for (int xcd = 0; xcd < 8; ++xcd) {
+            int T, full, rem, f;
+            mg_gemm_split(xcd, nrb, nct, rps, jmax, W, nk, T, full, rem, f);
+            if (f && rem > max_rem) max_rem = rem;
+        }
+        if (!max_rem) ws_part = nullptr;                           // no XCD has a splittable last round
+    }
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(8 * per_xcd), dim3(NTHR_WS), SMEM_BYTES, stream,
                        reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
-                       ldc, act, nrb, nct, rps, jmax, m_dev, c_bf16);
+                       ldc, act, nrb, nct, rps, jmax, m_dev, c_bf16, ws_part);
     MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd");
+    if (ws_part) {
+        hipLaunchKernelGGL(gemm_bf16_fixup_kernel, dim3(8 * max_rem), dim3(512), 0, stream, (const float*)ws_part, M, N, bias, C, ldc, act,
+                           nrb, nct, rps, jmax, W, nk, c_bf16);
+        MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(fix-up)");
+    }
     return 0;
 }
 
+extern "C" size_t mgnns_gemm_bf16_workspace_bytes(void) { return (size_t)256 * TM * TN * sizeof(float); }
+
 extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
-                                      int c_bf16, int act, mgnns_stream_t stream) {
-    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, static_cast<float*>(C), ldc, act, nullptr, (hipStream_t)stream, c_bf16 ? 1 : 0);
+                                      int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream) {
+    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, static_cast<float*>(C), ldc, act, nullptr, (hipStream_t)stream, c_bf16 ? 1 : 0,
+                               workspace, workspace_bytes);
 }

@@ -20,7 +20,7 @@
 int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                      const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream);
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
-                        const int32_t* m_dev, hipStream_t stream, int c_bf16);
+                        const int32_t* m_dev, hipStream_t stream, int c_bf16, void* workspace, size_t workspace_bytes);
 
 namespace {
 
@@ -670,7 +670,7 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
             const void* wih = wb;
             if (pp) wih = pp + prepack_whh_bytes();
             else if (int rc = mgnns_cast_pad_bf16(w_ih_cat[layer], 2 * G4, K, XKP, wb, stream)) return rc;
-            if (int rc = mg_launch_gemm_bf16(xb, wih, (int)rows, 2 * G4, XKP, b_ih_cat[layer], Gx, 2 * G4, MGNNS_ACT_NONE, offs + B, s, 0)) return rc;
+            if (int rc = mg_launch_gemm_bf16(xb, wih, (int)rows, 2 * G4, XKP, b_ih_cat[layer], Gx, 2 * G4, MGNNS_ACT_NONE, offs + B, s, 0, nullptr, 0)) return rc;
         } else {
             mg_launch_linear(X, (int)rows, K, w_ih_cat[layer], b_ih_cat[layer], 2 * G4, Gx, 2 * G4, gidx, offs + B, s);
         }

@@ -1223,6 +1223,23 @@ def transpose_cast_bf16(x):
     return y
 
 
+GEMM_BF16_KSPLIT = os.environ.get("MGNNS_GEMM_BF16_KSPLIT", "1") == "1"
+_gemm_bf16_ws = {}
+
+
+def _gemm_bf16_workspace(device):
+    """Partial-sum slots + arrival counters of the dense bf16 GEMM's last-round K split: one buffer per (device, capture epoch,
+    stream) -- launches on one stream are ordered, a captured graph may replay next to anything -- counters zero from the pool."""
+    key = (str(device),) + _scratch_key()
+    ws = _gemm_bf16_ws.get(key)
+    if ws is None:
+        ws = zeros_bytes(_lib.lib().mgnns_gemm_bf16_workspace_bytes(), device)
+        _gemm_bf16_ws[key] = ws
+        if key[1]:
+            _EPOCH_SLOTS.setdefault(key[1], []).append((_gemm_bf16_ws, key))
+    return ws
+
+
 def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None, out_dtype=torch.float32):
     """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 or bf16 [M, N].
     out: optional preallocated result; it may be a column slice [M, N] of a wider row-major matrix (row stride = its stride(0)),
@@ -1242,8 +1259,10 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=Non
         if not (torch.is_tensor(c) and c.is_cuda and c.dim() == 2 and tuple(c.shape) == (M, N) and c.stride(1) == 1
                 and c.dtype in (torch.float32, torch.bfloat16)):
             raise ValueError("out must be a [%d, %d] fp32 / bf16 device matrix with unit column stride" % (M, N))
+    ws = _gemm_bf16_workspace(a_bf16.device) if (GEMM_BF16_KSPLIT and M * N >= (1 << 20)) else None
     _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), c.stride(0),
-                                                 1 if c.dtype == torch.bfloat16 else 0, act, _stream()), "mgnns_gemm_bf16_nt_fwd")
+                                                 1 if c.dtype == torch.bfloat16 else 0, act, _p(ws), 0 if ws is None else ws.numel(),
+                                                 _stream()), "mgnns_gemm_bf16_nt_fwd")
     return c
 
 

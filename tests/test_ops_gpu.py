@@ -1222,3 +1222,29 @@ def test_imgbank_pool_split_vs_fp64(B, P, N):
         assert torch.isinf(pooled[:, 1]).all() and (pooled[:, 1] < 0).all()
     b2, _ = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), None, N, want_pool=False)
     assert np.abs(b2.cpu().numpy() - (ref - bias)).max() / scale < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(10000, 1024, 320), (5000, 512, 704), (2600, 128, 192), (512, 10000, 256), (300, 260, 64)])
+def test_gemm_bf16_nt_last_round_k_split_equals_whole_tiles(M, N, K):
+    """Dense bf16 GEMM with the workspace (a last, at most quarter-full round of tiles cut along K over the idle workgroups, partial
+    sums added in part order by the fix-up launch) against the same GEMM without it: shapes whose XCDs end on a partial round
+    (10 000 x 1024: 40 tiles on 32 workgroups per XCD), ragged row blocks, the column-split map (512 rows), bias + activation +
+    bf16 output through the fix-up path; fp32 partial sums in another order only (<= 1e-6 of the output scale), repeatable bits."""
+    rs = np.random.RandomState(M + N + K)
+    a = ops.cast_pad_bf16(dev(rs.standard_normal((M, K)).astype(np.float32) * 0.1), ld=K)
+    bt = ops.cast_pad_bf16(dev(rs.standard_normal((N, K)).astype(np.float32) * 0.1), ld=K)
+    bias = dev(rs.standard_normal(N).astype(np.float32))
+    old = ops.GEMM_BF16_KSPLIT
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            ops.GEMM_BF16_KSPLIT = False
+            ref = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            ops.GEMM_BF16_KSPLIT = True
+            got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            got2 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            assert torch.equal(got, got2)
+            scale = float(ref.float().abs().max())
+            tol = 1e-6 if dt == torch.float32 else 8e-3          # (bf16 output: one ulp where a sum sits on a rounding boundary)
+            assert float((got.float() - ref.float()).abs().max()) <= tol * scale, (dt, M, N, K)
+    finally:
+        ops.GEMM_BF16_KSPLIT = old
