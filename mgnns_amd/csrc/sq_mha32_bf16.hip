@@ -141,6 +141,7 @@ __device__ __forceinline__ uint4 wfrag(const WStream& w, int soff) {
 #define MG_MHA32_GROUP 2
 #endif
 
+
 // Fragments in flight.  bq: the weight fragments of the next BD k-steps (L2 resident, ~1 us away under load: the fewer row tiles
 // a k-step has, the more k-steps run ahead); they stay in flight ACROSS a unit boundary -- k-step j of a unit is expected in
 // slot j % BD, and the last BD k-steps of a unit refill their slot with the NEXT unit's k-step ks % BD (the slot the next unit
@@ -163,12 +164,36 @@ __device__ __forceinline__ void frags_prime(Frags<NT>& f, const WStream& w, int 
 // a ring that runs RA tiles ahead, ONE counted s_waitcnt per GRP row tiles, the refill of a ring slot right behind the MFMA
 // that consumed it; sched_barrier(0) fences pin the order.  The whole GEMM is ONE basic block (wb_next, the next unit's weight
 // stream, is computed by the caller: a branch in the middle made hipcc spill the ring fragments that were live across it).
-template <int NT, bool VT>
+// One LDS ticket (ds_add_rtn_u32 by lane 0 only) WITHOUT a branch: the exec mask is narrowed inside the asm statement, so the
+// draw can sit in the middle of the GEMM's basic block.  The result lands like any LDS read (in order): read it with
+// lds_ticket_value() behind a wait that covers it.
+__device__ __forceinline__ int lds_ticket_issue(unsigned addr) {
+    int ret;
+    unsigned long long sv;
+    const int one = 1;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                 : "=&v"(ret), "=&s"(sv) : "v"(addr), "v"(one) : "memory");
+    return ret;
+}
+template <int N>
+__device__ __forceinline__ int lds_ticket_value(int raw) {          // s_waitcnt lgkmcnt(N), then lane 0's value as a scalar
+    int t;
+    asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_readfirstlane_b32 %0, %1" : "=s"(t) : "v"(raw), "n"(N) : "memory");
+    return t;
+}
+
+// LATE (the 7-tile class): the next unit's ticket is drawn INSIDE the GEMM, two k-steps before its weight stream is first needed
+// (k-step KS - BD - 2: issue; k-step KS - BD: value -> next_stream(t) gives the stream's byte offset), so the faster wave of a
+// slice takes the next unit when it gets there -- drawn a whole unit ahead, the slower wave's reserved unit held everybody up
+// (tools/dev/mha32_trace.py: epilogues of 5-8 k cycles waiting for it).  !LATE: wb_next is the caller's.
+template <int NT, bool VT, bool LATE, typename NextStream>
 __device__ __forceinline__ void kv_gemm(f32x16 (&acc)[NT], Frags<NT>& f, unsigned a_lo, unsigned a_hi, const WStream& w, int wb,
-                                        int wb_next) {
+                                        int wb_next, unsigned ticket_addr, NextStream&& next_stream) {
     constexpr int BD = Frags<NT>::BD, RA = Frags<NT>::RA, TOTAL = Frags<NT>::TOTAL;
     constexpr int GRP = MG_MHA32_GROUP < RA ? MG_MHA32_GROUP : 1;
+    static_assert(!LATE || KS - BD - 2 >= 0, "late draw needs two k-steps in front of the first next-unit fragment");
     u32x4 ga[RA];
+    int raw_ticket = 0;
     auto fetch = [&](auto nc) {
         constexpr int n = decltype(nc)::v;
         constexpr int ks = n / NT, i = n % NT;
@@ -180,11 +205,18 @@ __device__ __forceinline__ void kv_gemm(f32x16 (&acc)[NT], Frags<NT>& f, unsigne
     static_for<0, KS>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::v;
         const bfx8 wv = __builtin_bit_cast(bfx8, f.bq[ks % BD]);
+        if constexpr (LATE && ks == KS - BD) {
+            // >= 2 NT fragment reads were issued behind the draw and at most RA are in flight: it has landed
+            wb_next = next_stream(lds_ticket_value<RA>(raw_ticket));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         static_for<0, (NT + GRP - 1) / GRP>([&](auto gc) {
             constexpr int i0 = decltype(gc)::v * GRP;
             constexpr int cnt = i0 + GRP <= NT ? GRP : NT - i0;
             constexpr int n0 = ks * NT + i0;
             constexpr int issued = n0 + RA < TOTAL ? n0 + RA : TOTAL;
+            // (LATE: between the draw and its read one more LDS operation is in flight, OLDER than every fragment requested after
+            //  it: the count below then waits for one fragment more than needed, never for fewer)
             mg_lds_wait<issued - n0 - cnt>();
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, cnt>([&](auto jc) {
@@ -198,6 +230,7 @@ __device__ __forceinline__ void kv_gemm(f32x16 (&acc)[NT], Frags<NT>& f, unsigne
                 constexpr int n2 = n0 + decltype(jc)::v + RA;
                 if constexpr (n2 < TOTAL) fetch(IC<n2>{});
             });
+            if constexpr (LATE && ks == KS - BD - 2 && i0 == 0) raw_ticket = lds_ticket_issue(ticket_addr);
             __builtin_amdgcn_sched_barrier(0);
         });
         if (ks + BD < KS) f.bq[ks % BD] = wfrag(w, wb + (ks + BD) * FRAG);
@@ -223,10 +256,12 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
 //      fills 1 KiB of CONTIGUOUS LDS from per-lane global addresses); lanes on the pad chunk of a row are switched off.
 //      src(row) -> the row's first chunk in HBM, or nullptr for a row that reads as zeros (then the 16 zero bytes `zero`).
 template <typename RowSrc>
-__device__ __forceinline__ void stage_rows(unsigned char* smem, int rows_live, const uint4* zero, RowSrc&& src) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void stage_pieces(unsigned char* smem, int rows_live, const uint4* zero, RowSrc&& src, int pc0, int pc1,
+                                             int first, int step) {
+    // pieces [pc0, pc1) of the image (1 KiB each), this wave taking pc0 + first, + step, ...
+    const int lane = threadIdx.x & 63;
     const int total = rows_live * LSTR;
-    for (int pc = wave; pc * 64 < total; pc += NTHR / 64) {
+    for (int pc = pc0 + first; pc < pc1 && pc * 64 < total; pc += step) {
         const int g = pc * 64 + lane;
         const int row = g / LSTR, c = g - row * LSTR;
         if (g < total && c < KCH) {
@@ -236,6 +271,10 @@ __device__ __forceinline__ void stage_rows(unsigned char* smem, int rows_live, c
                                              (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)pc * 1024), 16, 0, 0);
         }
     }
+}
+template <typename RowSrc>
+__device__ __forceinline__ void stage_rows(unsigned char* smem, int rows_live, const uint4* zero, RowSrc&& src) {
+    stage_pieces(smem, rows_live, zero, src, 0, 0x7fffffff, (int)(threadIdx.x >> 6), NTHR / 64);
 }
 
 // =====================================================================================================================
@@ -290,24 +329,33 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, int B, int L, int 
     WStream wsr;
     wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wp), 0, 0x7fffffff, 0x00027000);
     wsr.voff = lane * 16;
-    // this workgroup's head pairs: blockIdx.y, + gridDim.y, ...; ticket t -> pair t / 4, head t & 1 of the pair, V if t & 2
+    // this workgroup's head pairs: blockIdx.y, + gridDim.y, ...: local head n = 2 (pair index) + (0 | 1); tickets per slice in the
+    // order K(2p) K(2p+1) V(2p) V(2p+1) per pair p -- and K(2p) V(2p) for a last pair with ONE head (odd H): every ticket below
+    // nunits is a unit (no skipped tickets: a draw is one atomic, branch free)
     const int gy = (int)gridDim.y, y = (int)blockIdx.y;
     const int pairs = (H + 1) / 2;
     const int npairs = (pairs - y + gy - 1) / gy;
-    const int nunits = npairs * 4;
-    auto head_of = [&](int t) { return (y + (t >> 2) * gy) * 2 + (t & 1); };
-    auto draw = [&]() {                                 // next unit of this slice; tickets of a head beyond H (odd H) are skipped
-        int t;
-        do {
-            int v = 0;
-            if (lane == 0) v = __hip_atomic_fetch_add(s_ticket + wq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            t = __builtin_amdgcn_readfirstlane(v);
-        } while (t < nunits && head_of(t) >= H);
-        return t;
+    const int last_h0 = (y + (npairs - 1) * gy) * 2;                // first head of this workgroup's last pair
+    const int nheads = npairs * 2 - (last_h0 + 1 >= H ? 1 : 0);
+    const int nunits = 2 * nheads;
+    auto unit_of = [&](int t, int& n, bool& vunit) {                // ticket -> (local head, K or V); anything for t >= nunits
+        const int p = t >> 2, j = t & 3;
+        const bool single = 2 * p + 1 >= nheads;
+        n = 2 * p + (single ? 0 : (j & 1));
+        vunit = single ? (j & 1) != 0 : (j >> 1) != 0;
+    };
+    auto head_of = [&](int n) { return (y + (n >> 1) * gy) * 2 + (n & 1); };
+    const unsigned ticket_addr = mg_lds_addr(s_ticket + wq);
+    auto draw = [&]() {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(s_ticket + wq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(v);
     };
     auto wstream = [&](int t) {                         // byte offset of the unit's first fragment; past the end: a harmless re-read
-        const int h = t < nunits ? head_of(t) : 0;
-        return (((h * 2 + ((t >> 1) & 1)) * 4 + wq) * KS) * FRAG;
+        int n;
+        bool v;
+        unit_of(t < nunits ? t : 0, n, v);
+        return (((head_of(n) * 2 + (v ? 1 : 0)) * 4 + wq) * KS) * FRAG;
     };
     const __amdgpu_buffer_rsrc_t attn_rsrc = __builtin_amdgcn_make_buffer_rsrc(attn, 0, attn ? 0x7fffffff : 0, 0x00027000);
 
@@ -321,15 +369,19 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, int B, int L, int 
     int stamp = 3;
     (void)stamp;
 
+    constexpr bool LATE = NT >= MT;                     // (the small classes run their weight fragments a whole unit ahead)
     while (t < nunits) {
-        const int t_next = draw();                      // (its latency hides behind the GEMM)
-        const int n = (t >> 2) * 2 + (t & 1);           // workgroup-local index of the head
-        const int h = head_of(t);
-        const int wb = wstream(t), wb_next = wstream(t_next);
+        int t_next = LATE ? nunits : draw();            // !LATE: drawn a unit ahead (its latency hides behind the GEMM)
+        int n;
+        bool vunit;
+        unit_of(t, n, vunit);
+        const int h = head_of(n);
+        const int wb = wstream(t), wb_next = LATE ? 0 : wstream(t_next);
+        auto next_stream = [&](int tn) { t_next = tn; return wstream(tn); };
         f32x16 acc[NT];
         acc_zero<NT>(acc);
-        if (!(t & 2)) {
-            kv_gemm<NT, false>(acc, f, a_lo, a_hi, wsr, wb, wb_next);
+        if (!vunit) {
+            kv_gemm<NT, false, LATE>(acc, f, a_lo, a_hi, wsr, wb, wb_next, ticket_addr, next_stream);
             MG_STAMP(stamp++);
             // ---- partial scores of this slice's 32 head dims: lane = bank row, registers = dims (r&3) + 8 (r>>2) + 4 half.
             //      q.(K_l + b_k) = q.K_l + const: b_k never enters (softmax invariant).
@@ -393,7 +445,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, int B, int L, int 
             }
             MG_STAMP(stamp++);
         } else {
-            kv_gemm<NT, true>(acc, f, a_lo, a_hi, wsr, wb, wb_next);
+            kv_gemm<NT, true, LATE>(acc, f, a_lo, a_hi, wsr, wb, wb_next, ticket_addr, next_stream);
             MG_STAMP(stamp++);
             // ---- o[d] = sum_l p[l] (V[l,d] + bv[d]) = sum_l p[l] V[l,d] + bv[d]: lane = head dim, registers = bank rows
             //      (r&3) + 8 (r>>2) + 4 half of the tile; the probabilities of a tile are four 16-byte LDS broadcasts
@@ -411,7 +463,7 @@ __device__ __forceinline__ void mha_body(unsigned char* smem, int B, int L, int 
                     t3 = fmaf(pv[3], acc[i][4 * g + 3], t3);
                 }
             }
-            if (npairs * 2 > NSLOT_P) lds_arrive(s_pvdone + n, lane);       // (only then is the row ever reused)
+            if (nheads > NSLOT_P) lds_arrive(s_pvdone + n, lane);           // (only then is the row ever reused)
             const float th = (t0 + t1) + (t2 + t3);
             const float tot = halves_sum2(th, th);                          // both halves: the sum over all rows
             if (lane < 32) {
@@ -447,6 +499,11 @@ __global__ __launch_bounds__(NTHR) void sq_mha32_core_kernel(const float* __rest
             s_mb[t] = (t < L && !live) ? -INFINITY : 0.0f;
         }
         if (last) atomicMax(s_lvalid, last);
+        {                               // this sample's query row -> LDS (visible behind the barrier)
+            float* s_q = reinterpret_cast<float*>(smem + OFF_Q);
+            for (int i = tid * 4; i < H * DK; i += NTHR * 4)
+                *reinterpret_cast<f32x4*>(s_q + i) = *reinterpret_cast<const f32x4*>(qh + (size_t)b * H * DK + i);
+        }
         __syncthreads();
     }
     const int lvalid = *s_lvalid;
@@ -454,11 +511,6 @@ __global__ __launch_bounds__(NTHR) void sq_mha32_core_kernel(const float* __rest
     const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : MT;
     // rows >= L of the class read the zero padding at the end of bank row 0 (columns 312..319)
     stage_rows(smem, n_sel * RT, xb + (CH - 1), [&](int row) { return row < L ? xb + (size_t)row * CH : (const uint4*)nullptr; });
-    {                                   // this sample's query row -> LDS (visible after the staging barrier in mha_body)
-        float* s_q = reinterpret_cast<float*>(smem + OFF_Q);
-        for (int i = tid * 4; i < H * DK; i += NTHR * 4)
-            *reinterpret_cast<f32x4*>(s_q + i) = *reinterpret_cast<const f32x4*>(qh + (size_t)b * H * DK + i);
-    }
 #ifdef MG_MHA32_ONLY                   // measurement builds: one tile-count class (register / code-size studies)
     mha_body<MG_MHA32_ONLY>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid);
     return;
@@ -613,7 +665,7 @@ __device__ __forceinline__ void packed_body(unsigned char* smem, int B, int L, i
         acc_zero<NT>(acc);
         if (t < hl) {
             const int n = t, h = h0 + n;
-            kv_gemm<NT, false>(acc, f, a_lo, a_hi, wsr, wb, wb_next);
+            kv_gemm<NT, false, false>(acc, f, a_lo, a_hi, wsr, wb, wb_next, 0u, [](int) { return 0; });
             // ---- partial scores: the row's OWN sample's query (lane = packed row)
             float v[(NT + 1) / 2 * 2];
 #pragma unroll
@@ -695,7 +747,7 @@ __device__ __forceinline__ void packed_body(unsigned char* smem, int B, int L, i
             }
         } else {
             const int n = t - hl, h = h0 + n;
-            kv_gemm<NT, true>(acc, f, a_lo, a_hi, wsr, wb, wb_next);
+            kv_gemm<NT, true, false>(acc, f, a_lo, a_hi, wsr, wb, wb_next, 0u, [](int) { return 0; });
             // ---- weighted sums per 8-row block (samples are 8-row aligned): registers 4g..4g+3 of both halves are the block's
             //      rows; one swap + add per pair of blocks, 128-B rows of block sums to LDS
             lds_wait_ge(s_smdone + n, 1);

@@ -27,6 +27,13 @@ buf = (ctypes.c_ulonglong * 256)()
 fn = _lib.lib().mgnns_debug_mha32_trace
 fn.argtypes = [ctypes.c_void_p]
 assert fn(ctypes.addressof(buf)) == 0
+if os.environ.get("MGNNS_TRACE_RAW") == "1":       # rows_body: stamps 3.. = [unit-0 GEMM] then per unit (GEMM+epilogue inside, finish)
+    for w in range(4):
+        t = list(buf[w * 64:(w + 1) * 64])
+        d = [t[i + 1] - t[i] for i in range(2, 40) if t[i + 1] > t[i]]
+        print("workgroup %d wave %d: DMA landed %d, staged %d; deltas: %s ; end at %d"
+              % (0 if w < 2 else 129, 0 if w % 2 == 0 else 4, t[1] - t[0], t[2] - t[0], d, max(t) - t[0]))
+    sys.exit(0)
 for w in range(4):
     t = list(buf[w * 64:(w + 1) * 64])
     print("workgroup %d wave %d: own DMA landed %d, staged (barrier) %d ticks after entry"
