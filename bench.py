@@ -621,7 +621,9 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
     H, dk, D, T = cfg.n_head, cfg.d_kv, cfg.emb_size, cfg.T
     rows = []
 
-    def add(kernel, key, bound, work, note, pmc_key=None):
+    L2_PER_CU_GBPS = 64 * 2.4          # a CU fetches 64 B/clk from its XCD's L2 (MI355X_MICROARCH.md), 2.4 GHz
+
+    def add(kernel, key, bound, work, note, pmc_key=None, l2_stream_bytes=None):
         v = d.get(key, [])
         if not v:
             return
@@ -635,8 +637,13 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
                "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "note": note}
         if pmc_key:                      # HBM bytes per launch of the committed PMC passes (refused when the kernel changed since)
             row["traffic"], row["traffic_source"] = pmc_traffic(pmc_key)
+        if l2_stream_bytes:              # kernels whose workgroups stream packed weights from L2: the bound that matters for them
+            row["l2_stream"] = {"bytes_per_workgroup_on_its_critical_path": int(l2_stream_bytes),
+                                "per_cu_l2_rate_GBps": L2_PER_CU_GBPS,
+                                "frac_of_per_cu_l2_rate": round(l2_stream_bytes / (us * 1e-6) / 1e9 / L2_PER_CU_GBPS, 4)}
         rows.append(row)
 
+    pk = lambda n, k: ((n + 15) // 16) * ((k + 31) // 32) * 1024          # bytes of one packed bf16 image of an [n, k] weight
     bf = dtype == "bf16"
     core = "mgnns_sq_mha_core_bf16_fwd" if bf else "mgnns_sq_mha_core_fwd"
     mfma = "mfma_bf16" if bf else "mfma_f32"
@@ -656,12 +663,15 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
             B * 2.0 * (H * D * D + 2 * D * D) + B * 2.0 * D * H * D / 2,
             "the layer tail behind the folded attention: composed output map (H*D -> D) + FFN per launch; the next layer's "
             "composed query map (D -> H*D) is fused into every other launch (averaged in); bound by streaming the packed "
-            "weights from L2 (1.44 MB per composed map), not by the matrix pipe")
+            "weights from L2 (1.44 MB per composed map), not by the matrix pipe",
+            l2_stream_bytes=pk(D, H * D) / 4 + 2 * pk(D, D))
         add("imgbank_pool_bf16", ("mgnns_imgbank_pool_bf16_fwd",), "hbm", B * (2048.0 * P * 4 + P * D * 2 + 2048 * 4),
             "fp32 map read once + bf16 bank + pooled row written", pmc_key="imgbank_pool_bf16@B%d" % B)
         add("mha_tail_bf16", ("mgnns_mha_tail_bf16_fwd",), "mfma_bf16",
             B * 2.0 * (H * dk * D + 2 * D * D) + B * 2.0 * D * H * dk / 2,
-            "fc + FFN per launch; the next layer's w_qs is fused into every other launch (averaged in)")
+            "fc + FFN per launch (K of fc split over a cluster of 4 workgroups, the last arriver runs LN / FFN / LN); the next "
+            "layer's w_qs is a second launch behind every other tail (inside this timing): a chain of small phases on 64 "
+            "CUs, bound by L2 latency / streaming, not by the matrix pipe", l2_stream_bytes=pk(D, H * dk) / 4 + 2 * pk(D, D))
     else:
         add("imgbank_pool (fp32)", ("mgnns_imgbank_pool_fwd",), "mfma_f32", B * 2.0 * P * 2048 * D, "bank projection FLOPs")
         add("mha_tail (fp32)", ("mgnns_mha_tail_fwd",), "mfma_f32",
@@ -681,7 +691,8 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
                 ("mgnns_label_tail_bf16_fwd", C), "mfma_bf16",
                 B * 2.0 * (2048 * C + 2 * C * D + 7 * D * 100 + 700 * D + D * H * dk),
                 "4-workgroup clusters per 16 samples, split-bf16 operands (3 MFMAs per product, not counted); bound by "
-                "streaming the packed weights from L2, not by the matrix pipe")
+                "streaming the packed weights from L2, not by the matrix pipe",
+                l2_stream_bytes=2 * (pk(C, 2048) / 4 + 2 * pk(D, C) + pk(100, D) + pk(D, 700) + pk(H * dk, D) / 4))
         for F in (1024, 2048):
             nnz = int((np.asarray(getattr(model, nm + "_A").detach().cpu()) != 0).sum())
             add("spmm_csr (%s graph, F=%d)" % (nm, F), ("mgnns_spmm_csr_fwd", C, F), "hbm", nnz * 8.0 + 2.0 * C * F * 4,
@@ -1040,6 +1051,11 @@ def run_rank(args):
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
+    try:            # the placement assumption of the slab / row-range kernels (speed only), measured on this device
+        ok, ids = _lib.xcd_probe()
+        line["config"]["xcd_map"] = {"blockIdx_and_7_selects_the_xcd": ok, "xcc_id_per_residue": ids}
+    except Exception as e:
+        line["config"]["xcd_map"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # `steps` steps per region; ms_per_step / value = the median of these regions (one warm-up in front of the first)
     line["timing"] = {"regions": len(head["regions_ms"]), "steps_per_region": args.steps, "statistic": "median region",
                       "regions_ms_per_step": head["regions_ms"], "min_ms_per_step": min(head["regions_ms"]),

@@ -52,6 +52,10 @@ int mgnns_take_status(void);
 const char* mgnns_last_error(void);
 /* ABI version (bumped on any signature change). */
 int mgnns_abi_version(void);
+/* Measurement, not an operator: does `blockIdx.x & 7` select the XCD on this device / runtime?  Several kernels place work that
+ * way (SpMM feature slabs, the dense GEMM's row-block ranges) -- only their SPEED depends on it.  out9[0] = 1 / 0, out9[1 + k] =
+ * the hardware XCC_ID observed for block indices with b & 7 == k (-1: more than one).  Synchronises the device. */
+int mgnns_xcd_probe(int32_t* out9);
 
 /* ---- a1: text-level GCN channel -------------------------------------------------------
  * Replaces Text_GCN.Model.forward (models/Text_GCN.py:213-275) including the host graph

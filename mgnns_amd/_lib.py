@@ -73,6 +73,7 @@ SIGNATURES = {
     "mgnns_label_gcn_supported": [_I, _I, _I, _I, _I],
     "mgnns_label_tail_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
     "mgnns_label_tail_bf16_supported": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "mgnns_xcd_probe": [_P],
     "mgnns_set_status_word": [_P],
     "mgnns_take_status": [],
     "mgnns_debug_slabcopy": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -158,6 +159,15 @@ def _register_status_word(L):
         return
     L.mgnns_set_status_word(w.data_ptr())
     _status_word = w                     # keeps the allocation alive for the life of the process
+
+
+def xcd_probe():
+    """-> (ok, [XCC_ID seen for block indices b & 7 == k]): whether `blockIdx.x & 7` selects the XCD here (the placement several
+    kernels use for SPEED; HIP promises nothing).  Synchronises the device: a set-up time measurement."""
+    import ctypes
+    out = (ctypes.c_int32 * 9)()
+    check(lib().mgnns_xcd_probe(ctypes.addressof(out)), "mgnns_xcd_probe")
+    return bool(out[0]), [int(out[1 + k]) for k in range(8)]
 
 
 def take_status():

@@ -105,6 +105,52 @@ extern "C" const char* mgnns_last_error(void) { return g_err; }
 extern "C" int mgnns_abi_version(void) { return 13; }
 
 namespace {
+// which XCD (hardware XCC_ID) a workgroup runs on, per block index
+__global__ void xcd_probe_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(id));      // HW_REG_XCC_ID, bits 3:0
+        out[blockIdx.x] = (int)id;
+    }
+}
+}  // namespace
+
+// Several kernels place work by `blockIdx.x & 7 == XCD` (feature slabs of the SpMM kernels, the dense GEMM's row-block ranges,
+// the tiled SpMM's slab order): HIP promises no workgroup -> XCD map, ONLY SPEED depends on it, and this is the measurement that
+// says whether the assumption holds on this device / runtime: 1024 one-wave workgroups report their XCC_ID.
+// out[0] = 1 if block b always ran on one XCD per value of b & 7 and the eight values map to eight different XCDs, else 0;
+// out[1 + k] = the XCC_ID seen for b & 7 == k (-1: several).  Synchronises the device (call it at set-up, not in a forward).
+extern "C" int mgnns_xcd_probe(int32_t* out9) {
+    MG_REQUIRE(out9, "mgnns_xcd_probe: null pointer");
+    constexpr int NB = 1024;
+    int* d = nullptr;
+    if (hipMalloc(&d, NB * sizeof(int)) != hipSuccess) {
+        mgnns_set_error("mgnns_xcd_probe: hipMalloc failed");
+        return MGNNS_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(NB), dim3(64), 0, 0, d);
+    int h[NB];
+    const hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        mgnns_set_error("mgnns_xcd_probe: %s", hipGetErrorString(e));
+        return MGNNS_ERR_LAUNCH;
+    }
+    int ok = 1;
+    for (int k = 0; k < 8; ++k) {
+        int id = h[k];
+        for (int b = k; b < NB; b += 8)
+            if (h[b] != id) id = -1;
+        out9[1 + k] = id;
+        if (id < 0) ok = 0;
+        for (int j = 0; j < k; ++j)
+            if (out9[1 + j] == id) ok = 0;
+    }
+    out9[0] = ok;
+    return 0;
+}
+
+namespace {
 __global__ void stamp_kernel(unsigned long long* slots, int idx) { slots[idx] = __builtin_amdgcn_s_memrealtime(); }
 __global__ void spin_kernel(unsigned long long ticks, unsigned long long* slots, int idx) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -1248,3 +1248,13 @@ def test_gemm_bf16_nt_last_round_k_split_equals_whole_tiles(M, N, K):
             assert float((got.float() - ref.float()).abs().max()) <= tol * scale, (dt, M, N, K)
     finally:
         ops.GEMM_BF16_KSPLIT = old
+
+
+def test_xcd_probe_confirms_the_block_index_placement():
+    """`blockIdx.x & 7 == XCD` is an observed dispatch order several kernels place work by (SpMM feature slabs, the dense GEMM's
+    row-block ranges): only speed depends on it, and mgnns_xcd_probe measures it on the device the tests run on -- eight distinct
+    XCC_IDs, one per residue.  (A device where this fails still computes the same results; the assertion documents the box.)"""
+    from mgnns_amd import _lib
+    ok, ids = _lib.xcd_probe()
+    assert len(ids) == 8
+    assert ok and sorted(ids) == list(range(8)), ids

@@ -35,7 +35,11 @@ def kernel_stats(db):
         lines.append("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (short, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
     # the attention core runs on two problem sizes (image banks L=196 / text bank L=100) with one grid: split at the median
     split = {}
+    # (round 4: in bf16 mode the masked text-bank launches run sq_mha32_packed_kernel -- every sq_mha_core_bf16_kernel launch is L=196)
+    packed = any("sq_mha32_packed" in r[0] for r in rows)
     for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "folded_attn_kernel", "folded_attn_bf16_kernel"):
+        if packed and sub == "sq_mha_core_bf16_kernel":
+            continue
         v = sorted(r[0] for r in cur.execute("select d.end - d.start from %s d join %s s on d.kernel_id = s.id where s.kernel_name like ?"
                                              % (disp, sym), ("%" + sub + "%",)))
         if len(v) >= 2:
@@ -87,8 +91,11 @@ def main():
         return sum(w) / max(len(w), 1)
     dbs = {c: os.path.join(GO, "pmc_%s_%s" % (tag, c), "%s_%s_results.db" % (tag, c)) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES")}
     if all(os.path.exists(p) for p in dbs.values()):
-        kern = [("sq_mha_core_bf16_kernel L=196 (image banks)", "sq_mha_core_bf16_kernel", True, "32.1 bank + 1.3 W + 1.0 q + 1.0 out"),
-                ("sq_mha_core_bf16_kernel L=100 (text bank, masked)", "sq_mha_core_bf16_kernel", False, "16.4 bank + 1.3 W + 1.0 q + 1.0 out"),
+        has_packed = bool(pmc(dbs["FETCH_SIZE"], "sq_mha32_packed"))
+        kern = [("sq_mha_core_bf16_kernel L=196 (image banks)", "sq_mha_core_bf16_kernel", None if has_packed else True, "32.1 bank + 1.3 W + 1.0 q + 1.0 out"),
+                ("sq_mha_core_bf16_kernel L=100 (text bank, masked)", "sq_mha_core_bf16_kernel_NOT_RUN" if has_packed else "sq_mha_core_bf16_kernel", False, "16.4 bank + 1.3 W + 1.0 q + 1.0 out"),
+                ("sq_mha32_packed_kernel L=100 (text bank, masked: live rows packed)", "sq_mha32_packed_kernel", None, "~2.7 live rows (x4 head pairs from L2) + 1.2 W per head pair + 1.0 q + 1.0 out"),
+                ("sq_mha32_plan_kernel", "sq_mha32_plan_kernel", None, "0.1 mask"),
                 ("folded_attn_bf16_kernel L=196 (image banks)", "folded_attn_bf16_kernel", True, "32.1 bank + 2.5 u + 1.2 c"),
                 ("folded_attn_bf16_kernel L=100 (text bank, masked)", "folded_attn_bf16_kernel", False, "<= 16.4 bank (live row tiles only) + 2.5 u + 1.2 c"),
                 ("mha_tail_c16", "mha_tail_c16", None, "1.2 c + 3.3 W (L2) + exchange"),
@@ -133,7 +140,7 @@ def main():
             f.write("| kernel | launches | FETCH_SIZE raw KiB | read MB (x2) | WRITE_SIZE KiB | write MB | algorithmic MB |\n|---|---|---|---|---|---|---|\n")
             f.write("\n".join(rows) + "\n\n")
             if busy:
-                hi = half(busy, True)
+                hi = sum(busy) / len(busy) if has_packed else half(busy, True)
                 f.write("MFMA pipe: `SQ_VALU_MFMA_BUSY_CYCLES` = %.4e per L=196 launch of sq_mha_core_bf16 (= 256 WG x 8 waves x 2080 MFMA x "
                         "16 cycles: every issued 16x16x32 MFMA, padding included). Divide by 1024 SIMDs x launch time x clock for the pipe "
                         "occupancy; algorithmic utilisation (61.86 GFLOP / time / 2.5 PF) is what bench.py reports.\n" % hi)
