@@ -649,9 +649,18 @@ def roofline_all(timer, cfg, B, P, inp, dtype, model):
     mfma = "mfma_bf16" if bf else "mfma_f32"
     add("sq_mha_core%s (L=%d image bank)" % ("_bf16" if bf else "", P), (core, P, False), mfma,
         mha_core_flops(B, P, D, H, dk), "K/V projection + QK^T + softmax + PV, all rows valid")
-    add("sq_mha_core%s (L=%d text bank, masked)" % ("_bf16" if bf else "", T), (core, T, True), mfma,
-        mha_core_flops(B, T, D, H, dk), "FLOPs counted over all T rows; masked row tiles are skipped, so this can exceed "
-                                        "the unmasked figure")
+    from mgnns_amd import ops as _ops
+    if bf and _ops.MHA_CORE == 32 and _ops.MHA_PACKED and T <= _ops.PLAN_MAX_L:
+        live = float(np.asarray(inp["text_mask"]).sum())
+        add("sq_mha32_packed (L=%d text bank, masked: the live rows of short samples share a workgroup)" % T, (core, T, True), mfma,
+            mha_core_flops(B, T, D, H, dk) * live / (B * T),
+            "FLOPs of the LIVE rows only (%d of %d; the kernel pads every sample to 8 rows and every group to 32): a latency-"
+            "bound launch of ~40 groups x 4 head pairs, not a roofline kernel; the plan launch (once per channel) is separate"
+            % (int(live), B * T))
+    else:
+        add("sq_mha_core%s (L=%d text bank, masked)" % ("_bf16" if bf else "", T), (core, T, True), mfma,
+            mha_core_flops(B, T, D, H, dk), "FLOPs counted over all T rows; masked row tiles are skipped, so this can exceed "
+                                            "the unmasked figure")
     if bf:
         for L_, nm in ((P, "image bank"), (T, "text bank, masked")):
             add("sq_mha_folded_bf16 (L=%d %s)" % (L_, nm), ("mgnns_sq_mha_folded_bf16_fwd", L_), "hbm",
