@@ -75,9 +75,8 @@ __host__ __device__ inline void mg_gemm_split(int xcd, int nrb, int nct, int rps
     if (rem > 0 && 4 * rem <= W) {
         f = W / rem;
         if (f > 8) f = 8;
-        if (f > nk) f = nk;
-        if (f < 2) f = 0;
-    }
+        if (f * 8 > nk) f = 0;                          // a part needs >= 8 slices: with K = 320 (5 slices per tile) the fix-up launch
+    }                                                   // and its 33 MB of partial sums cost more than the round they save
 }
 
 __global__ __launch_bounds__(NTHR_WS) void gemm_bf16_nt_kernel(const unsigned short* __restrict__ A,

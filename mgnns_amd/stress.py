@@ -194,7 +194,7 @@ class StressWorkload:
         can = (len(chans) > 1 and ch0.dtype == "bf16" and not ch0.dense
                and ch0.sadj.avg_nnz < ops.SparseAdjBf16.TILED_MIN_AVG_NNZ)
         if union is None:
-            union = can
+            union = can         # measured: 0.520 ms against 0.540 channel by channel (eager, density 4e-4)
         if not union:
             return {(c, b0, b1): self.channels[c].forward(self.pooled[c][b0:b1].contiguous()) for c, b0, b1 in self.shards}
         if not can:
