@@ -73,31 +73,25 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
 
 // ---- LDS map ------------------------------------------------------------------------------------------------------------
 constexpr int KROWS = 32;                                // feature rows per k-step
-constexpr int HROWS = 16;                                // ... per ring slot (half a k-step)
-constexpr int NHS = 7;                                   // slots of the fp32 ring
+constexpr int UROWS = 4;                                 // ... per ring unit (half a k-octet)
+constexpr int NUS = 7;                                   // unit slots of a map wave's private ring (3.5 k-steps of its octet)
 constexpr int PMAX = MT * 16;                            // 208 regions at most
-constexpr int HSLOT = HROWS * PMAX * 4;                  // 13,312 B: a slot holds 16 rows of P * 4 bytes, packed
+constexpr int USLOT = UROWS * PMAX * 4;                  // 3,328 B: a unit holds 4 rows of P * 4 bytes, packed
+constexpr int WRING = NUS * USLOT;                       // 23,296 B per map wave
 constexpr int ABUF = PMAX * 64;                          // 13,312 B: bf16 operand image of one k-step, [p][4 chunks of 8 k]
 constexpr int WBUF = (NT + 1) * 1024;                    // 20 KB: the 19 W fragments of one k-step (+ 1 KB that takes a dummy request)
-constexpr size_t OFF_A = (size_t)NHS * HSLOT;
+constexpr size_t OFF_A = (size_t)4 * WRING;
 constexpr size_t OFF_W = OFF_A + 2 * ABUF;
 constexpr size_t SMEM_BYTES = OFF_W + 2 * WBUF;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 static_assert((size_t)PMAX * OSTR <= SMEM_BYTES, "the epilogue stages the bank rows over the ring");
+#ifndef MG_IMG_NRW
+#define MG_IMG_NRW 8
+#endif
+constexpr int NRW = MG_IMG_NRW, NRM = MT - NRW;                   // row tiles of a W wave / of a map wave (the map waves also convert and pool)
 
 // LDS accesses of the main loop are inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an
 // LDS-DMA may be in flight, which would drain the ring at every step.  The caller orders them (lgkmcnt / barriers).
-__device__ __forceinline__ void wait_vm(int n) {         // s_waitcnt vmcnt(n) for a run-time n (the immediate is an instruction field)
-    switch (n) {
-#define MG_VM_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
-        MG_VM_CASE(1) MG_VM_CASE(2) MG_VM_CASE(3) MG_VM_CASE(4) MG_VM_CASE(5) MG_VM_CASE(6) MG_VM_CASE(7) MG_VM_CASE(8)
-        MG_VM_CASE(12) MG_VM_CASE(13) MG_VM_CASE(14) MG_VM_CASE(15) MG_VM_CASE(16) MG_VM_CASE(17) MG_VM_CASE(18) MG_VM_CASE(19)
-        MG_VM_CASE(20) MG_VM_CASE(21) MG_VM_CASE(22) MG_VM_CASE(23) MG_VM_CASE(24)
-#undef MG_VM_CASE
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 template <int N> struct ICI { static constexpr int v = N; };
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for_img(F&& f) {
@@ -107,53 +101,80 @@ __device__ __forceinline__ void static_for_img(F&& f) {
     }
 }
 
-// One wave's share of a sample.  NR x NW accumulator tiles: row tiles 7 rg .. 7 rg + NR - 1, column tiles 5 cg .. 5 cg + NW - 1.
-// STAGER (row group 1 = waves 4-7): the wave requests map rows; otherwise (waves 0-3) the W fragments.  Vector-memory
-// operations of a wave complete IN ORDER: a wave that has map rows in flight (HBM latency, several k-steps ahead) would get
-// nothing else back before them -- W fragments requested into registers behind the rows made every k-step wait out the
-// latency of rows it needs four steps later (122 us).  So the two streams are issued by DIFFERENT waves, both into LDS, and
-// each wave's counted wait covers only its own stream.
-template <int NR, int NW, bool STAGER, int PT>
+// Max over the four 16-lane rows of the wave for FOUR values at once (a transposing reduction, sq_mha_bf16.hip::rows4_sum4 with
+// max): on return the rows of the result hold [a, c, b, d] folded over the rows.
+// (v_max_f32 through asm: fmaxf costs a canonicalising v_max_f32 v, v, v per operand in front of the real one)
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float rows4_max4(float a, float b, float c, float d) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    float ab = vmax(a, b), cd = vmax(c, d);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ab), "+v"(cd));
+    return vmax(ab, cd);
+}
+// max over each 16-lane row for TWO values, the DPP operand folded into the v_max_f32 (one instruction per level and value; the
+// two chains alternate, s_nop 0 completes the two wait states between a VALU write and a DPP read of the same register)
+__device__ __forceinline__ void row16_max2(float& a, float& b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(a), "+v"(b));
+}
+
+// One wave's share of a sample.  Waves 0-3 ("W waves", MAPW = false): row tiles 0 .. NRW - 1; they request the W fragments.
+// Waves 4-7 ("map waves"): row tiles NRW .. 12; map wave w owns k-OCTET w - 4 of every k-step end to end -- it requests those
+// eight rows (two units of four, LDS-DMA into its private ring), waits for them on its OWN vmcnt, turns them into the octet's
+// chunk of the bf16 operand image, takes their max-pool from the same registers and re-requests into the unit slots it has
+// just read.  Round 4: before, the rows were converted by the W waves and pooled by everybody, so that "landed" had to be
+// published through the step's barrier a whole step early (a request had ~1.9 steps to land, every k-step's rows were read from
+// LDS twice and the pool's reads sat inside the MFMA stream's counted waits); the compute on top of the stream was additive
+// (ablations, profiles/NOTES_r04.md section 7).  Now a row has ~3 steps to land and nobody waits for anybody else's rows.
+// Vector-memory operations of a wave complete IN ORDER: the W stream and the map stream are issued by different waves, each
+// wave's counted wait covers only its own stream.
+template <int NR, int NW, bool MAPW, int PT>
 __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __restrict__ feat, int b, int K, int Prt,
                                          const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
-                                         unsigned short* __restrict__ bank, float* __restrict__ pooled_part,
-                                         float* __restrict__ pooled, int wave, int lane, int tid) {
-    // row group: the W waves also convert, so they take the 6-tile group and the map waves the 7-tile one
-    const int rg = STAGER ? 0 : 1, cg = wave & 3;
+                                         float* __restrict__ pooled_part, float* __restrict__ pooled, int wave, int lane) {
+    const int tile0 = MAPW ? NRW : 0, cg = wave & 3, oct = wave & 3;
     const int nks = K / KROWS;
     const int P = PT ? PT : Prt;                         // PT: the region count as a compile-time constant (row offsets become immediates)
     const int RB = P * 4;                                // bytes of a map row
-    const unsigned ring = mg_lds_addr(smem), abuf = ring + (unsigned)OFF_A, wbuf = ring + (unsigned)OFF_W;
+    const unsigned lds0 = mg_lds_addr(smem), abuf = lds0 + (unsigned)OFF_A, wbuf = lds0 + (unsigned)OFF_W;
+    const unsigned myring = lds0 + (unsigned)(oct * WRING);
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(feat + (size_t)b * K * P), 0, K * P * (int)sizeof(float), 0x00027000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(Wp), 0, NT * nks * 1024, 0x00027000);
+    const int nquad = P >> 2;
 
-    // ---- the map stream (waves 4-7): slot h of the ring takes the 16 rows of half-step h, wave w rows 4 (w - 4) .. + 3, one
-    //      row (P / 4 lanes x 16 B) per DMA instruction; half-steps past the end are out of range and arrive as zeros in a slot
-    //      nobody reads (the request count per step stays constant: the counted waits depend on it)
-    const bool dma_lane = lane < (P >> 2);
-    auto dma_half = [&](int h) {
+    // ---- the map stream: unit n of this wave = rows 4 (n & 1) .. + 3 of its octet of k-step n >> 1 -> unit slot n % 7; one row
+    //      (P / 4 lanes x 16 B) per DMA instruction; units past the end are out of range and arrive as zeros in a slot nobody
+    //      reads (the request count per step stays constant: the counted waits depend on it)
+    const bool dma_lane = lane < nquad;
+    auto dma_unit = [&](int n) {
         if (dma_lane) {
+            const int row0 = (n >> 1) * KROWS + oct * 8 + (n & 1) * UROWS;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = (wave - 4) * 4 + j;
+            for (int j = 0; j < UROWS; ++j) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    f_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)(h % NHS) * HSLOT + r * RB), 16,
-                    lane * 16, (h * HROWS + r) * RB, 0, MG_IMG_AUX);
+                    f_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)oct * WRING + (size_t)(n % NUS) * USLOT + j * RB),
+                    16, lane * 16, (row0 + j) * RB, 0, MG_IMG_AUX);
             }
         }
     };
-    // ---- the W stream (waves 0-3): the 19 fragments (1 KiB each, fragment-major in memory) of k-step s -> W image s & 1; wave w
+    // ---- the W stream (W waves): the 19 fragments (1 KiB each, fragment-major in memory) of k-step s -> W image s & 1; wave w
     //      takes fragments w, w + 4, ..: five requests each, the 20th is a dummy (out of range: zeros into the image's spare KB)
-    auto dma_w = [&](int s) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int t = wave + 4 * j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                w_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + OFF_W + (size_t)(s & 1) * WBUF + t * 1024), 16,
-                lane * 16, t < NT && s < nks ? (t * nks + s) * 1024 : 0x7ffffc00, 0, 0);
-        }
+    auto dma_w = [&](int s, int j) {
+        const int t = wave + 4 * j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            w_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + OFF_W + (size_t)(s & 1) * WBUF + t * 1024), 16,
+            lane * 16, t < NT && s < nks ? (t * nks + s) * 1024 : 0x7ffffc00, 0, 0);
     };
 
     f32x4 acc[NR][NW];
@@ -162,145 +183,124 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #pragma unroll
         for (int t = 0; t < NW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // conversion task (threads of waves 0-3 only: the map waves carry eight DMA requests per step, the W waves five cheap ones, so
-    // the conversion is the W waves' to keep the two sides of a SIMD level): (k-octet ko, region quad pq): 8 rows x 4 regions
-    // -> four 16-B chunks of the operand image
-    const int nquad = P >> 2;
-    const bool cv_on = !STAGER && tid < 4 * nquad;
-    const int ko = cv_on ? tid / nquad : 0, pq = cv_on ? tid - ko * nquad : 0;
-    const unsigned cv_src = (unsigned)((ko & 1) * 8 * RB + pq * 16);         // inside half-slot ko >> 1 of the k-step
-    // image: [p][4 chunks], chunk c of row p at slot (c + 2 (p >> 2)) & 3: conflict-free for the MFMA operand reads
-    // (a ds_read_b128's 16-lane groups take rows 0-3 / 12-15 of chunk c and rows 4-11 of chunk c + 1)
-    auto a_off = [](int p, int c) { return (unsigned)(p * 64 + (((c + 2 * (p >> 2)) & 3) << 4)); };
-    const unsigned cv_dst = a_off(4 * pq, ko);           // rows 4 pq .. 4 pq + 3 share (p >> 2): consecutive 64-B rows, same slot
-    // max-pool task: row tid >> 4 of the k-step, region quads (tid & 15) + 16 m
-    const int pk = tid >> 4, psub = tid & 15;
-    // MFMA operand reads: map fragment = row 16 (7 rg + i) + (lane & 15), chunk lane >> 4; W fragment t of this wave
-    const unsigned a_rd = abuf + (unsigned)(rg * 7 * 16 * 64) + a_off(lane & 15, lane >> 4);
+    // operand image: [p][4 chunks of 16 B], chunk c of row p at slot c ^ g[(p >> 2) & 3], g = {2, 0, 1, 3}: the MFMA operand
+    // reads are conflict-free (a ds_read_b128's 16-lane groups take rows 0-3 / 12-15 of chunk c and rows 4-11 of chunk c ^ 1:
+    // slots {c^2, c^3} and {c^1^0, c^1^1} = all four, each with the four rows of a 256-B bank line) and the conversion's
+    // ds_write_b128 (8 consecutive lanes = 8 consecutive region quads, rows 256 B apart) spread over all four slots: 2-way,
+    // inside the store's own 13 cycles (round 3's c + 2 (p >> 2) put them on two slots: 4-way)
+    auto a_off = [](int p, int c) { return (unsigned)(p * 64 + (((c ^ (0xD2 >> (2 * ((p >> 2) & 3)))) & 3) << 4)); };
+    // conversion task of a map lane: region quad pq = lane (lanes past the last quad read the last quad again: their maxima
+    // change nothing, their image writes are masked), the wave's octet: 8 rows x 4 regions -> four 16-B chunks + 8 row maxima
+    const int pq = lane < nquad ? lane : nquad - 1;
+    const unsigned cv_dst = a_off(4 * pq, oct);          // rows 4 pq .. 4 pq + 3 share (p >> 2): consecutive 64-B rows, same slot
+    // MFMA operand reads: map fragment = row 16 (tile0 + i) + (lane & 15), chunk lane >> 4; W fragment t of this wave
+    const unsigned a_rd = abuf + (unsigned)(tile0 * 16 * 64) + a_off(lane & 15, lane >> 4);
     const unsigned w_rd = wbuf + (unsigned)(cg * 5 * 1024 + lane * 16);
 
-    float* const pp0 = pooled_part + ((size_t)b * 2) * K + pk;
-    float* const pp1 = pp0 + K;
-    float* const ppo = pooled ? pooled + (size_t)b * K + pk : nullptr;
+    // pooled maxima leave as ONE store per map wave and k-step: after the transposing reduction the 16-lane rows of o0 / o1 hold
+    // the maxima of octet rows {0, 2, 1, 3} / {4, 6, 5, 7}; lanes 0-2 of a row store o0, lanes 3-5 o1, to the two partial arrays
+    // (both get the complete maxima: callers that combine them keep working) and, if asked for, the combined one
+    const int grp = lane >> 4, sub = lane & 15, ndst = pooled ? 3 : 2;
+    const int hsel = sub / ndst, dsel = sub - hsel * ndst;
+    const bool pst_on = MAPW && sub < 2 * ndst;
+    float* const pst = (dsel == 0 ? pooled_part + (size_t)b * 2 * K : dsel == 1 ? pooled_part + ((size_t)b * 2 + 1) * K : pooled + (size_t)b * K) +
+                       oct * 8 + (hsel & 1) * 4 + ((grp & 1) << 1 | (grp >> 1));
     auto max3 = [](float a, float b2, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c)); return r; };
-    // ---- (a) fp32 half-slots of k-step s -> bf16 operand image A[s & 1] (W waves)
-    auto convert = [&](int s) {
-        if (!cv_on) return;
-        const unsigned ab = abuf + (unsigned)((s & 1) * ABUF);
-        const unsigned src = ring + (unsigned)(((2 * s + (ko >> 1)) % NHS) * HSLOT) + cv_src;
-        f32x4 v[8];
+    // ---- fp32 octet of k-step s1 (this wave's units 2 s1, 2 s1 + 1: landed, see the counted wait at the call) -> chunk `oct` of
+    //      the bf16 operand image A[s1 & 1] + the max-pool of its eight rows.  In PIECES (cv_piece<k>), so that a map wave can
+    //      spread the work over the gaps of its MFMA stream: reads | image chunk e (4 conversions + one 16-B write) x 4 | row
+    //      maxima x 4 | the transposing reduction over the wave | the store
+    f32x4 v[8];
+    float m[8];
+    unsigned cv_ab = 0;
+    auto cv_reads = [&](int s1) {
+        // (lanes past the last quad write into the W image's spare KB, which also takes the W waves' dummy request: no exec mask)
+        cv_ab = lane < nquad ? abuf + (unsigned)((s1 & 1) * ABUF) + cv_dst : wbuf + (unsigned)(NT * 1024 + (lane & 15) * 16);
+        const unsigned ua = myring + (unsigned)(((2 * s1) % NUS) * USLOT + pq * 16), ub = myring + (unsigned)(((2 * s1 + 1) % NUS) * USLOT + pq * 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (PT > 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(src), "n"(j * PT * 4) : "memory");
-            else asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(src + j * RB) : "memory");
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (PT > 0) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(ua), "n"(j * PT * 4) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[4 + j]) : "v"(ub), "n"(j * PT * 4) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(ua + j * RB) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v[4 + j]) : "v"(ub + j * RB) : "memory");
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
+    };
+    auto cv_piece = [&](auto kc, int s1) {
+        constexpr int k = decltype(kc)::v;
+        if constexpr (k < 4) {                           // image chunk of regions 4 pq + k
             u32x4 c;
-            c[0] = pack2(v[0][e], v[1][e]); c[1] = pack2(v[2][e], v[3][e]); c[2] = pack2(v[4][e], v[5][e]); c[3] = pack2(v[6][e], v[7][e]);
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ab + cv_dst), "v"(c), "n"(e * 64) : "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // ---- (b) max-pool of the 32 rows of k-step s: row pk, quads psub + 16 m.  In pieces, so that it can be spread over the gaps
-    //      of an MFMA stream: reads | first maxima | second maxima + the 16-lane reduction | stores
-    f32x4 q[4];
-    float pmx = 0.f;
-    auto pool_reads = [&](int s) {
-        const unsigned src = ring + (unsigned)(((2 * s + (pk >> 4)) % NHS) * HSLOT) + (unsigned)((pk & 15) * RB + psub * 16);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            // (a compile-time region count: the first quads of every thread exist, no branch around their reads, no default)
-            if (!(PT > 0 && 16 * m + 15 < PT / 4)) q[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if ((PT > 0 && 16 * m + 15 < PT / 4) || psub + 16 * m < nquad)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[m]) : "v"(src), "n"(m * 256) : "memory");
+            c[0] = pack2(v[0][k], v[1][k]); c[1] = pack2(v[2][k], v[3][k]); c[2] = pack2(v[4][k], v[5][k]); c[3] = pack2(v[6][k], v[7][k]);
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(cv_ab), "v"(c), "n"(k * 64) : "memory");
+        } else if constexpr (k < 8) {                    // maxima of rows 2 (k - 4), + 1 over this lane's four regions
+            constexpr int j = 2 * (k - 4);
+            m[j] = vmax(max3(v[j][0], v[j][1], v[j][2]), v[j][3]);
+            m[j + 1] = vmax(max3(v[j + 1][0], v[j + 1][1], v[j + 1][2]), v[j + 1][3]);
+        } else if constexpr (k == 8) {
+            m[0] = rows4_max4(m[0], m[1], m[2], m[3]);   // rows of the wave: octet rows {0, 2, 1, 3}
+        } else if constexpr (k == 9) {
+            m[4] = rows4_max4(m[4], m[5], m[6], m[7]);   // ... {4, 6, 5, 7}
+        } else if constexpr (k == 10) {
+            row16_max2(m[0], m[4]);
+        } else if constexpr (k == 11) {
+            if (pst_on) pst[s1 * KROWS] = hsel ? m[4] : m[0];
         }
     };
-    auto pool_max_a = [&]() { pmx = max3(max3(q[0][0], q[0][1], q[0][2]), max3(q[0][3], q[1][0], q[1][1]), max3(q[1][2], q[1][3], q[2][0])); };
-    auto pool_max_b = [&]() {
-        pmx = max3(pmx, max3(q[2][1], q[2][2], q[2][3]), max3(q[3][0], q[3][1], max3(q[3][2], q[3][3], q[3][3])));
-        pmx = row16_max(pmx);
-    };
-    // after the 16-lane reduction every lane of a row holds the maximum: lanes 0 / 1 / 2 of the row store it to the two partial
-    // arrays and (if asked for) the combined one -- ONE store instruction per wave and k-step (counted below)
-    float* const pdst = psub == 0 ? pp0 : psub == 1 ? pp1 : ppo;
-    const bool pst_on = psub < (pooled ? 3 : 2);
-    auto pool_store = [&](int s) {
-        if (pst_on) pdst[s * KROWS] = pmx;
-    };
-    // ---- (c) the MFMAs of k-step s (map fragments from A[s & 1], W fragments from W[s & 1]), and IN THEIR GAPS -- a SIMD
-    //      issues about one other instruction in the shadow of a 16-cycle MFMA -- this wave's requests of the step and the
-    //      max-pool of k-step s + 1 (PT > 0: the number of LDS reads in flight is known at compile time, which the counted
-    //      waits for the operand fragments need; otherwise the pool runs behind the MFMAs)
-    auto mfma_step = [&](int s, bool pool) {
+    constexpr int NCV = 12;                              // conversion pieces
+    // ---- the MFMAs of k-step s (map fragments from A[s & 1], W fragments from W[s & 1]), and IN THEIR GAPS -- a SIMD issues
+    //      about one other instruction in the shadow of a 16-cycle MFMA -- behind MFMA number q of the step (q = 0 ..): a W wave's
+    //      request q of the next W image; a map wave's row requests 2 q, 2 q + 1 (q < 4) and conversion piece q - 4 of k-step
+    //      s + 1, whose reads were issued in front of the operand reads (LDS operations complete in order)
+    auto mfma_step = [&](int s, auto cvc) {
+        constexpr bool cv = decltype(cvc)::v != 0;
         const unsigned ab = (unsigned)((s & 1) * ABUF), wb = (unsigned)((s & 1) * WBUF);
         u32x4 wf[NW], bf[NR];
+        if (MAPW && cv) cv_reads(s + 1);
 #pragma unroll
         for (int t = 0; t < NW; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[t]) : "v"(w_rd + wb), "n"(t * 1024) : "memory");
 #pragma unroll
         for (int i = 0; i < NR; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[i]) : "v"(a_rd + ab), "n"(i * 1024) : "memory");
-        // LDS reads of a wave complete in order: row tile i's MFMAs wait for the W fragments and map fragments 0 .. i only
         static_for_img<0, NR>([&](auto ic) {
             constexpr int i = decltype(ic)::v;
-            constexpr int NPR = 4;                       // pool reads behind the operand reads (PT > 0: all four are issued)
-            if constexpr (PT > 0 && i == 1) {
-                if (pool) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2 + NPR) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2) : "memory");
-            }
-            else if constexpr (PT > 0 && i >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // row tile i's MFMAs wait for the W fragments and map fragments 0 .. i only: younger are the other fragments and the
+            // image writes of the conversion pieces issued so far (pieces 0-3 sit behind MFMAs 4-7)
+            constexpr int wr = !MAPW ? 0 : (i * NW - 4 < 0 ? 0 : i * NW - 4 > 4 ? 4 : i * NW - 4);
+            if (MAPW && cv) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i + wr) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 bv = __builtin_bit_cast(bf16x8, bf[i]);
-#pragma unroll
-            for (int t = 0; t < NW; ++t)
+            static_for_img<0, NW>([&](auto tc) {
+                constexpr int t = decltype(tc)::v, q = i * NW + t;
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), bv, acc[i][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // the gap behind row tile i
-            if constexpr (i == 0) {
-                if (STAGER) dma_half(2 * s + NHS);       // the half-slots of k-step s were converted in the step before
-                else dma_w(s + 1);                       // the other W image was read by the MFMAs of the step before
-                if (PT > 0 && pool) pool_reads(s + 1);
-            }
-            if constexpr (i == 1) { if (STAGER) dma_half(2 * s + NHS + 1); }
-            if constexpr (PT > 0 && i == 2) { if (pool) pool_max_a(); }
-            if constexpr (PT > 0 && i == 3) { if (pool) pool_max_b(); }
-            if constexpr (PT > 0 && i == 4) { if (pool) pool_store(s + 1); }
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!MAPW) {
+                    if constexpr (q < 5) dma_w(s + 1, q);
+                } else {
+                    if constexpr (q == 0 || q == 2) dma_unit(2 * s + NUS + (q >> 1));
+                    else if constexpr (q < 4) {}                // (the four requests of a unit share one exec mask)
+                    else if constexpr (q - 4 < NCV) { if (cv) cv_piece(ICI<q - 4>{}, s + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         });
-        if (PT == 0 && pool) {
-            pool_reads(s + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            pool_max_a();
-            pool_max_b();
-            pool_store(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
     };
-    const int nst = 1;                                   // pool store instructions per wave and k-step
     // "My requests up to x have landed" is a COUNT (in-order completion): at most as many operations outstanding as this wave
-    // has issued after them.  Request order of a step j -- map waves: [rows of half-steps 2j+7, 2j+8 (4 + 4)] [pool stores of
-    // k-step j+1]; W waves: [5 fragments of k-step j+1] [pool stores of k-step j+1].
-    if (STAGER) {
+    // has issued after them.  A map wave's order: prologue [units 0-6] [store 0]; step j [units 2j+7, 2j+8] [store j+1].
+    if (MAPW) {
 #pragma unroll
-        for (int h = 0; h < NHS; ++h) dma_half(h);
-        wait_vm(4 * (NHS - 2));                          // own rows of k-step 0 (half-steps 0, 1)
+        for (int n = 0; n < NUS; ++n) dma_unit(n);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS * (NUS - 2)) : "memory");       // units 0, 1
+        cv_reads(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        static_for_img<0, NCV>([&](auto kc) { cv_piece(kc, 0); });
     } else {
-        dma_w(0);
-        wait_vm(0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dma_w(0, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_barrier" ::: "memory");              // ... everyone's
-    convert(0);
-    pool_reads(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    pool_max_a();
-    pool_max_b();
-    pool_store(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAGER) wait_vm(4 * (NHS - 4) + nst);            // own rows of k-step 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #ifdef MG_IMG_TRACE
@@ -309,25 +309,31 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #else
 #define MG_TT(i, t0)
 #endif
-    // Step s: the MFMAs of k-step s (with the step's requests and the pool of k-step s + 1 in their gaps) on every wave; the W
-    // waves then convert k-step s + 1 into the other operand image; one barrier.
-    for (int s = 0; s < nks; ++s) {
+    // Step s: the MFMAs of k-step s on every wave, with the step's requests and -- map waves -- the conversion + pool of their
+    // octet of k-step s + 1 (into the other operand image) in the gaps; one barrier.
+    auto step = [&](int s, auto cvc) {
 #ifdef MG_IMG_TRACE
         unsigned long long t0 = IMG_T();
 #endif
-        mfma_step(s, s + 1 < nks);
+        if (MAPW) {
+            // units 2s+2, 2s+3 of this wave; younger: unit 2s+4, units 2s+5, 2s+6 (12 rows) and the stores of the two steps
+            // before (s = 0: units 4-6 and the prologue's store)
+            if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * UROWS + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * UROWS + 2) : "memory");
+            MG_TT(3, t0);
+        }
+        mfma_step(s, cvc);
         MG_TT(2, t0);
-        if (!STAGER && s + 1 < nks) convert(s + 1);
-        MG_TT(1, t0);
-        // map waves: own rows of k-step s + 2 (half-steps 2s+4, 2s+5; the latter requested first in step s - 1 or, s = 0, sixth
-        // in the prologue): younger are 4 rows + the stores of that step and all of this step.  W waves: own fragments of
-        // k-step s + 1: younger are this step's stores.
-        wait_vm(STAGER ? 12 + 2 * nst : nst);
-        MG_TT(3, t0);
+        if (!MAPW) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the fragments of k-step s + 1
+            MG_TT(3, t0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MG_TT(4, t0);
-    }
+    };
+    for (int s = 0; s + 1 < nks; ++s) step(s, ICI<1>{});
+    step(nks - 1, ICI<0>{});                             // (nothing left to convert)
 #ifdef MG_IMG_TRACE
     if (lane == 0 && (wave == 0 || wave == 4) && (blockIdx.x == 0 || blockIdx.x == 129)) {
         unsigned long long* g = g_img_trace[(blockIdx.x ? 2 : 0) + (wave >> 2)];
@@ -336,7 +342,7 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #endif
     // ---- epilogue: + bias, bf16, through LDS (over the ring: every request has landed), 16-B row stores; columns N..319 zero.
     // The tiles were computed TRANSPOSED (A operand = W fragment, B operand = map fragment): this lane's accumulator element
-    // [i][t][r] is output column (5 cg + t) * 16 + 4 * (lane >> 4) + r of region row 16 (7 rg + i) + (lane & 15), i.e. four
+    // [i][t][r] is output column (5 cg + t) * 16 + 4 * (lane >> 4) + r of region row 16 (tile0 + i) + (lane & 15), i.e. four
     // CONSECUTIVE bank columns per tile -> one 8-byte LDS write.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -351,7 +357,7 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int row = (rg * 7 + i) * 16 + (lane & 15);
+            const int row = (tile0 + i) * 16 + (lane & 15);
             uint2 o;
             o.x = pack2(n + 0 < N ? acc[i][t][0] + bvv[0] : 0.f, n + 1 < N ? acc[i][t][1] + bvv[1] : 0.f);
             o.y = pack2(n + 2 < N ? acc[i][t][2] + bvv[2] : 0.f, n + 3 < N ? acc[i][t][3] + bvv[3] : 0.f);
@@ -371,11 +377,11 @@ __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     if ((wave >> 2) == 0) {
-        if ((wave & 3) == 3) img_wave<6, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
-        else img_wave<6, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        if ((wave & 3) == 3) img_wave<NRW, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        else img_wave<NRW, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
     } else {
-        if ((wave & 3) == 3) img_wave<7, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
-        else img_wave<7, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, bank, pooled_part, pooled, wave, lane, tid);
+        if ((wave & 3) == 3) img_wave<NRM, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        else img_wave<NRM, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
     }
     // zero the pad columns 304..319 (two chunks per row), then the rows leave as 16-B lanes (all eight waves)
     unsigned char* osb = smem;

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BKR, int RING, int READBACK>
+template <int BKR, int RING, int READBACK, int MODE = 0>
 __global__ __launch_bounds__(512) void k(const float* __restrict__ feat, float* __restrict__ out, int K, int P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLICE = BKR * 784;                       // bytes (P = 196)
@@ -19,6 +19,30 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ feat, float* 
     const int nslice = K / BKR;
     auto issue = [&](int c) {                              // this wave's pieces of slice c (dummy beyond the end: out of range -> zeros)
         const int slot = c % RING;
+        if (MODE == 1) {                                   // the kernel's round-3 form: ROWS of 784 B (49 lanes), waves 4-7 only, BKR / 4 each
+            if (wave >= 4 && lane < 49) {
+#pragma unroll
+                for (int j = 0; j < BKR / 4; ++j) {
+                    const int r = (wave - 4) * (BKR / 4) + j;
+                    const int off = c < nslice ? (c * BKR + r) * 784 + lane * 16 : 0x7ffffff0;
+                    unsigned char* dst = smem + (size_t)slot * (PIECES * 1024) + r * 784;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, off, 0, 0, 2);
+                }
+            }
+            return;
+        }
+        if (MODE == 2) {                                   // 1-KiB pieces, waves 4-7 only
+            if (wave >= 4) {
+#pragma unroll
+                for (int j = 0; j < (PIECES + 3) / 4; ++j) {
+                    const int pc = (wave - 4) + 4 * j;
+                    const int off = c < nslice && pc < PIECES ? c * SLICE + pc * 1024 + lane * 16 : 0x7ffffff0;
+                    unsigned char* dst = smem + (size_t)slot * (PIECES * 1024) + (pc < PIECES ? pc : 0) * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, off, 0, 0, 2);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int pc = wave + 8 * j;
@@ -33,7 +57,9 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ feat, float* 
     for (int c = 0; c < nslice; ++c) {
         issue(c + RING - 1);
         // slice c has landed when at most (RING - 1) * PPW younger pieces are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PPW) : "memory");
+        if (MODE == 1) { if (wave >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * (BKR / 4)) : "memory"); }
+        else if (MODE == 2) { if (wave >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * ((PIECES + 3) / 4)) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
         if (READBACK) {
             const unsigned char* src = smem + (size_t)(c % RING) * (PIECES * 1024);
@@ -48,23 +74,23 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ feat, float* 
     out[(size_t)blockIdx.x * 512 + tid] = m[0] + m[1] + m[2] + m[3];
 }
 
-template <int BKR, int RING, int RB>
+template <int BKR, int RING, int RB, int MODE = 0>
 void run(const float* feat, float* out, int B, size_t stride_f, int nbuf) {
     constexpr int PIECES = (BKR * 784 + 1023) / 1024;
     const size_t lds = (size_t)RING * PIECES * 1024;
-    (void)hipFuncSetAttribute((const void*)k<BKR, RING, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k<BKR, RING, RB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<BKR, RING, RB>), dim3(B), dim3(512), lds, 0, feat + (i % nbuf) * stride_f, out, 2048, 196);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<BKR, RING, RB, MODE>), dim3(B), dim3(512), lds, 0, feat + (i % nbuf) * stride_f, out, 2048, 196);
     (void)hipEventRecord(a);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<BKR, RING, RB>), dim3(B), dim3(512), lds, 0, feat + (i % nbuf) * stride_f, out, 2048, 196);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<BKR, RING, RB, MODE>), dim3(B), dim3(512), lds, 0, feat + (i % nbuf) * stride_f, out, 2048, 196);
     (void)hipEventRecord(b);
     (void)hipEventSynchronize(b);
     float ms;
     (void)hipEventElapsedTime(&ms, a, b);
     const double bytes = (double)B * 2048 * 784;
-    printf("BK=%3d ring=%d readback=%d LDS=%3zu KB: %.1f us  %.2f TB/s (%s)\n", BKR, RING, RB, lds / 1024, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12,
+    printf("mode=%d BK=%3d ring=%d readback=%d LDS=%3zu KB: %.1f us  %.2f TB/s (%s)\n", MODE, BKR, RING, RB, lds / 1024, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12,
            hipGetErrorString(hipGetLastError()));
 }
 
@@ -82,5 +108,11 @@ int main() {
     run<64, 3, 1>(feat, out, B, stride_f, nbuf);
     run<16, 8, 1>(feat, out, B, stride_f, nbuf);
     run<16, 10, 1>(feat, out, B, stride_f, nbuf);
+    run<32, 4, 1, 1>(feat, out, B, stride_f, nbuf);
+    run<32, 5, 1, 1>(feat, out, B, stride_f, nbuf);
+    run<32, 4, 1, 2>(feat, out, B, stride_f, nbuf);
+    run<32, 5, 1, 2>(feat, out, B, stride_f, nbuf);
+    run<32, 4, 0, 1>(feat, out, B, stride_f, nbuf);
+    run<32, 4, 0, 2>(feat, out, B, stride_f, nbuf);
     return 0;
 }
