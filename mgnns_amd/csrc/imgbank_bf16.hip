@@ -20,6 +20,7 @@
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef MG_IMG_TRACE
 // profiling aid (off by default): per-phase cycle sums of wave 0 / wave 7 of two workgroups
@@ -73,22 +74,22 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float* __restrict__ W
 
 // ---- LDS map ------------------------------------------------------------------------------------------------------------
 constexpr int KROWS = 32;                                // feature rows per k-step
-constexpr int UROWS = 4;                                 // ... per ring unit (half a k-octet)
-constexpr int NUS = 7;                                   // unit slots of a map wave's private ring (3.5 k-steps of its octet)
+constexpr int UROWS = 4;                                 // ... per ring unit: HALF a k-octet, one wave's share of a k-step
+constexpr int NUS = 3;                                   // unit slots of a wave's private ring
 constexpr int PMAX = MT * 16;                            // 208 regions at most
 constexpr int USLOT = UROWS * PMAX * 4;                  // 3,328 B: a unit holds 4 rows of P * 4 bytes, packed
-constexpr int WRING = NUS * USLOT;                       // 23,296 B per map wave
+constexpr int WRING = NUS * USLOT;                       // 9,984 B per wave
 constexpr int ABUF = PMAX * 64;                          // 13,312 B: bf16 operand image of one k-step, [p][4 chunks of 8 k]
 constexpr int WBUF = (NT + 1) * 1024;                    // 20 KB: the 19 W fragments of one k-step (+ 1 KB that takes a dummy request)
-constexpr size_t OFF_A = (size_t)4 * WRING;
+constexpr size_t OFF_A = (size_t)8 * WRING;
 constexpr size_t OFF_W = OFF_A + 2 * ABUF;
 constexpr size_t SMEM_BYTES = OFF_W + 2 * WBUF;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 static_assert((size_t)PMAX * OSTR <= SMEM_BYTES, "the epilogue stages the bank rows over the ring");
 #ifndef MG_IMG_NRW
-#define MG_IMG_NRW 8
+#define MG_IMG_NRW 6
 #endif
-constexpr int NRW = MG_IMG_NRW, NRM = MT - NRW;                   // row tiles of a W wave / of a map wave (the map waves also convert and pool)
+constexpr int NRW = MG_IMG_NRW, NRM = MT - NRW;          // row tiles of a W wave (it also requests the W fragments) / of the others
 
 // LDS accesses of the main loop are inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while an
 // LDS-DMA may be in flight, which would drain the ring at every step.  The caller orders them (lgkmcnt / barriers).
@@ -101,10 +102,10 @@ __device__ __forceinline__ void static_for_img(F&& f) {
     }
 }
 
-// Max over the four 16-lane rows of the wave for FOUR values at once (a transposing reduction, sq_mha_bf16.hip::rows4_sum4 with
-// max): on return the rows of the result hold [a, c, b, d] folded over the rows.
 // (v_max_f32 through asm: fmaxf costs a canonicalising v_max_f32 v, v, v per operand in front of the real one)
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Max over the four 16-lane rows of the wave for FOUR values at once (a transposing reduction, sq_mha_bf16.hip::rows4_sum4 with
+// max): on return the rows of the result hold [a, c, b, d] folded over the rows.
 __device__ __forceinline__ float rows4_max4(float a, float b, float c, float d) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -112,59 +113,55 @@ __device__ __forceinline__ float rows4_max4(float a, float b, float c, float d) 
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ab), "+v"(cd));
     return vmax(ab, cd);
 }
-// max over each 16-lane row for TWO values, the DPP operand folded into the v_max_f32 (one instruction per level and value; the
-// two chains alternate, s_nop 0 completes the two wait states between a VALU write and a DPP read of the same register)
-__device__ __forceinline__ void row16_max2(float& a, float& b) {
+// max over each 16-lane row, the DPP operand folded into the v_max_f32 (one instruction per level; s_nop 1 = the two wait states
+// between a VALU write and a DPP read of the same register, which the compiler does not see through an asm block)
+__device__ __forceinline__ float row16_max_dpp(float a) {
     asm volatile("s_nop 1\n\t"
-                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-                 : "+v"(a), "+v"(b));
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(a));
+    return a;
 }
 
-// One wave's share of a sample.  Waves 0-3 ("W waves", MAPW = false): row tiles 0 .. NRW - 1; they request the W fragments.
-// Waves 4-7 ("map waves"): row tiles NRW .. 12; map wave w owns k-OCTET w - 4 of every k-step end to end -- it requests those
-// eight rows (two units of four, LDS-DMA into its private ring), waits for them on its OWN vmcnt, turns them into the octet's
-// chunk of the bf16 operand image, takes their max-pool from the same registers and re-requests into the unit slots it has
-// just read.  Round 4: before, the rows were converted by the W waves and pooled by everybody, so that "landed" had to be
-// published through the step's barrier a whole step early (a request had ~1.9 steps to land, every k-step's rows were read from
-// LDS twice and the pool's reads sat inside the MFMA stream's counted waits); the compute on top of the stream was additive
-// (ablations, profiles/NOTES_r04.md section 7).  Now a row has ~3 steps to land and nobody waits for anybody else's rows.
-// Vector-memory operations of a wave complete IN ORDER: the W stream and the map stream are issued by different waves, each
-// wave's counted wait covers only its own stream.
-template <int NR, int NW, bool MAPW, int PT>
+// One wave's share of a sample.  Round 4: every wave owns HALF a k-octet of every k-step end to end -- wave w = (octet w & 3,
+// half w >> 2) requests those four rows (LDS-DMA into its private ring of three units), waits for them on its OWN vmcnt, turns
+// them into its 8-byte halves of the octet's chunks of the bf16 operand image, takes their max-pool from the same registers and
+// re-requests into the unit slot it has just read; all of it in the gaps of its MFMA stream.  Waves 0-3 ("W waves", WS) also
+// request the W fragments and take NRW of the 13 row tiles, the others NRM.  Before (round 3): waves 4-7 requested all rows, waves
+// 0-3 converted them, everybody pooled them from LDS a second time -- "landed" had to be published through the step's barrier a
+// step early, the pool's reads sat inside the MFMA stream's counted waits, the compute on top of the stream was additive
+// (ablations: profiles/NOTES_r04.md section 7).  Vector-memory operations of a wave complete IN ORDER: a W wave requests its
+// fragments of the next k-step BEFORE the step's rows, so that they wait only for rows requested a step earlier.
+template <int NR, int NW, bool WS, int PT>
 __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __restrict__ feat, int b, int K, int Prt,
                                          const unsigned short* __restrict__ Wp, const float* __restrict__ bias, int N,
                                          float* __restrict__ pooled_part, float* __restrict__ pooled, int wave, int lane) {
-    const int tile0 = MAPW ? NRW : 0, cg = wave & 3, oct = wave & 3;
+    const int tile0 = WS ? 0 : NRW, cg = wave & 3, oct = wave & 3, half = wave >> 2;
     const int nks = K / KROWS;
     const int P = PT ? PT : Prt;                         // PT: the region count as a compile-time constant (row offsets become immediates)
     const int RB = P * 4;                                // bytes of a map row
     const unsigned lds0 = mg_lds_addr(smem), abuf = lds0 + (unsigned)OFF_A, wbuf = lds0 + (unsigned)OFF_W;
-    const unsigned myring = lds0 + (unsigned)(oct * WRING);
+    const unsigned myring = lds0 + (unsigned)(wave * WRING);
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(feat + (size_t)b * K * P), 0, K * P * (int)sizeof(float), 0x00027000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(Wp), 0, NT * nks * 1024, 0x00027000);
     const int nquad = P >> 2;
 
-    // ---- the map stream: unit n of this wave = rows 4 (n & 1) .. + 3 of its octet of k-step n >> 1 -> unit slot n % 7; one row
-    //      (P / 4 lanes x 16 B) per DMA instruction; units past the end are out of range and arrive as zeros in a slot nobody
-    //      reads (the request count per step stays constant: the counted waits depend on it)
+    // ---- the map stream: unit j of this wave = rows 8 oct + 4 half .. + 3 of k-step j -> unit slot j % 3; one row (P / 4 lanes
+    //      x 16 B) per DMA instruction; units past the end are out of range and arrive as zeros in a slot nobody reads (the
+    //      request count per step stays constant: the counted waits depend on it)
     const bool dma_lane = lane < nquad;
-    auto dma_unit = [&](int n) {
+    auto dma_rows = [&](int j, int r0, int nr) {
         if (dma_lane) {
-            const int row0 = (n >> 1) * KROWS + oct * 8 + (n & 1) * UROWS;
+            const int row0 = j * KROWS + oct * 8 + half * UROWS;
 #pragma unroll
-            for (int j = 0; j < UROWS; ++j) {
+            for (int r = r0; r < r0 + nr; ++r) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    f_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)oct * WRING + (size_t)(n % NUS) * USLOT + j * RB),
-                    16, lane * 16, (row0 + j) * RB, 0, MG_IMG_AUX);
+                    f_rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)wave * WRING + (size_t)(j % NUS) * USLOT + r * RB),
+                    16, lane * 16, (row0 + r) * RB, 0, MG_IMG_AUX);
             }
         }
     };
@@ -186,78 +183,88 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
     // operand image: [p][4 chunks of 16 B], chunk c of row p at slot c ^ g[(p >> 2) & 3], g = {2, 0, 1, 3}: the MFMA operand
     // reads are conflict-free (a ds_read_b128's 16-lane groups take rows 0-3 / 12-15 of chunk c and rows 4-11 of chunk c ^ 1:
     // slots {c^2, c^3} and {c^1^0, c^1^1} = all four, each with the four rows of a 256-B bank line) and the conversion's
-    // ds_write_b128 (8 consecutive lanes = 8 consecutive region quads, rows 256 B apart) spread over all four slots: 2-way,
-    // inside the store's own 13 cycles (round 3's c + 2 (p >> 2) put them on two slots: 4-way)
+    // 8-byte writes (16 consecutive lanes = 16 consecutive region quads, rows 256 B apart) spread over all four slots
     auto a_off = [](int p, int c) { return (unsigned)(p * 64 + (((c ^ (0xD2 >> (2 * ((p >> 2) & 3)))) & 3) << 4)); };
-    // conversion task of a map lane: region quad pq = lane (lanes past the last quad read the last quad again: their maxima
-    // change nothing, their image writes are masked), the wave's octet: 8 rows x 4 regions -> four 16-B chunks + 8 row maxima
+    // conversion task of a lane: region quad pq = lane (lanes past the last quad read the last quad again: their maxima change
+    // nothing, their image writes go to the W image's spare KB), the wave's half octet: 4 rows x 4 regions -> four 8-B half chunks
+    // + 4 row maxima
     const int pq = lane < nquad ? lane : nquad - 1;
-    const unsigned cv_dst = a_off(4 * pq, oct);          // rows 4 pq .. 4 pq + 3 share (p >> 2): consecutive 64-B rows, same slot
+    const unsigned cv_dst = lane < nquad ? abuf + a_off(4 * pq, oct) + (unsigned)(half * 8)      // rows 4 pq .. + 3 share (p >> 2): same slot
+                                         : wbuf + (unsigned)(NT * 1024 + (lane & 15) * 16);
+    const unsigned cv_step = lane < nquad ? (unsigned)ABUF : 0u;                                 // image s1 & 1
     // MFMA operand reads: map fragment = row 16 (tile0 + i) + (lane & 15), chunk lane >> 4; W fragment t of this wave
     const unsigned a_rd = abuf + (unsigned)(tile0 * 16 * 64) + a_off(lane & 15, lane >> 4);
     const unsigned w_rd = wbuf + (unsigned)(cg * 5 * 1024 + lane * 16);
 
-    // pooled maxima leave as ONE store per map wave and k-step: after the transposing reduction the 16-lane rows of o0 / o1 hold
-    // the maxima of octet rows {0, 2, 1, 3} / {4, 6, 5, 7}; lanes 0-2 of a row store o0, lanes 3-5 o1, to the two partial arrays
-    // (both get the complete maxima: callers that combine them keep working) and, if asked for, the combined one
-    const int grp = lane >> 4, sub = lane & 15, ndst = pooled ? 3 : 2;
-    const int hsel = sub / ndst, dsel = sub - hsel * ndst;
-    const bool pst_on = MAPW && sub < 2 * ndst;
-    float* const pst = (dsel == 0 ? pooled_part + (size_t)b * 2 * K : dsel == 1 ? pooled_part + ((size_t)b * 2 + 1) * K : pooled + (size_t)b * K) +
-                       oct * 8 + (hsel & 1) * 4 + ((grp & 1) << 1 | (grp >> 1));
+    // pooled maxima leave as ONE store per wave and k-step: after the transposing reduction the 16-lane rows of the wave hold the
+    // maxima of the unit's rows {0, 2, 1, 3}; lanes 0 .. of a row store it to the two partial arrays (both get the complete
+    // maxima: callers that combine them keep working) and, if asked for, the combined one
+    const int grp = lane >> 4, sub = lane & 15;
+    const bool pst_on = sub < (pooled ? 3 : 2);
+    float* const pst = (sub == 0 ? pooled_part + (size_t)b * 2 * K : sub == 1 ? pooled_part + ((size_t)b * 2 + 1) * K : pooled + (size_t)b * K) +
+                       oct * 8 + half * UROWS + ((grp & 1) << 1 | (grp >> 1));
     auto max3 = [](float a, float b2, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c)); return r; };
-    // ---- fp32 octet of k-step s1 (this wave's units 2 s1, 2 s1 + 1: landed, see the counted wait at the call) -> chunk `oct` of
-    //      the bf16 operand image A[s1 & 1] + the max-pool of its eight rows.  In PIECES (cv_piece<k>), so that a map wave can
-    //      spread the work over the gaps of its MFMA stream: reads | image chunk e (4 conversions + one 16-B write) x 4 | row
-    //      maxima x 4 | the transposing reduction over the wave | the store
-    f32x4 v[8];
-    float m[8];
+    // ---- this wave's unit of k-step s1 (landed: see the counted wait at the call) -> its half of chunk `oct` of the bf16 operand
+    //      image A[s1 & 1] + the max-pool of its four rows.  In PIECES (cv_piece<k>) for the gaps of the MFMA stream: reads |
+    //      half chunk of region e (2 conversions + one 8-B write) x 4 | row maxima x 2 | the transposing reduction | the store
+    f32x4 v[4];
+    float m[4];
     unsigned cv_ab = 0;
     auto cv_reads = [&](int s1) {
-        // (lanes past the last quad write into the W image's spare KB, which also takes the W waves' dummy request: no exec mask)
-        cv_ab = lane < nquad ? abuf + (unsigned)((s1 & 1) * ABUF) + cv_dst : wbuf + (unsigned)(NT * 1024 + (lane & 15) * 16);
-        const unsigned ua = myring + (unsigned)(((2 * s1) % NUS) * USLOT + pq * 16), ub = myring + (unsigned)(((2 * s1 + 1) % NUS) * USLOT + pq * 16);
+        cv_ab = cv_dst + (s1 & 1) * cv_step;
+        const unsigned ua = myring + (unsigned)((s1 % NUS) * USLOT + pq * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (PT > 0) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(ua), "n"(j * PT * 4) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[4 + j]) : "v"(ub), "n"(j * PT * 4) : "memory");
-            } else {
-                asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(ua + j * RB) : "memory");
-                asm volatile("ds_read_b128 %0, %1" : "=v"(v[4 + j]) : "v"(ub + j * RB) : "memory");
-            }
+            if constexpr (PT > 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(ua), "n"(j * PT * 4) : "memory");
+            else asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(ua + j * RB) : "memory");
         }
     };
+    // (pieces of at most three instructions: a SIMD issues about that much in the shadow of one 16-cycle MFMA; the s_nop are the
+    //  wait states of the lane-swap / DPP operands, which the compiler does not see through the asm blocks)
+    float mab = 0.f, mcd = 0.f;
     auto cv_piece = [&](auto kc, int s1) {
         constexpr int k = decltype(kc)::v;
-        if constexpr (k < 4) {                           // image chunk of regions 4 pq + k
-            u32x4 c;
-            c[0] = pack2(v[0][k], v[1][k]); c[1] = pack2(v[2][k], v[3][k]); c[2] = pack2(v[4][k], v[5][k]); c[3] = pack2(v[6][k], v[7][k]);
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(cv_ab), "v"(c), "n"(k * 64) : "memory");
-        } else if constexpr (k < 8) {                    // maxima of rows 2 (k - 4), + 1 over this lane's four regions
-            constexpr int j = 2 * (k - 4);
+        if constexpr (k < 4) {                           // half chunk of region 4 pq + k
+            u32x2 c;
+            c[0] = pack2(v[0][k], v[1][k]); c[1] = pack2(v[2][k], v[3][k]);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(cv_ab), "v"(c), "n"(k * 64) : "memory");
+        } else if constexpr (k < 8) {                    // maximum of row k - 4 over this lane's four regions
+            constexpr int j = k - 4;
             m[j] = vmax(max3(v[j][0], v[j][1], v[j][2]), v[j][3]);
-            m[j + 1] = vmax(max3(v[j + 1][0], v[j + 1][1], v[j + 1][2]), v[j + 1][3]);
-        } else if constexpr (k == 8) {
-            m[0] = rows4_max4(m[0], m[1], m[2], m[3]);   // rows of the wave: octet rows {0, 2, 1, 3}
+        } else if constexpr (k == 8) {                   // the transposing reduction over the four 16-lane rows of the wave ...
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
         } else if constexpr (k == 9) {
-            m[4] = rows4_max4(m[4], m[5], m[6], m[7]);   // ... {4, 6, 5, 7}
+            asm volatile("s_nop 1\n\tv_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5" : "=&v"(mab), "=&v"(mcd) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]));
         } else if constexpr (k == 10) {
-            row16_max2(m[0], m[4]);
-        } else if constexpr (k == 11) {
-            if (pst_on) pst[s1 * KROWS] = hsel ? m[4] : m[0];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(mab), "+v"(mcd));
+        } else if constexpr (k == 11) {                  // ... rows hold unit rows {0, 2, 1, 3}
+            asm volatile("s_nop 1\n\tv_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(mab), "v"(mcd));
+        } else if constexpr (k == 12) {                  // the 16 lanes of a row, DPP operand folded into the v_max_f32
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(m[0]));
+        } else if constexpr (k == 13) {
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(m[0]));
+        } else if constexpr (k == 14) {
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(m[0]));
+        } else if constexpr (k == 15) {
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(m[0]));
+        } else if constexpr (k == 16) {
+            if (pst_on) pst[s1 * KROWS] = m[0];
         }
     };
-    constexpr int NCV = 12;                              // conversion pieces
+    constexpr int NCV = 17;                              // conversion pieces
+    constexpr int ND = NW >= 5 ? 4 : 2;                  // gaps the unit's four row requests are spread over
+    constexpr int Q0 = (WS ? 5 : 0) + ND;                // MFMAs in front of the first conversion piece
+    static_assert(Q0 + NCV <= NR * NW, "one piece per MFMA gap");
     // ---- the MFMAs of k-step s (map fragments from A[s & 1], W fragments from W[s & 1]), and IN THEIR GAPS -- a SIMD issues
-    //      about one other instruction in the shadow of a 16-cycle MFMA -- behind MFMA number q of the step (q = 0 ..): a W wave's
-    //      request q of the next W image; a map wave's row requests 2 q, 2 q + 1 (q < 4) and conversion piece q - 4 of k-step
-    //      s + 1, whose reads were issued in front of the operand reads (LDS operations complete in order)
+    //      about one other instruction in the shadow of a 16-cycle MFMA -- behind MFMA number q of the step: a W wave's request q
+    //      of the next W image (q < 5), then the four row requests of unit s + 3 (whose slot the conversion of the step before has
+    //      read), then the conversion pieces of k-step s + 1, whose reads were issued in front of the operand reads (LDS
+    //      operations complete in order)
     auto mfma_step = [&](int s, auto cvc) {
         constexpr bool cv = decltype(cvc)::v != 0;
         const unsigned ab = (unsigned)((s & 1) * ABUF), wb = (unsigned)((s & 1) * WBUF);
         u32x4 wf[NW], bf[NR];
-        if (MAPW && cv) cv_reads(s + 1);
+        if (cv) cv_reads(s + 1);
 #pragma unroll
         for (int t = 0; t < NW; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[t]) : "v"(w_rd + wb), "n"(t * 1024) : "memory");
 #pragma unroll
@@ -265,42 +272,36 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
         static_for_img<0, NR>([&](auto ic) {
             constexpr int i = decltype(ic)::v;
             // row tile i's MFMAs wait for the W fragments and map fragments 0 .. i only: younger are the other fragments and the
-            // image writes of the conversion pieces issued so far (pieces 0-3 sit behind MFMAs 4-7)
-            constexpr int wr = !MAPW ? 0 : (i * NW - 4 < 0 ? 0 : i * NW - 4 > 4 ? 4 : i * NW - 4);
-            if (MAPW && cv) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i + wr) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i) : "memory");
+            // image writes of the conversion pieces issued so far (pieces 0-3 sit behind MFMAs Q0 .. Q0 + 3)
+            constexpr int wr = !cv ? 0 : (i * NW - Q0 < 0 ? 0 : i * NW - Q0 > 4 ? 4 : i * NW - Q0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 1 - i + wr) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 bv = __builtin_bit_cast(bf16x8, bf[i]);
             static_for_img<0, NW>([&](auto tc) {
                 constexpr int t = decltype(tc)::v, q = i * NW + t;
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), bv, acc[i][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!MAPW) {
-                    if constexpr (q < 5) dma_w(s + 1, q);
-                } else {
-                    if constexpr (q == 0 || q == 2) dma_unit(2 * s + NUS + (q >> 1));
-                    else if constexpr (q < 4) {}                // (the four requests of a unit share one exec mask)
-                    else if constexpr (q - 4 < NCV) { if (cv) cv_piece(ICI<q - 4>{}, s + 1); }
-                }
+                if constexpr (WS && q < 5) dma_w(s + 1, q);
+                else if constexpr (q < Q0) dma_rows(s + NUS, (q - (Q0 - ND)) * (UROWS / ND), UROWS / ND);
+                else if constexpr (q - Q0 < NCV) { if (cv) cv_piece(ICI<q - Q0>{}, s + 1); }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
     };
     // "My requests up to x have landed" is a COUNT (in-order completion): at most as many operations outstanding as this wave
-    // has issued after them.  A map wave's order: prologue [units 0-6] [store 0]; step j [units 2j+7, 2j+8] [store j+1].
-    if (MAPW) {
-#pragma unroll
-        for (int n = 0; n < NUS; ++n) dma_unit(n);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS * (NUS - 2)) : "memory");       // units 0, 1
-        cv_reads(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        static_for_img<0, NCV>([&](auto kc) { cv_piece(kc, 0); });
-    } else {
+    // has issued after them.  A wave's order: prologue [W(0) x 5] [units 0, 1, 2] [store 0]; step j [W(j+1) x 5] [unit j+3]
+    // [store j+1] (the bracketed W requests: W waves only).
+    if (WS) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) dma_w(0, j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#pragma unroll
+    for (int j = 0; j < NUS; ++j) dma_rows(j, 0, UROWS);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS * (NUS - 1)) : "memory");           // W(0) and unit 0
+    cv_reads(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_img<0, NCV>([&](auto kc) { cv_piece(kc, 0); });
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #ifdef MG_IMG_TRACE
@@ -309,24 +310,23 @@ __device__ __forceinline__ void img_wave(unsigned char* smem, const float* __res
 #else
 #define MG_TT(i, t0)
 #endif
-    // Step s: the MFMAs of k-step s on every wave, with the step's requests and -- map waves -- the conversion + pool of their
-    // octet of k-step s + 1 (into the other operand image) in the gaps; one barrier.
+    // Step s: the MFMAs of k-step s on every wave, with the step's requests and the conversion + pool of the wave's unit of
+    // k-step s + 1 (into the other operand image) in the gaps; one barrier.
     auto step = [&](int s, auto cvc) {
 #ifdef MG_IMG_TRACE
         unsigned long long t0 = IMG_T();
 #endif
-        if (MAPW) {
-            // units 2s+2, 2s+3 of this wave; younger: unit 2s+4, units 2s+5, 2s+6 (12 rows) and the stores of the two steps
-            // before (s = 0: units 4-6 and the prologue's store)
-            if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * UROWS + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * UROWS + 2) : "memory");
-            MG_TT(3, t0);
-        }
+        // unit s + 1 of this wave (requested in step s - 2); younger: store s - 1, [W(s) x 5,] unit s + 2, store s
+        // (s = 0: unit 2 and store 0)
+        if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS + 2 + (WS ? 5 : 0)) : "memory");
+        MG_TT(3, t0);
         mfma_step(s, cvc);
         MG_TT(2, t0);
-        if (!MAPW) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the fragments of k-step s + 1
-            MG_TT(3, t0);
+        if (WS) {
+            // the fragments of k-step s + 1; younger: unit s + 3 and (not in the last step) store s + 1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UROWS + (decltype(cvc)::v ? 1 : 0)) : "memory");
+            MG_TT(1, t0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -377,11 +377,11 @@ __global__ __launch_bounds__(NTHR) void imgbank_pool_bf16_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     if ((wave >> 2) == 0) {
-        if ((wave & 3) == 3) img_wave<NRW, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
-        else img_wave<NRW, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        if ((wave & 3) == 3) img_wave<NRW, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        else img_wave<NRW, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
     } else {
-        if ((wave & 3) == 3) img_wave<NRM, 4, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
-        else img_wave<NRM, 5, true, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        if ((wave & 3) == 3) img_wave<NRM, 4, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
+        else img_wave<NRM, 5, false, PT>(smem, feat, b, K, P, Wp, bias, N, pooled_part, pooled, wave, lane);
     }
     // zero the pad columns 304..319 (two chunks per row), then the rows leave as 16-B lanes (all eight waves)
     unsigned char* osb = smem;
