@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--attn", default="faithful")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--schedule", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = synth.CONFIGS["mvsa_multiple_b256"]
@@ -29,6 +30,8 @@ def main():
     inp = synth.make_inputs(cfg, B=args.batch, seed=cfg.seed, pmi=pmi)
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
     model.set_precision("bf16" if args.dtype == "bf16" else "fp32").set_attention(args.attn)
+    if args.schedule:
+        model.schedule = args.schedule
     call = harness.call_args(inp, dev)
     with torch.no_grad():
         model(*call)                                  # weight packing etc. outside the recording
