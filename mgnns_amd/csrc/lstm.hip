@@ -469,13 +469,22 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
         // vmcnt(2) instead of vmcnt(0) -- behind a burst of output stores a vmcnt(0) costs a store round trip
         const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + row;
         const int lm1 = len > 0 ? len - 1 : 0;
-        auto gx_at = [&](int st) {
+        // (through inline asm, waited for by hand: the compiler's own bookkeeping put s_waitcnt vmcnt(0) at the top of the loop --
+        //  whatever the loop's shape -- i.e. a wait for the load issued one step earlier)
+        auto gx_load = [&](int st, float& dst) __attribute__((always_inline)) {
             const int sc = st < lm1 ? st : lm1;
-            return gx_base[(size_t)(dir ? lm1 - sc : sc) * (2 * G4)];
+            const float* p = gx_base + (size_t)(dir ? lm1 - sc : sc) * (2 * G4);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
         };
-        float gx = gx_at(0), gx1 = gx_at(1), gx2 = gx_at(2);
+        // three registers, three steps per trip of the loop, NO rotation: a rotation (gx = gx1; gx1 = gx2; gx2 = load) moves the
+        // register the newest load writes, so every step waited for the load issued one step earlier (vmcnt(0)): the
+        // recurrence's step was bound by a global-load round trip instead of running three loads ahead (round 4)
+        float gxa, gxb, gxc;
+        gx_load(0, gxa);
+        gx_load(1, gxb);
+        gx_load(2, gxc);
         int cur = 0, sm = 0;                                       // sm = s % och (no integer division in the step loop)
-        for (int s = 0; s < len; ++s) {
+        auto step = [&](int s, float& gx) __attribute__((always_inline)) {
             // h as the A operand through the MFMA's A-matrix BROADCAST (cbsz = 4: all 16 blocks take their A from block abid):
             // three 8-byte LDS reads put h[4 (16 c + b) .. + 3] into the four lanes of block b of register pair c, and k-step
             // ks = 16 c + b names that block -- instead of one 16-byte broadcast read (1 KB into the wave) per two k-steps
@@ -502,10 +511,9 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             float asum = a[0][0];
 #pragma unroll
             for (int i = 1; i < MG_LSTM_ACC; ++i) asum += a[i][0];
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(gx)::"memory");   // the oldest of the three loads in flight (younger stores of a flush only make the wait longer)
             const float pre = (gx + bias) + asum;
-            gx = gx1;
-            gx1 = gx2;
-            gx2 = gx_at(s + 3);
+            gx_load(s + 3, gx);                                    // this register's next turn is three steps away
             // one activation per lane: sigmoid(x), or tanh(x) = 2 sigmoid(2x) - 1 on the g rows
             const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(is_tanh ? -2.0f * pre : -pre));   // v_rcp_f32 (1 ulp), not a division sequence
             const float act = is_tanh ? 2.0f * sg - 1.0f : sg;
@@ -537,7 +545,13 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                     flush_rows(s_out, och, s0, s + 1, len, dir, b, T, out, out_bf16, ld_bf16, tid, MTHR);
                 }
             }
+                };
+        for (int s = 0; s < len; s += 3) {
+            step(s, gxa);
+            if (s + 1 < len) step(s + 1, gxb);
+            if (s + 2 < len) step(s + 2, gxc);
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gxa), "+v"(gxb), "+v"(gxc)::"memory");   // nothing of this chain's loads lands in a register that has moved on
         if (next_x) {
             __syncthreads();
             continue;
