@@ -570,6 +570,7 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
     }
 }
 
+
 }  // namespace
 
 extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers) {
