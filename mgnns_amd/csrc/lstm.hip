@@ -419,6 +419,14 @@ __global__ __launch_bounds__(MTHR) void lstm_pack_whh_kernel(const float* __rest
     packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane] = uint2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
 }
 
+#ifdef MG_LSTM_TRACE
+// profiling aid (off by default): cycle sums of the step's phases, waves 0 / 9 of workgroup 0 (tools/dev/lstm_trace.py)
+__device__ unsigned long long g_lstm_trace[2][8];
+#define LSTM_T(i) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tt[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define LSTM_T(i)
+#endif
+
 // Persistent: workgroup w walks the (rank, direction) pairs w, 2G-1-w, 2G+w, ... of the length-sorted order (long chains
 // first, each paired with a short one), the weights stay in registers across its samples.
 __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __restrict__ Gx, const int32_t* __restrict__ offs,
@@ -479,12 +487,18 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
         // three registers, three steps per trip of the loop, NO rotation: a rotation (gx = gx1; gx1 = gx2; gx2 = load) moves the
         // register the newest load writes, so every step waited for the load issued one step earlier (vmcnt(0)): the
         // recurrence's step was bound by a global-load round trip instead of running three loads ahead (round 4)
+#ifdef MG_LSTM_TRACE
+        unsigned long long tt[4] = {0, 0, 0, 0};
+#endif
         float gxa, gxb, gxc;
         gx_load(0, gxa);
         gx_load(1, gxb);
         gx_load(2, gxc);
         int cur = 0, sm = 0;                                       // sm = s % och (no integer division in the step loop)
         auto step = [&](int s, float& gx) __attribute__((always_inline)) {
+#ifdef MG_LSTM_TRACE
+            unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
             // h as the A operand through the MFMA's A-matrix BROADCAST (cbsz = 4: all 16 blocks take their A from block abid):
             // three 8-byte LDS reads put h[4 (16 c + b) .. + 3] into the four lanes of block b of register pair c, and k-step
             // ks = 16 c + b names that block -- instead of one 16-byte broadcast read (1 KB into the wave) per two k-steps
@@ -508,10 +522,15 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             MG_K(28) MG_K(29) MG_K(30) MG_K(31) MG_K(32) MG_K(33) MG_K(34) MG_K(35) MG_K(36) MG_K(37)
 #undef MG_K
             static_assert(MKS == 38, "k-steps written out");
+#ifdef MG_LSTM_TRACE
+            asm volatile("s_nop 0" : "+v"(a[0]), "+v"(a[MG_LSTM_ACC - 1]));
+            LSTM_T(0)                                              // h reads + the 38 MFMAs
+#endif
             float asum = a[0][0];
 #pragma unroll
             for (int i = 1; i < MG_LSTM_ACC; ++i) asum += a[i][0];
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(gx)::"memory");   // the oldest of the three loads in flight (younger stores of a flush only make the wait longer)
+            LSTM_T(1)                                              // wait for the input-projection row
             const float pre = (gx + bias) + asum;
             gx_load(s + 3, gx);                                    // this register's next turn is three steps away
             // one activation per lane: sigmoid(x), or tanh(x) = 2 sigmoid(2x) - 1 on the g rows
@@ -524,7 +543,9 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                 s_h[cur ^ 1][unit] = (unsigned short)(pack2_bf16(hh, 0.f) & 0xFFFFu);
                 s_out[sm * HPAD + unit] = hh;
             }
+            LSTM_T(2)                                              // activations, cell update, h to LDS
             mg_lds_barrier();
+            LSTM_T(3)                                              // barrier
             cur ^= 1;
             const bool flush = sm + 1 == och || s + 1 == len;
             const int s0 = s - sm;
@@ -552,6 +573,13 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             if (s + 2 < len) step(s + 2, gxc);
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(gxa), "+v"(gxb), "+v"(gxc)::"memory");   // nothing of this chain's loads lands in a register that has moved on
+#ifdef MG_LSTM_TRACE
+        if (lane == 0 && (wave == 0 || wave == MW - 1) && blockIdx.x < 2 && len > (int)g_lstm_trace[wave ? 1 : 0][4]) {
+            unsigned long long* g = g_lstm_trace[wave ? 1 : 0];
+            for (int i = 0; i < 4; ++i) g[i] = tt[i];
+            g[4] = (unsigned long long)len;
+        }
+#endif
         if (next_x) {
             __syncthreads();
             continue;
@@ -572,6 +600,12 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
 
 
 }  // namespace
+
+#ifdef MG_LSTM_TRACE
+extern "C" int mgnns_debug_lstm_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t mgnns_bilstm_workspace_bytes(int B, int T, int hidden, int num_layers) {
     (void)num_layers;
