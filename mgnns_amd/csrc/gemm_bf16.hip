@@ -393,6 +393,240 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
     return 0;
 }
 
+// ---- 256 x 256 tiles (round 4) -----------------------------------------------------------------------------------------------
+// The 256 x 128 kernel above is bound by what the XCD's L2 delivers, not by the matrix pipe: 10 000 x 1024 x 10 000 moves 2.5 GB
+// from L2 to LDS (TCC hits + misses: 20.1 M lines per launch) for 532 MB of HBM reads and 275 us = 9.3 TB/s over the eight L2s,
+// while its MFMAs are 35 % of the time.  A 256 x 256 tile needs 2 / 256 operand bytes per MAC instead of 3 / 256: a third less L2
+// traffic for the same product -- a tile's 157 slices take 270 us with every CU busy, against 200 us for half as many MACs.
+// 512 threads, eight waves = two per SIMD (the 128 accumulator registers of a 64 x 128 wave tile leave no room for a third wave,
+// i.e. for dedicated producer waves: every wave requests 4 + 4 of the 64 DMA pieces of a slice, between the MFMAs of the slice
+// before), BK = 64, two stages of 64 KB: slice g + 1 is requested while slice g's MFMAs run and has landed when they end.
+// Work list of a workgroup, as in the kernel above: whole tiles round robin over the XCD's W workgroups (tile jj0 + i W: the
+// workgroups of a round sit on neighbouring tiles and march along K together, which is what keeps their operand slices in the
+// XCD's L2 -- dealing the tile stream out in equal runs of SLICES balanced every workgroup to the slice but put neighbours at
+// different k: 1.6 GB from HBM instead of 0.5, 304 us instead of 270 for 10 000 x 1024), then the rem = T mod W left-over tiles cut
+// along K into f = W / rem parts each; partial sums go to the workgroup's slot of the workspace and gemm_bf16_fixup_256_kernel,
+// the next launch on the stream, adds a tile's parts in K order and runs the epilogue: deterministic, no counters, nobody waits.
+namespace {
+constexpr int TM2 = 256, TN2 = 256, STAGE2 = (TM2 + TN2) * BK * 2;                 // 64 KB
+constexpr size_t SMEM2_BYTES = (size_t)2 * STAGE2;
+
+// the epilogue of a 64 x 128 wave tile: acc[i][jj][r] = C[cm0 + wr*64 + 16 i + (lane & 15)][cn0 + wc*128 + 16 jj + 4 (lane >> 4) + r]
+__device__ __forceinline__ void gemm256_store(f32x4 (&acc)[4][8], int cm0, int cn0, int wr, int wc, int fr, int fg, int M, int N,
+                                              const float* __restrict__ bias, float* __restrict__ C, int ldc, int act, int c_bf16) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int n = cn0 + wc * 128 + jj * 16 + fg * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = cm0 + wr * 64 + i * 16 + fr;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+            if (m < M && n < N) {
+                if (c_bf16) {                                      // C is a bf16 matrix (ldc in elements): the operand of the next product
+                    unsigned lo, hi;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                } else {
+                    *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+
+// (full, rem, f) of an XCD with T tiles and W workgroups: `full` rounds of whole tiles, then rem tiles in f K parts each
+__host__ __device__ inline void gemm256_split(int T, int W, int nk, int& full, int& rem, int& f) {
+    full = T / W;
+    rem = T - full * W;
+    f = rem > 0 ? W / rem : 0;
+    if (f > 8) f = 8;
+    if (f < 2 || f * 4 > nk) f = rem > 0 ? 1 : 0;                  // (f == 1: the left-over tiles stay whole)
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+                                                               int M, int N, int Kp, const float* __restrict__ bias,
+                                                               float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16,
+                                                               float* __restrict__ ws_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nk = Kp / BK;
+    // XCD x owns the row blocks [x nrb / 8, (x + 1) nrb / 8); its tile j = (row block j / nct of the range, column tile j % nct)
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    int full, rem, f;
+    gemm256_split(T, W, nk, full, rem, f);
+    // item i of this workgroup: i < full: tile jj0 + i W, all of K; then at most one more: a left-over tile (f == 1) or K part
+    // jj0 % f of left-over tile jj0 / f
+    const bool last_on = f >= 1 && jj0 < rem * f;
+    const int nitem = full + (last_on ? 1 : 0);
+    if (nitem == 0) return;
+    const int l_tile = full * W + (last_on ? jj0 / f : 0), l_part = last_on ? jj0 % f : 0;
+    const int l_k0 = last_on ? l_part * nk / f : 0, l_k1 = last_on ? (l_part + 1) * nk / f : nk;
+    const int S = full * nk + (last_on ? l_k1 - l_k0 : 0);
+    auto item = [&](int i, int& j, int& k0, int& k1) {             // (wave-uniform: kept in scalar registers)
+        const bool whole = i < full;
+        j = __builtin_amdgcn_readfirstlane(whole ? jj0 + i * W : l_tile);
+        k0 = __builtin_amdgcn_readfirstlane(whole ? 0 : l_k0);
+        k1 = __builtin_amdgcn_readfirstlane(whole ? nk : l_k1);
+    };
+    // ---- requests: piece p of an operand tile covers 8 rows x 128 B; lane (row_in = lane >> 3, slot = lane & 7) fetches the chunk
+    //      that belongs in its slot: slot = chunk ^ ((row >> 1) & 7); wave w takes pieces w + 8 i: p & 1 == w & 1.  Through buffer
+    //      descriptors of the tile's operand rows: the lane part of the address is one VGPR for the whole kernel, piece and slice
+    //      go into the scalar offset, rows beyond M / N are out of range and arrive as zeros
+    const int row_in = lane >> 3, slot = lane & 7;
+    const int chunk = slot ^ (4 * (wave & 1) + (row_in >> 1));
+    const unsigned voff = (unsigned)((row_in * Kp + chunk * 8) * 2);
+    int ii = 0, it, ik, ik1;                                       // item, tile and slice of the next request
+    item(0, it, ik, ik1);
+    __amdgpu_buffer_rsrc_t ra, rb;
+    auto open_tile = [&](int j) {
+        const int m0 = (rb0 + j / nct) * TM2, n0 = (j % nct) * TN2;
+        const int mr = M - m0 < TM2 ? M - m0 : TM2, nr = N - n0 < TN2 ? N - n0 : TN2;
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A + (size_t)m0 * Kp), 0, mr * Kp * 2, 0x00027000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bt + (size_t)n0 * Kp), 0, nr * Kp * 2, 0x00027000);
+    };
+    open_tile(it);
+    // request i (0..7) of slice g: A pieces wave + 8 i (i < 4), then Bt pieces
+    auto issue_one = [&](int g, int i) {
+        unsigned char* sb = smem + (size_t)(g & 1) * STAGE2;
+        const int p = wave + 8 * (i & 3);
+        const unsigned soff = (unsigned)((p * 8 * Kp + ik * BK) * 2);
+        if (i < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, voff, soff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + TM2 * BK * 2 + (size_t)p * 1024), 16, voff, soff, 0, 0);
+    };
+    auto issue_done = [&]() {                                      // advance to the next slice of the stream
+        if (++ik == ik1 && ++ii < nitem) {
+            item(ii, it, ik, ik1);
+            open_tile(it);
+        }
+    };
+    // ---- compute: wave tile rows wr * 64 .., columns wc * 128 .. (4 x 8 MFMA tiles)
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+        boff[s2] = lds0 + TM2 * BK * 2 + ((wc * 128 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
+    }
+    u32x4 a[2][4], b[2][8];
+    auto reads = [&](int stage, int s, int buf) {
+        const unsigned so = (unsigned)stage * STAGE2;
+        a[buf][0] = mg_lds_read128<0>(aoff[s] + so);
+        a[buf][1] = mg_lds_read128<2048>(aoff[s] + so);
+        a[buf][2] = mg_lds_read128<4096>(aoff[s] + so);
+        a[buf][3] = mg_lds_read128<6144>(aoff[s] + so);
+        b[buf][0] = mg_lds_read128<0>(boff[s] + so);
+        b[buf][1] = mg_lds_read128<2048>(boff[s] + so);
+        b[buf][2] = mg_lds_read128<4096>(boff[s] + so);
+        b[buf][3] = mg_lds_read128<6144>(boff[s] + so);
+        b[buf][4] = mg_lds_read128<8192>(boff[s] + so);
+        b[buf][5] = mg_lds_read128<10240>(boff[s] + so);
+        b[buf][6] = mg_lds_read128<12288>(boff[s] + so);
+        b[buf][7] = mg_lds_read128<14336>(boff[s] + so);
+    };
+    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns; k-step 0's MFMAs
+    // carry the eight requests of the next slice, one behind every fourth MFMA
+    auto mmas = [&](int buf, int g, bool req) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
+                                                                    __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
+                if (buf == 0 && (jj & 3) == 3 && req) issue_one(g + 1, i * 2 + (jj >> 2));
+            }
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(0, i);
+    issue_done();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // slice 0 landed (everybody's pieces)
+    reads(0, 0, 0);
+    int ci = 0, ct, ck, ck1;                                       // item, tile and slice being computed
+    item(0, ct, ck, ck1);
+    for (int g = 0; g < S; ++g) {
+        const bool req = g + 1 < S;                                // the next slice's stage held slice g - 1: read by everybody before the last barrier
+        reads(g & 1, 1, 1);
+        mg_lds_wait<12>();                                         // k-step 0 landed (the 12 reads of k-step 1 are behind it)
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(0, g, req);
+        if (req) issue_done();
+        __builtin_amdgcn_sched_barrier(0);
+        mg_lds_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(1, g, false);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // slice g + 1 landed; done with the stage of slice g
+        if (req) reads((g + 1) & 1, 0, 0);
+        if (++ck < ck1) continue;
+        // ---- item ci ends here
+        const int cm0 = (rb0 + ct / nct) * TM2, cn0 = (ct % nct) * TN2;
+        if (ci < full || f == 1) {
+            gemm256_store(acc, cm0, cn0, wr, wc, fr, fg, M, N, bias, C, ldc, act, c_bf16);
+        } else {
+            float* wp = ws_part + (size_t)(xcd * W + jj0) * (TM2 * TN2) + ((size_t)(wave * 32) * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    __builtin_nontemporal_store(acc[i][jj], reinterpret_cast<f32x4*>(wp + (size_t)(i * 8 + jj) * 64 * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++ci < nitem) item(ci, ct, ck, ck1);
+    }
+}
+
+// Left-over tile r of XCD blockIdx.x & 7 (r = blockIdx.x >> 3): add its f parts in K order (= workgroup order) and run the
+// epilogue.  512 threads; thread t owns the accumulator slots of compute wave t >> 6 exactly as that wave wrote them.
+__global__ __launch_bounds__(512) void gemm_bf16_fixup_256_kernel(const float* __restrict__ ws_part, int M, int N, int Kp,
+                                                                  const float* __restrict__ bias, float* __restrict__ C, int ldc, int act,
+                                                                  int nrb, int nct, int W, int c_bf16) {
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int nk = Kp / BK;
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    int full, rem, f;
+    gemm256_split(T, W, nk, full, rem, f);
+    if (f < 2 || r >= rem) return;
+    const int t = full * W + r;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < f; ++p) {
+        const float* wp = ws_part + (size_t)(xcd * W + r * f + p) * (TM2 * TN2) + ((size_t)(wave * 32) * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)(i * 8 + jj) * 64 * 4));
+                acc[i][jj] += v;
+            }
+    }
+    gemm256_store(acc, (rb0 + t / nct) * TM2, (t % nct) * TN2, wave >> 1, wave & 1, lane & 15, lane >> 4, M, N, bias, C, ldc, act, c_bf16);
+}
+
+}  // namespace
+
 // internal launcher (also used by the bf16-mode LSTM input projections): m_dev != nullptr -> the row count is read on the
 // device and M is only its upper bound
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
@@ -404,6 +638,37 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     MG_REQUIRE(mg_aligned16(A) && mg_aligned16(Bt) && mg_aligned16(C) && (!bias || mg_aligned16(bias)),
                "mgnns_gemm_bf16_nt_fwd: operands must be 16-byte aligned");
     if (M == 0) return 0;
+    // at least 128 tiles of 256 x 256 (half a chip of workgroups) and the workspace for its pieces: the form with a third less
+    // L2 -> LDS traffic (MGNNS_GEMM_TILE=128: the 256 x 128 kernel)
+    if (!m_dev && workspace && mg_aligned16(workspace) && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256) {
+        const int nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
+        const int n_cu2 = mg_cu_count();
+        if (n_cu2 <= 0) return MGNNS_ERR_LAUNCH;
+        int per = n_cu2 / 8;
+        if (per < 1) per = 1;
+        // at least one full round of tiles on every XCD (fewer: the 256 x 128 kernel fills the chip better) and a long K (measured:
+        // 10 000 x 2048 with K = 1024 / 2048, the X.W products of configs[4], lose 20 % -- the fixed cost per tile counts there)
+        if (nrb2 / 8 * nct2 >= per && N >= TN2 && Kp / BK >= 64 && workspace_bytes >= (size_t)8 * per * TM2 * TN2 * sizeof(float)) {
+            MG_DYN_LDS(gemm_bf16_nt_256_kernel, SMEM2_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(8 * per), dim3(512), SMEM2_BYTES, stream,
+                               reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
+                               ldc, act, nrb2, nct2, c_bf16, static_cast<float*>(workspace));
+            MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(256)");
+            int max_rem = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int Tx = ((x + 1) * nrb2 / 8 - x * nrb2 / 8) * nct2;
+                int full, rem, f;
+                gemm256_split(Tx, per, Kp / BK, full, rem, f);
+                if (f >= 2 && rem > max_rem) max_rem = rem;
+            }
+            if (max_rem) {
+                hipLaunchKernelGGL(gemm_bf16_fixup_256_kernel, dim3(8 * max_rem), dim3(512), 0, stream, static_cast<const float*>(workspace), M, N,
+                                   Kp, bias, C, ldc, act, nrb2, nct2, per, c_bf16);
+                MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(256 fix-up)");
+            }
+            return 0;
+        }
+    }
     MG_DYN_LDS(gemm_bf16_nt_kernel, SMEM_BYTES);
     const int nrb = (M + TM - 1) / TM, nct = (N + TN - 1) / TN;
     int rps = 1;                                                   // row-block ranges per XCD (see the kernel)
@@ -444,7 +709,8 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     return 0;
 }
 
-extern "C" size_t mgnns_gemm_bf16_workspace_bytes(void) { return (size_t)256 * TM * TN * sizeof(float); }
+// 256 workgroups x one part of 256 x 256 fp32 (the 256 x 256 kernel); the 256 x 128 kernel's K split uses the first half
+extern "C" size_t mgnns_gemm_bf16_workspace_bytes(void) { return (size_t)256 * TM2 * TN2 * sizeof(float); }
 
 extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
                                       int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream) {

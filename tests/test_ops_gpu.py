@@ -1250,6 +1250,41 @@ def test_gemm_bf16_nt_last_round_k_split_equals_whole_tiles(M, N, K):
         ops.GEMM_BF16_KSPLIT = old
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 4096), (10000, 2048, 4200), (8300, 2312, 4100)])
+def test_gemm_bf16_nt_256_tiles(M, N, K):
+    """Products with at least a full round of 256 x 256 tiles on every XCD and K >= 4096 run
+    csrc/gemm_bf16.hip::gemm_bf16_nt_256_kernel (whole tiles round robin, the left-over tiles of an XCD cut along K and finished by
+    the fix-up launch) when the workspace is there: 32 / 40 / 45 tiles per XCD = no remainder / 8 left-over tiles in 4 parts / 13
+    in 2 parts; against the 256 x 128 kernel without workspace (fp32 sums in another order only), against fp64 on sampled entries,
+    ragged M / N / K, bias + activation + bf16 output, repeatable bits."""
+    rs = np.random.RandomState(M + N + K)
+    kp = (K + 63) // 64 * 64
+    a32 = rs.standard_normal((M, K)).astype(np.float32) * 0.1
+    b32 = rs.standard_normal((N, K)).astype(np.float32) * 0.1
+    a = ops.cast_pad_bf16(dev(a32), ld=kp)
+    bt = ops.cast_pad_bf16(dev(b32), ld=kp)
+    bias = dev(rs.standard_normal(N).astype(np.float32))
+    old = ops.GEMM_BF16_KSPLIT
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            ops.GEMM_BF16_KSPLIT = False
+            ref = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            ops.GEMM_BF16_KSPLIT = True
+            got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            got2 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            assert torch.equal(got, got2)
+            scale = float(ref.float().abs().max())
+            tol = 2e-6 if dt == torch.float32 else 8e-3
+            assert float((got.float() - ref.float()).abs().max()) <= tol * scale, (dt, M, N, K)
+        rows = rs.randint(0, M, size=48)
+        rows[:4] = (0, M - 1, 255, 256)
+        ref64 = _bf16_round(a32[rows]).double() @ _bf16_round(b32).double().t()
+        got = ops.gemm_bf16_nt(a, bt).cpu().double()[rows]
+        assert float((got - ref64).abs().max()) <= 1e-5 * max(1.0, float(ref64.abs().max()))
+    finally:
+        ops.GEMM_BF16_KSPLIT = old
+
+
 def test_xcd_probe_confirms_the_block_index_placement():
     """`blockIdx.x & 7 == XCD` is an observed dispatch order several kernels place work by (SpMM feature slabs, the dense GEMM's
     row-block ranges): only speed depends on it, and mgnns_xcd_probe measures it on the device the tests run on -- eight distinct

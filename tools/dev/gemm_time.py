@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Dense bf16 GEMM of configs[4] ([n, n] adjacency x [n, F]), cache-cold rotation, hipGraph replays: us and fraction of 2.5 PF.
+    python tools/dev/gemm_time.py [F ...]      MGNNS_GEMM_TILE=128 selects the 256 x 128 kernel"""
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mgnns_amd import ops  # noqa: E402
+
+dev = "cuda:0"
+n = 10000
+kp = (n + 63) // 64 * 64
+g = torch.Generator(device=dev).manual_seed(0)
+for F in [int(a) for a in sys.argv[1:]] or [1024, 2048]:
+    adjs = [torch.zeros(n, kp, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+    xts = [torch.zeros(F, kp, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+    for t in adjs + xts:
+        t[:, :n] = torch.randn(t.shape[0], n, device=dev, generator=g).bfloat16()
+    out = torch.empty(n, F, device=dev)
+    for i in range(3):
+        ops.gemm_bf16_nt(adjs[i], xts[i], out=out)
+    torch.cuda.synchronize()
+    ds = []
+    for r in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(6):
+            ops.gemm_bf16_nt(adjs[i % 3], xts[i % 3], out=out)
+        b.record()
+        torch.cuda.synchronize()
+        ds.append(a.elapsed_time(b) / 6 * 1e3)
+    us = statistics.median(ds)
+    print("F=%d: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (F, us, min(ds), 2.0 * n * n * F / us / 1e6 / 2.5e9 * 100), flush=True)
+    del adjs, xts
