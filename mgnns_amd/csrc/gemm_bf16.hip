@@ -399,8 +399,8 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
 // while its MFMAs are 35 % of the time.  A 256 x 256 tile needs 2 / 256 operand bytes per MAC instead of 3 / 256: a third less L2
 // traffic for the same product -- a tile's 157 slices take 270 us with every CU busy, against 200 us for half as many MACs.
 // 512 threads, eight waves = two per SIMD (the 128 accumulator registers of a 64 x 128 wave tile leave no room for a third wave,
-// i.e. for dedicated producer waves: every wave requests 4 + 4 of the 64 DMA pieces of a slice, between the MFMAs of the slice
-// before), BK = 64, two stages of 64 KB: slice g + 1 is requested while slice g's MFMAs run and has landed when they end.
+// i.e. for dedicated producer waves: every wave requests its share of the DMA pieces of a slice between the MFMAs of an earlier
+// one).
 // Work list of a workgroup, as in the kernel above: whole tiles round robin over the XCD's W workgroups (tile jj0 + i W: the
 // workgroups of a round sit on neighbouring tiles and march along K together, which is what keeps their operand slices in the
 // XCD's L2 -- dealing the tile stream out in equal runs of SLICES balanced every workgroup to the slice but put neighbours at
@@ -408,8 +408,7 @@ extern "C" int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int
 // along K into f = W / rem parts each; partial sums go to the workgroup's slot of the workspace and gemm_bf16_fixup_256_kernel,
 // the next launch on the stream, adds a tile's parts in K order and runs the epilogue: deterministic, no counters, nobody waits.
 namespace {
-constexpr int TM2 = 256, TN2 = 256, STAGE2 = (TM2 + TN2) * BK * 2;                 // 64 KB
-constexpr size_t SMEM2_BYTES = (size_t)2 * STAGE2;
+constexpr int TM2 = 256, TN2 = 256;
 
 // the epilogue of a 64 x 128 wave tile: acc[i][jj][r] = C[cm0 + wr*64 + 16 i + (lane & 15)][cn0 + wc*128 + 16 jj + 4 (lane >> 4) + r]
 __device__ __forceinline__ void gemm256_store(f32x4 (&acc)[4][8], int cm0, int cn0, int wr, int wc, int fr, int fg, int M, int N,
@@ -449,41 +448,49 @@ __host__ __device__ inline void gemm256_split(int T, int W, int nk, int& full, i
     if (f < 2 || f * 4 > nk) f = rem > 0 ? 1 : 0;                  // (f == 1: the left-over tiles stay whole)
 }
 
+// The tile stream runs through a FOUR-stage ring of 32-wide K slices (32 KB each): three slices in flight.  (First form: two
+// 64-wide stages, the next slice requested while the one before is multiplied -- one L2 round trip per slice; 427 us against 422
+// for 10 000 x 2048 x 10 000 on one box.  The difference is small because neither is what a slice costs, see mmas below.)
+// Operand rows are 64 B here: [row][4 chunks of 16 B], chunk c at slot c ^ g[(row >> 2) & 3], g = {2, 0, 1, 3} (the image bank's
+// operand image: conflict-free ds_read_b128 fragments); a DMA piece is 16 rows x 64 B.
+#ifdef MG_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[4];                     // profiling aid: s_memtime ticks of workgroup 0 / 100 (wave 0)
+#endif
+constexpr int BK3 = 32, NST3 = 4, OPB3 = TM2 * BK3 * 2, STG3 = 2 * OPB3;           // 16 KB per operand, 32 KB per stage
+constexpr size_t SMEM3_BYTES = (size_t)NST3 * STG3;
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
-                                                               int M, int N, int Kp, const float* __restrict__ bias,
-                                                               float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16,
-                                                               float* __restrict__ ws_part) {
+                                                                int M, int N, int Kp, const float* __restrict__ bias,
+                                                                float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16,
+                                                                float* __restrict__ ws_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef MG_GEMM_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
-    const int nk = Kp / BK;
-    // XCD x owns the row blocks [x nrb / 8, (x + 1) nrb / 8); its tile j = (row block j / nct of the range, column tile j % nct)
+    const int nk = Kp / BK;                                        // (the work list counts K in 64-wide slices, as the fix-up launch does)
     const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
     int full, rem, f;
     gemm256_split(T, W, nk, full, rem, f);
-    // item i of this workgroup: i < full: tile jj0 + i W, all of K; then at most one more: a left-over tile (f == 1) or K part
-    // jj0 % f of left-over tile jj0 / f
     const bool last_on = f >= 1 && jj0 < rem * f;
     const int nitem = full + (last_on ? 1 : 0);
     if (nitem == 0) return;
     const int l_tile = full * W + (last_on ? jj0 / f : 0), l_part = last_on ? jj0 % f : 0;
     const int l_k0 = last_on ? l_part * nk / f : 0, l_k1 = last_on ? (l_part + 1) * nk / f : nk;
-    const int S = full * nk + (last_on ? l_k1 - l_k0 : 0);
-    auto item = [&](int i, int& j, int& k0, int& k1) {             // (wave-uniform: kept in scalar registers)
+    const int S = 2 * (full * nk + (last_on ? l_k1 - l_k0 : 0));   // 32-wide slices of this workgroup
+    auto item = [&](int i, int& j, int& k0, int& k1) {             // tile, first and last + 1 32-wide slice (wave-uniform)
         const bool whole = i < full;
         j = __builtin_amdgcn_readfirstlane(whole ? jj0 + i * W : l_tile);
-        k0 = __builtin_amdgcn_readfirstlane(whole ? 0 : l_k0);
-        k1 = __builtin_amdgcn_readfirstlane(whole ? nk : l_k1);
+        k0 = __builtin_amdgcn_readfirstlane(whole ? 0 : 2 * l_k0);
+        k1 = __builtin_amdgcn_readfirstlane(whole ? 2 * nk : 2 * l_k1);
     };
-    // ---- requests: piece p of an operand tile covers 8 rows x 128 B; lane (row_in = lane >> 3, slot = lane & 7) fetches the chunk
-    //      that belongs in its slot: slot = chunk ^ ((row >> 1) & 7); wave w takes pieces w + 8 i: p & 1 == w & 1.  Through buffer
-    //      descriptors of the tile's operand rows: the lane part of the address is one VGPR for the whole kernel, piece and slice
-    //      go into the scalar offset, rows beyond M / N are out of range and arrive as zeros
-    const int row_in = lane >> 3, slot = lane & 7;
-    const int chunk = slot ^ (4 * (wave & 1) + (row_in >> 1));
+    // ---- requests: piece p of an operand tile covers 16 rows x 64 B; lane (row_in = lane >> 2, slot = lane & 3) fetches the chunk
+    //      that belongs in its slot; wave w takes A pieces w, w + 8 and Bt pieces w, w + 8 of every slice
+    const int row_in = lane >> 2, slot = lane & 3;
+    const int chunk = slot ^ ((0xD2 >> (2 * ((row_in >> 2) & 3))) & 3);
     const unsigned voff = (unsigned)((row_in * Kp + chunk * 8) * 2);
-    int ii = 0, it, ik, ik1;                                       // item, tile and slice of the next request
+    int ii = 0, it, ik, ik1;
     item(0, it, ik, ik1);
     __amdgpu_buffer_rsrc_t ra, rb;
     auto open_tile = [&](int j) {
@@ -493,17 +500,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const unsigned sh
         rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bt + (size_t)n0 * Kp), 0, nr * Kp * 2, 0x00027000);
     };
     open_tile(it);
-    // request i (0..7) of slice g: A pieces wave + 8 i (i < 4), then Bt pieces
-    auto issue_one = [&](int g, int i) {
-        unsigned char* sb = smem + (size_t)(g & 1) * STAGE2;
-        const int p = wave + 8 * (i & 3);
-        const unsigned soff = (unsigned)((p * 8 * Kp + ik * BK) * 2);
-        if (i < 4)
+    auto issue_one = [&](int g, int i) {                           // request i (0..3) of slice g
+        unsigned char* sb = smem + (size_t)(g & (NST3 - 1)) * STG3;
+        const int p = wave + 8 * (i & 1);
+        const unsigned soff = (unsigned)((p * 16 * Kp + ik * BK3) * 2);
+        if (i < 2)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, voff, soff, 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + TM2 * BK * 2 + (size_t)p * 1024), 16, voff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + OPB3 + (size_t)p * 1024), 16, voff, soff, 0, 0);
     };
-    auto issue_done = [&]() {                                      // advance to the next slice of the stream
+    auto issue_done = [&]() {
         if (++ik == ik1 && ++ii < nitem) {
             item(ii, it, ik, ik1);
             open_tile(it);
@@ -518,61 +524,64 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const unsigned sh
         for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     const unsigned lds0 = mg_lds_addr(smem);
-    unsigned aoff[2], boff[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        aoff[s2] = lds0 + ((wr * 64 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
-        boff[s2] = lds0 + TM2 * BK * 2 + ((wc * 128 + fr) * 8 + ((4 * s2 + fg) ^ ((fr >> 1) & 7))) * 16;
-    }
-    u32x4 a[2][4], b[2][8];
-    auto reads = [&](int stage, int s, int buf) {
-        const unsigned so = (unsigned)stage * STAGE2;
-        a[buf][0] = mg_lds_read128<0>(aoff[s] + so);
-        a[buf][1] = mg_lds_read128<2048>(aoff[s] + so);
-        a[buf][2] = mg_lds_read128<4096>(aoff[s] + so);
-        a[buf][3] = mg_lds_read128<6144>(aoff[s] + so);
-        b[buf][0] = mg_lds_read128<0>(boff[s] + so);
-        b[buf][1] = mg_lds_read128<2048>(boff[s] + so);
-        b[buf][2] = mg_lds_read128<4096>(boff[s] + so);
-        b[buf][3] = mg_lds_read128<6144>(boff[s] + so);
-        b[buf][4] = mg_lds_read128<8192>(boff[s] + so);
-        b[buf][5] = mg_lds_read128<10240>(boff[s] + so);
-        b[buf][6] = mg_lds_read128<12288>(boff[s] + so);
-        b[buf][7] = mg_lds_read128<14336>(boff[s] + so);
+    const unsigned swz = (unsigned)((fg ^ ((0xD2 >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
+    const unsigned aoff = lds0 + (unsigned)((wr * 64 + fr) * 64) + swz, boff = lds0 + OPB3 + (unsigned)((wc * 128 + fr) * 64) + swz;
+    u32x4 a[4], b[8];
+    auto reads = [&](int stage) {
+        const unsigned so = (unsigned)stage * STG3;
+        a[0] = mg_lds_read128<0>(aoff + so);
+        a[1] = mg_lds_read128<1024>(aoff + so);
+        a[2] = mg_lds_read128<2048>(aoff + so);
+        a[3] = mg_lds_read128<3072>(aoff + so);
+        b[0] = mg_lds_read128<0>(boff + so);
+        b[1] = mg_lds_read128<1024>(boff + so);
+        b[2] = mg_lds_read128<2048>(boff + so);
+        b[3] = mg_lds_read128<3072>(boff + so);
+        b[4] = mg_lds_read128<4096>(boff + so);
+        b[5] = mg_lds_read128<5120>(boff + so);
+        b[6] = mg_lds_read128<6144>(boff + so);
+        b[7] = mg_lds_read128<7168>(boff + so);
     };
-    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns; k-step 0's MFMAs
-    // carry the eight requests of the next slice, one behind every fourth MFMA
-    auto mmas = [&](int buf, int g, bool req) {
+    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns; half h = column
+    // tiles 4 h .. 4 h + 3; two of the four requests of slice g + 3 ride on each half, behind every eighth MFMA.  (Fragments of
+    // the NEXT slice read under these MFMAs -- 96 more registers, one slice less in flight -- measured no faster: a slice costs
+    // ~1850 cycles for 1024 of MFMAs either way; what the waves lose is the ISSUE of their 4 + 4 requests per 64 k, 100-185 cycles
+    // each next to fragment reads, and 128 accumulator registers leave no room for producer waves.)
+    auto mmas = [&](int h, int g, bool req) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
-                                                                    __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
-                if (buf == 0 && (jj & 3) == 3 && req) issue_one(g + 1, i * 2 + (jj >> 2));
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int jj = 4 * h + j4;
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[jj]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                    acc[i][jj], 0, 0, 0);
+                if (req && j4 == 3 && (i & 1)) issue_one(g + NST3 - 1, 2 * h + (i >> 1));
             }
     };
+    for (int g = 0; g < NST3 - 1; ++g) {                           // (S >= 16: a part is at least eight 64-wide slices)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) issue_one(0, i);
-    issue_done();
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // slice 0 landed (everybody's pieces)
-    reads(0, 0, 0);
-    int ci = 0, ct, ck, ck1;                                       // item, tile and slice being computed
+        for (int i = 0; i < 4; ++i) issue_one(g, i);
+        issue_done();
+    }
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // slice 0 landed (everybody's pieces)
+    int ci = 0, ct, ck, ck1;
     item(0, ct, ck, ck1);
     for (int g = 0; g < S; ++g) {
-        const bool req = g + 1 < S;                                // the next slice's stage held slice g - 1: read by everybody before the last barrier
-        reads(g & 1, 1, 1);
-        mg_lds_wait<12>();                                         // k-step 0 landed (the 12 reads of k-step 1 are behind it)
+        const bool req = g + NST3 - 1 < S;                         // slice g + 3 -> the stage of slice g - 1: read by everybody before the last barrier
+        reads(g & (NST3 - 1));
+        mg_lds_wait<4>();                                          // a[0..3], b[0..3]
         __builtin_amdgcn_sched_barrier(0);
         mmas(0, g, req);
-        if (req) issue_done();
         __builtin_amdgcn_sched_barrier(0);
         mg_lds_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
-        mmas(1, g, false);
+        mmas(1, g, req);
+        if (req) issue_done();
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // slice g + 1 landed; done with the stage of slice g
-        if (req) reads((g + 1) & 1, 0, 0);
+        // slice g + 1 landed (its own pieces: at most the 8 of slices g + 2, g + 3 are younger); everybody is done with slice g
+        if (req) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (g + 2 < S) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (++ck < ck1) continue;
         // ---- item ci ends here
         const int cm0 = (rb0 + ct / nct) * TM2, cn0 = (ct % nct) * TN2;
@@ -592,6 +601,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const unsigned sh
             for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (++ci < nitem) item(ci, ct, ck, ck1);
     }
+#ifdef MG_GEMM_TRACE
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+        g_gemm_trace[blockIdx.x ? 2 : 0] = __builtin_amdgcn_s_memtime() - tr0;
+        g_gemm_trace[blockIdx.x ? 3 : 1] = (unsigned long long)S;
+    }
+#endif
 }
 
 // Left-over tile r of XCD blockIdx.x & 7 (r = blockIdx.x >> 3): add its f parts in K order (= workgroup order) and run the
@@ -640,7 +655,7 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     if (M == 0) return 0;
     // at least 128 tiles of 256 x 256 (half a chip of workgroups) and the workspace for its pieces: the form with a third less
     // L2 -> LDS traffic (MGNNS_GEMM_TILE=128: the 256 x 128 kernel)
-    if (!m_dev && workspace && mg_aligned16(workspace) && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256) {
+    if (!m_dev && workspace && mg_aligned16(workspace) && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256) {     // (=128: the 256 x 128 kernel only)
         const int nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
         const int n_cu2 = mg_cu_count();
         if (n_cu2 <= 0) return MGNNS_ERR_LAUNCH;
@@ -649,8 +664,8 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
         // at least one full round of tiles on every XCD (fewer: the 256 x 128 kernel fills the chip better) and a long K (measured:
         // 10 000 x 2048 with K = 1024 / 2048, the X.W products of configs[4], lose 20 % -- the fixed cost per tile counts there)
         if (nrb2 / 8 * nct2 >= per && N >= TN2 && Kp / BK >= 64 && workspace_bytes >= (size_t)8 * per * TM2 * TN2 * sizeof(float)) {
-            MG_DYN_LDS(gemm_bf16_nt_256_kernel, SMEM2_BYTES);
-            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(8 * per), dim3(512), SMEM2_BYTES, stream,
+            MG_DYN_LDS(gemm_bf16_nt_256_kernel, SMEM3_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(8 * per), dim3(512), SMEM3_BYTES, stream,
                                reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
                                ldc, act, nrb2, nct2, c_bf16, static_cast<float*>(workspace));
             MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(256)");
@@ -710,6 +725,12 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
 }
 
 // 256 workgroups x one part of 256 x 256 fp32 (the 256 x 256 kernel); the 256 x 128 kernel's K split uses the first half
+#ifdef MG_GEMM_TRACE
+extern "C" int mgnns_debug_gemm_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" size_t mgnns_gemm_bf16_workspace_bytes(void) { return (size_t)256 * TM2 * TN2 * sizeof(float); }
 
 extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,

@@ -34,4 +34,13 @@ for F in [int(a) for a in sys.argv[1:]] or [1024, 2048]:
         ds.append(a.elapsed_time(b) / 6 * 1e3)
     us = statistics.median(ds)
     print("F=%d: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (F, us, min(ds), 2.0 * n * n * F / us / 1e6 / 2.5e9 * 100), flush=True)
+    if os.environ.get("MGNNS_GEMM_TRACE") == "1":
+        import ctypes
+        from mgnns_amd import _lib
+        buf = (ctypes.c_ulonglong * 4)()
+        fn = _lib.lib().mgnns_debug_gemm_trace
+        fn.argtypes = [ctypes.c_void_p]
+        assert fn(ctypes.addressof(buf)) == 0
+        print("   s_memtime: workgroup 0: %d ticks for %d 32-wide slices (%.0f per slice); workgroup 100: %d for %d  => %.2f GHz if the launch is %.1f us"
+              % (buf[0], buf[1], buf[0] / max(1, buf[1]), buf[2], buf[3], buf[0] / (us * 1e3), us))
     del adjs, xts
