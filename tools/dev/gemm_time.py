@@ -33,7 +33,7 @@ for F in [int(a) for a in sys.argv[1:]] or [1024, 2048]:
         torch.cuda.synchronize()
         ds.append(a.elapsed_time(b) / 6 * 1e3)
     us = statistics.median(ds)
-    print("F=%d: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (F, us, min(ds), 2.0 * n * n * F / us / 1e6 / 2.5e9 * 100), flush=True)
+    print("F=%d: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (F, us, min(ds), 2.0 * n * n * F / (us * 1e-6) / 2.5e15 * 100), flush=True)
     if os.environ.get("MGNNS_GEMM_TRACE") == "1":
         import ctypes
         from mgnns_amd import _lib
