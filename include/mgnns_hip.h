@@ -463,11 +463,12 @@ int mgnns_layernorm_fwd(const float* x, int rows, int D, const float* gamma, con
  * elements.  N % 4 == 0, ldc % 4 == 0.  UTIL:421-426 (`adj @ support`), MODEL:52-58.
  */
 int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int ld, void* y, mgnns_stream_t stream);
-/* workspace (optional, mgnns_gemm_bf16_workspace_bytes() bytes, 16-byte aligned, its first 4 KB ZERO before the first launch --
- * the kernel leaves them zero --, one per concurrently running launch): with it, a last PARTIAL round of 256 x 128 tiles on the
- * persistent workgroups (10 000 x 1024 on 256 compute units: 320 tiles = 1.25 rounds) is cut along K over the idle workgroups,
- * partial sums meet in the workspace and the part that arrives last adds them in part order (deterministic) and stores C.
- * NULL: every tile is computed whole. */
+/* workspace (optional, mgnns_gemm_bf16_workspace_bytes() bytes, 16-byte aligned, one per concurrently running launch): with it, a
+ * last PARTIAL round of tiles on the persistent workgroups (10 000 x 1024 on 256 compute units: 320 tiles of 256 x 128 = 1.25 rounds)
+ * is cut along K over the idle workgroups, partial sums go to the workspace and a second, small launch on the same stream adds a
+ * tile's parts in part order (deterministic: no counters, nobody waits) and stores C; and products with K >= 4096 and at least one
+ * full round of 256 x 256 tiles per XCD run the 256 x 256-tile kernel (a third less L2 traffic per MAC), whose left-over tiles are
+ * cut the same way.  NULL: every tile is computed whole by the 256 x 128 kernel. */
 size_t mgnns_gemm_bf16_workspace_bytes(void);
 int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
                            int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
