@@ -1060,6 +1060,8 @@ def run_rank(args):
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
+    if hasattr(model, "resolve_schedule"):      # segment -> stream schedule of the timed forward (mgnns_amd/model.py::SCHEDULES)
+        line["config"]["schedule"] = model.resolve_schedule(B)
     try:            # the placement assumption of the slab / row-range kernels (speed only), measured on this device
         ok, ids = _lib.xcd_probe()
         line["config"]["xcd_map"] = {"blockIdx_and_7_selects_the_xcd": ok, "xcc_id_per_residue": ids}

@@ -203,7 +203,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         self._lstm_cache = ops.LstmCache()     # derived LSTM weight forms live and die with this module
         self._streams = None
         self.use_streams = bool(opt.get('use_streams', True))
-        # 'auto': 'channels' for batches of at least 128 samples, 'channels2' below (resolve_schedule)
+        # 'auto': 'place_bank_first' for batches of at least 128 samples, 'channels2' below (resolve_schedule)
         self.schedule = opt.get('schedule', os.environ.get('MGNNS_SCHEDULE', 'auto'))
         # the classifier as four shares behind the four stacks instead of a segment of its own (forward_plan)
         self.split_head = os.environ.get('MGNNS_SPLIT_HEAD', '1') == '1'
@@ -626,11 +626,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
 
     def resolve_schedule(self, batch, schedule=None):
         """Name of the schedule a forward of `batch` samples runs.  'auto': at 128 samples and more the chip-filling kernels
-        decide and 'channels' is best; below, the BiLSTM chain on the caller's stream is the longest segment and 'channels2'
-        (no text->image stack queued behind it) wins: 0.424 vs 0.437 ms at B=32, 0.457 vs 0.481 at B=64, equal at B=256."""
+        decide: 'place_bank_first' -- 'channels' with the place channel's memory bank in FRONT of its label GCN (the longest head of a
+        channel's chain, C = 365).  Round 3 measured no difference to 'channels'; with round 4's kernels (three alternating runs on
+        one box, B = 256): 0.647-0.654 against 0.665-0.673 ms with two forwards in flight, 0.690-0.703 against 0.717-0.721 one at a
+        time; equal at B = 128 (0.502 / 0.503).  Below 128 the BiLSTM chain on the caller's stream is the longest segment and
+        'channels2' (no text->image stack queued behind it) wins: 0.381 vs 0.390 / 0.394 ms at B = 32, 0.412 vs 0.413 / 0.424 at
+        B = 64 ('channels' / 'place_bank_first')."""
         name = schedule or self.schedule
         if name == 'auto':
-            name = 'channels' if batch >= 128 else 'channels2'
+            name = 'place_bank_first' if batch >= 128 else 'channels2'
         if name not in self.SCHEDULES:
             raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
         return name
