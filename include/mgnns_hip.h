@@ -117,6 +117,24 @@ int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
 size_t mgnns_bilstm_bf16_prepack_bytes(int hidden, int num_layers);
 int mgnns_bilstm_bf16_prepack(const float* const* w_ih_cat, const float* const* w_hh, int emb_dim, int hidden, int num_layers,
                               void* packed, mgnns_stream_t stream);
+/* The layer-0 input projection FOLDED into the embedding table (weights only, once per weight version; MODEL:366-398: the embedding
+ * lookup feeds nn.LSTM's first W_ih and nothing else):
+ *   table[v, :] = bf16(emb_table[v, :]) . bf16(w_ih_cat0)^T + b_ih_cat0     [V, 2 * 4 * hidden] fp32 (mgnns_bilstm_bf16_table_bytes)
+ * by the same bf16 GEMM the forward would run on its gathered rows (same k order per element: bit-identical rows).
+ * mgnns_bilstm_bf16_table_fwd = mgnns_bilstm_bf16_fwd reading its layer-0 projection rows out of `gx_table` by token id: no
+ * gather / cast of embedding rows and no GEMM in front of the first recurrence.  workspace of the fold:
+ * mgnns_bilstm_bf16_fold_workspace_bytes(V) bytes (the bf16 copies of the table and of W_ih). */
+size_t mgnns_bilstm_bf16_table_bytes(int V, int hidden);
+size_t mgnns_bilstm_bf16_fold_workspace_bytes(int V);
+int mgnns_bilstm_bf16_fold_embedding(const float* emb_table, int V, int emb_dim, int hidden, const float* w_ih_cat0,
+                                     const float* b_ih_cat0, void* workspace, size_t workspace_bytes, float* table,
+                                     mgnns_stream_t stream);
+int mgnns_bilstm_bf16_table_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
+                     const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
+                     const float* const* w_ih_cat, const float* const* b_ih_cat,
+                     const float* const* w_hh, const float* const* b_hh,
+                     void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16, const void* prepacked,
+                     const float* gx_table, mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c = ctypes
 _P = _c.c_void_p
@@ -24,6 +24,8 @@ SIGNATURES = {
     "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P],
     "mgnns_bilstm_bf16_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P],
     "mgnns_bilstm_bf16_prepack": [_PP, _PP, _I, _I, _I, _P, _P],
+    "mgnns_bilstm_bf16_fold_embedding": [_P, _I, _I, _I, _P, _P, _P, _SZ, _P, _P],
+    "mgnns_bilstm_bf16_table_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
@@ -103,6 +105,8 @@ SIZE_GETTERS = {
     "mgnns_sq_mha_folded_workspace_bytes": [_I, _I, _I],
     "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
     "mgnns_bilstm_bf16_prepack_bytes": [_I, _I],
+    "mgnns_bilstm_bf16_table_bytes": [_I, _I],
+    "mgnns_bilstm_bf16_fold_workspace_bytes": [_I],
     "mgnns_label_gcn_scratch_bytes": [_I, _I, _I],
     "mgnns_mha_tail_c16_scratch_floats": [_I, _I],
 }

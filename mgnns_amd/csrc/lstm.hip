@@ -375,6 +375,7 @@ __global__ __launch_bounds__(PREP_THR) void lstm_prep_kernel(const int64_t* __re
         pack_tok[off + t] = s_tok[t];
         pack_pos[off + t] = b * T + t;
     }
+    if (!Xb) return;                                                 // folded layer-0 projection: the recurrence reads the table by token id
     // gather + cast: (row, 8-column chunk) items, four in flight per thread
     constexpr int per = XKP / 8;
     const int items = len * per;
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                                                              const float* __restrict__ bhh_f, const float* __restrict__ bhh_b,
                                                              const int32_t* __restrict__ order, float* __restrict__ out,
                                                              unsigned short* __restrict__ out_bf16, int ld_bf16, int och,
-                                                             unsigned short* __restrict__ next_x, int* __restrict__ queue) {
+                                                             unsigned short* __restrict__ next_x, int* __restrict__ queue,
+                                                             const int32_t* __restrict__ tok_idx) {
     __shared__ __attribute__((aligned(16))) unsigned short s_h[2][MH];
     __shared__ int s_rank;
     extern __shared__ __attribute__((aligned(16))) float s_out[];       // [och][HPAD]: the h rows of a whole chain (och = min(T, 200))
@@ -475,14 +477,32 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
         // input-projection rows of the next three steps in flight; the loads are UNCONDITIONAL (index clamped to the last
         // step; padding lanes read row 0 of their gate) so that the compiler knows how many are outstanding and waits with
         // vmcnt(2) instead of vmcnt(0) -- behind a burst of output stores a vmcnt(0) costs a store round trip
-        const float* gx_base = Gx + (size_t)off * (2 * G4) + dir * G4 + row;
+        // Row of the input projection for step st: row off + t of Gx -- or, with the layer-0 projection FOLDED into the embedding table
+        // (tok_idx != nullptr: Gx is the [V, 2 * 4H] table emb . W_ih^T + b_ih, one row per vocabulary entry), row tok_idx[off + t].
+        // The chain's token ids sit in a register, 64 steps per lane (one global load per 64 steps), and reach the scalar side by
+        // v_readlane; the load itself takes the row as a scalar base + this lane's constant column offset.
         const int lm1 = len > 0 ? len - 1 : 0;
+        const unsigned gx_col = (unsigned)((dir * G4 + row) * sizeof(float));
+        int tk_blk = -1;
+        int vtok = 0;
         // (through inline asm, waited for by hand: the compiler's own bookkeeping put s_waitcnt vmcnt(0) at the top of the loop --
         //  whatever the loop's shape -- i.e. a wait for the load issued one step earlier)
         auto gx_load = [&](int st, float& dst) __attribute__((always_inline)) {
             const int sc = st < lm1 ? st : lm1;
-            const float* p = gx_base + (size_t)(dir ? lm1 - sc : sc) * (2 * G4);
-            asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+            long long r;
+            if (tok_idx) {
+                if ((sc >> 6) != tk_blk) {                         // (uniform, once per 64 steps)
+                    tk_blk = sc >> 6;
+                    const int sl = tk_blk * 64 + lane, slc = sl < lm1 ? sl : lm1;
+                    vtok = tok_idx[off + (dir ? lm1 - slc : slc)];
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(vtok)::"memory");
+                }
+                r = __builtin_amdgcn_readlane(vtok, sc & 63);
+            } else {
+                r = off + (dir ? lm1 - sc : sc);
+            }
+            const float* p = Gx + (size_t)r * (2 * G4);            // wave-uniform
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(gx_col), "s"(p) : "memory");
         };
         // three registers, three steps per trip of the loop, NO rotation: a rotation (gx = gx1; gx1 = gx2; gx2 = load) moves the
         // register the newest load writes, so every step waited for the load issued one step earlier (vmcnt(0)): the
@@ -651,7 +671,7 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
                        int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                        const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                        void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                       mgnns_stream_t stream) {
+                       mgnns_stream_t stream, const float* gx_table = nullptr) {
     MG_REQUIRE(tok && lens && emb_table && w_ih_cat && w_hh && b_ih_cat && b_hh && workspace && out,
                "mgnns_bilstm_fwd: null pointer");
     MG_REQUIRE(!out_bf16 || (ld_bf16 >= 2 * hidden && ld_bf16 % 8 == 0), "mgnns_bilstm_fwd: bad bf16 row length %d", ld_bf16);
@@ -695,9 +715,11 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
 
     // bf16 mode, up to 1024 samples of up to 1024 tokens: pack + fill + the layer-0 gather as one launch
     const bool prep_fused = bf16_rec && B <= 1024 && T <= PREP_MAXT && emb_dim % 4 == 0 && emb_dim <= XKP;
+    // folded layer-0 projection (mgnns_bilstm_bf16_fold_embedding): no gather, no GEMM -- the recurrence reads table rows by token id
+    const bool folded = gx_table && prep_fused;
     if (prep_fused) {
         hipLaunchKernelGGL(lstm_prep_kernel, dim3(B), dim3(PREP_THR), 0, s, tok, lens, B, T, V, emb_table, emb_dim, offs, order, pack_tok,
-                           pack_pos, xb);
+                           pack_pos, folded ? (unsigned short*)nullptr : xb);
     } else {
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
         hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
@@ -710,7 +732,9 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
         // both directions' input projections in one GEMM: W_ih = [forward ; reverse] stacked to [2*4H, in]
         const unsigned char* pp = prepacked ? reinterpret_cast<const unsigned char*>(prepacked) + (size_t)layer * (prepack_whh_bytes() + prepack_wih_bytes())
                                             : nullptr;
-        if (bf16_rec && K % 4 == 0 && K <= XKP) {
+        if (folded && layer == 0) {
+            // nothing to compute: Gx of this layer is the table
+        } else if (bf16_rec && K % 4 == 0 && K <= XKP) {
             // bf16 mode: the projection on the dense bf16 GEMM (bf16 operands, fp32 accumulation and output): 8 us instead of 42.
             // Layer 0 gathers + casts the embedding rows; the later layers find their operand written by the recurrence below.
             if (layer == 0 && !prep_fused)
@@ -728,10 +752,12 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
             const uint2* whh = packed;
             if (pp) whh = reinterpret_cast<const uint2*>(pp);
             else hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(MKS, 2), dim3(MTHR), 0, s, w_hh[2 * layer], w_hh[2 * layer + 1], packed);
-            hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), (size_t)och * HPAD * sizeof(float), s, (const float*)Gx,
-                               (const int32_t*)offs, lens, B, T, whh, b_hh[2 * layer], b_hh[2 * layer + 1], (const int32_t*)order, dst,
-                               obf, ld_bf16, och, (layer + 1 < num_layers && 2 * HID <= XKP) ? xb : (unsigned short*)nullptr,
-                               order + B + 2 * layer);
+            const bool tab = folded && layer == 0;
+            hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3(grid_rec), dim3(MTHR), (size_t)och * HPAD * sizeof(float), s,
+                               tab ? gx_table : (const float*)Gx, (const int32_t*)offs, lens, B, T, whh, b_hh[2 * layer], b_hh[2 * layer + 1],
+                               (const int32_t*)order, dst, obf, ld_bf16, och,
+                               (layer + 1 < num_layers && 2 * HID <= XKP) ? xb : (unsigned short*)nullptr, order + B + 2 * layer,
+                               tab ? (const int32_t*)pack_tok : (const int32_t*)nullptr);
         }
         else
             hipLaunchKernelGGL(lstm_rec_kernel, dim3(2 * B), dim3(REC_THREADS), 0, s, (const float*)Gx, (const int32_t*)offs, lens,
@@ -758,4 +784,37 @@ extern "C" int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, in
                                      const void* prepacked, mgnns_stream_t stream) {
     return bilstm_impl(true, prepacked, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
                        workspace_bytes, out, out_bf16, ld_bf16, stream);
+}
+
+// ---- the layer-0 input projection folded into the embedding table (weights only: once per weight version) -------------------
+// Gx0[row] = bf16(emb[tok[row]]) . bf16(W_ih0)^T + b_ih0 depends on the token id alone: table[v] = bf16(emb[v]) . bf16(W_ih0)^T + b_ih0
+// for every vocabulary entry ([V, 2 * 4H] fp32: 97 MB for V = 20 154) is computed ONCE by the same GEMM (same k order per element:
+// the rows of the forward come out bit for bit), and a forward reads its rows by token id: no gather / cast of embedding rows, no
+// GEMM in front of the first recurrence -- 15-19 us off the head of the chain the forward follows.
+extern "C" size_t mgnns_bilstm_bf16_table_bytes(int V, int hidden) { return (size_t)(V > 0 ? V : 0) * 8 * (size_t)hidden * sizeof(float); }
+extern "C" size_t mgnns_bilstm_bf16_fold_workspace_bytes(int V) {
+    return (((size_t)(V > 0 ? V : 0) + 8 * (size_t)HID) * XKP * sizeof(unsigned short) + 255) & ~(size_t)255;
+}
+extern "C" int mgnns_bilstm_bf16_fold_embedding(const float* emb_table, int V, int emb_dim, int hidden, const float* w_ih_cat0,
+                                                const float* b_ih_cat0, void* workspace, size_t workspace_bytes, float* table,
+                                                mgnns_stream_t stream) {
+    MG_REQUIRE(emb_table && w_ih_cat0 && b_ih_cat0 && workspace && table, "mgnns_bilstm_bf16_fold_embedding: null pointer");
+    MG_REQUIRE(hidden == HID && V > 0 && emb_dim > 0 && emb_dim <= XKP && emb_dim % 4 == 0,
+               "mgnns_bilstm_bf16_fold_embedding: unsupported hidden=%d V=%d emb_dim=%d", hidden, V, emb_dim);
+    MG_REQUIRE(workspace_bytes >= mgnns_bilstm_bf16_fold_workspace_bytes(V), "mgnns_bilstm_bf16_fold_embedding: workspace too small (%zu < %zu)",
+               workspace_bytes, mgnns_bilstm_bf16_fold_workspace_bytes(V));
+    unsigned short* eb = reinterpret_cast<unsigned short*>(workspace);
+    unsigned short* wb = eb + (size_t)V * XKP;
+    if (int rc = mgnns_cast_pad_bf16(emb_table, V, emb_dim, XKP, eb, stream)) return rc;
+    if (int rc = mgnns_cast_pad_bf16(w_ih_cat0, 2 * G4, emb_dim, XKP, wb, stream)) return rc;
+    return mg_launch_gemm_bf16(eb, wb, V, 2 * G4, XKP, b_ih_cat0, table, 2 * G4, MGNNS_ACT_NONE, nullptr, (hipStream_t)stream, 0, nullptr, 0);
+}
+extern "C" int mgnns_bilstm_bf16_table_fwd(const int64_t* tok, const int64_t* lens, int B, int T, const float* emb_table, int V,
+                                           int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
+                                           const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
+                                           void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
+                                           const void* prepacked, const float* gx_table, mgnns_stream_t stream) {
+    MG_REQUIRE(gx_table, "mgnns_bilstm_bf16_table_fwd: null table (mgnns_bilstm_bf16_fold_embedding makes it)");
+    return bilstm_impl(true, prepacked, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
+                       workspace_bytes, out, out_bf16, ld_bf16, stream, gx_table);
 }

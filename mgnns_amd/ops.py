@@ -552,6 +552,7 @@ class LstmCache:
     def __init__(self):
         self.cat = None        # (sources, versions, value)
         self.prepack = None
+        self.table = None      # the layer-0 input projection folded into the embedding table
 
     @staticmethod
     def _hit(entry, sources):
@@ -574,12 +575,40 @@ def _lstm_cat(weights, num_layers, cache):
     return val
 
 
-def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32", cache=None):
+# bf16 recurrence: the layer-0 input projection folded into the embedding table once per weight version (mgnns_bilstm_bf16_fold_embedding:
+# [V, 8 * hidden] fp32, 97 MB for V = 20 154); MGNNS_LSTM_FOLD=0: the projection GEMM on the gathered rows in every forward
+LSTM_FOLD_EMBEDDING = os.environ.get("MGNNS_LSTM_FOLD", "1") != "0"
+
+
+def _lstm_table(emb_table, cat0, hidden, cache):
+    """table[v] = bf16(emb[v]) . bf16(W_ih0)^T + b_ih0 for every vocabulary entry; rebuilt when the embedding or layer 0's input
+    weights change.  Superseded tables go to the retirement list (a captured graph may still read them)."""
+    src = [emb_table, cat0[0], cat0[1]]
+    if cache is not None and LstmCache._hit(cache.table, src):
+        return cache.table[2]
+    L = _lib.lib()
+    V, E = emb_table.shape
+    table = torch.empty(V, 8 * hidden, device=emb_table.device, dtype=torch.float32)
+    assert table.numel() * 4 == L.mgnns_bilstm_bf16_table_bytes(V, hidden)
+    ws = torch.empty(L.mgnns_bilstm_bf16_fold_workspace_bytes(V), dtype=torch.uint8, device=emb_table.device)
+    _lib.check(L.mgnns_bilstm_bf16_fold_embedding(_p(emb_table), V, E, hidden, _p(cat0[0]), _p(cat0[1]), _p(ws), ws.numel(), _p(table),
+                                                  _stream()), "mgnns_bilstm_bf16_fold_embedding")
+    if cache is not None:
+        if cache.table is not None:
+            retire(cache.table[2])
+        cache.table = (src, tuple(t._version for t in src), table)
+    return table
+
+
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32", cache=None, fold=None):
     """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
     (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length
     (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16).  recurrence="bf16": W_hh . h of every step on the
     bf16 MFMA (bf16 operands, fp32 accumulation and state) instead of the exact fp32 GEMV.
-    cache: an LstmCache owned by the module that owns `weights` (None: derived weight forms are rebuilt per call)."""
+    cache: an LstmCache owned by the module that owns `weights` (None: derived weight forms are rebuilt per call).
+    fold (bf16 recurrence; default LSTM_FOLD_EMBEDDING when a cache is given): read the layer-0 input projection out of the
+    table folded from the embedding and W_ih once per weight version -- the same rows bit for bit, no GEMM in front of the first
+    recurrence."""
     import ctypes
     _chk(tok, "text", torch.int64, 2)
     _chk(lens, "text_lens", torch.int64, 1)
@@ -626,9 +655,17 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
                        "mgnns_bilstm_bf16_prepack")
             if cache is not None:
                 cache.prepack = (src, tuple(t._version for t in src), pre)
-        _launch("mgnns_bilstm_bf16_fwd", ("mgnns_bilstm_bf16_fwd",), L.mgnns_bilstm_bf16_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
-                emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
-                _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _stream())
+        if fold is None:
+            fold = LSTM_FOLD_EMBEDDING and cache is not None
+        if fold and B <= 1024 and T <= 1024 and emb_table.shape[1] % 4 == 0 and emb_table.shape[1] <= 320:
+            table = _lstm_table(emb_table, cat[0], hidden, cache)
+            _launch("mgnns_bilstm_bf16_table_fwd", ("mgnns_bilstm_bf16_table_fwd",), L.mgnns_bilstm_bf16_table_fwd, _p(tok), _p(lens), B, T,
+                    _p(emb_table), emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
+                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _p(table), _stream())
+        else:
+            _launch("mgnns_bilstm_bf16_fwd", ("mgnns_bilstm_bf16_fwd",), L.mgnns_bilstm_bf16_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
+                    emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
+                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _stream())
     return (out, out_bf) if want_bf16 else out
 
 

@@ -1201,6 +1201,52 @@ def test_bilstm_bf16_mfma_recurrence_vs_fp32_recurrence():
             assert (o1 - r1).abs().max().item() < 5e-3 and (o1b[:, :, :2 * Hh].float() - o1).abs().max().item() <= 2.0 ** -8
 
 
+def test_bilstm_bf16_layer0_projection_folded_into_the_embedding_table():
+    """bf16 recurrence with the layer-0 input projection read out of table[v] = bf16(emb[v]) . bf16(W_ih0)^T + b_ih0 (folded once per
+    weight version, mgnns_bilstm_bf16_fold_embedding) against the projection GEMM on the gathered rows in every forward: the same bank
+    BIT FOR BIT (the GEMM adds an element's k terms in the same order whichever row it sits in), ragged / empty / clamped ids, one
+    and two layers, long texts (more than 64 steps: the token ids travel 64 per register), and the table follows a weight update."""
+    import numpy as np
+    rs = np.random.RandomState(11)
+    for B, T in ((37, 100), (256, 100), (5, 24), (3, 230)):
+        V, E, Hh = 700, 300, 150
+        lens = rs.randint(1, T + 1, size=B)
+        lens[0], lens[-1] = T, 1
+        if B == 5:
+            lens[1] = 0
+        tok = np.zeros((B, T), np.int64)
+        for b in range(B):
+            tok[b, :lens[b]] = rs.randint(1, V, size=lens[b])
+        if B == 5:
+            tok[2, 0], tok[3, 1] = V + 7, -3
+        emb = torch.from_numpy((0.4 * rs.standard_normal((V, E))).astype(np.float32)).to(DEV)
+        weights = []
+        for layer in range(2):
+            for d in range(2):
+                ind = E if layer == 0 else 2 * Hh
+                weights.append(tuple(torch.from_numpy(rs.uniform(-0.08, 0.08, size=s).astype(np.float32)).to(DEV)
+                                     for s in ((4 * Hh, ind), (4 * Hh, Hh), (4 * Hh,), (4 * Hh,))))
+        t, l = torch.from_numpy(tok).to(DEV), torch.from_numpy(lens.astype(np.int64)).to(DEV)
+        for nl in (2, 1):
+            w = weights[:2 * nl]
+            cache = ops.LstmCache()
+            ref, ref_bf = ops.bilstm(t, l, emb, w, Hh, nl, want_bf16=True, recurrence="bf16", cache=cache, fold=False)
+            out, out_bf = ops.bilstm(t, l, emb, w, Hh, nl, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
+            assert cache.table is not None and tuple(cache.table[2].shape) == (V, 8 * Hh)
+            assert torch.equal(out, ref) and torch.equal(out_bf, ref_bf), (B, T, nl)
+            again, _ = ops.bilstm(t, l, emb, w, Hh, nl, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
+            assert torch.equal(again, out)
+        if B == 37:                                                # a weight update: the table is rebuilt from the new version
+            cache = ops.LstmCache()
+            a0, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
+            first = cache.table[2]
+            with torch.no_grad():
+                emb.mul_(1.25)
+            a1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
+            b1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=ops.LstmCache(), fold=False)
+            assert cache.table[2] is not first and torch.equal(a1, b1) and not torch.equal(a1, a0)
+
+
 @pytest.mark.parametrize("B,P,N", [(5, 196, 300), (2, 100, 300), (3, 224, 304), (1, 112, 17)])
 def test_imgbank_pool_split_vs_fp64(B, P, N):
     """Split-bf16 image bank (csrc/imgbank_split.hip): bank within fp32-class error of fp64 (three bf16 MFMAs per product:
