@@ -943,6 +943,18 @@ def run_rank(args):
                     "same step with K and V projected from the memory bank as the reference does (csrc/sq_mha_bf16.hip: the kernel "
                     "the >= 40 % MFMA target is quoted on; its rows in roofline_all)", in_flight=max(1, args.in_flight))
             model.set_attention(args.attn)
+            if args.dtype == "bf16" and ops.LSTM_FOLD_EMBEDDING:
+                # the headline reads the BiLSTM's layer-0 input projection out of a table folded from the embedding and W_ih once per
+                # weight version (weights only: DESIGN 3); the same step with the projection GEMM on the gathered rows in every forward
+                ops.LSTM_FOLD_EMBEDDING = False
+                try:
+                    variants["lstm layer-0 projection computed per forward (MGNNS_LSTM_FOLD=0)"] = graphed_variant(
+                        model, call, B, args.steps, args.warmup,
+                        "same step, the BiLSTM's first input projection as a bf16 GEMM on the gathered embedding rows instead of rows of "
+                        "the table emb . W_ih^T + b_ih (computed once per weight version; the text bank is bit-identical either way: "
+                        "tests/test_ops_gpu.py)", in_flight=max(1, args.in_flight))
+                finally:
+                    ops.LSTM_FOLD_EMBEDDING = True
             if args.dtype == "bf16":
                 model.set_precision("fp32")
                 variants["dtype=f32 (parity-grade)"] = graphed_variant(
@@ -1062,6 +1074,9 @@ def run_rank(args):
     line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
     if hasattr(model, "resolve_schedule"):      # segment -> stream schedule of the timed forward (mgnns_amd/model.py::SCHEDULES)
         line["config"]["schedule"] = model.resolve_schedule(B)
+    if args.dtype == "bf16":
+        line["config"]["lstm_layer0_projection"] = ("rows of the table emb . W_ih^T + b_ih folded once per weight version (weights only)"
+                                                    if ops.LSTM_FOLD_EMBEDDING else "bf16 GEMM on the gathered rows, every forward")
     try:            # the placement assumption of the slab / row-range kernels (speed only), measured on this device
         ok, ids = _lib.xcd_probe()
         line["config"]["xcd_map"] = {"blockIdx_and_7_selects_the_xcd": ok, "xcc_id_per_residue": ids}
