@@ -494,7 +494,10 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
                 if ((sc >> 6) != tk_blk) {                         // (uniform, once per 64 steps)
                     tk_blk = sc >> 6;
                     const int sl = tk_blk * 64 + lane, slc = sl < lm1 ? sl : lm1;
-                    vtok = tok_idx[off + (dir ? lm1 - slc : slc)];
+                    // an EMPTY chain has no packed row: off == offs[b + 1] may be the total, a slot prep never wrote (a
+                    // trailing zero-length sample of a padded partial batch) -- it reads table row 0, whose value no output sees
+                    vtok = 0;
+                    if (len > 0) vtok = tok_idx[off + (dir ? lm1 - slc : slc)];
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(vtok)::"memory");
                 }
                 r = __builtin_amdgcn_readlane(vtok, sc & 63);

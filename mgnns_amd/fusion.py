@@ -62,7 +62,7 @@ def make_mask_plan(mask, precision='bf16', attention='faithful'):
     workgroup), or None where it does not apply.  Depends on the mask's VALUES only; whoever passes it to run_stack(plan=...)
     orders the launch that built it in front of the stack (an event if it ran on another stream)."""
     if (precision == 'bf16' and attention == 'faithful' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask is not None
-            and mask.shape[-1] <= ops.PLAN_MAX_L and not FUSED_LAYER):
+            and mask.shape[-1] <= ops.PLAN_MAX_L and mask.shape[0] <= ops.PLAN_MAX_B and not FUSED_LAYER):
         return ops.sq_mha_plan(mask.reshape(mask.shape[0], -1).float().contiguous())
     return None
 

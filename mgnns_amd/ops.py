@@ -953,6 +953,9 @@ def sq_mha_plan(mask):
     build it once per batch, every attention launch on that mask takes it."""
     _chk(mask, "mask", ndim=2)
     B, L_ = mask.shape
+    if B > PLAN_MAX_B:
+        raise ValueError("sq_mha_plan: batch %d beyond the plan kernel's limit %d (fusion.make_mask_plan falls back to the "
+                         "one-workgroup-per-sample core)" % (B, PLAN_MAX_B))
     L = _lib.lib()
     plan = torch.empty(L.mgnns_sq_mha32_plan_ints(B), dtype=torch.int32, device=mask.device)
     _lib.check(L.mgnns_sq_mha32_plan(_p(mask), B, L_, _p(plan), _stream()), "mgnns_sq_mha32_plan")
@@ -960,6 +963,7 @@ def sq_mha_plan(mask):
 
 
 PLAN_MAX_L = 128
+PLAN_MAX_B = 4096          # mgnns_sq_mha32_plan: one workgroup scans the batch ((8 B + 4) * 4 bytes of LDS)
 
 
 def cast_pad_bf16(x, ld=BANK_LD):
@@ -991,8 +995,10 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     if form == 32:
         if plan is not None:
             _chk(plan, "plan", torch.int32, 1)
-            if mask is None or L_ > PLAN_MAX_L or plan.numel() < L.mgnns_sq_mha32_plan_ints(B):
-                raise ValueError("a packing plan needs a mask, L <= %d and %d ints" % (PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
+            # (4 + 6 B ints: the size names the batch the plan was built for -- a plan of another batch is refused here)
+            if mask is None or L_ > PLAN_MAX_L or plan.numel() != L.mgnns_sq_mha32_plan_ints(B):
+                raise ValueError("a packing plan needs a mask, L <= %d and exactly %d ints (a plan built for this batch size)"
+                                 % (PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
         _launch("mgnns_sq_mha_core_bf16_fwd", ("mgnns_sq_mha_core_bf16_fwd", L_, mask is not None),
                 L.mgnns_sq_mha32_core_bf16_fwd, _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk),
                 _p(bv), _p(o), _p(attn), _p(plan), _stream())
@@ -1266,11 +1272,13 @@ _gemm_bf16_ws = {}
 
 def _gemm_bf16_workspace(device):
     """Partial-sum slots + arrival counters of the dense bf16 GEMM's last-round K split: one buffer per (device, capture epoch,
-    stream) -- launches on one stream are ordered, a captured graph may replay next to anything -- counters zero from the pool."""
+    stream) -- launches on one stream are ordered, a captured graph may replay next to anything.  The K split is a two-launch scheme
+    (partial sums, then a fix-up launch that reads exactly the slots the first wrote): no counters, nothing to zero, so the buffer
+    is plain torch.empty (64 MB from the zero pool would be a fresh torch.zeros + stream synchronise per request)."""
     key = (str(device),) + _scratch_key()
     ws = _gemm_bf16_ws.get(key)
     if ws is None:
-        ws = zeros_bytes(_lib.lib().mgnns_gemm_bf16_workspace_bytes(), device)
+        ws = torch.empty(_lib.lib().mgnns_gemm_bf16_workspace_bytes(), dtype=torch.uint8, device=device)
         _gemm_bf16_ws[key] = ws
         if key[1]:
             _EPOCH_SLOTS.setdefault(key[1], []).append((_gemm_bf16_ws, key))

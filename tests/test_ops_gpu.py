@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from mgnns_amd import ops, synth
+from mgnns_amd import _lib, ops, synth
 from oracle import golden_inputs as GI
 from oracle import restatement as R
 from tests import helpers as H
@@ -1245,6 +1245,46 @@ def test_bilstm_bf16_layer0_projection_folded_into_the_embedding_table():
             a1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
             b1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=ops.LstmCache(), fold=False)
             assert cache.table[2] is not first and torch.equal(a1, b1) and not torch.equal(a1, a0)
+
+
+def test_bilstm_trailing_empty_samples_never_index_the_table_with_unwritten_tokens():
+    """A padded partial batch (batching.BatchAssembler: trailing rows with lens == 0): the offset of an empty sample at the END of the
+    batch is the total, a slot of pack_tok that prep never writes.  The workspace is poisoned with 0x7f bytes (the caching allocator
+    hands the freed block back): the folded-table recurrence must not use that slot as a table row (0x7f7f7f7f * 4800 B is far
+    outside the table), the bank of the empty samples is zero and the live samples equal the same samples run alone, bit for bit."""
+    import numpy as np
+    rs = np.random.RandomState(23)
+    V, E, Hh = 700, 300, 150
+    emb = torch.from_numpy((0.4 * rs.standard_normal((V, E))).astype(np.float32)).to(DEV)
+    weights = []
+    for layer in range(2):
+        for d in range(2):
+            ind = E if layer == 0 else 2 * Hh
+            weights.append(tuple(torch.from_numpy(rs.uniform(-0.08, 0.08, size=s).astype(np.float32)).to(DEV)
+                                 for s in ((4 * Hh, ind), (4 * Hh, Hh), (4 * Hh,), (4 * Hh,))))
+    L = _lib.lib()
+    for B, T, n_empty in ((8, 24, 3), (64, 100, 17), (2, 70, 1)):
+        lens = rs.randint(1, T + 1, size=B)
+        lens[0] = T
+        lens[B - n_empty:] = 0
+        tok = np.zeros((B, T), np.int64)
+        for b in range(B):
+            tok[b, :lens[b]] = rs.randint(1, V, size=lens[b])
+        t, l = torch.from_numpy(tok).to(DEV), torch.from_numpy(lens.astype(np.int64)).to(DEV)
+        live = B - n_empty
+        for fold in (True, False):
+            cache = ops.LstmCache()
+            alone, alone_bf = ops.bilstm(t[:live].contiguous(), l[:live].contiguous(), emb, weights, Hh, 2, want_bf16=True,
+                                         recurrence="bf16", cache=cache, fold=fold)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                poison = torch.full((max(L.mgnns_bilstm_workspace_bytes(B, T, Hh, 2), 16),), 0x7f, dtype=torch.uint8, device=DEV)
+                torch.cuda.synchronize()
+                del poison
+                out, out_bf = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=fold)
+                torch.cuda.synchronize()
+                assert (out[live:] == 0).all() and (out_bf[live:] == 0).all()
+                assert torch.equal(out[:live], alone) and torch.equal(out_bf[:live], alone_bf), (B, T, fold)
 
 
 @pytest.mark.parametrize("B,P,N", [(5, 196, 300), (2, 100, 300), (3, 224, 304), (1, 112, 17)])
