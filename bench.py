@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="mvsa_multiple_b256")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="which figure is the headline `value` at N>1 (both are always measured)")
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "bf16x3"],
                     help="bf16 = BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate); f32 = exact-f32 MFMA parity path")
     ap.add_argument("--attn", default="faithful", choices=["auto", "faithful", "folded"],
                     help="fusion attention: faithful = K/V projected from the memory bank as the reference does (the headline: the "
@@ -764,13 +764,13 @@ def run_rank(args):
     A_obj, A_place = harness.synthetic_adjacencies(cfg)
     label_query = synth.make_inputs(cfg, B=1, seed=cfg.seed, pmi=pmi)["label_query"]
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, label_query, dev)
-    model.set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    model.set_precision({"bf16": "bf16", "bf16x3": "bf16x3"}.get(args.dtype, "fp32"))
     model.set_attention(args.attn)
     attn = model.attention                         # 'auto' resolved: folded in bf16 mode, faithful in fp32 mode
     folded_c16 = attn == "folded" and args.dtype == "bf16"      # the composed-map kernels (sq_mha_folded_bf16.hip + the c16 tail)
     if args.single_stream:
         model.use_streams = False
-    core = "mgnns_sq_mha_core_bf16_fwd" if args.dtype == "bf16" else "mgnns_sq_mha_core_fwd"
+    core = {"bf16": "mgnns_sq_mha_core_bf16_fwd", "bf16x3": "mgnns_sq_mha_core_split_fwd"}.get(args.dtype, "mgnns_sq_mha_core_fwd")
     if attn == "folded":
         core = "mgnns_sq_mha_folded_bf16_fwd" if folded_c16 else "mgnns_sq_mha_folded_fwd"
 
@@ -967,6 +967,15 @@ def run_rank(args):
                     "same step with every heavy product in split-bf16 (bf16 hi + lo operands, three bf16 MFMAs per product, fp32 "
                     "accumulation: image banks, label GCN, channel and layer tails), exact fp32 LSTM and the exact-fp32 folded "
                     "attention: inside the 1e-4 logit gate (tests/test_model_gpu.py) without the exact-f32 MFMA's 1/16 rate")
+                model.set_precision("bf16x3").set_attention("faithful")
+                variants["dtype=bf16x3 + faithful attention (parity-grade, the reference's formulation)"] = graphed_variant(
+                    model, call, B, args.steps, args.warmup,
+                    "same step, split-bf16 everywhere as above but K and V PROJECTED from the memory bank as the reference does "
+                    "(models/submodules.py:55-119) on the split-bf16 attention core (csrc/sq_mha_split_bf16.hip: hi + lo operands, "
+                    "three bf16 MFMAs per product = 3 x the 61.86 GFLOP of a launch executed, bank rows in two halves joined by an "
+                    "online-softmax merge): the reference's own formulation inside the 1e-4 logit gate "
+                    "(tests/test_model_gpu.py::test_bf16x3_mode_stays_inside_the_parity_gate[*-faithful])",
+                    in_flight=max(1, args.in_flight))
                 model.set_precision("bf16").set_attention(args.attn)
         # the per-GPU shards of a strong-scaling run (global batch 256 over 2 / 4 / 8 GPUs), measured here on one GPU: what the
         # 1 -> 8 curve of configs[3] is bounded by while no multi-GPU node has run it

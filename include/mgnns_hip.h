@@ -343,6 +343,25 @@ int mgnns_sq_mha32_core_bf16_fwd(const float* qh, const void* bank_bf16, const f
                                  const void* Wp, const float* bk, const float* bv,
                                  float* o, float* attn, const int32_t* plan, mgnns_stream_t stream);
 
+/* ---- a8, split-bf16 operands ("bf16x3", round 5): the reference's formulation inside the 1e-4 parity gate on the bf16 pipe ----
+ * Same contract as mgnns_sq_mha_core_fwd (models/submodules.py:55-119, len_q == 1: K and V projected from the memory bank,
+ * scores / mask / softmax / weighted sum fp32, K and V never written to memory).  Every fp32 operand of the two projections is
+ * carried as hi = bf16(x), lo = bf16(x - hi) and a product is three v_mfma_f32_16x16x32_bf16 (hi hi + lo hi + hi lo, fp32
+ * accumulation, ~2^-16 relative per product).  The memory bank arrives as two bf16 images [B, L, ld], ld == 320 (model dim 300
+ * zero padded): build them with mgnns_split_pad_bf16 from the fp32 bank.  The K/V weights are packed once per weight version by
+ * mgnns_sq_mha_pack_weights_split into mgnns_sq_mha_split_packed_weight_bytes(H) bytes (hi image, then lo image, each in the
+ * fragment-major order of mgnns_sq_mha_pack_weights_bf16).  The bank rows are walked in two halves of at most 112 (the two images
+ * of 196 rows do not fit the 160 KB of LDS) joined by an exact fp32 online-softmax merge.  dk == 128, L <= 208, H <= 16.
+ */
+size_t mgnns_sq_mha_split_packed_weight_bytes(int H);
+int mgnns_sq_mha_pack_weights_split(const float* Wk, const float* Wv, int H, int dk, int D, void* Wp,
+                                    mgnns_stream_t stream);
+int mgnns_split_pad_bf16(const float* x, int64_t rows, int D, int ld, void* hi, void* lo, mgnns_stream_t stream);
+int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi, const void* bank_lo, const float* mask,
+                                int B, int L, int ld, int H, int dk,
+                                const void* Wp, const float* bk, const float* bv,
+                                float* o, float* attn, mgnns_stream_t stream);
+
 /* ---- a8, folded variant: the K/V projections folded into the query side ---------------------------------
  * Same inputs and outputs as mgnns_sq_mha_core_fwd (submodules.py:55-119, len_q == 1) computed as
  *   U_h = Wk_h^T qh_h;   p = softmax_l(U_h . bank[b,l,:] / sqrt(dk)) (masked);   o_h = Wv_h (sum_l p_l bank[b,l,:]) + bv_h

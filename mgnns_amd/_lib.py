@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c = ctypes
 _P = _c.c_void_p
@@ -56,6 +56,9 @@ SIGNATURES = {
     "mgnns_sq_mha32_pack_weights_bf16": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_sq_mha32_plan": [_P, _I, _I, _P, _P],
     "mgnns_sq_mha32_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mgnns_sq_mha_pack_weights_split": [_P, _P, _I, _I, _I, _P, _P],
+    "mgnns_split_pad_bf16": [_P, _L, _I, _I, _P, _P, _P],
+    "mgnns_sq_mha_core_split_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_sq_mha_layer_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                     _I, _P, _P, _P],
     "mgnns_sq_mha_folded_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _P],
@@ -102,6 +105,7 @@ SIZE_GETTERS = {
     "mgnns_sq_mha_packed_weight_bytes": [_I],
     "mgnns_sq_mha32_packed_weight_bytes": [_I],
     "mgnns_sq_mha32_plan_ints": [_I],
+    "mgnns_sq_mha_split_packed_weight_bytes": [_I],
     "mgnns_sq_mha_folded_workspace_bytes": [_I, _I, _I],
     "mgnns_bilstm_workspace_bytes": [_I, _I, _I, _I],
     "mgnns_bilstm_bf16_prepack_bytes": [_I, _I],

@@ -19,7 +19,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
 FLAGS += os.environ.get("MGNNS_HIPCC_FLAGS", "").split()      # e.g. -DMG_MHA_TRACE for the in-kernel phase timer
 # per-file additions.  sq_mha_bf16: the SLP vectoriser packs the epilogues' fp32 FMAs into v_pk_fma_f32, which issue no
 # faster next to a partner wave's MFMAs and cost the kernel 3 % (60.5 -> 58.6 us)
-FILE_FLAGS = {"sq_mha_bf16.hip": ["-fno-slp-vectorize"], "sq_mha32_bf16.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"sq_mha_bf16.hip": ["-fno-slp-vectorize"], "sq_mha32_bf16.hip": ["-fno-slp-vectorize"],
+              "sq_mha_split_bf16.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

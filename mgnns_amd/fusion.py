@@ -26,6 +26,8 @@ FUSED_LAYER = _os.environ.get('MGNNS_FUSED_LAYER', '0') == '1'
 # bf16 mode + set_attention('folded'): the composed-map kernels (sq_mha_folded_bf16.hip + mgnns_mha_tail_c16_fwd); 0 = the three
 # exact-fp32 launches of sq_mha_folded.hip as in fp32 / bf16x3 mode
 FOLDED_BF16 = _os.environ.get('MGNNS_FOLDED_BF16', '1') == '1'
+# bf16x3 mode + faithful attention: the split-bf16 core (sq_mha_split_bf16.hip); 0 = the exact-f32 MFMA core of fp32 mode
+SPLIT_CORE = _os.environ.get('MGNNS_SPLIT_CORE', '1') == '1'
 
 
 def _require_eval(mod):
@@ -35,15 +37,25 @@ def _require_eval(mod):
 
 
 class MemoryBank:
-    """A key/value memory bank in the forms the kernels consume: fp32 [B,L,D] and/or bf16 [B,L,320]
-    (zero padded).  MyMultiHeadAttention accepts it wherever the reference passes the bank tensor, so a
+    """A key/value memory bank in the forms the kernels consume: fp32 [B,L,D], bf16 [B,L,320]
+    (zero padded) and/or the split-bf16 pair [2,B,L,320] (hi + lo images of the fp32 bank).  MyMultiHeadAttention accepts it wherever the reference passes the bank tensor, so a
     bank that feeds several layers is converted once."""
 
-    def __init__(self, f32=None, bf16=None):
+    def __init__(self, f32=None, bf16=None, split=None):
         if f32 is None and bf16 is None:
             raise ValueError("empty MemoryBank")
         self.f32 = f32
         self._bf16 = bf16
+        self._split = split
+
+    @property
+    def split(self):
+        """bf16 [2, B, L, 320]: the fp32 bank as hi + lo images (the split-bf16 attention core's operand)."""
+        if self._split is None:
+            if self.f32 is None:
+                raise ValueError("the split-bf16 attention needs the fp32 memory bank")
+            self._split = ops.split_pad_bf16(self.f32.contiguous())
+        return self._split
 
     @property
     def bf16(self):
@@ -118,6 +130,9 @@ class MultiHeadAttention(nn.Module):
         elif self.precision == 'bf16':
             o, attn = ops.sq_mha_core_bf16(qh, bank.bf16, m2, self.n_head, self.d_k, self._packed_kv(ops.MHA_CORE_PLAIN),
                                            self.w_ks.bias.detach(), self.w_vs.bias.detach())
+        elif self._split_core():
+            o, attn = ops.sq_mha_core_split(qh, bank.split, m2, self.n_head, self.d_k, self._packed_kv("split"),
+                                            self.w_ks.bias.detach(), self.w_vs.bias.detach())
         else:
             if bank.f32 is None:
                 raise ValueError("fp32 attention needs the fp32 memory bank")
@@ -138,6 +153,12 @@ class MultiHeadAttention(nn.Module):
         return ops.sq_mha_folded(qh, x, m2, self.n_head, self.d_k, self.w_ks.weight.detach(),
                                  self.w_vs.weight.detach(), self.w_vs.bias.detach(), want_attn=want_attn)
 
+    def _split_core(self):
+        """'bf16x3' + 'faithful': the K/V projections on split-bf16 operands (csrc/sq_mha_split_bf16.hip) -- the reference's
+        formulation inside the 1e-4 gate without the exact-f32 MFMA's 16x lower rate (MGNNS_SPLIT_CORE=0: the exact-f32 core)."""
+        return (self.precision == 'bf16x3' and self.attention == 'faithful' and SPLIT_CORE and self.d_k == 128
+                and self.n_head <= 16 and self.w_ks.in_features <= ops.BANK_LD)
+
     def _packed_kv(self, form=None):
         """w_ks / w_vs in the MFMA-fragment-major bf16 layout of the attention core's build `form` (ops.MHA_CORE; the fused
         layer kernel takes 16), rebuilt when either weight changes."""
@@ -149,7 +170,10 @@ class MultiHeadAttention(nn.Module):
             self._wp = (key, {})
         packs = self._wp[1]
         if form not in packs:
-            packs[form] = ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k, form=form)
+            if form == "split":
+                packs[form] = ops.pack_kv_weights_split(wk.detach(), wv.detach(), self.n_head, self.d_k)
+            else:
+                packs[form] = ops.pack_kv_weights_bf16(wk.detach(), wv.detach(), self.n_head, self.d_k, form=form)
         return packs[form]
 
 
@@ -410,6 +434,9 @@ def run_stack(layers, q, bank, mask=None, qh=None, plan=None):
             o, _ = ops.sq_mha_core_bf16(qh, bank.bf16, m2, a.n_head, a.d_k,
                                         a._packed_kv(32 if plan is not None else ops.MHA_CORE_PLAIN), a.w_ks.bias.detach(),
                                         a.w_vs.bias.detach(), want_attn=False, plan=plan)
+        elif a._split_core():
+            o, _ = ops.sq_mha_core_split(qh, bank.split, m2, a.n_head, a.d_k, a._packed_kv("split"), a.w_ks.bias.detach(),
+                                         a.w_vs.bias.detach(), want_attn=False)
         else:
             o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
                                    a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)

@@ -1011,6 +1011,54 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
     return o, attn
 
 
+def pack_kv_weights_split(wk, wv, n_head, d_kv):
+    """w_ks / w_vs [H*dk, D] fp32 -> the split-bf16 (hi image, lo image) fragment-major buffer of sq_mha_core_split."""
+    _chk(wk, "w_ks.weight", ndim=2)
+    _chk(wv, "w_vs.weight", ndim=2)
+    L = _lib.lib()
+    buf = torch.empty(L.mgnns_sq_mha_split_packed_weight_bytes(n_head), dtype=torch.uint8, device=wk.device)
+    _lib.check(L.mgnns_sq_mha_pack_weights_split(_p(wk), _p(wv), n_head, d_kv, wk.shape[1], _p(buf), _stream()),
+               "mgnns_sq_mha_pack_weights_split")
+    buf._mg_form = "split"
+    return buf
+
+
+def split_pad_bf16(x, ld=BANK_LD):
+    """[..., D] fp32 -> bf16 [2, ..., ld]: [0] = hi = bf16(x), [1] = lo = bf16(x - hi), zero padded (x = hi + lo to ~2^-17)."""
+    D = x.shape[-1]
+    x2 = _chk(x.reshape(-1, D), "x")
+    y = torch.empty(2, x2.shape[0], ld, dtype=torch.bfloat16, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.mgnns_split_pad_bf16(_p(x2), x2.shape[0], D, ld, _p(y[0]), _p(y[1]), _stream()), "mgnns_split_pad_bf16")
+    return y.view(2, *x.shape[:-1], ld)
+
+
+def sq_mha_core_split(qh, bank_split, mask, n_head, d_kv, wp, bk, bv, want_attn=True):
+    """The faithful attention core on split-bf16 operands (csrc/sq_mha_split_bf16.hip): bank_split = split_pad_bf16(bank)
+    [2, B, L, 320], wp = pack_kv_weights_split(...).  -> (o [B, H*dk], attn [H*B, 1, L] or None)"""
+    _chk(qh, "qh", ndim=2)
+    _chk(bank_split, "memory bank (split bf16)", torch.bfloat16, 4)
+    _chk(wp, "packed K/V weights", torch.uint8, 1)
+    if getattr(wp, "_mg_form", None) != "split":
+        raise ValueError("sq_mha_core_split takes pack_kv_weights_split(...) weights")
+    two, B, L_, ld = bank_split.shape
+    if two != 2:
+        raise ValueError("bank_split must be [2, B, L, %d] (hi, lo)" % BANK_LD)
+    if qh.shape != (B, n_head * d_kv):
+        raise ValueError("qh shape %s, expected %s" % (tuple(qh.shape), (B, n_head * d_kv)))
+    if mask is not None:
+        _chk(mask, "mask", ndim=2)
+        if mask.shape != (B, L_):
+            raise ValueError("mask shape %s, expected %s" % (tuple(mask.shape), (B, L_)))
+    o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
+    attn = torch.empty(n_head * B, 1, L_, device=qh.device, dtype=torch.float32) if want_attn else None
+    L = _lib.lib()
+    _launch("mgnns_sq_mha_core_split_fwd", ("mgnns_sq_mha_core_split_fwd", L_, mask is not None), L.mgnns_sq_mha_core_split_fwd,
+            _p(qh), _p(bank_split[0]), _p(bank_split[1]), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk), _p(bv), _p(o),
+            _p(attn), _stream())
+    return o, attn
+
+
 def sq_mha_layer_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, q, packed, eps, counters, next_packed=None):
     """One fusion layer in one launch (mgnns_sq_mha_layer_bf16_fwd): attention core + fused tail (plain bf16 operands).
     q: the layer input [B,300]; packed / next_packed as for mha_tail_bf16; counters: int32 zeros [ceil(B/16)] owned by the

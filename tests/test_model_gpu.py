@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from mgnns_amd import synth
+from mgnns_amd import ops, synth
 from oracle import restatement as R
 from tests import helpers as H
 from tests.model_util import build_model, call_args
@@ -56,8 +56,8 @@ def test_folded_attention_forward_matches_reference_golden_logits(cfg_name, prec
 @pytest.mark.parametrize("attention", ["folded", "faithful"])
 def test_bf16x3_mode_stays_inside_the_parity_gate(cfg_name, attention):
     """precision 'bf16x3' (split-bf16: three bf16 MFMAs per product, fp32 accumulation) against the REFERENCE's golden logits
-    under the same 1e-4 gate as the fp32 mode, with the folded (exact fp32) attention it is meant to run with and with the
-    faithful exact-f32 core."""
+    under the same 1e-4 gate as the fp32 mode, with the folded (exact fp32) attention and with the faithful attention on the
+    split-bf16 core (csrc/sq_mha_split_bf16.hip; the launch record says which kernels ran)."""
     g = H.load_golden("full_%s.npz" % cfg_name)
     adj = H.load_golden("adjacency.npz")
     cfg = synth.CONFIGS[cfg_name]
@@ -65,10 +65,20 @@ def test_bf16x3_mode_stays_inside_the_parity_gate(cfg_name, attention):
     pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], g["label_query"], DEV)
     model.set_precision("bf16x3").set_attention(attention)
-    logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV))
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        logits = model(*call_args(synth.make_inputs(cfg, B=B, pmi=pmi), DEV))
+    finally:
+        ops.set_timer(None)
     err = H.maxabs(logits.cpu(), g["logits"])
     print("bf16x3 + %s attention, %s: max |dlogit| vs reference golden = %.3e" % (attention, cfg_name, err))
     assert err < TOL
+    ran = {k[0] for k in timer.events}
+    if attention == "faithful":      # the split-bf16 core is the kernel that ran -- not the exact-f32 core, not the fold
+        assert "mgnns_sq_mha_core_split_fwd" in ran and not ran & {"mgnns_sq_mha_core_fwd", "mgnns_sq_mha_folded_fwd"}, sorted(ran)
+    else:
+        assert "mgnns_sq_mha_folded_fwd" in ran and "mgnns_sq_mha_core_split_fwd" not in ran, sorted(ran)
 
 
 def test_bf16x3_full_size_b256():

@@ -639,6 +639,129 @@ def test_sq_mha_core_bf16_more_heads_than_probability_rows(Hn):
         assert H.maxabs(o.cpu(), o32.cpu()) < 2e-2, (B, L)
 
 
+def _split_ref(qh, bank, mask, Hn, wk, wv, bv):
+    """fp64 attention core (submodules.py:55-119, len_q == 1) on the fp32 operands -> (o [B, H*128], attn [H*B, 1, L])."""
+    B, L, _ = bank.shape
+    q64 = qh.double().view(B, Hn, 128)
+    kh = (bank.double() @ wk.double().t()).view(B, L, Hn, 128)
+    vh = (bank.double() @ wv.double().t() + bv.double()).view(B, L, Hn, 128)
+    s = torch.einsum("bhd,blhd->bhl", q64, kh) / float(np.sqrt(128.0))
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, :] == 0.0, float("-inf"))
+    pa = torch.softmax(s, dim=2)
+    o = torch.einsum("bhl,blhd->bhd", pa, vh).reshape(B, Hn * 128)
+    return o, pa.permute(1, 0, 2).reshape(Hn * B, 1, L)
+
+
+@pytest.mark.parametrize("Hn,tag,L,masked", GI.MHA_CASES)
+def test_sq_mha_core_split_against_goldens(Hn, tag, L, masked):
+    """Split-bf16 attention core (csrc/sq_mha_split_bf16.hip: hi + lo operands, three bf16 MFMAs per product, bank rows in two
+    halves joined by an online-softmax merge) against the REFERENCE's goldens under the fp32 kernel's own bounds: returned
+    attention <= 1e-5, layer output <= 2e-5 (submodules.py:55-119 -> moudles.py:207-230)."""
+    g = H.load_golden("mha.npz")
+    name = "h%d_%s" % (Hn, tag)
+    pc = H.params_for(H.mha_shapes(Hn), prefix=name + ".")
+    p = dparams(pc)
+    q, bank, mask = GI.mha_case(Hn, tag, L, masked)
+    a = name + ".slf_attn."
+    qh = ops.linear(dev(q), p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    sp = ops.split_pad_bf16(dev(bank))
+    assert sp.shape == (2,) + tuple(bank.shape[:2]) + (ops.BANK_LD,)
+    hi, lo = sp[0][..., :300].float().cpu(), sp[1][..., :300].float().cpu()
+    assert torch.equal(hi, _bf16_round(bank)) and torch.equal(lo, _bf16_round(torch.as_tensor(bank) - hi))
+    assert float(sp[..., 300:].float().abs().max()) == 0.0
+    wp = ops.pack_kv_weights_split(p[a + "w_ks.weight"], p[a + "w_vs.weight"], Hn, 128)
+    dm = None if mask is None else dev(mask)
+    o, attn = ops.sq_mha_core_split(qh, sp, dm, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"])
+    err_a = H.maxabs(attn.cpu(), g[name + "_attn"])
+    o32, _ = ops.sq_mha_core(qh, dev(bank), dm, Hn, 128, p[a + "w_ks.weight"], p[a + "w_ks.bias"], p[a + "w_vs.weight"],
+                             p[a + "w_vs.bias"])
+    err_o = H.maxabs(o.cpu(), o32.cpu())
+    y = ops.linear(o, p[a + "fc.weight"], p[a + "fc.bias"], residual=dev(q))
+    y = ops.layernorm(y, p[a + "layer_norm.gamma"], p[a + "layer_norm.beta"])
+    f = name + ".pos_ffn."
+    h1 = ops.linear(y, p[f + "w_1.weight"].squeeze(-1).contiguous(), p[f + "w_1.bias"], act=ops.ACT_RELU)
+    z = ops.linear(h1, p[f + "w_2.weight"].squeeze(-1).contiguous(), p[f + "w_2.bias"], residual=y)
+    out = ops.layernorm(z, p[f + "layer_norm.gamma"], p[f + "layer_norm.beta"])
+    err_y = H.maxabs(out.cpu(), g[name + "_out"])
+    print("split core %s: attn %.2e, o vs exact-f32 core %.2e, layer out %.2e" % (name, err_a, err_o, err_y))
+    assert err_a < 1e-5 and err_y < 2e-5 and err_o < 2e-5
+    o2, none = ops.sq_mha_core_split(qh, sp, dm, Hn, 128, wp, p[a + "w_ks.bias"], p[a + "w_vs.bias"], want_attn=False)
+    assert none is None and torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("Hn", [1, 3, 8, 16])
+def test_sq_mha_core_split_random_batches_vs_fp64(Hn):
+    """Split-bf16 core against fp64 on the fp32 operands: chip-filling batches (one workgroup owns every head pair) and small ones
+    (head pairs split over workgroups; 16 heads always split: a workgroup owns at most eight), odd head counts, one half
+    (L <= 112) and two halves (L = 113: one tile in the second; 196; 208), masks with ragged lengths, holes, a sample whose live
+    rows all sit in the SECOND half (the first half's maximum is -inf) and one whose live rows all sit in the first; repeated
+    launches give identical bits.  Bounds: hi + lo carry 16 mantissa bits (2^-17 per operand) against fp32's 24, so the split core
+    sits ~15x above the exact-f32 core's own error against fp64 (printed next to it: 5e-6 / 3e-5 against 3e-7 / 2e-6 at B = 256,
+    L = 196, |o| ~ 5) -- gated at 2e-5 on the probabilities and 1e-4 on o; the model-level gate is the 1e-4 on the logits."""
+    rs = np.random.RandomState(100 + Hn)
+    wq, wk, wv = (dev((0.06 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
+    bq, bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(3))
+    wp = ops.pack_kv_weights_split(wk, wv, Hn, 128)
+    for B, L, masked in ((5, 196, False), (256, 196, False), (256, 37, False), (7, 113, False), (3, 208, False), (2, 1, False),
+                         (256, 100, True), (9, 196, True), (4, 112, True), (300, 128, True)):
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        bank32 = dev((1.5 * rs.standard_normal((B, L, 300))).astype(np.float32))
+        mask = None
+        if masked:
+            lens = np.clip(np.round(np.exp(rs.normal(2.4, 0.75, B))), 1, L).astype(int)
+            lens[0] = L
+            lens[1] = 1
+            m = np.zeros((B, L), np.float32)
+            for b in range(B):
+                m[b, :lens[b]] = 1
+            if L > 120:
+                m[2, :] = 0
+                m[2, 115:L - 3] = 1                          # live rows in the second half only
+                m[3, :] = 1
+                m[3, 50:] = 0                               # ... in the first half only (whole batch still takes two halves)
+            m[B - 1, ::3] = 0                               # holes
+            m[B - 1, 0] = 1
+            mask = dev(m)
+        qh = ops.linear(q, wq, bq)
+        sp = ops.split_pad_bf16(bank32)
+        o, attn = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv)
+        o2, attn2 = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv)
+        assert torch.equal(o, o2) and torch.equal(attn, attn2)
+        assert torch.isfinite(attn).all() and torch.isfinite(o).all()
+        o64, a64 = _split_ref(qh.cpu(), bank32.cpu(), None if mask is None else mask.cpu(), Hn, wk.cpu(), wv.cpu(), bv.cpu())
+        o32, a32 = ops.sq_mha_core(qh, bank32, mask, Hn, 128, wk, bk, wv, bv)
+        ea, eo = H.maxabs(attn.cpu().double(), a64), H.maxabs(o.cpu().double(), o64)
+        print("split core H=%d B=%d L=%d masked=%s: attn %.2e (f32 core %.2e), o %.2e (f32 core %.2e)"
+              % (Hn, B, L, masked, ea, H.maxabs(a32.cpu().double(), a64), eo, H.maxabs(o32.cpu().double(), o64)))
+        assert ea < 2e-5 and eo < 1e-4, (B, L, masked)
+        if mask is not None:
+            assert float(attn.view(Hn, B, L)[:, mask == 0].abs().max()) == 0.0       # masked positions: exactly 0
+
+
+def test_sq_mha_core_split_fully_masked_sample_is_nan_like_the_reference():
+    """softmax of an all -inf row is NaN in the reference (submodules.py:113-116); the exact-f32 core and the split core agree on
+    which outputs are NaN, and the other samples of the batch are untouched."""
+    rs = np.random.RandomState(5)
+    Hn, B = 4, 6
+    wq, wk, wv = (dev((0.06 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
+    bq, bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(3))
+    wp = ops.pack_kv_weights_split(wk, wv, Hn, 128)
+    for L in (100, 196):
+        q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+        bank32 = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+        m = np.ones((B, L), np.float32)
+        m[2, :] = 0
+        mask = dev(m)
+        qh = ops.linear(q, wq, bq)
+        o, attn = ops.sq_mha_core_split(qh, ops.split_pad_bf16(bank32), mask, Hn, 128, wp, bk, bv)
+        o32, attn32 = ops.sq_mha_core(qh, bank32, mask, Hn, 128, wk, bk, wv, bv)
+        assert torch.equal(torch.isnan(o), torch.isnan(o32)) and torch.isnan(o[2]).all() and not torch.isnan(o[[0, 1, 3, 4, 5]]).any()
+        assert torch.equal(torch.isnan(attn), torch.isnan(attn32))
+        keep = [0, 1, 3, 4, 5]
+        assert H.maxabs(o[keep].cpu(), o32[keep].cpu()) < 1e-4
+
+
 def _decode_plan(plan, B):
     pl = plan.cpu().numpy()
     ng = int(pl[0])

@@ -72,6 +72,12 @@ def mha(kind, B=256, L=196, H=8, masked=False):
             print("  sq_mha_plan: %.1f us" % (timeit(lambda: ops.sq_mha_plan(mask)) * 1e3))
         ms = timeit(lambda: ops.sq_mha_core_bf16(qh, bb, mask, H, 128, wp, bk, bv, want_attn=False, plan=plan))
         print("  [core form %d%s]" % (ops.MHA_CORE, ", packed" if plan is not None else ""))
+    elif kind == "split":
+        sp = ops.split_pad_bf16(bank)
+        wp = ops.pack_kv_weights_split(wk, wv, H, 128)
+        print("  split_pad_bf16 (fp32 bank -> hi + lo images): %.1f us" % (timeit(lambda: ops.split_pad_bf16(bank)) * 1e3))
+        ms = timeit(lambda: ops.sq_mha_core_split(qh, sp, mask, H, 128, wp, bk, bv, want_attn=False))
+        print("  [3 MFMAs per product: %.1f TFLOP/s executed]" % (3 * fl / ms / 1e9))
     elif kind == "folded_c16":
         bb = ops.cast_pad_bf16(bank)
         u = torch.randn(B, H * 300, device=DEV, generator=g) * 0.3
@@ -150,6 +156,11 @@ if __name__ == "__main__":
     if "mha_bf16" in what:
         mha("bf16")
         mha("bf16", L=100, masked=True)
+    if "mha_split" in what:
+        mha("split")
+        mha("split", L=100, masked=True)
+        mha("split", B=32)
+        mha("split", B=32, L=100, masked=True)
     if "mha_f32" in what:
         mha("f32")
         mha("f32", L=100, masked=True)
