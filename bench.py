@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}       # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBPS = 8000.0
 GLOBAL_BATCH = 256                                  # BASELINE.json: "forward samples/sec at batch 256"
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -1033,7 +1033,7 @@ def run_rank(args):
             avg_ms = float(np.mean(durs))
             fl = mha_core_flops(B, P, cfg.emb_size, cfg.n_head, cfg.d_kv)
             ach = fl / (avg_ms * 1e-3) / 1e12
-            kname = "sq_mha_core_bf16_kernel" if args.dtype == "bf16" else "sq_mha_core_kernel"
+            kname = {"bf16": "sq_mha_core_bf16_kernel", "bf16x3": "sq_mha_core_split_kernel"}.get(args.dtype, "sq_mha_core_kernel")
             roofline = {"bound": "mfma", "kernel": "%s (L=%d, H=%d)" % (kname, P, cfg.n_head),
                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,

@@ -232,9 +232,12 @@ int mgnns_imgbank_pool_bf16_fwd(const float* feat, int B, int K, int P, const vo
  * fp32 accumulation: ~2^-16 relative per product) at bf16-MFMA speed -- the parity-grade mode's image bank.
  * (Wp_hi, Wp_lo) = mgnns_pack_weight_bf16_split of liner_img_*.weight [N,K]; bank [B,P,N] fp32 (+ bias);
  * pooled_halves [B,2,K] fp32 or NULL: exact maxima over the region halves [0,112) / [112,P) (-inf for an empty half).
+ * bank_hi / bank_lo (both or neither; round 5): the same bank as split-bf16 images hi = bf16(x), lo = bf16(x - hi), bf16
+ * [B,P,320] each, columns [N,320) zero -- what mgnns_sq_mha_core_split_fwd consumes; `bank` may then be NULL (N even).
  * K % 64 == 0, P % 4 == 0, P <= 224, N <= 304. */
 int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int P, const void* Wp_hi, const void* Wp_lo,
-                                 const float* bias, int N, float* bank, float* pooled_halves, mgnns_stream_t stream);
+                                 const float* bias, int N, float* bank, float* pooled_halves, void* bank_hi, void* bank_lo,
+                                 mgnns_stream_t stream);
 
 /* out[c, r] = in[r, c] for r < rows, c < cols; out is [cols, ld] with zero padding. */
 int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld, mgnns_stream_t stream);

@@ -41,7 +41,7 @@ SIGNATURES = {
     "mgnns_imgbank_set_form": [_I],
     "mgnns_head_diff_fwd": [_P, _I, _I, _I, _P, _P],
     "mgnns_classifier_part_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P],
-    "mgnns_imgbank_pool_split_fwd": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
+    "mgnns_imgbank_pool_split_fwd": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mgnns_label_gcn_fwd": [_P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _I, _P],

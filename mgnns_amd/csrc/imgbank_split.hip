@@ -12,8 +12,12 @@
 // written to LDS as 16-B chunks of 8 consecutive k per region row (chunk index XOR row tile: conflict-free for the transposing
 // ds_write_b128 and for the MFMA A-fragment ds_read_b128); wave w owns column tiles w, w + 8, w + 16 (3,3,3,2,2,2,2,2 of the
 // 19) for all row tiles; the W fragments (hi, lo; mgnns_pack_weight_bf16_split layout, L2 resident) of the next k-step are
-// requested before the current k-step's MFMAs.
+// ring of three k-steps: requested TWO k-steps (~2000 cycles of MFMAs) before their use -- round 4's one k-step ahead left every
+// k-step waiting for an L2 round trip (312 us per launch, 24 % of the pipe).
+// Outputs (round 5): the fp32 bank and / or its split-bf16 images hi = bf16(x), lo = bf16(x - hi) as [B, P, 320] bf16 each (zero
+// padded) -- the operand of the split-bf16 attention core (sq_mha_split_bf16.hip), written here instead of by a conversion pass.
 #include "common.hpp"
+#include "sq_mha_util.hpp"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -35,10 +39,15 @@ __device__ __forceinline__ unsigned is_pack2(float a, float b) {
     return r;
 }
 
+constexpr int IS_WD = 3;                 // W-fragment ring: two k-steps in flight + the one being multiplied (four: 21 spilled registers)
+constexpr int IS_LD = 320;               // row length of the split-bf16 bank images
+
 __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __restrict__ feat, int K, int P,
                                                               const uint4* __restrict__ Wh, const uint4* __restrict__ Wl,
                                                               const float* __restrict__ bias, int N,
-                                                              float* __restrict__ bank, float* __restrict__ pooled) {
+                                                              float* __restrict__ bank, float* __restrict__ pooled,
+                                                              unsigned short* __restrict__ bank_hi,
+                                                              unsigned short* __restrict__ bank_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* Ahi = reinterpret_cast<uint4*>(smem);                                   // [2][IS_ROWS][IS_STR]
     uint4* Alo = Ahi + 2 * IS_ROWS * IS_STR;
@@ -106,7 +115,8 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
         ton[t] = nt < IS_NT && nt * 16 < N;
         woff[t] = (size_t)(ton[t] ? nt : 0) * KS * 64 + lane;
     }
-    uint4 bh[2][IS_TPW], bl[2][IS_TPW];
+    const bool has3 = wave + 16 < IS_NT && (wave + 16) * 16 < N;      // (wave-uniform: a scalar branch)
+    uint4 bh[IS_WD][IS_TPW], bl[IS_WD][IS_TPW];
     auto wload = [&](int ks, int slot) {
 #pragma unroll
         for (int t = 0; t < IS_TPW; ++t) {
@@ -117,70 +127,172 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
     const int fr = lane & 15, fg = lane >> 4;
 
     gload(0);
-    wload(0, 0);
-    emit(0);
-    __syncthreads();
-    for (int c = 0; c < nk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nk) gload(c + 1);
-        // the slice's partial maxima (written before the barrier that opened this iteration) -> pooled, 64 threads
-        if (pooled && tid < 64) {
-            const float* r = pm + buf * 64 * IS_PMS + tid * IS_PMS;
-            float m = -INFINITY;
-            for (int q = 0; q < nq; ++q) m = fmaxf(m, r[q]);
-            pooled[((size_t)b * 2 + mh) * K + c * IS_BK + tid] = m;
-        }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+    for (int d = 0; d < IS_WD - 1; ++d)
+        if (d < KS) wload(d, d);
+    emit(0);
+    gload(nk > 1 ? 1 : 0);
+    __syncthreads();
+    // The two waves of a SIMD (w and w + 4) run a slice's two phases in OPPOSITE order: waves 0-3 first convert the next slice into
+    // the other LDS buffer (VALU + LDS writes), then multiply; waves 4-7 multiply first.  While one wave of the SIMD holds the
+    // matrix pipe the other converts -- in lock step (round 4) the pipe idled through every conversion and both waves then
+    // contended for it.  The feature rows of slice c + 2 are requested right behind the conversion of slice c + 1 (the same 32
+    // registers), i.e. at least one multiply phase before their use.
+    // Every global load of the loop is UNCONDITIONAL (indices clamped to the last slice / k-step) and the two orders are two
+    // instances of the loop, not a branch inside it: the compiler counts the loads in flight per path, and behind a join of paths
+    // with different counts it waits for the weight fragments with the smaller count -- i.e. for the feature rows requested after
+    // them, an HBM round trip in every k-step.
+    // one slice; PH = c % 6 is a compile-time constant (the loop below is unrolled by six), so the LDS buffer c & 1 and the ring slots
+    // (2 c + s) % 3 of its two k-steps are static register indices
+    const bool convert_first = wave < 4;
+    auto slice = [&](auto phc, int c) {
+        constexpr int PH = decltype(phc)::v;
+        constexpr int buf = PH & 1;
+        auto convert = [&]() {
+            emit(buf ^ 1);                                      // (behind the last slice: into the idle buffer, never read)
+            gload(c + 2 < nk ? c + 2 : nk - 1);
+        };
+        if (convert_first) convert();
+        // the slice's partial maxima (written before the barrier that opened this iteration) -> pooled: eight threads per feature
+        // row take four region quads each, three DPP steps join them
+        if (pooled) {
+            const int row = tid >> 3, part = tid & 7;
+            const float* r = pm + buf * 64 * IS_PMS + row * IS_PMS;
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (part + 8 * q < nq) m = fmaxf(m, r[part + 8 * q]);
+            m = fmaxf(m, MG_DPP(m, 0xB1));                       // quad_perm [1,0,3,2]
+            m = fmaxf(m, MG_DPP(m, 0x4E));                       // quad_perm [2,3,0,1]
+            m = fmaxf(m, MG_DPP(m, 0x141));                      // row_half_mirror: lanes 0-3 <-> 7-4 of each eight
+            if (part == 0) pooled[((size_t)b * 2 + mh) * K + c * IS_BK + row] = m;
+        }
+        mg_mha::static_for<0, 2>([&](auto sc) {
+            constexpr int s = decltype(sc)::v;
+            constexpr int SL = (2 * PH + s) % IS_WD;
             const int ks = c * 2 + s;
-            if (ks + 1 < KS) wload(ks + 1, (s + 1) & 1);
+            wload(ks + IS_WD - 1 < KS ? ks + IS_WD - 1 : KS - 1, (SL + IS_WD - 1) % IS_WD);
+            // Two branch-free blocks per k-step (a branch per (row tile, column tile) cut the MFMA stream into blocks of three, each
+            // behind its own LDS wait): every wave's first two column tiles for ALL seven row tiles (row tiles behind the half's
+            // last region multiply rows nobody stores), then -- waves 0-2 only, one scalar branch -- the third column tile with the
+            // A fragments read a second time.
+            // (A fragments one row tile ahead, by hand, with a scheduling fence per row tile: left alone the scheduler hoists all
+            //  fourteen reads of a block in front of its MFMAs -- 127 spilled registers)
+            uint4 ah[2], al[2];
+            auto aread = [&](int i, int slot) {
+                const int at = (buf * IS_ROWS + i * 16 + fr) * IS_STR + ((4 * s + fg) ^ (i & 7));
+                ah[slot] = Ahi[at];
+                al[slot] = Alo[at];
+            };
+            aread(0, 0);
+            mg_mha::static_for<0, IS_MT>([&](auto ic) {
+                constexpr int i = decltype(ic)::v;
+                if constexpr (i + 1 < IS_MT) aread(i + 1, (i + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);              // (the reads stay IN FRONT of this tile's MFMAs: they were sunk behind four of them)
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i & 1]), xl = __builtin_bit_cast(bf16x8, al[i & 1]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[SL][t]), wl = __builtin_bit_cast(bf16x8, bl[SL][t]);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[i][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (has3) {
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[SL][2]), wl = __builtin_bit_cast(bf16x8, bl[SL][2]);
+                aread(0, 0);
+                mg_mha::static_for<0, IS_MT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::v;
+                    if constexpr (i + 1 < IS_MT) aread(i + 1, (i + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i & 1]), xl = __builtin_bit_cast(bf16x8, al[i & 1]);
+                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[i][2], 0, 0, 0);
+                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[i][2], 0, 0, 0);
+                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[i][2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        });
+        if (!convert_first) convert();
+        __syncthreads();
+    };
+    static_assert(IS_WD == 3, "the slice loop is unrolled for a ring of three");
+    for (int c = 0; c < nk; c += 6) {
+        slice(mg_mha::IC<0>{}, c);
+        if (c + 1 < nk) slice(mg_mha::IC<1>{}, c + 1);
+        if (c + 2 < nk) slice(mg_mha::IC<2>{}, c + 2);
+        if (c + 3 < nk) slice(mg_mha::IC<3>{}, c + 3);
+        if (c + 4 < nk) slice(mg_mha::IC<4>{}, c + 4);
+        if (c + 5 < nk) slice(mg_mha::IC<5>{}, c + 5);
+    }
+    auto epilogue = [&]() {
+    // ---- epilogue: + bias; acc[i][t][r] = bank[p0 + 16 i + 4 (lane >> 4) + r][16 nt + (lane & 15)] ----
+    if (bank) {
+        float* ob = bank + ((size_t)b * P + p0) * N;
+#pragma unroll
+        for (int t = 0; t < IS_TPW; ++t) {
+            const int n = (wave + 8 * t) * 16 + fr;
+            if (!ton[t] || n >= N) continue;
+            const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < IS_MT; ++i) {
-                if (i < mtn) {
-                    const int at = (buf * IS_ROWS + i * 16 + fr) * IS_STR + ((4 * s + fg) ^ (i & 7));
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi[at]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, Alo[at]);
+                if (i >= mtn) continue;
 #pragma unroll
-                    for (int t = 0; t < IS_TPW; ++t) {
-                        if (ton[t]) {
-                            const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[s & 1][t]), wl = __builtin_bit_cast(bf16x8, bl[s & 1][t]);
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc[i][t], 0, 0, 0);
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc[i][t], 0, 0, 0);
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc[i][t], 0, 0, 0);
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const int p = i * 16 + fg * 4 + r;
+                    if (p < rows) ob[(size_t)p * N + n] = acc[i][t][r] + bv;
+                }
+            }
+        }
+    }
+    if (bank_hi) {
+        // split-bf16 images: a lane and its right neighbour (quad_perm [1,1,3,3]: pure VALU) give one packed pair of columns, the
+        // even lanes store 4 bytes to each image; columns [N, 320) are zero (N even: the launcher checks)
+        unsigned* oh = reinterpret_cast<unsigned*>(bank_hi + ((size_t)b * P + p0) * IS_LD);
+        unsigned* ol = reinterpret_cast<unsigned*>(bank_lo + ((size_t)b * P + p0) * IS_LD);
+#pragma unroll
+        for (int t = 0; t < IS_TPW; ++t) {
+            const int n = (wave + 8 * t) * 16 + fr;
+            const bool on = ton[t] && n < N;
+            const float bv = (on && bias) ? bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < IS_MT; ++i) {
+                if (i >= mtn) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = i * 16 + fg * 4 + r;
+                    const float v = acc[i][t][r] + bv;
+                    const float vn = MG_DPP(v, 0xF5);
+                    const unsigned h2 = is_pack2(v, vn);
+                    const unsigned l2 = is_pack2(v - __builtin_bit_cast(float, h2 << 16), vn - __builtin_bit_cast(float, h2 & 0xFFFF0000u));
+                    if (on && !(fr & 1) && p < rows) {
+                        oh[((size_t)p * IS_LD + n) >> 1] = h2;
+                        ol[((size_t)p * IS_LD + n) >> 1] = l2;
                     }
                 }
             }
         }
-        if (c + 1 < nk) emit(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: + bias; acc[i][t][r] = bank[p0 + 16 i + 4 (lane >> 4) + r][16 nt + (lane & 15)] ----
-    float* ob = bank + ((size_t)b * P + p0) * N;
-#pragma unroll
-    for (int t = 0; t < IS_TPW; ++t) {
-        const int n = (wave + 8 * t) * 16 + fr;
-        if (!ton[t] || n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < IS_MT; ++i) {
-            if (i >= mtn) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = i * 16 + fg * 4 + r;
-                if (p < rows) ob[(size_t)p * N + n] = acc[i][t][r] + bv;
-            }
+        const int zc = (IS_LD - N) >> 1;                               // zero pairs per row
+        for (int idx = tid; idx < rows * zc; idx += IS_THR) {
+            const int p = idx / zc, q = idx - p * zc;
+            oh[((size_t)p * IS_LD + N) / 2 + q] = 0u;
+            ol[((size_t)p * IS_LD + N) / 2 + q] = 0u;
         }
     }
+    };
+    epilogue();
 }
 
 }  // namespace
 
 extern "C" int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int P, const void* Wp_hi, const void* Wp_lo,
-                                            const float* bias, int N, float* bank, float* pooled_halves,
-                                            mgnns_stream_t stream) {
-    MG_REQUIRE(feat && Wp_hi && Wp_lo && bank, "mgnns_imgbank_pool_split_fwd: null pointer");
+                                            const float* bias, int N, float* bank, float* pooled_halves, void* bank_hi,
+                                            void* bank_lo, mgnns_stream_t stream) {
+    MG_REQUIRE(feat && Wp_hi && Wp_lo && (bank || bank_hi), "mgnns_imgbank_pool_split_fwd: null pointer");
+    MG_REQUIRE(!bank_hi == !bank_lo, "mgnns_imgbank_pool_split_fwd: bank_hi and bank_lo come together");
+    MG_REQUIRE(!bank_hi || (N % 2 == 0 && mg_aligned16(bank_hi) && mg_aligned16(bank_lo)),
+               "mgnns_imgbank_pool_split_fwd: the split-bf16 images need an even N (%d) and 16-byte aligned buffers", N);
     MG_REQUIRE(B >= 0 && K > 0 && K % IS_BK == 0, "mgnns_imgbank_pool_split_fwd: K=%d must be a positive multiple of %d", K, IS_BK);
     MG_REQUIRE(P > 0 && P % 4 == 0 && P <= IS_PSPLIT + IS_ROWS, "mgnns_imgbank_pool_split_fwd: P=%d unsupported (multiple of 4, <= %d)", P,
                IS_PSPLIT + IS_ROWS);
@@ -190,7 +302,8 @@ extern "C" int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int
     const size_t lds = (size_t)4 * IS_ROWS * IS_STR * 16 + (size_t)2 * 64 * IS_PMS * sizeof(float);
     MG_DYN_LDS(imgbank_split_kernel, lds);
     hipLaunchKernelGGL(imgbank_split_kernel, dim3(2 * B), dim3(IS_THR), lds, (hipStream_t)stream, feat, K, P,
-                       reinterpret_cast<const uint4*>(Wp_hi), reinterpret_cast<const uint4*>(Wp_lo), bias, N, bank, pooled_halves);
+                       reinterpret_cast<const uint4*>(Wp_hi), reinterpret_cast<const uint4*>(Wp_lo), bias, N, bank, pooled_halves,
+                       reinterpret_cast<unsigned short*>(bank_hi), reinterpret_cast<unsigned short*>(bank_lo));
     MG_CHECK_LAUNCH("mgnns_imgbank_pool_split_fwd");
     return 0;
 }

@@ -42,7 +42,7 @@ class MemoryBank:
     bank that feeds several layers is converted once."""
 
     def __init__(self, f32=None, bf16=None, split=None):
-        if f32 is None and bf16 is None:
+        if f32 is None and bf16 is None and split is None:
             raise ValueError("empty MemoryBank")
         self.f32 = f32
         self._bf16 = bf16
@@ -65,8 +65,9 @@ class MemoryBank:
 
     @property
     def shape(self):
-        t = self.f32 if self.f32 is not None else self._bf16
-        return t.shape
+        if self.f32 is not None:
+            return self.f32.shape
+        return self._bf16.shape if self._bf16 is not None else self._split.shape[1:]
 
 
 def make_mask_plan(mask, precision='bf16', attention='faithful'):

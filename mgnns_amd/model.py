@@ -376,6 +376,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
             return MemoryBank(bf16=bank), pooled
         if self.precision == 'bf16x3' and f3.shape[2] % 4 == 0 and f3.shape[2] <= 224 and f3.shape[1] % 64 == 0 \
                 and lin.out_features <= 304:
+            consumers = (self.text_img_object_multi_head_att if lin is self.liner_img_object else self.text_img_place_multi_head_att)
+            if lin.out_features % 2 == 0 and len(consumers) and all(m.slf_attn._split_core() for m in consumers):
+                # the split-bf16 attention core's operand straight from the bank kernel: no fp32 bank, no conversion pass
+                _, pooled, sp = ops.imgbank_pool_split(f3, self._wp_split(lin), lin.bias.detach(), lin.out_features,
+                                                       want_f32=False, want_split=True)
+                return MemoryBank(split=sp), pooled
             bank, pooled = ops.imgbank_pool_split(f3, self._wp_split(lin), lin.bias.detach(), lin.out_features)
             return MemoryBank(f32=bank), pooled            # pooled: [B, 2, K] region-half maxima (the fused tail combines them)
         bank, pooled = ops.imgbank_pool(f3, self._wt(lin), lin.bias.detach(), lin.out_features)

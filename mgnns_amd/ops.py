@@ -771,9 +771,10 @@ def imgbank_set_form(form):
 
 
 # ---- label attention core ---------------------------------------------------------------------------
-def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True):
+def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True, want_f32=True, want_split=False):
     """Split-bf16 (fp32-class) image bank + max-pool: feat [B,K,P] fp32, w_pair = pack_weight_bf16_split(liner_img.weight
-    [n_out,K]) -> (bank [B,P,n_out] fp32, pooled halves [B,2,K] fp32 or None)."""
+    [n_out,K]) -> (bank [B,P,n_out] fp32 or None, pooled halves [B,2,K] fp32 or None[, split images bf16 [2,B,P,320] when
+    want_split: hi = bf16(bank), lo = bf16(bank - hi), zero padded -- the split-bf16 attention core's operand])."""
     _chk(feat, "feature map", ndim=3)
     B, K, P = feat.shape
     hi, lo = w_pair
@@ -781,12 +782,16 @@ def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True):
     _chk(lo, "packed lo", torch.uint8, 1)
     if bias is not None:
         _chk(bias, "bias", ndim=1)
-    bank = torch.empty(B, P, n_out, device=feat.device, dtype=torch.float32)
+    if not (want_f32 or want_split):
+        raise ValueError("imgbank_pool_split: nothing to compute (want_f32 or want_split)")
+    bank = torch.empty(B, P, n_out, device=feat.device, dtype=torch.float32) if want_f32 else None
+    split = torch.empty(2, B, P, BANK_LD, device=feat.device, dtype=torch.bfloat16) if want_split else None
     pooled = torch.empty(B, 2, K, device=feat.device, dtype=torch.float32) if want_pool else None
     L = _lib.lib()
     _launch("mgnns_imgbank_pool_split_fwd", ("mgnns_imgbank_pool_split_fwd", P), L.mgnns_imgbank_pool_split_fwd, _p(feat), B, K, P,
-            _p(hi), _p(lo), _p(bias), n_out, _p(bank), _p(pooled), _stream())
-    return bank, pooled
+            _p(hi), _p(lo), _p(bias), n_out, _p(bank), _p(pooled), _p(split[0]) if want_split else None,
+            _p(split[1]) if want_split else None, _stream())
+    return (bank, pooled, split) if want_split else (bank, pooled)
 
 
 def label_attn_core(Q, K, V, n_heads):

@@ -740,8 +740,8 @@ def test_sq_mha_core_split_random_batches_vs_fp64(Hn):
 
 
 def test_sq_mha_core_split_fully_masked_sample_is_nan_like_the_reference():
-    """softmax of an all -inf row is NaN in the reference (submodules.py:113-116); the exact-f32 core and the split core agree on
-    which outputs are NaN, and the other samples of the batch are untouched."""
+    """softmax of an all -inf row is NaN in the reference (submodules.py:113-116) and so is bmm(attn, v): the split core returns NaN
+    probabilities AND a NaN output row for such a sample, and the other samples of the batch are untouched."""
     rs = np.random.RandomState(5)
     Hn, B = 4, 6
     wq, wk, wv = (dev((0.06 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
@@ -756,8 +756,9 @@ def test_sq_mha_core_split_fully_masked_sample_is_nan_like_the_reference():
         qh = ops.linear(q, wq, bq)
         o, attn = ops.sq_mha_core_split(qh, ops.split_pad_bf16(bank32), mask, Hn, 128, wp, bk, bv)
         o32, attn32 = ops.sq_mha_core(qh, bank32, mask, Hn, 128, wk, bk, wv, bv)
-        assert torch.equal(torch.isnan(o), torch.isnan(o32)) and torch.isnan(o[2]).all() and not torch.isnan(o[[0, 1, 3, 4, 5]]).any()
-        assert torch.equal(torch.isnan(attn), torch.isnan(attn32))
+        # (the exact-f32 core skips the V pass of a sample without live rows: its attn is NaN like the reference's, its o is 0)
+        assert torch.isnan(o[2]).all() and not torch.isnan(o[[0, 1, 3, 4, 5]]).any() and not torch.isnan(o32[[0, 1, 3, 4, 5]]).any()
+        assert torch.equal(torch.isnan(attn), torch.isnan(attn32)) and torch.isnan(attn.view(Hn, B, L)[:, 2]).all()
         keep = [0, 1, 3, 4, 5]
         assert H.maxabs(o[keep].cpu(), o32[keep].cpu()) < 1e-4
 
@@ -1431,6 +1432,15 @@ def test_imgbank_pool_split_vs_fp64(B, P, N):
         assert torch.isinf(pooled[:, 1]).all() and (pooled[:, 1] < 0).all()
     b2, _ = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), None, N, want_pool=False)
     assert np.abs(b2.cpu().numpy() - (ref - bias)).max() / scale < 2e-5
+    if N % 2 == 0:
+        # the same bank as split-bf16 images (hi = bf16(x), lo = bf16(x - hi), [2, B, P, 320], zero padded), with and without the
+        # fp32 bank next to them: exactly the conversion pass's result on the fp32 bank (ops.split_pad_bf16)
+        b3, p3, sp = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), dev(bias), N, want_split=True)
+        assert torch.equal(b3, bank) and torch.equal(p3, pooled) and tuple(sp.shape) == (2, B, P, ops.BANK_LD)
+        assert torch.equal(sp, ops.split_pad_bf16(bank))
+        none, p4, sp4 = ops.imgbank_pool_split(dev(feat), ops.pack_weight_bf16_split(dev(W)), dev(bias), N, want_f32=False,
+                                               want_split=True)
+        assert none is None and torch.equal(sp4, sp) and torch.equal(p4, pooled)
 
 
 @pytest.mark.parametrize("M,N,K", [(10000, 1024, 320), (5000, 512, 704), (2600, 128, 192), (512, 10000, 256), (300, 260, 64)])

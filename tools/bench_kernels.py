@@ -113,6 +113,11 @@ def imgbank(B=256):
         wp = ops.pack_imgbank_weights_bf16(w)
         ms = timeit(lambda: ops.imgbank_pool_bf16(feat, wp, bias, 300))
         print("imgbank_pool bf16 B=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s (map read)" % (B, ms * 1e3, fl / ms / 1e9, by / ms / 1e6))
+    ws = ops.pack_weight_bf16_split(w)
+    ms = timeit(lambda: ops.imgbank_pool_split(feat, ws, bias, 300))
+    print("imgbank_pool split (bf16x3) B=%d, fp32 bank: %.1f us  %.1f TFLOP/s executed (3 MFMAs per product)" % (B, ms * 1e3, 3 * fl / ms / 1e9))
+    ms = timeit(lambda: ops.imgbank_pool_split(feat, ws, bias, 300, want_f32=False, want_split=True))
+    print("imgbank_pool split (bf16x3) B=%d, hi + lo images out: %.1f us" % (B, ms * 1e3))
 
 
 def tail(B=256, H=8):
