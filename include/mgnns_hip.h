@@ -75,6 +75,13 @@ int mgnns_textgcn_fwd(const int64_t* tok, int B, int T,
                       const float* edge_w, int n_edge_w,
                       const int32_t* pmi_row_ptr, const int32_t* pmi_col, const int32_t* pmi_eid,
                       int ngram, int max_length, float* out, mgnns_stream_t stream);
+/* Launch form of mgnns_textgcn_fwd (results agree to fp32 summation order; a test / measurement knob, process wide):
+ * 0 = by batch and shape (default): batches of at least 64 documents run ONE launch of the lean kernel (256 threads, 8 KB of LDS,
+ *     <= 64 registers, node rows read from L2: it fits beside an image-bank workgroup of the same forward; also MGNNS_TEXTGCN_LEAN),
+ *     smaller ones one launch of 1024-thread workgroups with the document's node rows in LDS;
+ * 1 = always that 1024-thread form, 2 = two launches (documents of <= 24 tokens on 256-thread workgroups, then the others on the
+ *     1024-thread form; round 3-4's form for large batches), 3 = always the lean kernel (needs D % 4 == 0). */
+int mgnns_textgcn_set_form(int form);
 
 /* ---- a2: embedding gather ---------------------------------------------------------------
  * nn.Embedding lookups (Multi_GCN_Multihead_att.py:371; Text_GCN.py:184,206):
@@ -105,13 +112,17 @@ int mgnns_bilstm_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
                      mgnns_stream_t stream);
 /* Same contract, bf16-mode recurrence: the per-step W_hh . h on v_mfma_f32_4x4x4_16b_bf16 (W_hh and h rounded to bf16 for
  * the product; fp32 accumulation, gates and cell state; fast exp / rcp): ~2e-3 absolute on the bank, 2.5x shorter chain.  The
- * input projections stay on the exact-f32 GEMM. */
+ * input projections stay on the exact-f32 GEMM.
+ * plan_mask / plan (both or neither; round 5): the batch's text mask [B, T] float and mgnns_sq_mha32_plan_ints(B) int32 -- the
+ * packing plan of that mask (exactly what mgnns_sq_mha32_plan(plan_mask, B, T, plan) writes) is built by one extra workgroup of
+ * this call's first launch, for the two image->text stacks that consume the text bank (Multi_GCN_Multihead_att.py:509-527).
+ * Needs B <= 1024, T <= 128, emb_dim % 4 == 0. */
 int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, int B, int T,
                      const float* emb_table, int V, int emb_dim, int hidden, int num_layers,
                      const float* const* w_ih_cat, const float* const* b_ih_cat,
                      const float* const* w_hh, const float* const* b_hh,
                      void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16, const void* prepacked,
-                     mgnns_stream_t stream);
+                     const float* plan_mask, int32_t* plan, mgnns_stream_t stream);
 /* Weights of the bf16 recurrence / projections in their kernel layouts (depends on the weights only: build once per weight
  * version, pass as `prepacked`; NULL = packed on the fly inside every call). */
 size_t mgnns_bilstm_bf16_prepack_bytes(int hidden, int num_layers);
@@ -134,7 +145,7 @@ int mgnns_bilstm_bf16_table_fwd(const int64_t* tok, const int64_t* lens, int B, 
                      const float* const* w_ih_cat, const float* const* b_ih_cat,
                      const float* const* w_hh, const float* const* b_hh,
                      void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16, const void* prepacked,
-                     const float* gx_table, mgnns_stream_t stream);
+                     const float* gx_table, const float* plan_mask, int32_t* plan, mgnns_stream_t stream);
 
 /* ---- a3: adjacency normalisation ----------------------------------------------------------
  * gen_adj (utils/util.py:421-426): d = rowsum(A)^-1/2; adj[i,j] = (A[j,i]*d[i])*d[j].

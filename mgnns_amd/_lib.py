@@ -22,10 +22,10 @@ _PP = _c.POINTER(_c.c_void_p)
 SIGNATURES = {
     "mgnns_textgcn_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P],
     "mgnns_bilstm_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P],
-    "mgnns_bilstm_bf16_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P],
+    "mgnns_bilstm_bf16_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P, _P, _P],
     "mgnns_bilstm_bf16_prepack": [_PP, _PP, _I, _I, _I, _P, _P],
     "mgnns_bilstm_bf16_fold_embedding": [_P, _I, _I, _I, _P, _P, _P, _SZ, _P, _P],
-    "mgnns_bilstm_bf16_table_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P, _P],
+    "mgnns_bilstm_bf16_table_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _SZ, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgnns_embedding_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "mgnns_gen_adj": [_P, _I, _P, _P, _P, _P, _P, _P],
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
@@ -39,6 +39,7 @@ SIGNATURES = {
     "mgnns_imgbank_pack_weights_bf16": [_P, _I, _I, _P, _P],
     "mgnns_imgbank_pool_bf16_fwd": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P],
     "mgnns_imgbank_set_form": [_I],
+    "mgnns_textgcn_set_form": [_I],
     "mgnns_head_diff_fwd": [_P, _I, _I, _I, _P, _P],
     "mgnns_classifier_part_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P],
     "mgnns_imgbank_pool_split_fwd": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],

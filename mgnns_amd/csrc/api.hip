@@ -90,8 +90,8 @@ int mg_cu_count() {
 // integer tuning knob from the environment, read ONCE per process (the launchers sit on the per-forward path)
 int mg_env_int(const char* name, int fallback, int slot) {
     static std::mutex mu;
-    static bool have[8] = {false};
-    static int val[8] = {0};
+    static bool have[16] = {false};
+    static int val[16] = {0};
     std::lock_guard<std::mutex> lk(mu);
     if (!have[slot]) {
         const char* e = getenv(name);

@@ -14,7 +14,7 @@ void mgnns_set_error(const char* fmt, ...);
 int mg_ensure_dyn_lds(const void* fn, int bytes);   // api.hip; 0 or MGNNS_ERR_LAUNCH (error text set)
 int32_t* mg_status_word();                           // api.hip: the registered status word (host-pinned) or nullptr
 int mg_cu_count();                                     // api.hip: CUs of the current device (cached); 0 + error text on failure
-int mg_env_int(const char* name, int fallback, int slot);   // api.hip: environment knob read once per process (slot 0..7 = its cache entry)
+int mg_env_int(const char* name, int fallback, int slot);   // api.hip: environment knob read once per process (slot 0..15 = its cache entry)
 int mg_check_status(const char* who);                // api.hip: MGNNS_ERR_LAUNCH (+ text, word cleared) if an earlier bounded wait ran out
 #define MG_DYN_LDS(fn, bytes)                                                              \
     do {                                                                                   \

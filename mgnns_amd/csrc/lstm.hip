@@ -16,6 +16,7 @@
 //      zero-filled by the same workgroup (pad_packed_sequence(total_length=T)).
 // Gate order i, f, g, o (PyTorch).  All arithmetic fp32; the k-loop is a sequential fmaf chain.
 #include "common.hpp"
+#include "sq_mha_plan.hpp"
 
 int mg_launch_linear(const float* X, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                      const int32_t* gather_idx, const int32_t* m_dev, hipStream_t stream);
@@ -337,11 +338,20 @@ __global__ __launch_bounds__(PREP_THR) void lstm_prep_kernel(const int64_t* __re
                                                             int T, int V, const float* __restrict__ X, int K,
                                                             int32_t* __restrict__ offs, int32_t* __restrict__ order,
                                                             int32_t* __restrict__ pack_tok, int32_t* __restrict__ pack_pos,
-                                                            unsigned short* __restrict__ Xb) {
+                                                            unsigned short* __restrict__ Xb, const float* __restrict__ plan_mask,
+                                                            int32_t* __restrict__ plan) {
     __shared__ int s_len[1024];
     __shared__ int s_tok[PREP_MAXT];
     __shared__ int s_red[3][PREP_THR / 64];
+    extern __shared__ int s_dyn[];                                  // the plan workgroup's scratch (mg_plan::lds_bytes(B))
     const int tid = threadIdx.x, b = blockIdx.x;
+    // One workgroup MORE than samples when a packing plan is asked for (round 5): it builds the plan of the batch's text mask for the
+    // packed masked attention launches (sq_mha_plan.hpp) next to the B workgroups that pack the batch -- both image->text stacks wait
+    // for this stream anyway (the text bank), so neither pays a launch of its own for the plan (10-20 us each in round 4).
+    if (b == B) {
+        mg_plan::build<PREP_THR>(plan_mask, B, T, plan, s_dyn);
+        return;
+    }
     for (int i = tid; i < B; i += PREP_THR) {
         const long long l = lens[i];
         s_len[i] = (int)(l < 0 ? 0 : (l > T ? T : l));
@@ -674,7 +684,8 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
                        int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                        const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                        void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                       mgnns_stream_t stream, const float* gx_table = nullptr) {
+                       mgnns_stream_t stream, const float* gx_table = nullptr, const float* plan_mask = nullptr,
+                       int32_t* plan = nullptr) {
     MG_REQUIRE(tok && lens && emb_table && w_ih_cat && w_hh && b_ih_cat && b_hh && workspace && out,
                "mgnns_bilstm_fwd: null pointer");
     MG_REQUIRE(!out_bf16 || (ld_bf16 >= 2 * hidden && ld_bf16 % 8 == 0), "mgnns_bilstm_fwd: bad bf16 row length %d", ld_bf16);
@@ -720,9 +731,15 @@ static int bilstm_impl(bool bf16_rec, const void* prepacked, const int64_t* tok,
     const bool prep_fused = bf16_rec && B <= 1024 && T <= PREP_MAXT && emb_dim % 4 == 0 && emb_dim <= XKP;
     // folded layer-0 projection (mgnns_bilstm_bf16_fold_embedding): no gather, no GEMM -- the recurrence reads table rows by token id
     const bool folded = gx_table && prep_fused;
+    MG_REQUIRE(!plan == !plan_mask, "mgnns_bilstm_bf16_fwd: plan and plan_mask come together");
+    MG_REQUIRE(!plan || (prep_fused && T <= mg_plan::PR),
+               "mgnns_bilstm_bf16_fwd: the packing plan rides on the fused prep launch (bf16 recurrence, B <= 1024, T <= %d, emb_dim %% 4 == 0); "
+               "build it with mgnns_sq_mha32_plan instead", mg_plan::PR);
     if (prep_fused) {
-        hipLaunchKernelGGL(lstm_prep_kernel, dim3(B), dim3(PREP_THR), 0, s, tok, lens, B, T, V, emb_table, emb_dim, offs, order, pack_tok,
-                           pack_pos, folded ? (unsigned short*)nullptr : xb);
+        const size_t plan_lds = plan ? mg_plan::lds_bytes(B) : 0;
+        if (plan) MG_DYN_LDS(lstm_prep_kernel, plan_lds);
+        hipLaunchKernelGGL(lstm_prep_kernel, dim3(B + (plan ? 1 : 0)), dim3(PREP_THR), plan_lds, s, tok, lens, B, T, V, emb_table, emb_dim, offs,
+                           order, pack_tok, pack_pos, folded ? (unsigned short*)nullptr : xb, plan_mask, plan);
     } else {
         hipLaunchKernelGGL(lstm_pack_kernel, dim3(1), dim3(1024), 0, s, lens, B, T, offs, order);
         hipLaunchKernelGGL(lstm_fill_kernel, dim3(B), dim3(128), 0, s, tok, lens, T, V, (const int32_t*)offs, pack_tok, pack_pos);
@@ -784,9 +801,9 @@ extern "C" int mgnns_bilstm_bf16_fwd(const int64_t* tok, const int64_t* lens, in
                                      int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                                      const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                                      void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                                     const void* prepacked, mgnns_stream_t stream) {
+                                     const void* prepacked, const float* plan_mask, int32_t* plan, mgnns_stream_t stream) {
     return bilstm_impl(true, prepacked, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
-                       workspace_bytes, out, out_bf16, ld_bf16, stream);
+                       workspace_bytes, out, out_bf16, ld_bf16, stream, nullptr, plan_mask, plan);
 }
 
 // ---- the layer-0 input projection folded into the embedding table (weights only: once per weight version) -------------------
@@ -816,8 +833,9 @@ extern "C" int mgnns_bilstm_bf16_table_fwd(const int64_t* tok, const int64_t* le
                                            int emb_dim, int hidden, int num_layers, const float* const* w_ih_cat,
                                            const float* const* b_ih_cat, const float* const* w_hh, const float* const* b_hh,
                                            void* workspace, size_t workspace_bytes, float* out, void* out_bf16, int ld_bf16,
-                                           const void* prepacked, const float* gx_table, mgnns_stream_t stream) {
+                                           const void* prepacked, const float* gx_table, const float* plan_mask, int32_t* plan,
+                                           mgnns_stream_t stream) {
     MG_REQUIRE(gx_table, "mgnns_bilstm_bf16_table_fwd: null table (mgnns_bilstm_bf16_fold_embedding makes it)");
     return bilstm_impl(true, prepacked, tok, lens, B, T, emb_table, V, emb_dim, hidden, num_layers, w_ih_cat, b_ih_cat, w_hh, b_hh, workspace,
-                       workspace_bytes, out, out_bf16, ld_bf16, stream, gx_table);
+                       workspace_bytes, out, out_bf16, ld_bf16, stream, gx_table, plan_mask, plan);
 }

@@ -24,6 +24,7 @@
 //                           Scores use the row's own sample's query, the softmax is segmented per sample, the weighted sum
 //                           is taken per 8-row block in registers and the blocks of a sample are added through LDS.
 #include "common.hpp"
+#include "sq_mha_plan.hpp"
 
 #ifdef MG_MHA32_TRACE
 // profiling aid (off by default; tools/dev/mha32_trace.py): s_memtime stamps of waves 0 (K units) and 4 (V units) of workgroups
@@ -526,80 +527,16 @@ __global__ __launch_bounds__(NTHR) void sq_mha32_core_kernel(const float* __rest
 // =====================================================================================================================
 // packed masked banks
 // =====================================================================================================================
-constexpr int PR = 128;                 // rows a group holds (4 tiles)
-constexpr int PS = 16;                  // samples a group holds
+using mg_plan::PR;                      // rows a group holds (4 tiles)
+using mg_plan::PS;                      // samples a group holds
 constexpr int PHL = 2;                  // heads a workgroup owns (one pair)
 constexpr int PQS = PHL * DK + 4;       // floats per sample in the query image (+4: samples on different LDS banks)
-constexpr int PLAN_HDR = 4;
+using mg_plan::PLAN_HDR;
 
-// plan = int32 [PLAN_HDR + 4 B + 2 B]: [0] number of groups, [1] B; group g at PLAN_HDR + 4 g: first sample, samples, rows;
-// sample b at PLAN_HDR + 4 B + 2 b: first row inside its group, live rows (last unmasked position + 1).
-// Greedy first fit in batch order (a group closes at 16 samples or when the next sample's 8-aligned rows would pass 128),
-// computed without a serial pass over the samples: every sample finds where a group STARTING at it would end (<= 16 steps,
-// all samples at once), one thread follows that chain from sample 0 (one hop per group), every group lays out its samples.
+// (plan layout and construction: sq_mha_plan.hpp)
 __global__ __launch_bounds__(1024) void sq_mha32_plan_kernel(const float* __restrict__ mask, int B, int L, int* __restrict__ plan) {
-    extern __shared__ int s_plan[];             // [B] live rows, [B] row offsets, [B] next group start, [B] rows of a group from here, [4 B] groups
-    int* s_lv = s_plan;
-    int* s_off = s_plan + B;
-    int* s_next = s_plan + 2 * B;
-    int* s_rows = s_plan + 3 * B;
-    int* s_grp = s_plan + 4 * B;
-    int* s_ng = s_plan + 8 * B;
-    const int tid = threadIdx.x;
-    for (int b = tid; b < B; b += 1024) s_lv[b] = 0;
-    __syncthreads();
-    const int total = B * L;
-    for (int i = tid; i < total; i += 1024) {            // coalesced sweep of the mask: live rows = last unmasked position + 1
-        if (mask[i] != 0.0f) {
-            const int b = i / L;
-            atomicMax(&s_lv[b], i - b * L + 1);
-        }
-    }
-    __syncthreads();
-    for (int b = tid; b < B; b += 1024) {
-        int rows = 0, j = b;
-        while (j < B && j - b < PS) {
-            const int lv = s_lv[j];
-            const int l8 = lv <= 8 ? 8 : (lv + 7) & ~7;
-            if (rows + l8 > PR) break;
-            rows += l8;
-            ++j;
-        }
-        s_next[b] = j;
-        s_rows[b] = rows;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int g = 0;
-        for (int b = 0; b < B; ++g) {                    // one hop per group
-            s_grp[4 * g] = b;
-            b = s_next[b];
-        }
-        *s_ng = g;
-        plan[0] = g;
-        plan[1] = B;
-        plan[2] = plan[3] = 0;
-    }
-    __syncthreads();
-    const int ng = *s_ng;
-    for (int g = tid; g < ng; g += 1024) {
-        const int b0 = s_grp[4 * g];
-        s_grp[4 * g + 1] = s_next[b0] - b0;
-        s_grp[4 * g + 2] = s_rows[b0];
-        s_grp[4 * g + 3] = 0;
-        int rows = 0;
-        for (int b = b0; b < s_next[b0]; ++b) {
-            const int lv = s_lv[b];
-            s_off[b] = rows;
-            rows += lv <= 8 ? 8 : (lv + 7) & ~7;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 4 * ng; i += 1024) plan[PLAN_HDR + i] = s_grp[i];
-    for (int b = tid; b < B; b += 1024) {
-        plan[PLAN_HDR + 4 * B + 2 * b] = s_off[b];
-        plan[PLAN_HDR + 4 * B + 2 * b + 1] = s_lv[b];
-    }
+    extern __shared__ int s_plan[];
+    mg_plan::build<1024>(mask, B, L, plan, s_plan);
 }
 
 constexpr size_t P_OFF_PART = (size_t)PR * LSTR * 16;                         // float [PHL][4][PR] partial scores
@@ -869,7 +806,7 @@ extern "C" size_t mgnns_sq_mha32_plan_ints(int B) { return (size_t)PLAN_HDR + 6 
 extern "C" int mgnns_sq_mha32_plan(const float* mask, int B, int L, int32_t* plan, mgnns_stream_t stream) {
     MG_REQUIRE(mask && plan, "mgnns_sq_mha32_plan: null pointer");
     MG_REQUIRE(B >= 0 && B <= 4096 && L > 0 && L <= PR, "mgnns_sq_mha32_plan: B=%d (<= 4096), L=%d (1..%d) unsupported", B, L, PR);
-    const size_t lds = ((size_t)8 * B + 4) * sizeof(int);
+    const size_t lds = mg_plan::lds_bytes(B);
     MG_DYN_LDS(sq_mha32_plan_kernel, lds);
     hipLaunchKernelGGL(sq_mha32_plan_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, mask, B, L, plan);
     MG_CHECK_LAUNCH("mgnns_sq_mha32_plan");

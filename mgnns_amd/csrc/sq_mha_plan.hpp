@@ -1,0 +1,100 @@
+// Packing plan of a text mask for the packed masked attention launches (sq_mha32_bf16.hip: sq_mha32_packed_kernel): one
+// workgroup's worth of device code, shared by the stand-alone plan launch (mgnns_sq_mha32_plan) and by the BiLSTM's prep launch
+// (lstm.hip: an extra workgroup of lstm_prep_kernel builds the plan of the batch's mask while the others pack the batch, so
+// neither masked stack of the forward pays a launch for it -- Multi_GCN_Multihead_att.py:509-527 runs both on the same mask).
+#pragma once
+#include "common.hpp"
+
+namespace mg_plan {
+
+constexpr int PR = 128;                 // rows a group holds (4 tiles of 32)
+constexpr int PS = 16;                  // samples a group holds
+constexpr int PLAN_HDR = 4;
+constexpr int MAX_B = 4096;             // one workgroup scans the batch
+__host__ __device__ constexpr size_t lds_bytes(int B) { return ((size_t)8 * B + 4) * sizeof(int); }
+
+// plan = int32 [PLAN_HDR + 4 B + 2 B]: [0] number of groups, [1] B; group g at PLAN_HDR + 4 g: first sample, samples, rows;
+// sample b at PLAN_HDR + 4 B + 2 b: first row inside its group, live rows (last unmasked position + 1).
+// Greedy first fit in batch order (a group closes at 16 samples or when the next sample's 8-aligned rows would pass 128),
+// computed without a serial pass over the samples: every sample finds where a group STARTING at it would end (<= 16 steps,
+// all samples at once), one thread follows that chain from sample 0 (one hop per group), every group lays out its samples.
+// s_plan: lds_bytes(B) of LDS -- [B] live rows, [B] row offsets, [B] next group start, [B] rows of a group from here, [4 B] groups.
+// Called by ALL NT threads of one workgroup.
+template <int NT>
+__device__ __forceinline__ void build(const float* __restrict__ mask, int B, int L, int* __restrict__ plan, int* s_plan) {
+
+    int* s_lv = s_plan;
+    int* s_off = s_plan + B;
+    int* s_next = s_plan + 2 * B;
+    int* s_rows = s_plan + 3 * B;
+    int* s_grp = s_plan + 4 * B;
+    int* s_ng = s_plan + 8 * B;
+    const int tid = threadIdx.x;
+    // live rows = last unmasked position + 1: one thread per sample walks its row with independent 16-byte loads (L / 4 of them
+    // in flight; round 4 swept the mask coalesced with an LDS atomicMax per live position -- most of the launch's 11 us, and with the
+    // plan riding on the BiLSTM's prep launch that time sits on the chain the forward follows)
+    const bool vec = (L & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+    for (int b = tid; b < B; b += NT) {
+        const float* row = mask + (size_t)b * L;
+        int lv = 0;
+        if (vec) {
+            for (int p = 0; p < L; p += 4) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(row + p);
+                lv = m[0] != 0.0f ? p + 1 : lv;
+                lv = m[1] != 0.0f ? p + 2 : lv;
+                lv = m[2] != 0.0f ? p + 3 : lv;
+                lv = m[3] != 0.0f ? p + 4 : lv;
+            }
+        } else {
+            for (int p = 0; p < L; ++p) lv = row[p] != 0.0f ? p + 1 : lv;
+        }
+        s_lv[b] = lv;
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += NT) {
+        int rows = 0, j = b;
+        while (j < B && j - b < PS) {
+            const int lv = s_lv[j];
+            const int l8 = lv <= 8 ? 8 : (lv + 7) & ~7;
+            if (rows + l8 > PR) break;
+            rows += l8;
+            ++j;
+        }
+        s_next[b] = j;
+        s_rows[b] = rows;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int g = 0;
+        for (int b = 0; b < B; ++g) {                    // one hop per group
+            s_grp[4 * g] = b;
+            b = s_next[b];
+        }
+        *s_ng = g;
+        plan[0] = g;
+        plan[1] = B;
+        plan[2] = plan[3] = 0;
+    }
+    __syncthreads();
+    const int ng = *s_ng;
+    for (int g = tid; g < ng; g += NT) {
+        const int b0 = s_grp[4 * g];
+        s_grp[4 * g + 1] = s_next[b0] - b0;
+        s_grp[4 * g + 2] = s_rows[b0];
+        s_grp[4 * g + 3] = 0;
+        int rows = 0;
+        for (int b = b0; b < s_next[b0]; ++b) {
+            const int lv = s_lv[b];
+            s_off[b] = rows;
+            rows += lv <= 8 ? 8 : (lv + 7) & ~7;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * ng; i += NT) plan[PLAN_HDR + i] = s_grp[i];
+    for (int b = tid; b < B; b += NT) {
+        plan[PLAN_HDR + 4 * B + 2 * b] = s_off[b];
+        plan[PLAN_HDR + 4 * B + 2 * b + 1] = s_lv[b];
+    }
+}
+
+}  // namespace mg_plan

@@ -194,6 +194,133 @@ __global__ __launch_bounds__(NT) void textgcn_kernel(const int64_t* __restrict__
     }
 }
 
+// LEAN form for the documents of a large batch (round 5): 256 threads, <= 64 VGPRs, NO node rows in LDS -- 8.4 KB of LDS at
+// T = 100 (band of edge weights, token list, same-token chains, three chunk sums).  The 1024-thread form above keeps a document's
+// node rows in LDS (120 KB at T = 100): a workgroup of it -- even one that only EXITS because its document is short -- needs a CU
+// with that much LDS free, and next to the image-bank kernels (148 KB of LDS and 448 of a SIMD's 512 registers per workgroup, alive
+// for the whole launch) no CU has: the text GCN took 223 us instead of 37 inside a B = 256 forward and the text->place stack
+// started ~60 us late (NOTES_r04 11).  This form fits BESIDE a bank workgroup (12 KB of LDS and 64 registers per SIMD are left):
+// the aggregation reads the window's node rows straight from L2 (a row is read once per destination whose window holds it: 9 x
+// 1200 B per token, all in flight together), one (position chunk, 4-feature group) per thread as above.  Same arithmetic in the
+// same order as the LDS forms: bit-identical results.
+template <int GT>
+__global__ __launch_bounds__(TG_SHORT_THREADS) void textgcn_lean_kernel(const int64_t* __restrict__ tok, int T, int Tm,
+                               const float* __restrict__ node_hidden, int V, int D,
+                               const float* __restrict__ edge_w, int n_edge_w,
+                               const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                               const int32_t* __restrict__ eid, int g_rt, float* __restrict__ out, int C, int mode, int cap) {
+    constexpr int TG_THREADS = TG_SHORT_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = GT > 0 ? GT : g_rt;
+    const int W = 2 * g + 1;
+    const int D4 = D >> 2, Dp = D4 << 2;                 // (D % 4 == 0: the launcher checks)
+    float* s_part = smem;                                // [C][Dp]
+    float* s_w = s_part + (size_t)C * Dp;                // [Tm][W]
+    int* s_tok = reinterpret_cast<int*>(s_w + (size_t)Tm * W);   // [Tm]
+    int* s_next = s_tok + Tm;                            // [Tm] next position holding the same token, INT_MAX = none
+    int* s_first = s_next + Tm;                          // [Tm] 1 if first occurrence of its token
+    int* s_n = s_first + Tm;                             // [1]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+
+    if (tid < 64) {                                      // compact the non-PAD ids (Text_GCN.py:147-150), wave 0
+        int n = 0;
+        for (int p0 = 0; p0 < Tm; p0 += 64) {
+            const int p = p0 + lane;
+            long long id = p < Tm ? tok[(size_t)b * T + p] : 0;
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+            const bool nz = id != 0;
+            const unsigned long long m = __ballot(nz);
+            if (nz) s_tok[n + __popcll(m & ((1ull << lane) - 1ull))] = (int)id;
+            n += __popcll(m);
+        }
+        if (lane == 0) *s_n = n;
+    }
+    for (int j = tid; j < Tm; j += TG_THREADS) { s_first[j] = 1; s_next[j] = 0x7fffffff; }
+    __syncthreads();
+    const int n = *s_n;
+    if ((mode == 1 && n > cap) || (mode == 2 && n <= cap)) return;         // the other launch's document (uniform per workgroup)
+
+    for (int e = tid; e < n * W; e += TG_THREADS) {      // band of edge weights: s_w[j][o] = edge_w[pmi(t_i, t_j)], i = j - g + o
+        const int j = e / W, o = e - j * W;
+        const int i = j - g + o;
+        s_w[e] = (i >= 0 && i < n) ? pmi_weight(row_ptr, col, eid, edge_w, n_edge_w, s_tok[i], s_tok[j]) : 0.f;
+    }
+    for (int pidx = tid; pidx < n * n; pidx += TG_THREADS) {      // same-token chains (nodes = DISTINCT ids, Text_GCN.py:172)
+        const int j = pidx / n, k = pidx - j * n;
+        if (k < j && s_tok[k] == s_tok[j]) {
+            s_first[j] = 0;
+            atomicMin(&s_next[k], j);
+        }
+    }
+    __syncthreads();
+
+    const int cidx = tid / D4, f = tid - cidx * D4;
+    if (cidx < C) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        // this thread's 4 features of node row t: byte offset (t * D + 4 f) * 4 into a buffer resource over the table -- 32-bit
+        // offsets (64-bit pointers for the nine rows in flight put the ngram-4 instance at 66 registers; 64 is what is left
+        // beside an image-bank workgroup)
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(node_hidden), 0, 0x7fffffff, 0x00027000);
+        const int fo = f * 16, rowb = D * 4;
+        for (int j0 = cidx; j0 < n; j0 += C) {
+            if (!s_first[j0]) continue;
+            f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int j = j0; j < n; j = s_next[j]) {
+                const float* wrow = s_w + (size_t)j * W;
+                if (GT > 0) {
+                    float w[2 * GT + 1];
+                    f32x4 h[2 * GT + 1];
+#pragma unroll
+                    for (int o = 0; o < 2 * GT + 1; ++o) {
+                        const int i = min(max(j - GT + o, 0), n - 1);
+                        w[o] = wrow[o];
+                        h[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, s_tok[i] * rowb + fo, 0, 0));
+                    }
+#pragma unroll
+                    for (int o = 0; o < 2 * GT + 1; ++o) {
+                        const int i = j - GT + o;
+                        if (i >= 0 && i < n) {
+                            mx.x = fmaxf(mx.x, w[o] * h[o].x);
+                            mx.y = fmaxf(mx.y, w[o] * h[o].y);
+                            mx.z = fmaxf(mx.z, w[o] * h[o].z);
+                            mx.w = fmaxf(mx.w, w[o] * h[o].w);
+                        }
+                    }
+                } else {
+                    const int lo = max(0, j - g), hi = min(n, j + g + 1);
+                    for (int i = lo; i < hi; ++i) {
+                        const float w = wrow[i - (j - g)];
+                        const f32x4 h = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, s_tok[i] * rowb + fo, 0, 0));
+                        mx.x = fmaxf(mx.x, w * h.x);
+                        mx.y = fmaxf(mx.y, w * h.y);
+                        mx.z = fmaxf(mx.z, w * h.z);
+                        mx.w = fmaxf(mx.w, w * h.w);
+                    }
+                }
+            }
+            sum += mx;
+        }
+        *reinterpret_cast<f32x4*>(s_part + (size_t)cidx * Dp + 4 * f) = sum;
+    }
+    __syncthreads();
+    for (int d = tid; d < D; d += TG_THREADS) {
+        float total = 0.f;
+        for (int c = 0; c < C; ++c) total += s_part[(size_t)c * Dp + d];        // fixed order: deterministic
+        out[(size_t)b * D + d] = fmaxf(total, 0.f);
+    }
+}
+
+template <int GT>
+int launch_lean(const int64_t* tok, int B, int T, int Tm, const float* node_hidden, int V, int D, const float* edge_w, int n_edge_w,
+                const int32_t* rp, const int32_t* col, const int32_t* eid, int ngram, float* out, int C, int mode, int cap, size_t lds,
+                hipStream_t st) {
+    MG_DYN_LDS((textgcn_lean_kernel<GT>), 12 * 1024);
+    hipLaunchKernelGGL((textgcn_lean_kernel<GT>), dim3(B), dim3(TG_SHORT_THREADS), lds, st, tok, T, Tm, node_hidden, V, D, edge_w, n_edge_w,
+                       rp, col, eid, ngram, out, C, mode, cap);
+    MG_CHECK_LAUNCH("mgnns_textgcn_fwd");
+    return 0;
+}
+
 template <int GT, int NT>
 int launch(const int64_t* tok, int B, int T, int Tm, const float* node_hidden, int V, int D, const float* edge_w, int n_edge_w,
            const int32_t* rp, const int32_t* col, const int32_t* eid, int ngram, float* out, int vec, int C, int Tn, int mode, int cap,
@@ -206,6 +333,13 @@ int launch(const int64_t* tok, int B, int T, int Tm, const float* node_hidden, i
 }
 
 }  // namespace
+
+static int g_textgcn_form = 0;           // 0: by batch and shape; 1 one launch (1024 threads), 2 two launches (short + long), 3 lean
+extern "C" int mgnns_textgcn_set_form(int form) {
+    MG_REQUIRE(form >= 0 && form <= 3, "mgnns_textgcn_set_form: form=%d (0 by batch, 1 one launch, 2 two launches, 3 lean)", form);
+    g_textgcn_form = form;
+    return 0;
+}
 
 extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* node_hidden, int V, int D,
                                  const float* edge_w, int n_edge_w, const int32_t* pmi_row_ptr,
@@ -234,10 +368,22 @@ extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* 
     int Cs = TG_SHORT_THREADS / D4;
     Cs = Cs > TG_MAX_CHUNKS ? TG_MAX_CHUNKS : Cs;
     const size_t lds_s = lds_of(TG_SHORT_CAP, Cs);
-    const bool split = B >= 64 && Tm > TG_SHORT_CAP && Cs >= 1 && lds_s <= 40 * 1024 && mg_env_int("MGNNS_TEXTGCN_SPLIT", 1, 7) != 0;
+    const int form = g_textgcn_form;
+    const bool split_ok = Tm > TG_SHORT_CAP && Cs >= 1 && lds_s <= 40 * 1024;
+    const bool split = form == 2 ? split_ok : (form == 0 && B >= 64 && split_ok && mg_env_int("MGNNS_TEXTGCN_SPLIT", 1, 7) != 0);
+    // large batches (the forward of a B >= 64 batch runs the text GCN next to the image-bank kernels): ONE launch of the LEAN kernel,
+    // every document -- the 256-thread short form's 33 KB of LDS does not fit beside a bank workgroup either (12 KB are left), and
+    // its launch sat in front of the long documents' in the stream.  MGNNS_TEXTGCN_LEAN=0 or a shape it does not take (D % 4,
+    // alignment, a band beyond 12 KB): the two-launch form
+    const size_t lds_lean = ((size_t)Cs * Dp + (size_t)Tm * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
+    const bool lean_ok = Cs >= 1 && vec && D % 4 == 0 && lds_lean <= 12 * 1024;
+    const bool lean = form == 3 ? lean_ok : (form == 0 && B >= 64 && lean_ok && mg_env_int("MGNNS_TEXTGCN_LEAN", 1, 8) != 0);
 #define TG_ARGS(Tn_, C_, mode_, lds_) tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec, C_, Tn_, mode_, TG_SHORT_CAP, lds_, st
 #define TG_LAUNCH(GT_)                                                                                     \
     {                                                                                                      \
+        if (lean)                                                                                          \
+            return launch_lean<GT_>(tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, \
+                                    out, Cs, 0, TG_SHORT_CAP, lds_lean, st);                               \
         if (split) {                                                                                       \
             if (int rc = launch<GT_, TG_SHORT_THREADS>(TG_ARGS(TG_SHORT_CAP, Cs, 1, lds_s))) return rc;    \
             return launch<GT_, 1024>(TG_ARGS(Tm, C, 2, lds));                                              \

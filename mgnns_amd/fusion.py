@@ -70,12 +70,18 @@ class MemoryBank:
         return self._bf16.shape if self._bf16 is not None else self._split.shape[1:]
 
 
+def mask_plan_applies(mask, precision='bf16', attention='faithful'):
+    """Does a masked stack in this mode run the packed attention launches (a plan of the mask makes sense)?"""
+    return (precision == 'bf16' and attention == 'faithful' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask is not None
+            and mask.shape[-1] <= ops.PLAN_MAX_L and mask.shape[0] <= ops.PLAN_MAX_B and not FUSED_LAYER)
+
+
 def make_mask_plan(mask, precision='bf16', attention='faithful'):
     """The packing plan of a [B, L] attention mask for the bf16 core (ops.sq_mha_plan: the live rows of short samples share a
     workgroup), or None where it does not apply.  Depends on the mask's VALUES only; whoever passes it to run_stack(plan=...)
-    orders the launch that built it in front of the stack (an event if it ran on another stream)."""
-    if (precision == 'bf16' and attention == 'faithful' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask is not None
-            and mask.shape[-1] <= ops.PLAN_MAX_L and mask.shape[0] <= ops.PLAN_MAX_B and not FUSED_LAYER):
+    orders the launch that built it in front of the stack (an event if it ran on another stream).  The model's forward gets the
+    same plan out of the BiLSTM's prep launch instead (ops.bilstm(plan_mask=...))."""
+    if mask_plan_applies(mask, precision, attention):
         return ops.sq_mha_plan(mask.reshape(mask.shape[0], -1).float().contiguous())
     return None
 

@@ -18,8 +18,12 @@ from torch.nn import Parameter
 from . import _lib, ops
 from .adjacency import gen_A, gen_adj_csr
 from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention, MyMultiHeadAttention, first_query, make_mask_plan,
+                     mask_plan_applies,
                      first_query_pack, first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
+
+# the packed masked attention's plan of the text mask out of the BiLSTM's prep launch (one per batch) instead of a launch per channel
+PLAN_IN_PREP = os.environ.get("MGNNS_PLAN_IN_PREP", "1") != "0"
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
 
@@ -303,14 +307,20 @@ class Multi_GCN_Multihead_Att(nn.Module):
                                 for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")))
         return ws
 
-    def _text_bank(self, text, text_lens):
-        """MemoryBank of the text (fp32 + bf16 copy in bf16 mode, both written by the LSTM kernel)."""
+    def _text_bank(self, text, text_lens, plan_mask=None):
+        """MemoryBank of the text (fp32 + bf16 copy in bf16 mode, both written by the LSTM kernel).  plan_mask: the text mask
+        whose packing plan the bf16 prep launch builds on the side (bank.mask_plan; None where it cannot)."""
         lens = text_lens.to(device=text.device, dtype=torch.int64, non_blocking=True).contiguous()
         if self.precision == 'bf16':                        # ('bf16x3': the exact fp32 recurrence below)
-            f32, bf = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
-                                 self.hidden_size, self.lstm.num_layers, want_bf16=True,
-                                 recurrence=os.environ.get("MGNNS_LSTM_REC", "bf16"), cache=self._lstm_cache)
-            return MemoryBank(f32=f32, bf16=bf)
+            rec = os.environ.get("MGNNS_LSTM_REC", "bf16")
+            if plan_mask is not None and not ops.bilstm_can_plan(text.shape[0], text.shape[1], self.embedding.weight.shape[1], rec):
+                plan_mask = None
+            r = ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(), self._lstm_weights(),
+                           self.hidden_size, self.lstm.num_layers, want_bf16=True, recurrence=rec, cache=self._lstm_cache,
+                           plan_mask=plan_mask)
+            bank = MemoryBank(f32=r[0], bf16=r[1])
+            bank.mask_plan = r[2] if plan_mask is not None else None     # the text mask's packing plan, built by the prep launch
+            return bank
         return MemoryBank(f32=ops.bilstm(text.long().contiguous(), lens, self.embedding.weight.detach(),
                                          self._lstm_weights(), self.hidden_size, self.lstm.num_layers,
                                          cache=self._lstm_cache))
@@ -674,7 +684,11 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # input conversion first: a bool / int mask (the reference documents a bool tensor) is cast HERE, in the
             # segment both masked stacks wait for
             ctx['text_mask'] = text_mask.float().contiguous()
-            ctx['text_bank'] = self._text_bank(text, text_lens)
+            # the packing plan of the mask for both image->text stacks (MODEL:509-527) rides on the BiLSTM's prep launch: one more
+            # workgroup there instead of a launch per channel (round 4) on the stacks' critical paths
+            want_plan = PLAN_IN_PREP and mask_plan_applies(ctx['text_mask'], self.precision, self.attention)
+            ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if want_plan else None)
+            ctx['mha_plan'] = getattr(ctx['text_bank'], 'mask_plan', None)
             ops.stamp("text bank (LSTM) end")
 
         def lgcn(tag, A, inp, attention):
@@ -721,7 +735,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
                 # its masked attention launches, MODEL:509-527): one small launch per channel, HERE -- on the stack's own stream,
                 # which has slack; on the BiLSTM's stream (the longest chain) it cost the pipelined forward 3 %, and one plan for
                 # both stacks means a cross-stream dependency the runtime's one-graph capture of the schedule does not survive
-                ctx['mha_plan_' + next_name] = make_mask_plan(text_mask, self.precision, self.attention)
+                if not (PLAN_IN_PREP and mask_plan_applies(text_mask, self.precision, self.attention)
+                        and ops.bilstm_can_plan(text.shape[0], text.shape[1], self.embedding.weight.shape[1],
+                                                os.environ.get("MGNNS_LSTM_REC", "bf16"))):
+                    ctx['mha_plan_' + next_name] = make_mask_plan(text_mask, self.precision, self.attention)
                 ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
                     ctx['pooled_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag), ctx['Q_' + tag], attention, linear_5, x_linear,
                     next_stack)
@@ -748,7 +765,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
             def run():
                 ops.stamp("%s stack start" % name)
                 ctx[name] = run_stack(layers, ctx[q_key], ctx[bank_key], ctx['text_mask'] if masked else None,
-                                      qh=ctx.get('qh_' + name), plan=ctx.get('mha_plan_' + name) if masked else None)
+                                      qh=ctx.get('qh_' + name),
+                                      plan=(ctx.get('mha_plan_' + name) if ctx.get('mha_plan_' + name) is not None
+                                            else ctx.get('mha_plan')) if masked else None)
                 if split_head:
                     wc, bc, hstate = ctx['_head']
                     ops.classifier_head_part(ctx[name], part_of[name], 4, wc, bc, hstate)

@@ -600,7 +600,13 @@ def _lstm_table(emb_table, cat0, hidden, cache):
     return table
 
 
-def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32", cache=None, fold=None):
+def bilstm_can_plan(B, T, emb_dim, recurrence="bf16"):
+    """Can bilstm(..., plan_mask=...) build the packing plan of the text mask inside its prep launch?"""
+    return recurrence == "bf16" and B <= 1024 and T <= PLAN_MAX_L and emb_dim % 4 == 0 and emb_dim <= 320
+
+
+def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, recurrence="f32", cache=None, fold=None,
+           plan_mask=None):
     """tok [B,T] int64, lens [B] int64 (device), weights = list over (layer, direction) of
     (w_ih, w_hh, b_ih, b_hh) -> [B,T,2*hidden] with zeros behind each sample's length
     (+ the same bank as zero-padded bf16 [B,T,320] when want_bf16).  recurrence="bf16": W_hh . h of every step on the
@@ -608,7 +614,10 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
     cache: an LstmCache owned by the module that owns `weights` (None: derived weight forms are rebuilt per call).
     fold (bf16 recurrence; default LSTM_FOLD_EMBEDDING when a cache is given): read the layer-0 input projection out of the
     table folded from the embedding and W_ih once per weight version -- the same rows bit for bit, no GEMM in front of the first
-    recurrence."""
+    recurrence.
+    plan_mask (bf16 recurrence, bilstm_can_plan): the batch's text mask [B, T] float -- the packing plan of that mask for the packed
+    masked attention launches (== sq_mha_plan(plan_mask)) is built by an extra workgroup of the prep launch and returned as a
+    third / second value."""
     import ctypes
     _chk(tok, "text", torch.int64, 2)
     _chk(lens, "text_lens", torch.int64, 1)
@@ -638,6 +647,12 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=tok.device)
     out = torch.empty(B, T, 2 * hidden, device=tok.device, dtype=torch.float32)
     out_bf = torch.empty(B, T, BANK_LD, device=tok.device, dtype=torch.bfloat16) if want_bf16 else None
+    plan = None
+    if plan_mask is not None:
+        _chk(plan_mask, "plan_mask", ndim=2)
+        if tuple(plan_mask.shape) != (B, T) or not bilstm_can_plan(B, T, emb_table.shape[1], recurrence):
+            raise ValueError("plan_mask must be the [%d, %d] text mask and needs bilstm_can_plan(...)" % (B, T))
+        plan = torch.empty(L.mgnns_sq_mha32_plan_ints(B), dtype=torch.int32, device=tok.device)
     if recurrence not in ("f32", "bf16"):
         raise ValueError("recurrence must be 'f32' or 'bf16', got %r" % (recurrence,))
     if recurrence == "f32":
@@ -661,11 +676,13 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
             table = _lstm_table(emb_table, cat[0], hidden, cache)
             _launch("mgnns_bilstm_bf16_table_fwd", ("mgnns_bilstm_bf16_table_fwd",), L.mgnns_bilstm_bf16_table_fwd, _p(tok), _p(lens), B, T,
                     _p(emb_table), emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
-                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _p(table), _stream())
+                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _p(table), _p(plan_mask), _p(plan), _stream())
         else:
             _launch("mgnns_bilstm_bf16_fwd", ("mgnns_bilstm_bf16_fwd",), L.mgnns_bilstm_bf16_fwd, _p(tok), _p(lens), B, T, _p(emb_table),
                     emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
-                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _stream())
+                    _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _p(plan_mask), _p(plan), _stream())
+    if plan is not None:
+        return (out, out_bf, plan) if want_bf16 else (out, plan)
     return (out, out_bf) if want_bf16 else out
 
 
@@ -762,6 +779,11 @@ def head_diff(o, n_head):
     _launch("mgnns_head_diff_fwd", ("mgnns_head_diff_fwd",), L.mgnns_head_diff_fwd, _p(o), B, n_head, o.shape[1] // n_head, _p(out),
             _stream())
     return out
+
+
+def textgcn_set_form(form):
+    """0 by batch (default) | 1 one 1024-thread launch | 2 two launches (short + long documents) | 3 the lean kernel (tests)."""
+    _lib.check(_lib.lib().mgnns_textgcn_set_form(int(form)), "mgnns_textgcn_set_form")
 
 
 def imgbank_set_form(form):

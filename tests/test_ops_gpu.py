@@ -418,10 +418,13 @@ def test_textgcn_vs_oracle_full_length_and_edge_cases():
         assert H.relerr(y.cpu(), ref) < 1e-5
 
 
-def test_textgcn_two_launch_form_short_and_long_documents():
-    """From 64 documents on the text GCN runs as two launches (documents of at most 24 tokens four to a CU, then the longer ones):
-    lengths on both sides of the cap incl. exactly 24 / 25, empty and full-length documents, against the oracle and against the
-    same documents run in batches below the threshold (one launch; same values up to the summation order of the chunk sums)."""
+def test_textgcn_launch_forms_short_and_long_documents():
+    """From 64 documents on the text GCN runs as ONE launch of the lean kernel (round 5: 256 threads, node rows read from L2 instead
+    of staged in LDS, so that it fits beside an image-bank workgroup; ngram 4 = its unrolled window, 0 / 6 = its run-time window);
+    rounds 3-4 ran two launches (documents of at most 24 tokens four to a CU, then the longer ones on the 1024-thread form), small
+    batches run one 1024-thread launch.  Every form (ops.textgcn_set_form) on lengths on both sides of the cap incl. exactly
+    24 / 25, empty and full-length documents, PADs inside: against the oracle, against each other (same values up to the summation
+    order of the chunk sums) and against the same documents in batches below the threshold; repeated launches give identical bits."""
     V, T, B = 5000, 100, 96
     pmi, count = synth.synth_pmi(V, seed=6)
     tok, lens, _ = synth.synth_tokens(B, T, V, pmi, seed=12)
@@ -432,14 +435,25 @@ def test_textgcn_two_launch_form_short_and_long_documents():
     tok[9, ::3] = 0                                             # PADs inside: the cap counts non-PAD tokens
     p = H.params_for({"text_features.node_hidden.weight": (V, 300), "text_features.seq_edge_w.weight": (count, 1)})
     nh, ew = dev(p["text_features.node_hidden.weight"]), dev(p["text_features.seq_edge_w.weight"])
-    for ngram in (4, 0, 6):
-        ref = R.text_gcn(tok, p["text_features.node_hidden.weight"], p["text_features.seq_edge_w.weight"], pmi, ngram)
-        y = ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram)
-        assert H.relerr(y.cpu(), ref) < 1e-5, ngram
-        assert float(y[4].abs().max()) == 0.0
-        parts = torch.cat([ops.textgcn(dev(tok[i:i + 32]), nh, ew, pmi.device_arrays(DEV), ngram) for i in range(0, B, 32)])
-        assert H.relerr(y.cpu(), parts.cpu()) < 1e-6, ngram
-        assert torch.equal(y, ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram))
+    try:
+        for ngram in (4, 0, 6):
+            ref = R.text_gcn(tok, p["text_features.node_hidden.weight"], p["text_features.seq_edge_w.weight"], pmi, ngram)
+            ys = {}
+            for form in (0, 1, 2, 3):
+                ops.textgcn_set_form(form)
+                y = ys[form] = ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram)
+                assert H.relerr(y.cpu(), ref) < 1e-5, (ngram, form)
+                assert float(y[4].abs().max()) == 0.0
+                assert torch.equal(y, ops.textgcn(dev(tok), nh, ew, pmi.device_arrays(DEV), ngram))
+            assert torch.equal(ys[0], ys[3])                     # B >= 64: the default IS the lean launch
+            for form in (1, 2):
+                assert H.relerr(ys[form].cpu(), ys[3].cpu()) < 1e-6, (ngram, form)
+            ops.textgcn_set_form(0)
+            parts = torch.cat([ops.textgcn(dev(tok[i:i + 32]), nh, ew, pmi.device_arrays(DEV), ngram) for i in range(0, B, 32)])
+            assert H.relerr(ys[0].cpu(), parts.cpu()) < 1e-6, ngram
+            assert torch.equal(parts, ys[1])                     # B < 64: the default is the one 1024-thread launch
+    finally:
+        ops.textgcn_set_form(0)
 
 
 def test_textgcn_explicit_ids_long_rows_and_odd_width():
@@ -1369,6 +1383,48 @@ def test_bilstm_bf16_layer0_projection_folded_into_the_embedding_table():
             a1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=True)
             b1, _ = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=ops.LstmCache(), fold=False)
             assert cache.table[2] is not first and torch.equal(a1, b1) and not torch.equal(a1, a0)
+
+
+def test_bilstm_prep_launch_builds_the_mask_packing_plan():
+    """ops.bilstm(plan_mask=mask): the packing plan of the text mask built by an extra workgroup of the BiLSTM's prep launch is the
+    stand-alone plan kernel's (ops.sq_mha_plan) int for int -- ragged lengths, a mask with holes and one that differs from the lengths
+    (the plan is defined by the MASK), folded-table and per-forward projection forms -- and the bank is untouched by it."""
+    import numpy as np
+    rs = np.random.RandomState(31)
+    V, E, Hh = 700, 300, 150
+    emb = torch.from_numpy((0.4 * rs.standard_normal((V, E))).astype(np.float32)).to(DEV)
+    weights = []
+    for layer in range(2):
+        for d in range(2):
+            ind = E if layer == 0 else 2 * Hh
+            weights.append(tuple(torch.from_numpy(rs.uniform(-0.08, 0.08, size=s).astype(np.float32)).to(DEV)
+                                 for s in ((4 * Hh, ind), (4 * Hh, Hh), (4 * Hh,), (4 * Hh,))))
+    for B, T in ((256, 100), (37, 128), (1, 9), (1000, 24)):
+        lens = np.clip(np.round(np.exp(rs.normal(2.4, 0.75, B))), 1, T).astype(int)
+        lens[0] = T
+        tok = np.zeros((B, T), np.int64)
+        mask = np.zeros((B, T), np.float32)
+        for b in range(B):
+            tok[b, :lens[b]] = rs.randint(1, V, size=lens[b])
+            mask[b, :lens[b]] = 1
+        if B > 2:
+            mask[1, ::2] = 0                                   # holes
+            mask[2, :] = 0
+            mask[2, min(T - 1, 5)] = 1                         # a mask that is not the length vector's
+        t, l, m = torch.from_numpy(tok).to(DEV), torch.from_numpy(lens.astype(np.int64)).to(DEV), torch.from_numpy(mask).to(DEV)
+        assert ops.bilstm_can_plan(B, T, E)
+        want = ops.sq_mha_plan(m)
+        for fold in (True, False):
+            cache = ops.LstmCache()
+            ref, ref_bf = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=fold)
+            out, out_bf, plan = ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="bf16", cache=cache, fold=fold,
+                                           plan_mask=m)
+            # (group slots behind the last group are never written by either launch)
+            ng = int(want[0])
+            assert torch.equal(plan[:4 + 4 * ng], want[:4 + 4 * ng]) and torch.equal(plan[4 + 4 * B:], want[4 + 4 * B:]), (B, T, fold)
+            assert torch.equal(out, ref) and torch.equal(out_bf, ref_bf)
+    with pytest.raises(ValueError):
+        ops.bilstm(t, l, emb, weights, Hh, 2, want_bf16=True, recurrence="f32", plan_mask=m)
 
 
 def test_bilstm_trailing_empty_samples_never_index_the_table_with_unwritten_tokens():
