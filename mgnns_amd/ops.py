@@ -571,6 +571,8 @@ def _lstm_cat(weights, num_layers, cache):
     val = [(torch.cat([weights[2 * l][0], weights[2 * l + 1][0]], 0).contiguous(),
             torch.cat([weights[2 * l][2], weights[2 * l + 1][2]], 0).contiguous()) for l in range(num_layers)]
     if cache is not None:
+        if cache.cat is not None:
+            retire(cache.cat[2])                # a live capture holds the old concatenations' addresses (projection weights / biases)
         cache.cat = (src, tuple(t._version for t in src), val)
     return val
 
@@ -669,6 +671,8 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
             _lib.check(L.mgnns_bilstm_bf16_prepack(c_wih, c_whh, emb_table.shape[1], hidden, num_layers, _p(pre), _stream()),
                        "mgnns_bilstm_bf16_prepack")
             if cache is not None:
+                if cache.prepack is not None:
+                    retire(cache.prepack[2])
                 cache.prepack = (src, tuple(t._version for t in src), pre)
         if fold is None:
             fold = LSTM_FOLD_EMBEDDING and cache is not None

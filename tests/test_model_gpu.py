@@ -187,6 +187,52 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
         assert torch.equal(gf(*a1), ref1)
 
 
+def test_load_state_dict_under_a_live_graph_with_the_lstm_table_fold():
+    """bf16 mode folds the BiLSTM's layer-0 projection into a [V, 1200] table per weight version (ops.LSTM_FOLD_EMBEDDING) and a
+    captured hipGraph holds that table's ADDRESS.  load_state_dict() while a GraphedForward is alive: the superseded table (and
+    every other derived weight form) is parked, not freed -- the STALE capture still replays the OLD weights' logits bit for bit,
+    an eager forward and a FRESH capture give the new weights' logits, both captures keep replaying side by side, and the park
+    empties when the last graph goes."""
+    from mgnns_amd.graph import GraphedForward
+    assert ops.LSTM_FOLD_EMBEDDING
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    model.set_precision("bf16").set_attention("faithful")
+    a1 = call_args(synth.make_inputs(cfg, B=16, seed=1, pmi=pmi), DEV)
+    old_logits = model(*a1).clone()
+    stale = GraphedForward(model, a1)
+    assert torch.equal(stale.replay(), old_logits)
+    table_old = model._lstm_cache.table[2]
+    ptr_old = table_old.data_ptr()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    # new values for exactly the parameters that reach the forward through the folded table alone (embedding rows, layer 0's W_ih /
+    # b_ih of both directions): load_state_dict copies IN PLACE, so a stale capture sees every other parameter's new value through the
+    # parameter's own storage -- for these it must keep reading the old table
+    folded = ("embedding.weight", "lstm.weight_ih_l0", "lstm.weight_ih_l0_reverse", "lstm.bias_ih_l0", "lstm.bias_ih_l0_reverse")
+    for k in folded:
+        sd[k] = sd[k] * 1.25 + 0.01
+    sd["embedding.weight"][0] = 0
+    model.load_state_dict(sd)
+    new_logits = model(*a1).clone()                      # eager: new table, new packs
+    assert not torch.equal(new_logits, old_logits)
+    assert model._lstm_cache.table[2].data_ptr() != ptr_old
+    filler = [torch.full((table_old.numel(),), 7.0, device=DEV) for _ in range(3)]      # would land in a freed 97 MB block
+    torch.cuda.synchronize()
+    assert torch.equal(stale.replay(), old_logits)       # the stale capture reads the PARKED table, not recycled memory
+    fresh = GraphedForward(model, a1)
+    assert torch.equal(fresh.replay(), new_logits)
+    for _ in range(3):
+        assert torch.equal(stale.replay(), old_logits) and torch.equal(fresh.replay(), new_logits)
+    del filler
+    del stale, fresh
+    import gc
+    gc.collect()
+    assert torch.equal(model(*a1), new_logits)
+
+
 def test_pipelined_replays_two_forwards_in_flight_equal_serial_ones():
     """GraphedPipeline: captures with buffers of their own replayed round robin WITHOUT a join between them (the next batch
     starts on a stream as soon as that stream is done with the current one) give, batch by batch, the bits of the serial
