@@ -357,8 +357,52 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
     // split-bf16 streams twice the bytes per k-step: six k-steps in flight instead of the tail kernel's three (this kernel has
     // the registers: its accumulators are 12 VGPRs)
     LT_STAMP(0);
-    WRing<3, TERMS, (TERMS == 3 ? 4 : 10)> ring;
+#ifndef MG_LT_TOUCH
+#define MG_LT_TOUCH 0      // measured (NOTES_r05): touching the weights into L2 up front costs more (28 k cycles of scattered loads) than it saves
+#endif
+#ifndef MG_LT_PF3
+#define MG_LT_PF3 4
+#endif
+    WRing<3, TERMS, (TERMS == 3 ? MG_LT_PF3 : 10)> ring;
     ring_prime(ring, KSpp, w.g_h, w.g_l, NTc, wave, lane, 0, KSp, CL > 1 ? crank * KSpp : 0);     // G flies through the staging of pooled
+#if MG_LT_TOUCH
+    // Every weight this workgroup will stream is TOUCHED now (one dword per 128-byte line, results never read): the chain of small
+    // GEMMs below is bound by the latency of its weight fragments, and on a workgroup's XCD they are cold -- the launch has a few
+    // workgroups per XCD and each reads its 2.4 MB once -- so every k-step waited for an HBM round trip (KV: 1300 cycles per k-step
+    // of nine MFMAs).  Touched up front the lines sit in the XCD's L2 when the rings ask for them.  (asm loads: the compiler neither
+    // drops them nor waits for them; its own counted waits only get stricter with more loads in flight.  They all land in ONE
+    // register that stays allocated until the end of the kernel -- `touch_sink` is an in/out operand of every load and of the
+    // final wait: a dead destination would be handed to another value and overwritten when the load lands.)
+    int touch_sink = 0;
+    {
+        auto touch = [&](const unsigned short* base, int nt_n, int ks_total, int ks_lo, int ks_n, int nt_lo = 0) {
+            if (!base || nt_n <= 0) return;
+            base += ((size_t)nt_lo * ks_total) << 9;                   // (bf16 elements: 512 per fragment)
+            const int lines = nt_n * ks_n * 8;                         // 128-byte lines (a fragment = 1 KiB = 8 lines)
+            for (int i = tid; i < lines; i += LT_THR) {
+                const int nt = i / (ks_n * 8), rem = i - nt * (ks_n * 8);
+                const char* p = reinterpret_cast<const char*>(base) + ((size_t)(nt * ks_total + ks_lo + (rem >> 3)) << 10) + ((rem & 7) << 7);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(touch_sink) : "v"(p) : "memory");
+            }
+        };
+        const int NTq_ = (HKn + 15) / 16;
+        touch(w.g_h, NTc, KSp, CL > 1 ? crank * KSpp : 0, CL > 1 ? KSpp : KSp);
+        if (LO) touch(w.g_l, NTc, KSp, CL > 1 ? crank * KSpp : 0, CL > 1 ? KSpp : KSp);
+        touch(w.wk_h, NTh, KSx, 0, KSx);
+        if (LO) touch(w.wk_l, NTh, KSx, 0, KSx);
+        touch(w.wv_h, NTh, KSx, 0, KSx);
+        if (LO) touch(w.wv_l, NTh, KSx, 0, KSx);
+        touch(w.wc_h, NT5, KSh, 0, KSh);
+        if (LO) touch(w.wc_l, NT5, KSh, 0, KSh);
+        touch(w.xl_h, NTo, KSf, 0, KSf);
+        if (LO) touch(w.xl_l, NTo, KSf, 0, KSf);
+        // (the next query's column tiles of THIS rank only: slots q_lo .. q_hi of eight tiles, computed again below)
+        const int qs_ = (NTq_ + 7) / 8, qp_ = (qs_ + CL - 1) / CL;
+        const int qt_lo = crank * qp_ * 8, qt_hi = (crank * qp_ + qp_) * 8 < NTq_ ? (crank * qp_ + qp_) * 8 : NTq_;
+        touch(w.wq_h, qt_hi - qt_lo, KSh, 0, KSh, qt_lo);
+        if (LO) touch(w.wq_l, qt_hi - qt_lo, KSh, 0, KSh, qt_lo);
+    }
+#endif
     for (int i = tid; i < (1 + LO) * LT_ROWS * (sxc + shc); i += LT_THR) s_xh[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * LT_ROWS * shf; i += LT_THR) s_k[i] = 0.f;
     for (int i = tid; i < NLQ * hid; i += LT_THR) s_q[i] = Q[i];
@@ -584,6 +628,9 @@ __global__ __launch_bounds__(LT_THR) void label_tail_bf16_kernel(const float* __
             }
         }
     }
+#if MG_LT_TOUCH
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch_sink)::"memory");      // (long landed: keeps the register reserved up to here)
+#endif
     LT_STAMP(7);
 }
 

@@ -14,6 +14,12 @@ timeout 400 tools/prof.sh ${tag}_bf16 --steps 20 --warmup 5 --no-cpu-baseline --
 timeout 400 tools/prof.sh ${tag}_bf16_serial --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream
 timeout 400 tools/prof.sh ${tag}_f32 --steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32
 timeout 400 tools/prof.sh ${tag}_folded --steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded
+# the parity-grade mode with the reference's formulation (split-bf16 attention core): bench line, serial kernel stats, two PMC passes
+timeout 400 python bench.py --steps 20 --warmup 5 --dtype bf16x3 --attn faithful --no-variants --no-cpu-baseline > gpurun_out/${tag}_bench_bf16x3.log 2>&1; tail -1 gpurun_out/${tag}_bench_bf16x3.log > gpurun_out/${tag}_bench_bf16x3.json
+timeout 400 tools/prof.sh ${tag}_bf16x3_serial --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream --dtype bf16x3 --attn faithful
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 tools/pmc.sh ${tag}_x3_$c $c --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-graph --dtype bf16x3 --attn faithful > /dev/null
+done
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout 400 tools/pmc.sh ${tag}_$c $c --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-graph > /dev/null
 done

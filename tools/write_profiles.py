@@ -37,7 +37,7 @@ def kernel_stats(db):
     split = {}
     # (round 4: in bf16 mode the masked text-bank launches run sq_mha32_packed_kernel -- every sq_mha_core_bf16_kernel launch is L=196)
     packed = any("sq_mha32_packed" in r[0] for r in rows)
-    for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "folded_attn_kernel", "folded_attn_bf16_kernel"):
+    for sub in ("sq_mha_core_bf16_kernel", "sq_mha_core_kernel", "sq_mha_core_split_kernel", "folded_attn_kernel", "folded_attn_bf16_kernel"):
         if packed and sub == "sq_mha_core_bf16_kernel":
             continue
         v = sorted(r[0] for r in cur.execute("select d.end - d.start from %s d join %s s on d.kernel_id = s.id where s.kernel_name like ?"
@@ -62,7 +62,8 @@ def main():
     cmds = {"bf16": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants",
             "bf16_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream",
             "f32": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32",
-            "folded": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded"}
+            "folded": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants --attn folded",
+            "bf16x3_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream --dtype bf16x3 --attn faithful"}
     for m, args in cmds.items():
         db = os.path.join(GO, "prof_%s_%s" % (tag, m), "%s_%s_results.db" % (tag, m))
         if not os.path.exists(db):
@@ -144,6 +145,22 @@ def main():
                 f.write("MFMA pipe: `SQ_VALU_MFMA_BUSY_CYCLES` = %.4e per L=196 launch of sq_mha_core_bf16 (= 256 WG x 8 waves x 2080 MFMA x "
                         "16 cycles: every issued 16x16x32 MFMA, padding included). Divide by 1024 SIMDs x launch time x clock for the pipe "
                         "occupancy; algorithmic utilisation (61.86 GFLOP / time / 2.5 PF) is what bench.py reports.\n" % hi)
+        # the split-bf16 attention core (bf16x3 mode): its own two passes
+        dx = {c: os.path.join(GO, "pmc_%s_x3_%s" % (tag, c), "%s_x3_%s_results.db" % (tag, c)) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+        if all(os.path.exists(p) for p in dx.values()):
+            f3, w3 = pmc(dx["FETCH_SIZE"], "sq_mha_core_split_kernel"), pmc(dx["WRITE_SIZE"], "sq_mha_core_split_kernel")
+            if f3 and w3:
+                fv, wv = half(f3, True), half(w3, True)          # the upper half of the launches by traffic = the L = 196 image banks
+                with open(os.path.join(PR, "%s_pmc_summary.md" % pre), "a") as f:
+                    f.write("\nbf16x3 mode (`--dtype bf16x3 --attn faithful`), same passes:\n\n| kernel | launches | FETCH_SIZE raw KiB | read MB (x2) | "
+                            "WRITE_SIZE KiB | write MB | algorithmic MB |\n|---|---|---|---|---|---|---|\n")
+                    f.write("| sq_mha_core_split_kernel L=196 (image banks, hi + lo images) | %d | %.0f | %.1f | %.0f | %.1f | "
+                            "64.2 bank (hi + lo) + 2.6 W (hi + lo) + 1.0 q + 1.0 out |\n" % (len(f3) // 2, fv, 2 * fv * 1024 / 1e6, wv, wv * 1024 / 1e6))
+                traffic["sq_mha_core_split_kernel@L196"] = {
+                    "fetch_kib_raw": fv, "write_kib": wv, "hbm_bytes": int(2 * fv * 1024 + wv * 1024),
+                    "source": "profiles/%s_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, bf16x3 mode)" % pre,
+                    "kernel_source": "mgnns_amd/csrc/sq_mha_split_bf16.hip",
+                    "kernel_source_sha16": __import__("hashlib").sha256(open(os.path.join(ROOT, "mgnns_amd/csrc/sq_mha_split_bf16.hip"), "rb").read()).hexdigest()[:16]}
         if traffic:
             with open(os.path.join(PR, "pmc_traffic.json"), "w") as f:
                 json.dump(traffic, f, indent=1)
@@ -194,7 +211,7 @@ def main():
         src = os.path.join(GO, "%s_%s.jsonl" % (tag, name))
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(PR, "%s_%s.jsonl" % (pre, name)))
-    for name in ("bench_bf16", "bench_f32", "stress_gcn"):
+    for name in ("bench_bf16", "bench_f32", "bench_bf16x3", "stress_gcn"):
         src = os.path.join(GO, "%s_%s.json" % (tag, name))
         if os.path.exists(src):
             shutil.copy(src, os.path.join(PR, "%s_%s.json" % (pre, name)))
