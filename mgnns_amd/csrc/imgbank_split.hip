@@ -21,6 +21,15 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef MG_IS_TRACE
+// profiling aid (off by default; tools/dev/is_trace.py): s_memtime sums of a slice's phases, waves 0 (converts first) and 4
+// (multiplies first) of workgroup 0
+__device__ unsigned long long g_is_trace[2][8];
+#define IS_T(i) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tt[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define IS_T(i)
+#endif
+
 namespace {
 
 constexpr int IS_BK = 64;                // k per slice: 2 MFMA k-steps, 8 chunks of 8
@@ -96,6 +105,8 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
                     h[i] = __builtin_bit_cast(float, (is_pack2(x, 0.f) << 16));          // bf16(x) as fp32
                     l[i] = x - h[i];
                 }
+                // (converting PAIRS -- the packed hi word is the image's word, its halves shifted / masked back give both residuals:
+                //  six instructions per pair instead of eight -- measured 3 % SLOWER on the same box: 246 against 239 us)
                 uint4 ch, cl;
                 ch.x = is_pack2(h[0], h[1]); ch.y = is_pack2(h[2], h[3]); ch.z = is_pack2(h[4], h[5]); ch.w = is_pack2(h[6], h[7]);
                 cl.x = is_pack2(l[0], l[1]); cl.y = is_pack2(l[2], l[3]); cl.z = is_pack2(l[4], l[5]); cl.w = is_pack2(l[6], l[7]);
@@ -144,7 +155,15 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
     // them, an HBM round trip in every k-step.
     // one slice; PH = c % 6 is a compile-time constant (the loop below is unrolled by six), so the LDS buffer c & 1 and the ring slots
     // (2 c + s) % 3 of its two k-steps are static register indices
+    // (measured, NOTES_r05: the opposite orders buy little -- 233 us against 234 in lock step -- because the slice is bound by what ONE
+    //  wave does in a row: conversion 1570 + pooled maxima 590 + 126 MFMAs 2680 cycles of a 6100-cycle slice for a three-tile wave.
+    //  All loads as inline asm with hand-counted waits -- the compiler waits for a fragment with the count of the path that skipped
+    //  both `if (convert_first)` regions, vmcnt(12) where 20 loads follow -- changed nothing either: 230 us.)
     const bool convert_first = wave < 4;
+#ifdef MG_IS_TRACE
+    unsigned long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
     auto slice = [&](auto phc, int c) {
         constexpr int PH = decltype(phc)::v;
         constexpr int buf = PH & 1;
@@ -153,6 +172,7 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
             gload(c + 2 < nk ? c + 2 : nk - 1);
         };
         if (convert_first) convert();
+        IS_T(0)                                                 // conversion at the head of the slice (waves 0-3)
         // the slice's partial maxima (written before the barrier that opened this iteration) -> pooled: eight threads per feature
         // row take four region quads each, three DPP steps join them
         if (pooled) {
@@ -167,11 +187,13 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
             m = fmaxf(m, MG_DPP(m, 0x141));                      // row_half_mirror: lanes 0-3 <-> 7-4 of each eight
             if (part == 0) pooled[((size_t)b * 2 + mh) * K + c * IS_BK + row] = m;
         }
+        IS_T(1)                                                 // pooled maxima
         mg_mha::static_for<0, 2>([&](auto sc) {
             constexpr int s = decltype(sc)::v;
             constexpr int SL = (2 * PH + s) % IS_WD;
             const int ks = c * 2 + s;
             wload(ks + IS_WD - 1 < KS ? ks + IS_WD - 1 : KS - 1, (SL + IS_WD - 1) % IS_WD);
+            IS_T(2)                                             // fragment requests
             // Two branch-free blocks per k-step (a branch per (row tile, column tile) cut the MFMA stream into blocks of three, each
             // behind its own LDS wait): every wave's first two column tiles for ALL seven row tiles (row tiles behind the half's
             // last region multiply rows nobody stores), then -- waves 0-2 only, one scalar branch -- the third column tile with the
@@ -213,9 +235,12 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
+            IS_T(3)                                             // the k-step's MFMA blocks (incl. the wait for its fragments)
         });
         if (!convert_first) convert();
+        IS_T(4)                                                 // conversion at the tail (waves 4-7)
         __syncthreads();
+        IS_T(5)                                                 // barrier
     };
     static_assert(IS_WD == 3, "the slice loop is unrolled for a ring of three");
     for (int c = 0; c < nk; c += 6) {
@@ -226,6 +251,10 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
         if (c + 4 < nk) slice(mg_mha::IC<4>{}, c + 4);
         if (c + 5 < nk) slice(mg_mha::IC<5>{}, c + 5);
     }
+#ifdef MG_IS_TRACE
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+        for (int i = 0; i < 8; ++i) g_is_trace[wave >> 2][i] = tt[i];
+#endif
     auto epilogue = [&]() {
     // ---- epilogue: + bias; acc[i][t][r] = bank[p0 + 16 i + 4 (lane >> 4) + r][16 nt + (lane & 15)] ----
     if (bank) {
@@ -285,6 +314,12 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
 }
 
 }  // namespace
+
+#ifdef MG_IS_TRACE
+extern "C" int mgnns_debug_is_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_is_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int P, const void* Wp_hi, const void* Wp_lo,
                                             const float* bias, int N, float* bank, float* pooled_halves, void* bank_hi,
