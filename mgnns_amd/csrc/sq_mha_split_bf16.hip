@@ -588,7 +588,16 @@ extern "C" int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi,
     const int n_cu = mg_cu_count();
     if (n_cu <= 0) return MGNNS_ERR_LAUNCH;
     while (gy < pairs && B * gy < n_cu) gy *= 2;
+    // a MASKED bank (the text bank: mean 16 live rows of 100) has no packed form here: the one full-length document of a batch holds
+    // the launch open with all its 16 H units on one workgroup -- two workgroups per sample even when the batch fills the chip
+    // (B = 256, L = 100, H = 8: 62.7 / 51.3 / 54.4 us with 1 / 2 / 4; every workgroup streams its heads' weights whatever its rows, so
+    // more than two only multiplies workgroups); MGNNS_MHA_SPLIT_MASKED overrides
+    if (mask) {
+        if (gy < 2 && pairs >= 2) gy = 2;
+        if (const int e = mg_env_int("MGNNS_MHA_SPLIT_MASKED", 0, 5)) gy = e;
+    }
     if (const int e = mg_env_int("MGNNS_MHA_SPLIT", 0, 4)) gy = e > gy ? e : gy;        // measurement knob: workgroups per sample
+    while (gy < pairs && (pairs + gy - 1) / gy * 2 > MAXH) gy *= 2;
     if (gy > pairs) gy = pairs;
     const float temp = (float)sqrt((double)dk);
     const int lo_off = (int)(mgnns_sq_mha_split_packed_weight_bytes(H) / 2);
