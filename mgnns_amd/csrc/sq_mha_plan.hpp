@@ -20,7 +20,9 @@ __host__ __device__ constexpr size_t lds_bytes(int B) { return ((size_t)8 * B + 
 // all samples at once), one thread follows that chain from sample 0 (one hop per group), every group lays out its samples.
 // s_plan: lds_bytes(B) of LDS -- [B] live rows, [B] row offsets, [B] next group start, [B] rows of a group from here, [4 B] groups.
 // Called by ALL NT threads of one workgroup.
-template <int NT>
+// ALIGN / ROWS / SAMP: a sample's rows are padded to a multiple of ALIGN, a group holds at most ROWS rows and SAMP samples.  The packed
+// bf16 kernel: 8 / 128 / 16 (tiles of 32 rows, eight-row blocks); the grouped split-bf16 core: 16 / 112 / 7 (whole tiles of 16).
+template <int NT, int ALIGN = 8, int ROWS = PR, int SAMP = PS>
 __device__ __forceinline__ void build(const float* __restrict__ mask, int B, int L, int* __restrict__ plan, int* s_plan) {
 
     int* s_lv = s_plan;
@@ -53,10 +55,10 @@ __device__ __forceinline__ void build(const float* __restrict__ mask, int B, int
     __syncthreads();
     for (int b = tid; b < B; b += NT) {
         int rows = 0, j = b;
-        while (j < B && j - b < PS) {
+        while (j < B && j - b < SAMP) {
             const int lv = s_lv[j];
-            const int l8 = lv <= 8 ? 8 : (lv + 7) & ~7;
-            if (rows + l8 > PR) break;
+            const int l8 = lv <= ALIGN ? ALIGN : (lv + ALIGN - 1) & ~(ALIGN - 1);
+            if (rows + l8 > ROWS) break;
             rows += l8;
             ++j;
         }
@@ -86,7 +88,7 @@ __device__ __forceinline__ void build(const float* __restrict__ mask, int B, int
         for (int b = b0; b < s_next[b0]; ++b) {
             const int lv = s_lv[b];
             s_off[b] = rows;
-            rows += lv <= 8 ? 8 : (lv + 7) & ~7;
+            rows += lv <= ALIGN ? ALIGN : (lv + ALIGN - 1) & ~(ALIGN - 1);
         }
     }
     __syncthreads();

@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "tile_bf16.hpp"
 #include "sq_mha_util.hpp"
+#include "sq_mha_plan.hpp"
 
 #ifdef MG_MHAS_TRACE
 // profiling aid (off by default): s_memtime stamps of wave 0 / wave 4 of two workgroups at every phase boundary
@@ -529,6 +530,302 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_kernel(const float* __
             *a = p;
         }
     }
+}
+
+
+// =====================================================================================================================
+// Grouped form for MASKED banks of at most 112 positions (the text bank: mean 16 live rows of 100, MODEL:509-527).  A workgroup of
+// the per-sample kernel streams its heads' hi + lo weights (2.6 MB for eight heads) whatever its sample's rows: 256 samples = 666 MB
+// of L2 traffic for ~300 tiles of live rows (51-63 us per launch).  Here the samples of a GROUP -- whole 16-row tiles each, at most 7
+// tiles and 7 samples (plan: sq_mha_plan.hpp with ALIGN 16 / ROWS 112 / SAMP 7) -- share one staging of the two images and one pass
+// of the weight stream; a workgroup owns one head pair of one group (persistent over the groups).  K units: the score of a row uses
+// ITS sample's query (q rows of the group's samples in LDS).  Softmax: a 16-lane DPP row is a tile, tile maxima / sums are joined
+// per sample through eight LDS words.  V units: the weighted sum is flushed (row sum, 1 / z, + b_v, store) behind the last tile of
+// every sample -- compile-time tile index, wave-uniform flush mask.  No returned attention (the launcher takes the per-sample kernel
+// when it is asked for).
+constexpr int GS = 7;                                                     // samples a group holds
+constexpr int GHL = 2;                                                    // heads a workgroup owns (one pair)
+constexpr size_t G_OFF_PART = 2 * (size_t)IMG;                            // float [2][4][LH] partial scores (head of the pair, slice)
+constexpr size_t G_OFF_P = G_OFF_PART + 2 * 4 * LH * sizeof(float);       // float [GHL][LH] e_l
+constexpr size_t G_OFF_MB = G_OFF_P + GHL * LH * sizeof(float);           // float [LH] mask bias of the staged rows
+constexpr size_t G_OFF_Q = G_OFF_MB + LH * sizeof(float);                 // float [GS][GHL][DK] projected queries of the group's samples
+constexpr size_t G_OFF_Z = G_OFF_Q + GS * GHL * DK * sizeof(float);       // float [GS][GHL] softmax sums (+ pad)
+constexpr size_t G_OFF_TM = G_OFF_Z + 16 * sizeof(float);                 // float [8] tile maxima, [8] tile sums
+constexpr size_t G_OFF_INT = G_OFF_TM + 16 * sizeof(float);               // int [48]: see grouped_kernel
+constexpr size_t G_SMEM_BYTES = G_OFF_INT + 48 * sizeof(int);
+static_assert(G_SMEM_BYTES <= 160 * 1024 && G_OFF_Q % 16 == 0 && G_OFF_P % 16 == 0, "LDS (grouped)");
+
+struct GCtx {
+    unsigned char* smem;
+    int B, L, H, lo_off, b0, h0, nheads, flush;     // first sample of the group, first head of the pair, heads of the pair, flush mask
+    const unsigned short* Wp;
+    const float* bv;
+    float inv_temp;
+    float* o;
+};
+
+template <int NMT>
+__device__ __forceinline__ void group_body(const GCtx& c) {
+    unsigned char* smem = c.smem;
+    float* s_part = reinterpret_cast<float*>(smem + G_OFF_PART);
+    float* s_p = reinterpret_cast<float*>(smem + G_OFF_P);
+    const float* s_mb = reinterpret_cast<const float*>(smem + G_OFF_MB);
+    const float* s_q = reinterpret_cast<const float*>(smem + G_OFF_Q);
+    float* s_z = reinterpret_cast<float*>(smem + G_OFF_Z);
+    float* s_tm = reinterpret_cast<float*>(smem + G_OFF_TM);
+    int* s_int = reinterpret_cast<int*>(smem + G_OFF_INT);
+    int* s_ticket = s_int;                              // [4] next unit of a slice
+    int* s_kdone = s_int + 4;                           // [2] slices that delivered their partial scores of head n
+    int* s_smdone = s_int + 6;                          // [2] 1 = e_l / sums of head n published
+    const int* s_tsamp = s_int + 16;                    // [8] group-local sample of a tile
+    const int* s_tfirst = s_int + 24;                   // [8] first tile of that sample
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3;
+    const int H = c.H;
+    const unsigned a_h = mg_lds_addr(smem + ((lane & 15) * LSTR + (lane >> 4)) * 16), a_l = a_h + (unsigned)OFF_LO;
+    WStream wsr;
+    wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.Wp), 0, 0x7fffffff, 0x00027000);
+    wsr.voff = lane * 16;
+    const int lo_off = c.lo_off;
+    const int nunits = 4;                               // tickets K(h0) K(h1) V(h0) V(h1); a head beyond the pair's count is skipped
+    auto draw = [&]() {
+        int t;
+        do {
+            int v = 0;
+            if (lane == 0) v = __hip_atomic_fetch_add(s_ticket + wq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(v);
+        } while (t < nunits && (t & 1) >= c.nheads);
+        return t;
+    };
+    auto wstream = [&](int t) {
+        const int h = c.h0 + (t < nunits ? (t & 1) : 0);
+        return (((h * 2 + ((t >> 1) & 1)) * 8 + wq * 2) * KSTEPS) * FRAG;
+    };
+    const __amdgpu_buffer_rsrc_t bv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.bv), 0, c.bv ? H * DK * 4 : 0, 0x00027000);
+    const int dbase = wq * 32 + (lane >> 4) * 4;
+    // group-local sample of every tile: wave-uniform values (scalar registers)
+    int ts[HT];
+#pragma unroll
+    for (int i = 0; i < HT; ++i) ts[i] = __builtin_amdgcn_readfirstlane(s_tsamp[i < NMT ? i : 0]);
+
+    int t = draw();
+    Frags<NMT> f;
+    frags_prime_b<NMT>(f, wsr, wstream(t), lo_off);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA pieces (not tracked by hipcc)
+    __syncthreads();
+
+    while (t < nunits) {
+        const int n = t & 1;                            // head of the pair
+        const int h = c.h0 + n;
+        const bool vunit = (t & 2) != 0;
+        int t_next = nunits;
+        f32x4 acc[HT][2];
+#pragma unroll
+        for (int i = 0; i < HT; ++i) {
+            acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        kv_gemm3<NMT>(acc, f, a_h, a_l, wsr, wstream(t), lo_off, [&]() { t_next = draw(); return wstream(t_next); });
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]));
+
+        if (!vunit) {
+            // ---- partial scores: tile i against the query of ITS sample
+            float v[(NMT + 3) / 4 * 4];
+#pragma unroll
+            for (int i = 0; i < (NMT + 3) / 4 * 4; ++i) {
+                float a = 0.f, cc = 0.f;
+                if (i < NMT) {
+                    const float* qv = s_q + (ts[i] * GHL + n) * DK + dbase;
+                    const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv), qd1 = *reinterpret_cast<const f32x4*>(qv + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a = fmaf(qd0[r], acc[i][0][r], a);
+                        cc = fmaf(qd1[r], acc[i][1][r], cc);
+                    }
+                }
+                v[i] = a + cc;
+            }
+            float* part = s_part + (n * 4 + wq) * LH;
+            const int rt = ((lane >> 4) & 1) * 2 + (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < (NMT + 3) / 4; ++g) {
+                const float s4 = rows4_sum4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                if (4 * g + 3 < NMT || 4 * g + rt < NMT) part[(4 * g + rt) * 16 + (lane & 15)] = s4;
+            }
+            if (lds_arrive(s_kdone + n, lane) == 3) {
+                // ---- last slice of the head: a 16-lane row of the wave is a tile (two tiles per lane group: rows lane, lane + 64);
+                //      tile maxima / sums through eight LDS words each, joined per sample
+                const float* sp = s_part + n * 4 * LH + lane;
+                float sc[2];
+                int smp[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pos = lane + 64 * j, T = pos >> 4;
+                    smp[j] = T < NMT ? s_tsamp[T] : -1;
+                    sc[j] = -INFINITY;
+                    if (pos < NMT * 16)
+                        sc[j] = ((sp[64 * j] + sp[64 * j + LH]) + (sp[64 * j + 2 * LH] + sp[64 * j + 3 * LH])) * c.inv_temp + s_mb[pos];
+                    const float tm = row16_max(sc[j]);
+                    if ((lane & 15) == 0 && T < 8) s_tm[T] = tm;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float e[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < NMT; ++k) m = (ts[k] == smp[j]) ? fmaxf(m, s_tm[k]) : m;
+                    e[j] = (sc[j] != -INFINITY) ? __expf(sc[j] - m) : 0.f;
+                    const float tsum = row16_sum(e[j]);
+                    const int T = (lane + 64 * j) >> 4;
+                    if ((lane & 15) == 0 && T < 8) s_tm[8 + T] = tsum;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float* prow = s_p + n * LH;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pos = lane + 64 * j, T = pos >> 4;
+                    if (pos < LH) prow[pos] = e[j];
+                    if (T < NMT && (lane & 15) == 0 && s_tfirst[T] == T) {      // first tile of its sample: the sample's sum
+                        float z = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NMT; ++k) z += (ts[k] == smp[j]) ? s_tm[8 + k] : 0.f;
+                        s_z[smp[j] * GHL + n] = z;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(s_smdone + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            // ---- u[d] = sum_l e[l] V[l, d] per SAMPLE: flushed behind the last tile of every sample
+            f32x4 vb0 = {0.f, 0.f, 0.f, 0.f}, vb1 = vb0;
+            const int hoff = h * DK * 4;
+            if (c.bv) {
+                vb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4, hoff, 0));
+                vb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bv_rsrc, dbase * 4 + 64, hoff, 0));
+            }
+            lds_wait_ge(s_smdone + n, 1);
+            const float* pp = s_p + n * LH + (lane & 15);
+            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+            static_for<0, NMT>([&](auto ic) {
+                constexpr int i = decltype(ic)::v;
+                const float p = pp[i * 16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    t0[r] = fmaf(p, acc[i][0][r], t0[r]);
+                    t1[r] = fmaf(p, acc[i][1][r], t1[r]);
+                }
+                if ((c.flush >> i) & 1) {                  // (wave-uniform)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        t0[r] = row16_sum(t0[r]);
+                        t1[r] = row16_sum(t1[r]);
+                    }
+                    if ((lane & 15) == 0) {
+                        const float rz = 1.0f / s_z[ts[i] * GHL + n];      // all masked: 0 * inf = NaN, like the reference
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o0[r] = fmaf(t0[r], rz, vb0[r]);
+                            o1[r] = fmaf(t1[r], rz, vb1[r]);
+                        }
+                        float* op = c.o + ((size_t)(c.b0 + ts[i]) * H + h) * DK + dbase;
+                        *reinterpret_cast<f32x4*>(op) = o0;
+                        *reinterpret_cast<f32x4*>(op + 16) = o1;
+                    }
+                    t0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    t1 = t0;
+                }
+            });
+        }
+        t = t_next;
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const float* __restrict__ qh, const unsigned short* __restrict__ bank_hi,
+                                                                         const unsigned short* __restrict__ bank_lo,
+                                                                         const float* __restrict__ mask, int B, int L, int H,
+                                                                         const unsigned short* __restrict__ Wp, int lo_off,
+                                                                         const float* __restrict__ bv, float temp, float* __restrict__ o,
+                                                                         const int* __restrict__ plan) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_int = reinterpret_cast<int*>(smem + G_OFF_INT);
+    float* s_mb = reinterpret_cast<float*>(smem + G_OFF_MB);
+    float* s_q = reinterpret_cast<float*>(smem + G_OFF_Q);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ng = plan[0];
+    const int h0 = (int)blockIdx.y * GHL, nheads = H - h0 < GHL ? H - h0 : GHL;
+    for (int g = blockIdx.x; g < ng; g += gridDim.x) {
+        const int b0 = plan[mg_plan::PLAN_HDR + 4 * g], ns = plan[mg_plan::PLAN_HDR + 4 * g + 1], rows = plan[mg_plan::PLAN_HDR + 4 * g + 2];
+        const int nt = rows >> 4;
+        // ---- the group's tile maps, counters (s_int: [0..3] tickets, [4..5] kdone, [6..7] smdone, [8] flush mask, [16..23] sample of
+        //      a tile, [24..31] first tile of that sample, [32..38] first row of a sample, [40..46] its live rows)
+        if (tid < 48) s_int[tid] = 0;
+        __syncthreads();
+        if (tid < ns) {
+            const int off = plan[mg_plan::PLAN_HDR + 4 * B + 2 * (b0 + tid)], lv = plan[mg_plan::PLAN_HDR + 4 * B + 2 * (b0 + tid) + 1];
+            const int ntl = lv <= 16 ? 1 : (lv + 15) >> 4;
+            s_int[32 + tid] = off;
+            s_int[40 + tid] = lv;
+            for (int k = 0; k < ntl; ++k) {
+                s_int[16 + (off >> 4) + k] = tid;
+                s_int[24 + (off >> 4) + k] = off >> 4;
+            }
+            atomicOr(&s_int[8], 1 << ((off >> 4) + ntl - 1));             // the sample's last tile: flush
+        }
+        __syncthreads();
+        const int flush = s_int[8];
+        // ---- stage the group's rows (LDS row R = tile R >> 4 of sample s_tsamp: its row R - 16 first) + mask bias + queries
+        {
+            const int total = rows * LSTR;
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+                const uint4* xg = reinterpret_cast<const uint4*>(img ? bank_lo : bank_hi);
+                unsigned char* dst = smem + (img ? OFF_LO : 0);
+                for (int pc = wave; pc * 64 < total; pc += NTHR / 64) {
+                    const int gi = pc * 64 + lane;
+                    const int R = gi / LSTR, cidx = gi - R * LSTR;
+                    if (gi < total && cidx < CH) {
+                        const int T = R >> 4, sm = s_int[16 + T], r = R - 16 * s_int[24 + T];
+                        const uint4* xb = xg + (size_t)(b0 + sm) * L * CH;
+                        const uint4* src = r < L ? xb + (size_t)r * CH + cidx : xb + (CH - 1);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(uintptr_t)(dst + (size_t)pc * 1024), 16, 0, 0);
+                    }
+                }
+            }
+            for (int R = tid; R < LH; R += NTHR) {
+                float mbv = -INFINITY;
+                if (R < rows) {
+                    const int T = R >> 4, sm = s_int[16 + T], r = R - 16 * s_int[24 + T];
+                    if (r < L && mask[(size_t)(b0 + sm) * L + r] != 0.0f) mbv = 0.0f;
+                }
+                s_mb[R] = mbv;
+            }
+            for (int i = tid * 4; i < ns * GHL * DK; i += NTHR * 4) {
+                const int sm = i / (GHL * DK), rem = i - sm * (GHL * DK), n = rem / DK, d = rem - n * DK;
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                if (n < nheads) q = *reinterpret_cast<const f32x4*>(qh + ((size_t)(b0 + sm) * H + h0 + n) * DK + d);
+                *reinterpret_cast<f32x4*>(s_q + i) = q;
+            }
+        }
+        GCtx c{smem, B, L, H, lo_off, b0, h0, nheads, flush, Wp, bv, 1.0f / temp, o};
+        switch (tile_class(nt)) {
+            case 1: group_body<1>(c); break;
+            case 2: group_body<2>(c); break;
+            case 4: group_body<4>(c); break;
+            case 6: group_body<6>(c); break;
+            default: group_body<HT>(c); break;
+        }
+        __syncthreads();                               // every unit of this group is done with LDS before the next one stages
+    }
+}
+
+__global__ __launch_bounds__(1024) void sq_mha_split_plan_kernel(const float* __restrict__ mask, int B, int L, int* __restrict__ plan) {
+    extern __shared__ int s_plan[];
+    mg_plan::build<1024, 16, LH, GS>(mask, B, L, plan, s_plan);
 }
 
 }  // namespace

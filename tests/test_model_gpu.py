@@ -81,8 +81,10 @@ def test_bf16x3_mode_stays_inside_the_parity_gate(cfg_name, attention):
         assert "mgnns_sq_mha_folded_fwd" in ran and "mgnns_sq_mha_core_split_fwd" not in ran, sorted(ran)
 
 
-def test_bf16x3_full_size_b256():
-    """bf16x3 + folded attention at BASELINE's full B = 256: oracle subset under the 1e-4 gate, permutation equivariance,
+@pytest.mark.parametrize("attention", ["folded", "faithful"])
+def test_bf16x3_full_size_b256(attention):
+    """bf16x3 at BASELINE's full B = 256 with the folded (exact fp32) attention and with the faithful attention on the split-bf16
+    core (the launch record says it is the kernel that ran): oracle subset under the 1e-4 gate, permutation equivariance,
     determinism, hipGraph replay == eager."""
     from mgnns_amd.graph import GraphedForward
     cfg = synth.CONFIGS["mvsa_multiple_b256"]
@@ -92,16 +94,25 @@ def test_bf16x3_full_size_b256():
     B = 256
     inp = synth.make_inputs(cfg, B=B, seed=4244, pmi=pmi)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
-    model.set_precision("bf16x3").set_attention("folded")
+    model.set_precision("bf16x3").set_attention(attention)
     call = call_args(inp, DEV)
-    logits = model(*call).cpu()
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        logits = model(*call).cpu()
+    finally:
+        ops.set_timer(None)
+    ran = {k[0] for k in timer.events}
+    if attention == "faithful":
+        assert "mgnns_sq_mha_core_split_fwd" in ran and not ran & {"mgnns_sq_mha_core_fwd", "mgnns_sq_mha_folded_fwd"}, sorted(ran)
+        assert {k[1:] for k in timer.events if k[0] == "mgnns_sq_mha_core_split_fwd"} == {(196, False), (cfg.T, True)}
     idx = np.arange(0, B, 16)
     sub = {k: (v[idx] if k != "label_query" else v) for k, v in inp.items()}
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = R.forward(p, {k: torch.from_numpy(v) for k, v in sub.items()}, pmi, cfg.n_head, cfg.d_kv, cfg.stack_num, cfg.ngram,
                     label_query=torch.from_numpy(lq))
     err = H.maxabs(logits[idx], ref)
-    print("bf16x3 + folded, B=256: max |dlogit| on the oracle subset = %.3e" % err)
+    print("bf16x3 + %s, B=256: max |dlogit| on the oracle subset = %.3e" % (attention, err))
     assert err < TOL
     perm = np.random.RandomState(3).permutation(B)
     pin = {k: (v[perm] if k != "label_query" else v) for k, v in inp.items()}
