@@ -374,7 +374,13 @@ int mgnns_split_pad_bf16(const float* x, int64_t rows, int D, int ld, void* hi, 
 int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi, const void* bank_lo, const float* mask,
                                 int B, int L, int ld, int H, int dk,
                                 const void* Wp, const float* bk, const float* bv,
-                                float* o, float* attn, mgnns_stream_t stream);
+                                float* o, float* attn, const int32_t* plan, mgnns_stream_t stream);
+/* `plan` (optional: needs a mask, L <= 112, attn == NULL): the group plan of the batch's mask, mgnns_sq_mha32_plan_ints(B) int32 built
+ * by mgnns_sq_mha_split_plan(mask, B, L, plan) once per batch (the layout of mgnns_sq_mha32_plan with other constants: samples in
+ * whole tiles of 16 rows, at most 112 rows and 7 samples per group).  The samples of a group share one staging of the bank images
+ * and one pass of the weight stream (Multi_GCN_Multihead_att.py:509-527: the text bank, mean 16 live rows of 100).  Same results
+ * as without a plan up to fp32 summation order. */
+int mgnns_sq_mha_split_plan(const float* mask, int B, int L, int32_t* plan, mgnns_stream_t stream);
 
 /* ---- a8, folded variant: the K/V projections folded into the query side ---------------------------------
  * Same inputs and outputs as mgnns_sq_mha_core_fwd (submodules.py:55-119, len_q == 1) computed as

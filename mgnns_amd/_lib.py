@@ -59,7 +59,8 @@ SIGNATURES = {
     "mgnns_sq_mha32_core_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "mgnns_sq_mha_pack_weights_split": [_P, _P, _I, _I, _I, _P, _P],
     "mgnns_split_pad_bf16": [_P, _L, _I, _I, _P, _P, _P],
-    "mgnns_sq_mha_core_split_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgnns_sq_mha_core_split_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mgnns_sq_mha_split_plan": [_P, _I, _I, _P, _P],
     "mgnns_sq_mha_layer_bf16_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _PP, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                     _I, _P, _P, _P],
     "mgnns_sq_mha_folded_fwd": [_P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P, _P, _P],

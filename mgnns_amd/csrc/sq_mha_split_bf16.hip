@@ -550,8 +550,8 @@ constexpr size_t G_OFF_P = G_OFF_PART + 2 * 4 * LH * sizeof(float);       // flo
 constexpr size_t G_OFF_MB = G_OFF_P + GHL * LH * sizeof(float);           // float [LH] mask bias of the staged rows
 constexpr size_t G_OFF_Q = G_OFF_MB + LH * sizeof(float);                 // float [GS][GHL][DK] projected queries of the group's samples
 constexpr size_t G_OFF_Z = G_OFF_Q + GS * GHL * DK * sizeof(float);       // float [GS][GHL] softmax sums (+ pad)
-constexpr size_t G_OFF_TM = G_OFF_Z + 16 * sizeof(float);                 // float [8] tile maxima, [8] tile sums
-constexpr size_t G_OFF_INT = G_OFF_TM + 16 * sizeof(float);               // int [48]: see grouped_kernel
+constexpr size_t G_OFF_TM = G_OFF_Z + 16 * sizeof(float);                 // float [GHL][8 tile maxima | 8 tile sums]: the two heads' softmax waves run side by side
+constexpr size_t G_OFF_INT = G_OFF_TM + GHL * 16 * sizeof(float);               // int [48]: see grouped_kernel
 constexpr size_t G_SMEM_BYTES = G_OFF_INT + 48 * sizeof(int);
 static_assert(G_SMEM_BYTES <= 160 * 1024 && G_OFF_Q % 16 == 0 && G_OFF_P % 16 == 0, "LDS (grouped)");
 
@@ -572,7 +572,7 @@ __device__ __forceinline__ void group_body(const GCtx& c) {
     const float* s_mb = reinterpret_cast<const float*>(smem + G_OFF_MB);
     const float* s_q = reinterpret_cast<const float*>(smem + G_OFF_Q);
     float* s_z = reinterpret_cast<float*>(smem + G_OFF_Z);
-    float* s_tm = reinterpret_cast<float*>(smem + G_OFF_TM);
+    float* s_tm_all = reinterpret_cast<float*>(smem + G_OFF_TM);
     int* s_int = reinterpret_cast<int*>(smem + G_OFF_INT);
     int* s_ticket = s_int;                              // [4] next unit of a slice
     int* s_kdone = s_int + 4;                           // [2] slices that delivered their partial scores of head n
@@ -588,7 +588,10 @@ __device__ __forceinline__ void group_body(const GCtx& c) {
     wsr.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.Wp), 0, 0x7fffffff, 0x00027000);
     wsr.voff = lane * 16;
     const int lo_off = c.lo_off;
-    const int nunits = 4;                               // tickets K(h0) K(h1) V(h0) V(h1); a head beyond the pair's count is skipped
+    // tickets K(h0) K(h1) V(h0) V(h1); a head beyond the pair's count is skipped.  (Opaque to the compiler: with a literal 4 it
+    //  unrolls the unit loop into four GEMM instances -- 200 spilled registers.)
+    int nunits = 4;
+    asm volatile("" : "+s"(nunits));
     auto draw = [&]() {
         int t;
         do {
@@ -658,6 +661,7 @@ __device__ __forceinline__ void group_body(const GCtx& c) {
                 // ---- last slice of the head: a 16-lane row of the wave is a tile (two tiles per lane group: rows lane, lane + 64);
                 //      tile maxima / sums through eight LDS words each, joined per sample
                 const float* sp = s_part + n * 4 * LH + lane;
+                float* s_tm = s_tm_all + n * 16;
                 float sc[2];
                 int smp[2];
 #pragma unroll
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const f
         const int nt = rows >> 4;
         // ---- the group's tile maps, counters (s_int: [0..3] tickets, [4..5] kdone, [6..7] smdone, [8] flush mask, [16..23] sample of
         //      a tile, [24..31] first tile of that sample, [32..38] first row of a sample, [40..46] its live rows)
-        if (tid < 48) s_int[tid] = 0;
+        if (tid < 48) s_int[tid] = (tid >= 16 && tid < 24) ? -1 : 0;      // (a tile of the class behind the group's rows belongs to nobody)
         __syncthreads();
         if (tid < ns) {
             const int off = plan[mg_plan::PLAN_HDR + 4 * B + 2 * (b0 + tid)], lv = plan[mg_plan::PLAN_HDR + 4 * B + 2 * (b0 + tid) + 1];
@@ -779,7 +783,9 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const f
         const int flush = s_int[8];
         // ---- stage the group's rows (LDS row R = tile R >> 4 of sample s_tsamp: its row R - 16 first) + mask bias + queries
         {
-            const int total = rows * LSTR;
+            // every row of the tile-count CLASS the GEMM runs: rows behind the group's (and behind a sample's L) read a zero chunk
+            // (the padding at the end of a bank row) -- stale LDS there would put NaN bits into scores that -inf cannot mask
+            const int total = tile_class(nt) * 16 * LSTR;
 #pragma unroll
             for (int img = 0; img < 2; ++img) {
                 const uint4* xg = reinterpret_cast<const uint4*>(img ? bank_lo : bank_hi);
@@ -788,7 +794,7 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const f
                     const int gi = pc * 64 + lane;
                     const int R = gi / LSTR, cidx = gi - R * LSTR;
                     if (gi < total && cidx < CH) {
-                        const int T = R >> 4, sm = s_int[16 + T], r = R - 16 * s_int[24 + T];
+                        const int T = R >> 4, sm = R < rows ? s_int[16 + T] : 0, r = R < rows ? R - 16 * s_int[24 + T] : L;
                         const uint4* xb = xg + (size_t)(b0 + sm) * L * CH;
                         const uint4* src = r < L ? xb + (size_t)r * CH + cidx : xb + (CH - 1);
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -864,9 +870,20 @@ extern "C" int mgnns_split_pad_bf16(const float* x, int64_t rows, int D, int ld,
     return 0;
 }
 
+extern "C" int mgnns_sq_mha_split_plan(const float* mask, int B, int L, int32_t* plan, mgnns_stream_t stream) {
+    MG_REQUIRE(mask && plan, "mgnns_sq_mha_split_plan: null pointer");
+    MG_REQUIRE(B >= 0 && B <= mg_plan::MAX_B && L > 0 && L <= LH, "mgnns_sq_mha_split_plan: B=%d (<= %d), L=%d (1..%d) unsupported", B,
+               mg_plan::MAX_B, L, LH);
+    const size_t lds = mg_plan::lds_bytes(B);
+    MG_DYN_LDS(sq_mha_split_plan_kernel, lds);
+    hipLaunchKernelGGL(sq_mha_split_plan_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, mask, B, L, plan);
+    MG_CHECK_LAUNCH("mgnns_sq_mha_split_plan");
+    return 0;
+}
+
 extern "C" int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi, const void* bank_lo, const float* mask, int B,
                                            int L, int ld, int H, int dk, const void* Wp, const float* bk, const float* bv,
-                                           float* o, float* attn, mgnns_stream_t stream) {
+                                           float* o, float* attn, const int32_t* plan, mgnns_stream_t stream) {
     (void)bk;                                           // softmax-invariant (see half_body)
     MG_REQUIRE(qh && bank_hi && bank_lo && Wp && o, "mgnns_sq_mha_core_split_fwd: null pointer");
     MG_REQUIRE(dk == DK, "mgnns_sq_mha_core_split_fwd: d_kv=%d unsupported (128 only)", dk);
@@ -876,7 +893,22 @@ extern "C" int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi,
     MG_REQUIRE(H <= 2 * MAXH, "mgnns_sq_mha_core_split_fwd: n_head=%d unsupported (<= %d)", H, 2 * MAXH);
     MG_REQUIRE(mg_aligned16(bank_hi) && mg_aligned16(bank_lo) && mg_aligned16(Wp) && mg_aligned16(qh) && mg_aligned16(o),
                "mgnns_sq_mha_core_split_fwd: qh / banks / Wp / o must be 16-byte aligned");
+    MG_REQUIRE(!plan || (mask && L <= LH && !attn), "mgnns_sq_mha_core_split_fwd: a group plan needs a mask, L <= %d and no attn output", LH);
     if (B == 0) return 0;
+    if (plan) {
+        // grouped masked form: workgroup = (group of samples, head pair), persistent over the groups: a third of the batch is more
+        // groups than MVSA-like lengths make (59 for 256 samples); longer batches of long documents loop
+        MG_DYN_LDS(sq_mha_core_split_grouped_kernel, G_SMEM_BYTES);
+        int gx = (B + 2) / 3;
+        if (gx < 1) gx = 1;
+        const float temp_g = (float)sqrt((double)dk);
+        const int lo_g = (int)(mgnns_sq_mha_split_packed_weight_bytes(H) / 2);
+        hipLaunchKernelGGL(sq_mha_core_split_grouped_kernel, dim3(gx, (H + GHL - 1) / GHL), dim3(NTHR), G_SMEM_BYTES, (hipStream_t)stream, qh,
+                           reinterpret_cast<const unsigned short*>(bank_hi), reinterpret_cast<const unsigned short*>(bank_lo), mask, B, L,
+                           H, reinterpret_cast<const unsigned short*>(Wp), lo_g, bv, temp_g, o, plan);
+        MG_CHECK_LAUNCH("mgnns_sq_mha_core_split_fwd(grouped)");
+        return 0;
+    }
     MG_DYN_LDS(sq_mha_core_split_kernel, SMEM_BYTES);
     // one workgroup per sample owns all head pairs (at most MAXH heads) when the batch fills the chip; small batches split the pairs
     const int pairs = (H + 1) / 2;

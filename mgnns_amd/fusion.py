@@ -28,6 +28,8 @@ FUSED_LAYER = _os.environ.get('MGNNS_FUSED_LAYER', '0') == '1'
 FOLDED_BF16 = _os.environ.get('MGNNS_FOLDED_BF16', '1') == '1'
 # bf16x3 mode + faithful attention: the split-bf16 core (sq_mha_split_bf16.hip); 0 = the exact-f32 MFMA core of fp32 mode
 SPLIT_CORE = _os.environ.get('MGNNS_SPLIT_CORE', '1') == '1'
+# ... its masked launches (the text bank) in the GROUPED form: the samples of a group share a workgroup's staging and weight stream
+SPLIT_GROUPED = _os.environ.get('MGNNS_SPLIT_GROUPED', '1') == '1'
 
 
 def _require_eval(mod):
@@ -71,19 +73,29 @@ class MemoryBank:
 
 
 def mask_plan_applies(mask, precision='bf16', attention='faithful'):
-    """Does a masked stack in this mode run the packed attention launches (a plan of the mask makes sense)?"""
-    return (precision == 'bf16' and attention == 'faithful' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask is not None
-            and mask.shape[-1] <= ops.PLAN_MAX_L and mask.shape[0] <= ops.PLAN_MAX_B and not FUSED_LAYER)
+    """Does a masked stack in this mode run a packed / grouped attention launch (a plan of the mask makes sense)?  -> False, or the
+    kind of plan: 'packed' (bf16 mode: sq_mha32_packed_kernel) | 'grouped' (bf16x3 + faithful: the split-bf16 core's grouped form)."""
+    if mask is None or attention != 'faithful' or mask.shape[0] > ops.PLAN_MAX_B:
+        return False
+    if precision == 'bf16' and ops.MHA_CORE == 32 and ops.MHA_PACKED and mask.shape[-1] <= ops.PLAN_MAX_L and not FUSED_LAYER:
+        return 'packed'
+    if precision == 'bf16x3' and SPLIT_CORE and SPLIT_GROUPED and mask.shape[-1] <= ops.SPLIT_PLAN_MAX_L:
+        return 'grouped'
+    return False
 
 
 def make_mask_plan(mask, precision='bf16', attention='faithful'):
-    """The packing plan of a [B, L] attention mask for the bf16 core (ops.sq_mha_plan: the live rows of short samples share a
-    workgroup), or None where it does not apply.  Depends on the mask's VALUES only; whoever passes it to run_stack(plan=...)
-    orders the launch that built it in front of the stack (an event if it ran on another stream).  The model's forward gets the
-    same plan out of the BiLSTM's prep launch instead (ops.bilstm(plan_mask=...))."""
-    if mask_plan_applies(mask, precision, attention):
-        return ops.sq_mha_plan(mask.reshape(mask.shape[0], -1).float().contiguous())
-    return None
+    """The packing plan of a [B, L] attention mask for the masked attention launches of this mode (ops.sq_mha_plan / ops.sq_mha_split_plan:
+    the live rows of short samples share a workgroup), or None where it does not apply.  Depends on the mask's VALUES only; whoever
+    passes it to run_stack(plan=...) orders the launch that built it in front of the stack (an event if it ran on another stream).
+    The model's bf16 forward gets the same plan out of the BiLSTM's prep launch instead (ops.bilstm(plan_mask=...))."""
+    kind = mask_plan_applies(mask, precision, attention)
+    if not kind:
+        return None
+    m2 = mask.reshape(mask.shape[0], -1).float().contiguous()
+    plan = ops.sq_mha_plan(m2) if kind == 'packed' else ops.sq_mha_split_plan(m2)
+    plan._mg_plan_kind = kind
+    return plan
 
 
 class LayerNorm(nn.Module):
@@ -420,11 +432,13 @@ def run_stack(layers, q, bank, mask=None, qh=None, plan=None):
         return q
     if qh is None:
         qh = first_query(layers, q)
-    # masked bank, bf16 core: the caller's packing plan of this mask (model.py builds it once per batch), else one for this stack
-    if plan is None and m2 is not None:
-        plan = make_mask_plan(m2, a0.precision, a0.attention)
-    elif plan is not None and (m2 is None or a0.precision != 'bf16' or a0.attention != 'faithful'):
+    # masked bank: the caller's packing plan of this mask (model.py builds it once per batch), else one for this stack; a plan of
+    # another mode's kind (set_precision between building it and running the stack) is dropped
+    kind = mask_plan_applies(m2, a0.precision, a0.attention)
+    if plan is not None and (not kind or getattr(plan, "_mg_plan_kind", 'packed') != kind):
         plan = None
+    if plan is None and kind:
+        plan = make_mask_plan(m2, a0.precision, a0.attention)
     for i, layer in enumerate(layers):
         a = layer.slf_attn
         if a.attention == 'folded':
@@ -443,7 +457,7 @@ def run_stack(layers, q, bank, mask=None, qh=None, plan=None):
                                         a.w_vs.bias.detach(), want_attn=False, plan=plan)
         elif a._split_core():
             o, _ = ops.sq_mha_core_split(qh, bank.split, m2, a.n_head, a.d_k, a._packed_kv("split"), a.w_ks.bias.detach(),
-                                         a.w_vs.bias.detach(), want_attn=False)
+                                         a.w_vs.bias.detach(), want_attn=False, plan=plan)
         else:
             o, _ = ops.sq_mha_core(qh, bank.f32, m2, a.n_head, a.d_k, a.w_ks.weight.detach(), a.w_ks.bias.detach(),
                                    a.w_vs.weight.detach(), a.w_vs.bias.detach(), want_attn=False)

@@ -686,9 +686,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
             ctx['text_mask'] = text_mask.float().contiguous()
             # the packing plan of the mask for both image->text stacks (MODEL:509-527) rides on the BiLSTM's prep launch: one more
             # workgroup there instead of a launch per channel (round 4) on the stacks' critical paths
-            want_plan = PLAN_IN_PREP and mask_plan_applies(ctx['text_mask'], self.precision, self.attention)
-            ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if want_plan else None)
+            kind = mask_plan_applies(ctx['text_mask'], self.precision, self.attention)
+            ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if (PLAN_IN_PREP and kind == 'packed') else None)
             ctx['mha_plan'] = getattr(ctx['text_bank'], 'mask_plan', None)
+            if ctx['mha_plan'] is None and kind == 'grouped':
+                # bf16x3 + faithful: the group plan of the split-bf16 core's masked launches, once per batch, on this stream (both
+                # image->text stacks wait for it anyway)
+                ctx['mha_plan'] = make_mask_plan(ctx['text_mask'], self.precision, self.attention)
             ops.stamp("text bank (LSTM) end")
 
         def lgcn(tag, A, inp, attention):
@@ -735,9 +739,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
                 # its masked attention launches, MODEL:509-527): one small launch per channel, HERE -- on the stack's own stream,
                 # which has slack; on the BiLSTM's stream (the longest chain) it cost the pipelined forward 3 %, and one plan for
                 # both stacks means a cross-stream dependency the runtime's one-graph capture of the schedule does not survive
-                if not (PLAN_IN_PREP and mask_plan_applies(text_mask, self.precision, self.attention)
-                        and ops.bilstm_can_plan(text.shape[0], text.shape[1], self.embedding.weight.shape[1],
-                                                os.environ.get("MGNNS_LSTM_REC", "bf16"))):
+                kind = mask_plan_applies(text_mask, self.precision, self.attention)
+                in_text_bank = kind == 'grouped' or (kind == 'packed' and PLAN_IN_PREP and ops.bilstm_can_plan(
+                    text.shape[0], text.shape[1], self.embedding.weight.shape[1], os.environ.get("MGNNS_LSTM_REC", "bf16")))
+                if kind and not in_text_bank:
                     ctx['mha_plan_' + next_name] = make_mask_plan(text_mask, self.precision, self.attention)
                 ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
                     ctx['pooled_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag), ctx['Q_' + tag], attention, linear_5, x_linear,

@@ -686,6 +686,7 @@ def bilstm(tok, lens, emb_table, weights, hidden, num_layers, want_bf16=False, r
                     emb_table.shape[0], emb_table.shape[1], hidden, num_layers, c_wih, c_bih, c_whh, c_bhh,
                     _p(ws), ws.numel(), _p(out), _p(out_bf), BANK_LD, _p(pre), _p(plan_mask), _p(plan), _stream())
     if plan is not None:
+        plan._mg_plan_kind = 'packed'
         return (out, out_bf, plan) if want_bf16 else (out, plan)
     return (out, out_bf) if want_bf16 else out
 
@@ -990,6 +991,7 @@ def sq_mha_plan(mask):
     L = _lib.lib()
     plan = torch.empty(L.mgnns_sq_mha32_plan_ints(B), dtype=torch.int32, device=mask.device)
     _lib.check(L.mgnns_sq_mha32_plan(_p(mask), B, L_, _p(plan), _stream()), "mgnns_sq_mha32_plan")
+    plan._mg_plan_kind = 'packed'
     return plan
 
 
@@ -1064,9 +1066,27 @@ def split_pad_bf16(x, ld=BANK_LD):
     return y.view(2, *x.shape[:-1], ld)
 
 
-def sq_mha_core_split(qh, bank_split, mask, n_head, d_kv, wp, bk, bv, want_attn=True):
+SPLIT_PLAN_MAX_L = 112
+
+
+def sq_mha_split_plan(mask):
+    """Group plan of a [B, L] mask (L <= 112) for sq_mha_core_split(plan=...): which samples share a workgroup (whole 16-row tiles,
+    at most 7 tiles and 7 samples per group).  One launch; once per batch."""
+    _chk(mask, "mask", ndim=2)
+    B, L_ = mask.shape
+    if B > PLAN_MAX_B or L_ > SPLIT_PLAN_MAX_L:
+        raise ValueError("sq_mha_split_plan: B=%d (<= %d), L=%d (<= %d)" % (B, PLAN_MAX_B, L_, SPLIT_PLAN_MAX_L))
+    L = _lib.lib()
+    plan = torch.empty(L.mgnns_sq_mha32_plan_ints(B), dtype=torch.int32, device=mask.device)
+    _lib.check(L.mgnns_sq_mha_split_plan(_p(mask), B, L_, _p(plan), _stream()), "mgnns_sq_mha_split_plan")
+    plan._mg_plan_kind = 'grouped'
+    return plan
+
+
+def sq_mha_core_split(qh, bank_split, mask, n_head, d_kv, wp, bk, bv, want_attn=True, plan=None):
     """The faithful attention core on split-bf16 operands (csrc/sq_mha_split_bf16.hip): bank_split = split_pad_bf16(bank)
-    [2, B, L, 320], wp = pack_kv_weights_split(...).  -> (o [B, H*dk], attn [H*B, 1, L] or None)"""
+    [2, B, L, 320], wp = pack_kv_weights_split(...).  plan: sq_mha_split_plan(mask) (masked banks, L <= 112, no attn output): the
+    samples of a group share a workgroup.  -> (o [B, H*dk], attn [H*B, 1, L] or None)"""
     _chk(qh, "qh", ndim=2)
     _chk(bank_split, "memory bank (split bf16)", torch.bfloat16, 4)
     _chk(wp, "packed K/V weights", torch.uint8, 1)
@@ -1084,9 +1104,14 @@ def sq_mha_core_split(qh, bank_split, mask, n_head, d_kv, wp, bk, bv, want_attn=
     o = torch.empty(B, n_head * d_kv, device=qh.device, dtype=torch.float32)
     attn = torch.empty(n_head * B, 1, L_, device=qh.device, dtype=torch.float32) if want_attn else None
     L = _lib.lib()
+    if plan is not None:
+        _chk(plan, "plan", torch.int32, 1)
+        if mask is None or L_ > SPLIT_PLAN_MAX_L or want_attn or plan.numel() != L.mgnns_sq_mha32_plan_ints(B):
+            raise ValueError("a group plan needs a mask, L <= %d, want_attn=False and exactly %d ints (a plan built for this batch)"
+                             % (SPLIT_PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
     _launch("mgnns_sq_mha_core_split_fwd", ("mgnns_sq_mha_core_split_fwd", L_, mask is not None), L.mgnns_sq_mha_core_split_fwd,
             _p(qh), _p(bank_split[0]), _p(bank_split[1]), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk), _p(bv), _p(o),
-            _p(attn), _stream())
+            _p(attn), _p(plan), _stream())
     return o, attn
 
 

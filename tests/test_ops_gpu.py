@@ -777,6 +777,60 @@ def test_sq_mha_core_split_fully_masked_sample_is_nan_like_the_reference():
         assert H.maxabs(o[keep].cpu(), o32[keep].cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("Hn,B,L", [(8, 256, 100), (8, 300, 112), (4, 64, 100), (1, 5, 37), (3, 33, 64), (8, 1, 100), (8, 256, 9)])
+def test_sq_mha_core_split_grouped_plan_equals_one_workgroup_per_sample(Hn, B, L):
+    """Masked banks through the GROUPED form of the split-bf16 core (the samples of a group -- whole 16-row tiles, <= 7 tiles and 7
+    samples -- share a workgroup's staging and weight stream; scores against each row's own sample's query, softmax joined per sample,
+    weighted sums flushed per sample) against the same core with one workgroup per sample (fp32 summation order only) and against
+    fp64: MVSA-like lengths incl. 1 / 16 / 17 / 32 / L, a mask with holes, a mask whose live rows start late; the plan's groups
+    cover the batch in order; repeated launches give identical bits."""
+    rs = np.random.RandomState(Hn * 1000 + B + L)
+    wq, wk, wv = (dev((0.06 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(3))
+    bq, bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(3))
+    wp = ops.pack_kv_weights_split(wk, wv, Hn, 128)
+    q = dev(rs.standard_normal((B, 300)).astype(np.float32))
+    bank32 = dev((1.5 * rs.standard_normal((B, L, 300))).astype(np.float32))
+    lens = np.clip(np.round(np.exp(rs.normal(2.4, 0.75, B))), 1, L).astype(int)
+    lens[0] = L
+    for i, v in enumerate((1, 16, 17, 32)):
+        if i + 1 < B:
+            lens[i + 1] = min(v, L)
+    m = np.zeros((B, L), np.float32)
+    for b in range(B):
+        m[b, :lens[b]] = 1
+    if B > 8:
+        m[6, ::2] = 0
+        m[6, 0] = 1                                           # holes
+        m[7, :] = 0
+        m[7, min(L - 1, 20):min(L, 30)] = 1                   # live rows that start late
+    mask = dev(m)
+    qh = ops.linear(q, wq, bq)
+    sp = ops.split_pad_bf16(bank32)
+    plan = ops.sq_mha_split_plan(mask)
+    groups, off, lv = _decode_plan(plan, B)
+    assert groups[0][0] == 0 and sum(g[1] for g in groups) == B and all(g[2] <= 112 and g[2] % 16 == 0 and g[1] <= 7 for g in groups)
+    assert all(groups[i][0] + groups[i][1] == groups[i + 1][0] for i in range(len(groups) - 1))
+    live = np.array([np.flatnonzero(m[b]).max() + 1 for b in range(B)])
+    assert np.array_equal(lv, live) and (off % 16 == 0).all()
+    o, none = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv, want_attn=False, plan=plan)
+    o1, _ = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv, want_attn=False)
+    o2, _ = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv, want_attn=False, plan=plan)
+    assert none is None and torch.equal(o, o2) and torch.isfinite(o).all()
+    o64, _ = _split_ref(qh.cpu(), bank32.cpu(), mask.cpu(), Hn, wk.cpu(), wv.cpu(), bv.cpu())
+    e_same, e64 = H.maxabs(o.cpu(), o1.cpu()), H.maxabs(o.cpu().double(), o64)
+    print("grouped split core H=%d B=%d L=%d: %d groups; vs per-sample %.2e, vs fp64 %.2e" % (Hn, B, L, len(groups), e_same, e64))
+    assert e_same < 5e-6 and e64 < 1e-4
+    with pytest.raises(ValueError):
+        ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wp, bk, bv, want_attn=True, plan=plan)      # no attn output in the grouped form
+    if B > 2:                                                  # a sample without a live row: NaN output row like the reference, others untouched
+        m2 = m.copy()
+        m2[2, :] = 0
+        mk2 = dev(m2)
+        o3, _ = ops.sq_mha_core_split(qh, sp, mk2, Hn, 128, wp, bk, bv, want_attn=False, plan=ops.sq_mha_split_plan(mk2))
+        keep = [b for b in range(B) if b != 2]
+        assert torch.isnan(o3[2]).all() and H.maxabs(o3[keep].cpu(), o1[keep].cpu()) < 5e-6
+
+
 def _decode_plan(plan, B):
     pl = plan.cpu().numpy()
     ng = int(pl[0])

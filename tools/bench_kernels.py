@@ -76,7 +76,11 @@ def mha(kind, B=256, L=196, H=8, masked=False):
         sp = ops.split_pad_bf16(bank)
         wp = ops.pack_kv_weights_split(wk, wv, H, 128)
         print("  split_pad_bf16 (fp32 bank -> hi + lo images): %.1f us" % (timeit(lambda: ops.split_pad_bf16(bank)) * 1e3))
-        ms = timeit(lambda: ops.sq_mha_core_split(qh, sp, mask, H, 128, wp, bk, bv, want_attn=False))
+        plan = ops.sq_mha_split_plan(mask) if (masked and L <= ops.SPLIT_PLAN_MAX_L and os.environ.get("MGNNS_SPLIT_GROUPED", "1") == "1") else None
+        if plan is not None:
+            print("  group plan: %d groups for %d samples, %d live rows; sq_mha_split_plan %.1f us"
+                  % (int(plan[0]), B, int(mask.sum()), timeit(lambda: ops.sq_mha_split_plan(mask)) * 1e3))
+        ms = timeit(lambda: ops.sq_mha_core_split(qh, sp, mask, H, 128, wp, bk, bv, want_attn=False, plan=plan))
         print("  [3 MFMAs per product: %.1f TFLOP/s executed]" % (3 * fl / ms / 1e9))
     elif kind == "folded_c16":
         bb = ops.cast_pad_bf16(bank)
