@@ -32,25 +32,41 @@ __device__ __forceinline__ void build(const float* __restrict__ mask, int B, int
     int* s_grp = s_plan + 4 * B;
     int* s_ng = s_plan + 8 * B;
     const int tid = threadIdx.x;
-    // live rows = last unmasked position + 1: one thread per sample walks its row with independent 16-byte loads (L / 4 of them
-    // in flight; round 4 swept the mask coalesced with an LDS atomicMax per live position -- most of the launch's 11 us, and with the
-    // plan riding on the BiLSTM's prep launch that time sits on the chain the forward follows)
-    const bool vec = (L & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
-    for (int b = tid; b < B; b += NT) {
-        const float* row = mask + (size_t)b * L;
-        int lv = 0;
-        if (vec) {
-            for (int p = 0; p < L; p += 4) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(row + p);
-                lv = m[0] != 0.0f ? p + 1 : lv;
-                lv = m[1] != 0.0f ? p + 2 : lv;
-                lv = m[2] != 0.0f ? p + 3 : lv;
-                lv = m[3] != 0.0f ? p + 4 : lv;
+    // live rows = last unmasked position + 1.  A WAVE per sample row, four rows per trip: the row as coalesced dword loads (lane,
+    // lane + 64, ...: eight loads in flight per lane for L <= 128), the last live position of a lane's elements, a 64-lane max.
+    // (Round 4 swept the mask with an LDS atomicMax per live position; one thread per row with 16-byte loads was no better -- 25
+    // strided loads per thread that the compiler does not keep in flight together: ~10 us either way, and with the plan riding on the
+    // BiLSTM's prep launch that time sits on the chain the forward follows.)
+    {
+        const int lane = tid & 63, wv = tid >> 6, NW = NT / 64;
+        for (int b0 = wv * 4; b0 < B; b0 += NW * 4) {
+            int lv[4] = {0, 0, 0, 0};
+            for (int p0 = 0; p0 < L; p0 += 128) {
+                float m[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p = p0 + 64 * h + lane;
+                        m[r][h] = (b0 + r < B && p < L) ? mask[(size_t)(b0 + r) * L + p] : 0.0f;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (m[r][0] != 0.0f) lv[r] = p0 + lane + 1;
+                    if (m[r][1] != 0.0f) lv[r] = p0 + 64 + lane + 1;
+                }
             }
-        } else {
-            for (int p = 0; p < L; ++p) lv = row[p] != 0.0f ? p + 1 : lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int v = lv[r];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int u = __shfl_xor(v, o, 64);
+                    v = u > v ? u : v;
+                }
+                if (lane == 0 && b0 + r < B) s_lv[b0 + r] = v;
+            }
         }
-        s_lv[b] = lv;
     }
     __syncthreads();
     for (int b = tid; b < B; b += NT) {
