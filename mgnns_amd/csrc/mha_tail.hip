@@ -434,18 +434,26 @@ extern "C" int mgnns_mha_tail_bf16_fwd(const float* o, int HK, const float* q, i
     // share of the projection (MGNNS_TAIL_CLUSTER overrides: 1 = none).  Four while the chip has CUs to spare; TWO from 256
     // samples on, where the forward is bound by CU time and 64 workgroups x 21 us cost more than the shorter chain returns
     // (B=256: 0.811-0.820 ms per forward with 2, 0.830 with 4; B=128: equal; B=64: 0.453-0.458 with 4, 0.464-0.467 with 2)
-    if (cluster_scratch && terms == 1 && cluster != 1) {
+    // terms == 3 (round 5): the same K split on split-bf16 operands; it has no projection launch of its own -- the caller leaves the
+    // next layer's w_qs to an exact-fp32 GEMM behind this call (packed[6] == NULL)
+    if (cluster_scratch && cluster != 1 && (terms == 1 || !packed[6])) {
         // K-split form (round 4): the ranks of a tile split fc's K = n_head * d_v, the last arriver finishes the tile; the next
         // layer's w_qs as a launch of its own on 8 workgroups per tile (csrc: mha_proj_c16_kernel -- x -> bf16, one MFMA chain
         // per column tile, exactly what the tail's own projection phase does)
         int cl = cluster ? cluster : 4;
         if (cl > HK / 32) cl = HK / 32;                  // every rank needs a k-step of its own
         const unsigned tiles = (unsigned)((B + ROWS - 1) / ROWS);
-        MG_DYN_LDS(mha_tail_bf16_ks_kernel<1>, 160 * 1024);
         TailW w2 = w;
         w2.wq_h = w2.wq_l = nullptr;
-        hipLaunchKernelGGL(mha_tail_bf16_ks_kernel<1>, dim3(tiles * cl), dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w2, eps,
-                           out, cl, cluster_scratch, cluster_counters);
+        if (terms == 3) {
+            MG_DYN_LDS(mha_tail_bf16_ks_kernel<3>, 160 * 1024);
+            hipLaunchKernelGGL(mha_tail_bf16_ks_kernel<3>, dim3(tiles * cl), dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w2, eps,
+                               out, cl, cluster_scratch, cluster_counters);
+        } else {
+            MG_DYN_LDS(mha_tail_bf16_ks_kernel<1>, 160 * 1024);
+            hipLaunchKernelGGL(mha_tail_bf16_ks_kernel<1>, dim3(tiles * cl), dim3(NTHR), lds, (hipStream_t)stream, o, HK, q, B, w2, eps,
+                               out, cl, cluster_scratch, cluster_counters);
+        }
         MG_CHECK_LAUNCH("mgnns_mha_tail_bf16_fwd(K split)");
         if (packed[6]) {
             const int pcl = 8;

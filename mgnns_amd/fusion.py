@@ -30,6 +30,8 @@ FOLDED_BF16 = _os.environ.get('MGNNS_FOLDED_BF16', '1') == '1'
 SPLIT_CORE = _os.environ.get('MGNNS_SPLIT_CORE', '1') == '1'
 # ... its masked launches (the text bank) in the GROUPED form: the samples of a group share a workgroup's staging and weight stream
 SPLIT_GROUPED = _os.environ.get('MGNNS_SPLIT_GROUPED', '1') == '1'
+# split-bf16 (terms = 3) layer tails with fc's K split over a cluster of workgroups like the bf16 mode's
+TAIL3_KSPLIT = _os.environ.get('MGNNS_TAIL3_KSPLIT', '1') == '1'
 
 
 def _require_eval(mod):
@@ -464,8 +466,14 @@ def run_stack(layers, q, bank, mask=None, qh=None, plan=None):
         if a.precision in ('bf16', 'bf16x3') and a.n_head * a.d_v % 32 == 0:
             # bf16 MFMA tail; split-bf16 (hi + lo operands, fp32-class) with MGNNS_TAIL_TERMS=3 and always in 'bf16x3' mode
             nxt = _wq_pack_bf16(layers[i + 1]) if i + 1 < len(layers) else None
-            q, qh = ops.mha_tail_bf16(o, q, _tail_pack_bf16(layer), a.layer_norm.eps, nxt,
-                                      terms=3 if a.precision == 'bf16x3' else TAIL_TERMS)
+            terms = 3 if a.precision == 'bf16x3' else TAIL_TERMS
+            # split-bf16 tail: fc's K split over a cluster too (round 5); the next layer's w_qs then is an exact-fp32 GEMM behind it
+            nlin = None
+            if terms == 3 and nxt is not None and TAIL3_KSPLIT:
+                an = layers[i + 1].slf_attn
+                nlin = (an.w_qs.weight.detach(), an.w_qs.bias.detach())
+            q, qh = ops.mha_tail_bf16(o, q, _tail_pack_bf16(layer), a.layer_norm.eps, nxt, terms=terms,
+                                      ksplit=(None if terms == 1 else TAIL3_KSPLIT), next_linear=nlin)
         else:
             nxt = _wq_pack(layers[i + 1]) if i + 1 < len(layers) else None
             q, qh = ops.mha_tail(o, q, _tail_pack(layer), a.layer_norm.eps, nxt)

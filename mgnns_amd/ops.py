@@ -1258,11 +1258,13 @@ def pack_weight_bf16_split(w):
 TAIL_BF16_KSPLIT = os.environ.get("MGNNS_TAIL_BF16_KSPLIT", "1") == "1"
 
 
-def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3, cluster=0, ksplit=None):
+def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3, cluster=0, ksplit=None, next_linear=None):
     """bf16-MFMA fused tail.  packed: dict with fc, w1, w2 = (hi, lo) buffers and fc_b, g1, be1, b1, b2, g2, be2;
-    next_packed = ((hi, lo), bq, HK_next) or None.  ksplit (terms == 1, default on): a tile's cluster of workgroups splits the K
+    next_packed = ((hi, lo), bq, HK_next) or None.  ksplit (default on): a tile's cluster of workgroups splits the K
     of fc and exchanges partial sums through scratch owned by `packed` (one per capture epoch and launch stream), the next
-    layer's w_qs runs as a second launch; cluster: workgroups per 16-sample tile (0 = the library's default)."""
+    layer's w_qs runs as a second launch (terms == 1: mha_proj_c16; terms == 3: the exact-fp32 GEMM on next_linear = (weight
+    [HK_next, 300], bias), which the K-split form needs in place of next_packed); cluster: workgroups per 16-sample tile
+    (0 = the library's default)."""
     import ctypes
     _chk(o, "o", ndim=2)
     _chk(q, "q", ndim=2)
@@ -1274,14 +1276,18 @@ def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3, cluster=0, kspli
             packed["w1"][1].data_ptr(), packed["w2"][0].data_ptr(), packed["w2"][1].data_ptr(), None, None]
     bq = qh = None
     hkn = 0
-    if next_packed is not None:
+    use_ks = (TAIL_BF16_KSPLIT if ksplit is None else ksplit) and B > 0 and cluster != 1
+    if int(terms) == 3 and use_ks and next_packed is not None and next_linear is None:
+        use_ks = False                    # (the split-bf16 K split has no packed projection: without next_linear, the one-launch form)
+    split_proj = int(terms) == 3 and use_ks and next_linear is not None
+    if next_packed is not None and not split_proj:
         (wh, wl), bq, hkn = next_packed
         ptrs[6], ptrs[7] = wh.data_ptr(), wl.data_ptr()
         qh = torch.empty(B, hkn, device=o.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * 8)(*ptrs)
     L = _lib.lib()
     scratch = counters = None
-    if (TAIL_BF16_KSPLIT if ksplit is None else ksplit) and int(terms) == 1 and B > 0 and cluster != 1:
+    if use_ks and int(terms) in (1, 3):
         tiles = (B + 15) // 16
         slot = packed.setdefault("_cluster_ws_ks", {})
         key = _scratch_key()                                     # per (capture epoch, launch stream), like the c16 tail's
@@ -1297,6 +1303,8 @@ def mha_tail_bf16(o, q, packed, eps, next_packed=None, terms=3, cluster=0, kspli
             int(terms), arr, _p(packed["fc_b"]), _p(packed["g1"]), _p(packed["be1"]), _p(packed["b1"]), _p(packed["b2"]),
             _p(packed["g2"]), _p(packed["be2"]), float(eps), _p(out), _p(bq), hkn, _p(qh), int(cluster), _p(scratch), _p(counters),
             _stream())
+    if split_proj:
+        qh = linear(out, next_linear[0], next_linear[1])
     return out, qh
 
 

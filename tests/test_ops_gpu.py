@@ -1216,6 +1216,19 @@ def test_mha_tail_bf16_split_matches_fp32_tail(Hn):
     out1, qh1 = ops.mha_tail_bf16(o, q, pkbf, 1e-6, nxbf, terms=1)
     e1 = H.maxabs(out1.cpu(), out32.cpu())
     assert 1e-4 < e1 < 5e-2
+    # the split tail with fc's K split over a cluster (round 5; the next query through the exact-fp32 GEMM): fp32-class as well,
+    # every cluster size, batches that are not a multiple of the tile, repeated launches on the same scratch
+    nlin = (p[a + "w_qs.weight"], p[a + "w_qs.bias"])
+    for Bk in (37, 256, 1):
+        ok_, qk_ = o[:Bk].contiguous() if Bk <= B else dev(rs.standard_normal((Bk, Hn * 128)).astype(np.float32)), None
+        qq = q[:Bk].contiguous() if Bk <= B else dev(rs.standard_normal((Bk, 300)).astype(np.float32))
+        r_out, r_qh = ops.mha_tail(ok_, qq, pk32, 1e-6, nx32)
+        for cl in (0, 2, 8):
+            for rep in range(2):
+                outk, qhk = ops.mha_tail_bf16(ok_, qq, pkbf, 1e-6, nxbf, terms=3, ksplit=True, cluster=cl, next_linear=nlin)
+                assert H.maxabs(outk.cpu(), r_out.cpu()) < 5e-5 and H.relerr(qhk.cpu(), r_qh.cpu()) < 5e-5, (Bk, cl, rep)
+        outn, qhn = ops.mha_tail_bf16(ok_, qq, pkbf, 1e-6, None, terms=3, ksplit=True)
+        assert qhn is None and H.maxabs(outn.cpu(), r_out.cpu()) < 5e-5
 
 
 @pytest.mark.parametrize("Hn", [1, 4, 8])
