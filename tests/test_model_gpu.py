@@ -141,6 +141,44 @@ def test_forward_matches_oracle_batch32_ragged():
     assert H.maxabs(l2, logits[:B // 2]) < 1e-6
 
 
+@pytest.mark.parametrize("precision,attention", [("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded"), ("bf16x3", "faithful")])
+def test_padded_partial_batch_with_trailing_empty_samples(precision, attention):
+    """The last batch of an epoch is padded by the host pipeline with EMPTY rows (batching.BatchAssembler: ids 0, length 0, mask 0)
+    that the caller discards.  The live samples' logits must not depend on them (equal to the same samples as a batch of their own:
+    bit-equal in fp32, to the batch-composition spread in the bf16 modes -- packed / grouped masked rows share workgroups), stay
+    finite, and nothing may fault on the empty rows (a text without tokens, a BiLSTM chain of length 0 at the END of the batch,
+    a fully masked attention row), eager and as a replayed hipGraph."""
+    from mgnns_amd.graph import GraphedForward
+    cfg = synth.CONFIGS["tumemo_b64"]
+    adj = H.load_golden("adjacency.npz")
+    lq = H.load_golden("label_attention.npz")["label_query"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=91)
+    model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
+    model.set_precision(precision).set_attention(attention)
+    B, live = 16, 11
+    inp = synth.make_inputs(cfg, B=B, seed=31, pmi=pmi)
+    inp["text"][live:] = 0
+    inp["text_lens"][live:] = 0
+    inp["text_mask"][live:] = 0
+    sub = {k: (v[:live] if k != "label_query" else v) for k, v in inp.items()}
+    ref = model(*call_args(sub, DEV)).cpu()
+    assert torch.isfinite(ref).all()
+    call = call_args(inp, DEV)
+    for rep in range(3):          # (repeated: the workspaces of the second / third forward are recycled blocks, not fresh zeros)
+        junk = torch.full((1 << 22,), float("nan"), device=DEV)
+        del junk
+        out = model(*call).cpu()
+        assert torch.isfinite(out[:live]).all()
+        tol = 0.0 if precision == "fp32" else (2e-5 if precision == "bf16x3" else 2e-3)
+        assert H.maxabs(out[:live], ref) <= tol, (rep, H.maxabs(out[:live], ref))
+        # (the discarded rows: NaN where the attention form divides by the all-masked row's zero sum like the reference's softmax,
+        #  a finite placeholder from the exact-f32 core, which skips the value pass of a sample without a live row)
+    g = GraphedForward(model, call)
+    for rep in range(2):
+        got = g.replay().cpu()
+        assert H.maxabs(got[:live], out[:live]) == 0.0
+
+
 def test_module_surface_on_gpu():
     cfg = synth.CONFIGS["mvsa_single_b8"]
     adj = H.load_golden("adjacency.npz")
