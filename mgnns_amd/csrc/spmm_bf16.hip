@@ -477,6 +477,27 @@ __global__ __launch_bounds__(1024) void spmm_bf16_tiled_kernel(const uint32_t* _
         // scalar unit for its 16 waves and this loop is scalar-driven); entry fields split on the vector side and three
         // v_readlane per entry instead of one + three scalar operations 172 us (SGPR-write hazards).
         auto run_part = [&](unsigned rec) __attribute__((always_inline)) {
+#ifdef MG_SPMM_ABLATE_FIXED
+            // measurement build (results wrong on purpose; tools/dev/build_variant.py): the instruction mix of a record with TWO
+            // fixed-lane slots per row -- constant v_readlane indices, no counts, no loops, five rows' reads behind one wait --
+            // on whatever the first lanes of the record hold (offsets masked into the tile)
+            static_assert(U % 5 == 0, "ablation written for U = 10 / 20");
+#pragma unroll
+            for (int u0 = 0; u0 < U; u0 += 5) {
+                unsigned e[10];
+                xreg x[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    e[k] = __builtin_amdgcn_readlane(rec, (1 + HD + 2 * u0 + k) & 63);
+                    x[k] = sb_lds_read<LB>(tbase + ((e[k] >> 16) & (TILEB - 8)));
+                }
+                mg_lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) sb_fma<LB>(acc[u0 + (k >> 1)], x[k], e[k]);
+            }
+            return;
+#endif
             unsigned cnt[HD];
 #pragma unroll
             for (int i = 0; i < HD; ++i) cnt[i] = __builtin_amdgcn_readlane(rec, 1 + i);
