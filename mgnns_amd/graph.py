@@ -29,20 +29,23 @@ from . import _lib
 _PROBED = {}
 
 
-def single_graph_probe(schedule, timeout=900):
+def single_graph_probe(schedule, timeout=900, precision="fp32", attention="faithful"):
     """Can the runtime capture the multi-stream forward of `schedule` as ONE graph?  hipStreamEndCapture has been seen to
     SEGFAULT on some stream topologies (ROCm 7.0 / 7.2) -- not an exception a process survives -- so the first one-graph
     capture of a topology is tried in a CHILD process on a small synthetic model (the topology, not the size, is what the
     runtime trips over).  Cached per process."""
-    if schedule not in _PROBED:
+    # the TOPOLOGY also depends on the mode: with a packing plan of the text mask (bf16 / bf16x3 + faithful) the image->text stacks
+    # wait for the text-GCN segment as well (model.PLAN_SITE) -- the child captures the mode the caller is in
+    key = schedule if (precision, attention) == ("fp32", "faithful") else (schedule, precision, attention)
+    if key not in _PROBED:
         env = dict(os.environ, MGNNS_GRAPH_MODE="segments")
         try:
-            r = subprocess.run([sys.executable, "-m", "mgnns_amd.graph", "--probe-single", schedule], env=env, timeout=timeout,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            _PROBED[schedule] = r.returncode == 0
+            r = subprocess.run([sys.executable, "-m", "mgnns_amd.graph", "--probe-single", schedule, precision, attention], env=env,
+                               timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _PROBED[key] = r.returncode == 0
         except (subprocess.TimeoutExpired, OSError):
-            _PROBED[schedule] = False
-    return _PROBED[schedule]
+            _PROBED[key] = False
+    return _PROBED[key]
 
 
 class GraphedForward:
@@ -67,7 +70,7 @@ class GraphedForward:
             # tried but 'channels' (lgcn_side, banks_first, channels2: python -X faulthandler points at capture_end) -- not
             # an exception this process could survive: the one-graph form of a topology is first captured in a child process
             sched = model.resolve_schedule(example_args[0].shape[0])
-            if not single_graph_probe(sched):
+            if not single_graph_probe(sched, precision=getattr(model, "precision", "fp32"), attention=getattr(model, "attention", "faithful")):
                 warnings.warn("MGNNS_GRAPH_MODE=%s: the runtime cannot capture schedule %r as one graph (probe child failed); "
                               "using one graph per segment" % (self.mode, sched))
                 self.mode = "segments"
@@ -351,7 +354,7 @@ class GraphedPipeline:
 
 
 
-def _probe_single_main(schedule):
+def _probe_single_main(schedule, precision="fp32", attention="faithful"):
     """Child of single_graph_probe: one-graph capture of `schedule` on a small synthetic model; exit code 0 iff it captured,
     replayed and reproduced the eager logits."""
     from . import harness, synth
@@ -362,6 +365,7 @@ def _probe_single_main(schedule):
     inp = synth.make_inputs(cfg, B=8, seed=3, pmi=pmi)
     model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], dev)
     model.schedule = schedule
+    model.set_precision(precision).set_attention(attention)
     args = list(harness.call_args(inp, dev))
     args[1] = args[1].to(dev)
     with torch.no_grad():
@@ -369,10 +373,10 @@ def _probe_single_main(schedule):
     g = GraphedForward(model, args, mode="single", _probe_child=True)
     out = g.replay().clone()
     torch.cuda.synchronize()
-    return 0 if g.mode == "single" and torch.allclose(out, ref, atol=1e-5) else 1
+    return 0 if g.mode == "single" and torch.allclose(out, ref, atol=1e-5 if precision == "fp32" else 1e-2) else 1
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 3 and sys.argv[1] == "--probe-single":
-        sys.exit(_probe_single_main(sys.argv[2]))
+    if len(sys.argv) in (3, 5) and sys.argv[1] == "--probe-single":
+        sys.exit(_probe_single_main(*sys.argv[2:]))
     sys.exit(2)

@@ -22,8 +22,17 @@ from .fusion import (MemoryBank, MultiHeadAttention, MyAnotherMultiHeadAttention
                      first_query_pack, first_query_pack_bf16, run_stack)
 from .text_gcn import Model as Text_GCN_Model
 
-# the packed masked attention's plan of the text mask out of the BiLSTM's prep launch (one per batch) instead of a launch per channel
-PLAN_IN_PREP = os.environ.get("MGNNS_PLAN_IN_PREP", "1") != "0"
+# Where the packing plan of the text mask (both masked stacks' attention launches) is built, once per batch:
+#   'text_gcn' (default, round 5)  one small launch at the END of the text-GCN segment -- a stream with 200 us of slack before the
+#              image->text stacks start; they wait for that segment in addition to their own producers;
+#   'prep'     an extra workgroup of the BiLSTM's prep launch (ops.bilstm(plan_mask=...)): no launch at all, but the prep launch --
+#              the head of the chain the forward follows -- is as long as its slowest workgroup, and the plan workgroup (10-15 us of
+#              serial LDS chains) is that: place_bank_first 0.691-0.702 ms two in flight against 0.626-0.628 (NOTES_r05 4);
+#   'tails'    round 4: one launch per channel at the head of its label-attention tail segment.
+PLAN_SITE = os.environ.get("MGNNS_PLAN_SITE", "prep" if os.environ.get("MGNNS_PLAN_IN_PREP") == "1" else "text_gcn")
+if PLAN_SITE not in ("text_gcn", "prep", "tails"):
+    raise ValueError("MGNNS_PLAN_SITE must be text_gcn | prep | tails")
+PLAN_IN_PREP = PLAN_SITE == "prep"
 
 LABEL_GLOVE_CANDIDATES = ('data/glove/tumblr_label_glove.pkl', 'data/tumblr_label_glove.pkl')
 
@@ -669,6 +678,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
         ctx = _PlanCtx()
         fused_bf16 = (self.precision in ('bf16', 'bf16x3') and self.fused_label_tail and self.fused_label_tail_bf16
                       and text.shape[0] >= self.fused_label_tail_bf16_min_batch)
+        plan_kind = mask_plan_applies(text_mask, self.precision, self.attention)        # False | 'packed' | 'grouped'
 
         def text_gcn():
             ops.stamp("text GCN start")
@@ -677,6 +687,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
             for nm, layers in (('tio', self.text_img_object_multi_head_att), ('tip', self.text_img_place_multi_head_att)):
                 if len(layers):
                     ctx['qh_' + nm] = first_query(layers, tf)
+            if plan_kind and PLAN_SITE == "text_gcn":
+                # the mask's packing plan for both image->text stacks (MODEL:509-527), here: this stream is idle from now until
+                # the place bank is done, the stacks that take the plan start ~200 us later (and wait for this segment)
+                ctx['mha_plan'] = make_mask_plan(text_mask.float().contiguous(), self.precision, self.attention)
             ops.stamp("text GCN end")
 
         def text_bank():
@@ -686,12 +700,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
             ctx['text_mask'] = text_mask.float().contiguous()
             # the packing plan of the mask for both image->text stacks (MODEL:509-527) rides on the BiLSTM's prep launch: one more
             # workgroup there instead of a launch per channel (round 4) on the stacks' critical paths
-            kind = mask_plan_applies(ctx['text_mask'], self.precision, self.attention)
-            ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if (PLAN_IN_PREP and kind == 'packed') else None)
-            ctx['mha_plan'] = getattr(ctx['text_bank'], 'mask_plan', None)
-            if ctx['mha_plan'] is None and kind == 'grouped':
-                # bf16x3 + faithful: the group plan of the split-bf16 core's masked launches, once per batch, on this stream (both
-                # image->text stacks wait for it anyway)
+            ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if (PLAN_IN_PREP and plan_kind == 'packed') else None)
+            prep_plan = getattr(ctx['text_bank'], 'mask_plan', None)
+            if prep_plan is not None:
+                ctx['mha_plan'] = prep_plan
+            elif PLAN_IN_PREP and plan_kind:
+                # (no prep launch to ride on -- the fp32 LSTM of bf16x3 mode, a shape the fused prep does not take: a launch here)
                 ctx['mha_plan'] = make_mask_plan(ctx['text_mask'], self.precision, self.attention)
             ops.stamp("text bank (LSTM) end")
 
@@ -739,10 +753,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
                 # its masked attention launches, MODEL:509-527): one small launch per channel, HERE -- on the stack's own stream,
                 # which has slack; on the BiLSTM's stream (the longest chain) it cost the pipelined forward 3 %, and one plan for
                 # both stacks means a cross-stream dependency the runtime's one-graph capture of the schedule does not survive
-                kind = mask_plan_applies(text_mask, self.precision, self.attention)
-                in_text_bank = kind == 'grouped' or (kind == 'packed' and PLAN_IN_PREP and ops.bilstm_can_plan(
-                    text.shape[0], text.shape[1], self.embedding.weight.shape[1], os.environ.get("MGNNS_LSTM_REC", "bf16")))
-                if kind and not in_text_bank:
+                if plan_kind and PLAN_SITE == "tails":
                     ctx['mha_plan_' + next_name] = make_mask_plan(text_mask, self.precision, self.attention)
                 ctx['att_' + tag], ctx['qh_' + next_name] = self._channel_tail(
                     ctx['pooled_' + tag], ctx['G_' + tag], ctx.get('Gp_' + tag), ctx['Q_' + tag], attention, linear_5, x_linear,
@@ -814,6 +825,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         for entry, skey in sched:
             name, *extra = entry.split("+")          # "seg+other": also wait for `other` (ordering only, no data)
             deps = tuple(self.SEGMENT_DEPS[name]) + tuple(extra)
+            if name in ("iot", "ipt") and plan_kind and PLAN_SITE == "text_gcn" and "text_gcn" not in deps:
+                deps += ("text_gcn",)                # the mask's packing plan is built at the end of that segment
             for d in deps:
                 if d not in where:
                     raise ValueError("schedule runs %s before %s" % (name, d))

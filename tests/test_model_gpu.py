@@ -341,12 +341,14 @@ def test_every_schedule_gives_the_same_logits_eager_and_graphed():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             ga = GraphedForward(model, a, mode="auto")                  # times both forms where the probe child survived
-        assert name in _PROBED and (ga.pick_ms is not None) == _PROBED[name], (name, ga.mode, ga.pick_ms, _PROBED)
+        key = (name, "bf16", "faithful")                                 # the probe child captures the caller's mode: its topology
+        assert key in _PROBED and (ga.pick_ms is not None) == _PROBED[key], (name, ga.mode, ga.pick_ms, _PROBED)
         assert torch.equal(ga.replay(), ref), name
-    assert _PROBED["channels"] is True
+    model.set_precision("fp32")
+    ref32 = model(*a).clone()
     model.schedule = "channels"
-    gs = GraphedForward(model, a, mode="single")
-    assert gs.mode == "single" and torch.equal(gs.replay(), ref)
+    gs = GraphedForward(model, a, mode="single")                         # (fp32 mode: no packing plan, round 1's topology)
+    assert _PROBED["channels"] is True and gs.mode == "single" and torch.equal(gs.replay(), ref32)
     model.schedule = "nope"
     with pytest.raises(ValueError):
         model(*a)
