@@ -430,6 +430,9 @@ __global__ __launch_bounds__(MTHR) void lstm_pack_whh_kernel(const float* __rest
     packed[((size_t)(dir * MW + wave) * MKS + ks) * 64 + lane] = uint2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
 }
 
+#ifndef MG_LSTM_KM
+#define MG_LSTM_KM 38                 // k-steps of the recurrence's GEMV on the matrix pipe; the other 38 - KM run as v_dot2c on the VALU (measured: loses)
+#endif
 #ifdef MG_LSTM_TRACE
 // profiling aid (off by default): cycle sums of the step's phases, waves 0 / 9 of workgroup 0 (tools/dev/lstm_trace.py)
 __device__ unsigned long long g_lstm_trace[2][8];
@@ -471,6 +474,11 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
     }
     const float bias = row_on ? (dir ? bhh_b : bhh_f)[row] : 0.f;
     (void)G; (void)npair;
+    // The weights are loaded ONCE, in front of the chain loop: a real s_waitcnt here (the compiler's counter model sees the builtin)
+    // tells it that none of these loads is pending at the loop header -- otherwise it guards the first use of every weight register
+    // inside the step loop with vmcnt(n) down to vmcnt(0), and a vmcnt(0) in a step also waits for the input-projection rows that
+    // the inline-asm loads keep three steps ahead
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), expcnt / lgkmcnt untouched
     for (;;) {
         if (tid == 0) s_rank = atomicAdd(&queue[dir], 1);
         __syncthreads();
@@ -533,15 +541,32 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #endif
             // h as the A operand through the MFMA's A-matrix BROADCAST (cbsz = 4: all 16 blocks take their A from block abid):
-            // three 8-byte LDS reads put h[4 (16 c + b) .. + 3] into the four lanes of block b of register pair c, and k-step
+            // 8-byte LDS reads put h[4 (16 c + b) .. + 3] into the four lanes of block b of register pair c, and k-step
             // ks = 16 c + b names that block -- instead of one 16-byte broadcast read (1 KB into the wave) per two k-steps
+            //
+            // Round 5, measured and NOT the default (MG_LSTM_KM = 38 keeps all k-steps on the matrix pipe): the k range split between
+            // the matrix pipe and the VALU.  A step is the three waves of a SIMD running their 38 MFMAs back to back (3 x 38 x 8 =
+            // 912 pipe cycles of ~1450); on paper v_mfma_f32_4x4x4 with one useful row in four and v_dot2c_f32_bf16 both retire
+            // 32 useful MACs per cycle and SIMD and run side by side.  The last KD = 38 - KM k-steps as v_dot2c on the SAME packed
+            // weight registers (a k-step's uint2 = two bf16 pairs), the h pairs WITHOUT extra data movement: lane r of every
+            // 16-lane row holds pair 2 KM + 16 c + r (one 4-byte LDS read per 16 pairs) and the DPP modifier row_newbcast:n hands
+            // pair n of the row to all of its lanes inside the dot instruction.  Text bank, B = 256 / 32, us: KM = 38: 175 / 168,
+            // 30: 208 / 202, 26: 216 / 211, 22: 226 / 220 -- sixteen dots cost a step ~350 cycles: the dot is nowhere near one
+            // issue slot on this chip (NOTES_r05 section 5).
+            constexpr int KM = MG_LSTM_KM, KD = MKS - KM, NHD = (2 * KD + 15) / 16;
+            static_assert(KM >= 19 && KM <= MKS, "the interleave below emits at most one dot k-step per MFMA");
+            static_assert(2 * KM + 16 * NHD <= MH / 2, "the pair reads stay inside the zero-padded h row");
             const uint2* hq = reinterpret_cast<const uint2*>(s_h[cur]);
+            const unsigned* hp = reinterpret_cast<const unsigned*>(s_h[cur]);
             s16x4_t hreg[3];
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
+            for (int cc = 0; cc < (KM + 15) / 16; ++cc) {
                 const uint2 hv = hq[16 * cc + (lane >> 2)];
                 hreg[cc] = s16x4_t{(short)(hv.x & 0xFFFFu), (short)(hv.x >> 16), (short)(hv.y & 0xFFFFu), (short)(hv.y >> 16)};
             }
+            unsigned hd[NHD > 0 ? NHD : 1];
+#pragma unroll
+            for (int cc = 0; cc < NHD; ++cc) hd[cc] = hp[2 * KM + 16 * cc + (lane & 15)];
 #ifndef MG_LSTM_ACC
 #define MG_LSTM_ACC 2
 #endif
@@ -549,11 +574,25 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             f32x4 a[MG_LSTM_ACC];
 #pragma unroll
             for (int i = 0; i < MG_LSTM_ACC; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define MG_K(ks) a[(ks) % MG_LSTM_ACC] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hreg[(ks) >> 4], w[ks], a[(ks) % MG_LSTM_ACC], 4, (ks) & 15, 0);
+            float d0 = 0.f, d1 = 0.f;
+#define MG_DOT(acc, hv, wv, n) asm("v_dot2c_f32_bf16_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(hv), "v"(wv), "n"(n))
+            // MFMA k-step ks, and behind it dot k-step KM + j whenever j = ks KD / KM moves on: the two kinds alternate in the
+            // instruction stream in the ratio of their counts
+#define MG_K(ks)                                                                                                                    \
+    if constexpr ((ks) < KM) {                                                                                                      \
+        a[(ks) % MG_LSTM_ACC] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hreg[(ks) >> 4], w[ks], a[(ks) % MG_LSTM_ACC], 4, (ks) & 15, 0); \
+        if constexpr (((ks) + 1) * KD / KM > (ks) * KD / KM) {                                                                      \
+            constexpr int j_ = (ks) * KD / KM;                                                                                      \
+            const uint2 wv_ = __builtin_bit_cast(uint2, w[(KM + j_) < MKS ? (KM + j_) : 0]);                                        \
+            MG_DOT(d0, hd[(2 * j_) >> 4], wv_.x, (2 * j_) & 15);                                                                    \
+            MG_DOT(d1, hd[(2 * j_ + 1) >> 4], wv_.y, (2 * j_ + 1) & 15);                                                            \
+        }                                                                                                                           \
+    }
             MG_K(0) MG_K(1) MG_K(2) MG_K(3) MG_K(4) MG_K(5) MG_K(6) MG_K(7) MG_K(8) MG_K(9) MG_K(10) MG_K(11) MG_K(12) MG_K(13) MG_K(14)
             MG_K(15) MG_K(16) MG_K(17) MG_K(18) MG_K(19) MG_K(20) MG_K(21) MG_K(22) MG_K(23) MG_K(24) MG_K(25) MG_K(26) MG_K(27)
             MG_K(28) MG_K(29) MG_K(30) MG_K(31) MG_K(32) MG_K(33) MG_K(34) MG_K(35) MG_K(36) MG_K(37)
 #undef MG_K
+#undef MG_DOT
             static_assert(MKS == 38, "k-steps written out");
 #ifdef MG_LSTM_TRACE
             asm volatile("s_nop 0" : "+v"(a[0]), "+v"(a[MG_LSTM_ACC - 1]));
@@ -562,6 +601,7 @@ __global__ __launch_bounds__(MTHR) void lstm_rec_bf16_kernel(const float* __rest
             float asum = a[0][0];
 #pragma unroll
             for (int i = 1; i < MG_LSTM_ACC; ++i) asum += a[i][0];
+            if constexpr (KD > 0) asum += d0 + d1;
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(gx)::"memory");   // the oldest of the three loads in flight (younger stores of a flush only make the wait longer)
             LSTM_T(1)                                              // wait for the input-projection row
             const float pre = (gx + bias) + asum;
