@@ -170,6 +170,10 @@ int mgnns_matmul_fwd(const float* X, int M, int K, const float* W, int N, float*
                      void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
 int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
                        const float* X, int F, float* Y, int act, mgnns_stream_t stream);
+/* GraphConvolution(bias=True) (MODEL:40-41,55-56): Y[i,:] = act(sum_p ... + bias[:]); bias [F] (the reference's
+ * [1,1,F] parameter), NULL = the call above. */
+int mgnns_spmm_csr_bias_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
+                            const float* X, int F, const float* bias, float* Y, int act, mgnns_stream_t stream);
 
 /* ---- a3/a4 at BASELINE configs[4] scale: bf16-feature sparse propagation ---------------------------------
  * Y[i,:] = act(sum_p val[p] * X[col[p],:]) as above (MODEL:54, adjacency of UTIL:421-426 held sparse) with the
@@ -261,6 +265,11 @@ int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld,
  */
 int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
                               int n_heads, int dh, float* x, mgnns_stream_t stream);
+/* Attention.forward(mask=...) (MODEL:118-119): energy.masked_fill(mask == 0, -1e10) behind the scaling, in front of
+ * the softmax over d.  mask = the byte image [B,NLQ,hid] of the caller's mask broadcast against the energy
+ * [B,NLQ,heads,dh] (0 = masked); NULL = the call above. */
+int mgnns_label_attn_core_masked_fwd(const float* Q, const float* K, const float* V, const unsigned char* mask,
+                                     int B, int NLQ, int n_heads, int dh, float* x, mgnns_stream_t stream);
 
 /* ---- a5 + a7 (fused): everything of an image channel behind the memory-bank kernel, one launch ----------------
  * Read-out (MODEL:454-455 max-pool halves + 474 `matmul(feature, x)`), Attention.forward (MODEL:88-133) without its

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c = ctypes
 _P = _c.c_void_p
@@ -31,6 +31,7 @@ SIGNATURES = {
     "mgnns_dense_to_csr": [_P, _I, _P, _P, _P, _P],
     "mgnns_matmul_fwd": [_P, _I, _I, _P, _I, _P, _I, _P, _SZ, _P],
     "mgnns_spmm_csr_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _P],
+    "mgnns_spmm_csr_bias_fwd": [_P, _P, _P, _I, _P, _I, _P, _P, _I, _P],
     "mgnns_cast_bf16": [_P, _c.c_longlong, _P, _P],
     "mgnns_spmm_csr_bf16_fwd": [_P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _P],
     "mgnns_spmm_tiled_bf16_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
@@ -45,6 +46,7 @@ SIGNATURES = {
     "mgnns_imgbank_pool_split_fwd": [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgnns_transpose_pad": [_P, _I, _I, _P, _I, _P],
     "mgnns_label_attn_core_fwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "mgnns_label_attn_core_masked_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mgnns_label_gcn_fwd": [_P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _I, _P],
     "mgnns_classifier_head_fwd": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P],
     "mgnns_label_tail_bf16_fwd": [_P, _I, _I, _I, _I, _I, _PP, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P],

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const float* __restrict__
 template <int NCH>
 __device__ __forceinline__ void spmm_row(const int32_t* __restrict__ col, const float* __restrict__ val,
                                          const float* __restrict__ X, int F, int f0, int lo, int hi, int row,
-                                         float* __restrict__ Y, int act, int lane) {
+                                         float* __restrict__ Y, int act, int lane, const float* __restrict__ bias) {
     f32x4 acc[NCH];
     bool on[NCH];
 #pragma unroll
@@ -153,6 +153,8 @@ __device__ __forceinline__ void spmm_row(const int32_t* __restrict__ col, const 
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
         if (on[c]) {
+            // GraphConvolution(bias=True): output + bias behind the product (MODEL:55-56), in front of the activation
+            if (bias) acc[c] += *reinterpret_cast<const f32x4*>(bias + f0 + c * 256 + lane * 4);
             const f32x4 o = {mg_act(acc[c][0], act), mg_act(acc[c][1], act), mg_act(acc[c][2], act), mg_act(acc[c][3], act)};
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row * F + f0 + c * 256 + lane * 4));
         }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
                                                        const int32_t* __restrict__ col,
                                                        const float* __restrict__ val,
                                                        const float* __restrict__ X, int n_rows, int F,
-                                                       float* __restrict__ Y, int act) {
+                                                       float* __restrict__ Y, int act, const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
@@ -170,10 +172,10 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
         const int lo = row_ptr[row], hi = row_ptr[row + 1];
         int f0 = 0;
         for (; f0 + 1024 <= F || (f0 < F && F - f0 > 512); f0 += 1024)
-            spmm_row<4>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
+            spmm_row<4>(col, val, X, F, f0, lo, hi, row, Y, act, lane, bias);
         if (f0 < F) {
-            if (F - f0 > 256) spmm_row<2>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
-            else spmm_row<1>(col, val, X, F, f0, lo, hi, row, Y, act, lane);
+            if (F - f0 > 256) spmm_row<2>(col, val, X, F, f0, lo, hi, row, Y, act, lane, bias);
+            else spmm_row<1>(col, val, X, F, f0, lo, hi, row, Y, act, lane, bias);
         }
     }
 }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float* __restrict__ X, int n_rows, int F,
-                                                            float* __restrict__ Y, int act) {
+                                                            float* __restrict__ Y, int act, const float* __restrict__ bias) {
     constexpr int SW = 4 * LPR;                 // slab width in floats
     constexpr int GPW = 64 / LPR;               // row groups per wave
     const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3, nb = gridDim.x >> 3;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(256) void spmm_csr_slab_kernel(const int32_t* __res
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
                     if (fon[q] && row[u] < n_rows) {
+                        if (bias) acc[u][q] += *reinterpret_cast<const f32x4*>(bias + f[q]);
                         const f32x4 o = {mg_act(acc[u][q][0], act), mg_act(acc[u][q][1], act), mg_act(acc[u][q][2], act),
                                          mg_act(acc[u][q][3], act)};
                         __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Y + (size_t)row[u] * F + f[q]));
@@ -316,9 +319,10 @@ extern "C" int mgnns_dense_to_csr(const float* M, int C, int32_t* csr_row_ptr, i
     return 0;
 }
 
-extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
-                                  const float* X, int F, float* Y, int act, mgnns_stream_t stream) {
+extern "C" int mgnns_spmm_csr_bias_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
+                                       const float* X, int F, const float* bias, float* Y, int act, mgnns_stream_t stream) {
     MG_REQUIRE(row_ptr && col && val && X && Y, "mgnns_spmm_csr_fwd: null pointer");
+    MG_REQUIRE(!bias || mg_aligned16(bias), "mgnns_spmm_csr_bias_fwd: bias must be 16-byte aligned");
     MG_REQUIRE(n_rows >= 0 && F > 0 && F % 4 == 0, "mgnns_spmm_csr_fwd: F=%d must be a positive multiple of 4", F);
     MG_REQUIRE(mg_aligned16(X) && mg_aligned16(Y), "mgnns_spmm_csr_fwd: X/Y must be 16-byte aligned");
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_spmm_csr_fwd: unknown activation %d", act);
@@ -334,16 +338,21 @@ extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, co
         const dim3 blk(256);
         hipStream_t st = (hipStream_t)stream;
         if (spx >= 2)
-            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 2, 1>), dim3(8 * 384), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 2, 1>), dim3(8 * 384), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act, bias);
         else
-            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 1, 2>), dim3(8 * 192), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act);
+            hipLaunchKernelGGL((spmm_csr_slab_kernel<16, 1, 2>), dim3(8 * 192), blk, 0, st, row_ptr, col, val, X, n_rows, F, Y, act, bias);
         MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
         return 0;
     }
     long long blocks = ((long long)n_rows + 3) / 4;    // one wave per row
     if (blocks > 256 * 8) blocks = 256 * 8;            // 8 workgroups (32 waves) per CU, grid-stride beyond
     hipLaunchKernelGGL(spmm_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, row_ptr, col, val, X,
-                       n_rows, F, Y, act);
+                       n_rows, F, Y, act, bias);
     MG_CHECK_LAUNCH("mgnns_spmm_csr_fwd");
     return 0;
+}
+
+extern "C" int mgnns_spmm_csr_fwd(const int32_t* row_ptr, const int32_t* col, const float* val, int n_rows,
+                                  const float* X, int F, float* Y, int act, mgnns_stream_t stream) {
+    return mgnns_spmm_csr_bias_fwd(row_ptr, col, val, n_rows, X, F, nullptr, Y, act, stream);
 }

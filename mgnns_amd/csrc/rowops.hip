@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void label_attn_core_kernel(const float* __res
                                                               const float* __restrict__ K,
                                                               const float* __restrict__ V, int B, int NLQ,
                                                               int n_heads, int dh, float inv_scale,
-                                                              float* __restrict__ x) {
+                                                              float* __restrict__ x, const unsigned char* __restrict__ mask) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t total = (int64_t)B * NLQ * n_heads;
@@ -77,8 +77,11 @@ __global__ __launch_bounds__(256) void label_attn_core_kernel(const float* __res
     const int b = (int)(item / ((int64_t)n_heads * NLQ));
     const int hid = n_heads * dh;
     const bool on = lane < dh;
-    const float e = on ? Q[(size_t)l * hid + h * dh + lane] * K[(size_t)b * hid + h * dh + lane] * inv_scale
-                       : -INFINITY;
+    float e = on ? Q[(size_t)l * hid + h * dh + lane] * K[(size_t)b * hid + h * dh + lane] * inv_scale
+                 : -INFINITY;
+    // Attention(mask=...): energy.masked_fill(mask == 0, -1e10) behind the scaling (MODEL:118-119); mask is the byte
+    // image of the broadcast mask, [B, NLQ, heads * dh]
+    if (mask && on && mask[((size_t)b * NLQ + l) * hid + h * dh + lane] == 0) e = -1e10f;
     const float m = wave_max(e);
     const float p = on ? expf(e - m) : 0.f;
     const float z = wave_sum(p);
@@ -290,17 +293,22 @@ extern "C" int mgnns_layernorm_fwd(const float* x, int rows, int D, const float*
     return 0;
 }
 
-extern "C" int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
-                                         int n_heads, int dh, float* x, mgnns_stream_t stream) {
+extern "C" int mgnns_label_attn_core_masked_fwd(const float* Q, const float* K, const float* V, const unsigned char* mask,
+                                                int B, int NLQ, int n_heads, int dh, float* x, mgnns_stream_t stream) {
     MG_REQUIRE(Q && K && V && x, "mgnns_label_attn_core_fwd: null pointer");
     MG_REQUIRE(B >= 0 && NLQ > 0 && n_heads > 0 && dh > 0 && dh <= 64,
                "mgnns_label_attn_core_fwd: bad dims B=%d NLQ=%d heads=%d dh=%d (dh<=64)", B, NLQ, n_heads, dh);
     if (B == 0) return 0;
     const int64_t total = (int64_t)B * NLQ * n_heads;
     hipLaunchKernelGGL(label_attn_core_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       Q, K, V, B, NLQ, n_heads, dh, 1.0f / sqrtf((float)dh), x);
+                       Q, K, V, B, NLQ, n_heads, dh, 1.0f / sqrtf((float)dh), x, mask);
     MG_CHECK_LAUNCH("mgnns_label_attn_core_fwd");
     return 0;
+}
+
+extern "C" int mgnns_label_attn_core_fwd(const float* Q, const float* K, const float* V, int B, int NLQ,
+                                         int n_heads, int dh, float* x, mgnns_stream_t stream) {
+    return mgnns_label_attn_core_masked_fwd(Q, K, V, nullptr, B, NLQ, n_heads, dh, x, stream);
 }
 
 extern "C" int mgnns_transpose_pad(const float* in, int rows, int cols, float* out, int ld,

@@ -59,12 +59,11 @@ class GraphConvolution(nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, adj, act=ops.ACT_NONE):
-        if self.bias is not None:
-            raise NotImplementedError("GraphConvolution(bias=True) is never built by the reference model")
         support = ops.matmul(input.float().contiguous(), self.weight.detach())
         if torch.is_tensor(adj):
             adj = ops.dense_to_csr(adj.contiguous())
-        return ops.spmm_csr(adj, support, act=act)
+        # bias=True (never built by the reference model, MODEL:40-41,55-56): output + bias in the propagation's epilogue
+        return ops.spmm_csr(adj, support, act=act, bias=None if self.bias is None else self.bias.detach())
 
     def __repr__(self):
         return '%s (%d -> %d)' % (self.__class__.__name__, self.in_features, self.out_features)
@@ -88,14 +87,12 @@ class Attention(nn.Module):
         """query [NLQ,hid] (label GloVe, any float dtype), key = value [B,image_dim] -> [B,NLQ,hid]."""
         if self.training:
             raise RuntimeError("Attention: eval-mode forward only on the HIP path; call .eval()")
-        if mask is not None:
-            raise NotImplementedError("Attention(mask=...) is never used by the reference forward")
         if key.data_ptr() != value.data_ptr():
             raise ValueError("key and value must be the same tensor (as at MODEL:476,503)")
         Q = ops.linear(query.float().contiguous(), self.w_q.weight.detach(), self.w_q.bias.detach())
         K = ops.linear(key.contiguous(), self.w_k.weight.detach(), self.w_k.bias.detach())
         V = ops.linear(key.contiguous(), self.w_v.weight.detach(), self.w_v.bias.detach())
-        x = ops.label_attn_core(Q, K, V, self.n_heads)
+        x = ops.label_attn_core(Q, K, V, self.n_heads, mask=mask)      # mask: MODEL:118-119 (no reference call site passes one)
         return ops.linear(x, self.fc.weight.detach(), self.fc.bias.detach())
 
 

@@ -375,8 +375,9 @@ def dense_to_csr(m):
     return rp, col, val
 
 
-def spmm_csr(csr, x, act=ACT_NONE, out=None):
-    """act(adj @ x) with adj in CSR (row_ptr, col, val); x [C, F].  out: optional preallocated [C, F] result."""
+def spmm_csr(csr, x, act=ACT_NONE, out=None, bias=None):
+    """act(adj @ x [+ bias]) with adj in CSR (row_ptr, col, val); x [C, F].  out: optional preallocated [C, F] result;
+    bias: GraphConvolution(bias=True)'s [1,1,F] parameter (MODEL:40-41,55-56), any shape with F elements."""
     rp, col, val = csr
     _chk(rp, "row_ptr", torch.int32, 1)
     _chk(col, "col", torch.int32, 1)
@@ -390,6 +391,13 @@ def spmm_csr(csr, x, act=ACT_NONE, out=None):
         if tuple(y.shape) != (n, x.shape[1]) or y.data_ptr() == x.data_ptr():
             raise ValueError("out must be a [%d, %d] tensor distinct from x" % (n, x.shape[1]))
     L = _lib.lib()
+    if bias is not None:
+        bias = _chk(bias.reshape(-1), "bias", ndim=1)
+        if bias.shape[0] != x.shape[1]:
+            raise ValueError("bias has %d elements, x has %d features" % (bias.shape[0], x.shape[1]))
+        _launch("mgnns_spmm_csr_fwd", ("mgnns_spmm_csr_bias_fwd", n, x.shape[1]), L.mgnns_spmm_csr_bias_fwd, _p(rp), _p(col), _p(val), n,
+                _p(x), x.shape[1], _p(bias), _p(y), act, _stream())
+        return y
     _launch("mgnns_spmm_csr_fwd", ("mgnns_spmm_csr_fwd", n, x.shape[1]), L.mgnns_spmm_csr_fwd, _p(rp), _p(col), _p(val), n,
             _p(x), x.shape[1], _p(y), act, _stream())
     return y
@@ -821,7 +829,9 @@ def imgbank_pool_split(feat, w_pair, bias, n_out, want_pool=True, want_f32=True,
     return (bank, pooled, split) if want_split else (bank, pooled)
 
 
-def label_attn_core(Q, K, V, n_heads):
+def label_attn_core(Q, K, V, n_heads, mask=None):
+    """x[b,l,:] of Attention.forward between its projections (MODEL:101-131).  mask: anything that broadcasts against the
+    energy [B, NLQ, heads, dh] (MODEL:118-119: positions where mask == 0 get -1e10 in front of the softmax over dh)."""
     _chk(Q, "Q", ndim=2)
     _chk(K, "K", ndim=2)
     _chk(V, "V", ndim=2)
@@ -831,6 +841,14 @@ def label_attn_core(Q, K, V, n_heads):
         raise ValueError("label attention shapes Q%s K%s V%s" % (tuple(Q.shape), tuple(K.shape), tuple(V.shape)))
     x = torch.empty(B, NLQ, hid, device=K.device, dtype=torch.float32)
     L = _lib.lib()
+    if mask is not None:
+        if mask.device != K.device:
+            raise ValueError("mask is on %s, K on %s" % (mask.device, K.device))
+        # the byte image of the broadcast mask (layout only: the comparison with 0 and the fill run in the kernel)
+        m8 = torch.broadcast_to(mask != 0, (B, NLQ, n_heads, hid // n_heads)).to(torch.uint8).contiguous()
+        _lib.check(L.mgnns_label_attn_core_masked_fwd(_p(Q), _p(K), _p(V), _p(m8), B, NLQ, n_heads, hid // n_heads, _p(x), _stream()),
+                   "mgnns_label_attn_core_masked_fwd")
+        return x
     _lib.check(L.mgnns_label_attn_core_fwd(_p(Q), _p(K), _p(V), B, NLQ, n_heads, hid // n_heads, _p(x), _stream()),
                "mgnns_label_attn_core_fwd")
     return x

@@ -75,8 +75,10 @@ def max_pool(feat):
 # ---------------------------------------------------------------------------
 # A.4  label-query "attention"
 # ---------------------------------------------------------------------------
-def label_attention(p, prefix, query, key, n_heads=5):
-    """MODEL:88-133.  query [NLQ,300] (any float dtype), key=value [B,C] -> [B,NLQ,300]."""
+def label_attention(p, prefix, query, key, n_heads=5, mask=None):
+    """MODEL:88-133.  query [NLQ,300] (any float dtype), key=value [B,C] -> [B,NLQ,300].
+    mask (MODEL:118-119; no call site of the reference passes one, so no golden vector pins this branch):
+    broadcast against the energy [B,NLQ,heads,dh], zeros are filled with -1e10 in front of the softmax."""
     hid = p[prefix + ".w_q.weight"].shape[0]
     dh = hid // n_heads
     Q = F.linear(query.float(), p[prefix + ".w_q.weight"], p[prefix + ".w_q.bias"])
@@ -87,6 +89,8 @@ def label_attention(p, prefix, query, key, n_heads=5):
     K = K.view(B, 1, n_heads, dh)
     V = V.view(B, 1, n_heads, dh)
     energy = (Q * K) / torch.sqrt(torch.tensor([float(dh)]))
+    if mask is not None:
+        energy = energy.masked_fill(mask == 0, -1e10)
     att = torch.softmax(energy, dim=-1)
     x = (att * V).contiguous().view(B, NLQ, hid)
     return F.linear(x, p[prefix + ".fc.weight"], p[prefix + ".fc.bias"])

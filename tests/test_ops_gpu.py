@@ -118,6 +118,68 @@ def test_spmm_csr_ragged_rows_both_kernels(N, F):
     assert float(y[::7].abs().max()) == 0.0          # empty rows produce exact zeros
 
 
+def test_graph_convolution_with_bias_both_kernels():
+    """GraphConvolution(bias=True) (MODEL:40-41,55-56: `output + self.bias`, a [1,1,F] parameter the reference model never
+    builds): the bias rides in the propagation's epilogue, in front of an optional activation.  Module and operator against
+    an fp64 dense product, wave-per-row kernel (300 nodes) and slab kernel (10 000 nodes x 256 features)."""
+    from mgnns_amd.model import GraphConvolution
+    for N, Fin, Fout in ((300, 64, 1000), (10000, 32, 256)):
+        rs = np.random.RandomState(N)
+        per = rs.poisson(3.0, size=N)
+        per[::5] = 0
+        rp = np.zeros(N + 1, np.int32)
+        rp[1:] = np.cumsum(per)
+        col = np.concatenate([np.sort(rs.choice(N, size=k, replace=False)) for k in per] + [np.zeros(0, np.int64)]).astype(np.int32)
+        val = rs.uniform(-1.0, 1.0, size=col.size).astype(np.float32)
+        x = rs.standard_normal((N, Fin)).astype(np.float32)
+        torch.manual_seed(N)
+        gc = GraphConvolution(Fin, Fout, bias=True).to(DEV)
+        assert tuple(gc.bias.shape) == (1, 1, Fout)
+        csr = (dev(rp), dev(col), dev(val))
+        A = torch.zeros(N, N, dtype=torch.float64)
+        for i in range(N):
+            A[i, col[rp[i]:rp[i + 1]].astype(np.int64)] = torch.from_numpy(val[rp[i]:rp[i + 1]]).double()
+        ref = A @ (torch.from_numpy(x).double() @ gc.weight.detach().cpu().double()) + gc.bias.detach().cpu().double().reshape(1, Fout)
+        with torch.no_grad():
+            y = gc(dev(x), csr).cpu().double()
+            ya = gc(dev(x), csr, act=ops.ACT_LRELU2).cpu().double()
+        assert float((y - ref).abs().max()) < 1e-5
+        assert float((ya - torch.nn.functional.leaky_relu(ref, 0.2)).abs().max()) < 1e-5
+        assert torch.equal(y[::5], gc.bias.detach().cpu().double().reshape(1, Fout).expand(len(y[::5]), Fout))   # empty rows: the bias alone
+        gc0 = GraphConvolution(Fin, Fout).to(DEV)
+        gc0.weight.data.copy_(gc.weight.data)
+        with torch.no_grad():
+            assert float((gc0(dev(x), csr).cpu().double() + gc.bias.detach().cpu().double().reshape(1, Fout) - y).abs().max()) < 1e-6
+
+
+def test_label_attention_with_a_mask():
+    """Attention.forward(mask=...) (MODEL:118-119; never passed by the reference's own forward, so the oracle's branch is a
+    restatement without a golden vector): full-shape, per-sample, per-head-dim and all-masked rows (uniform softmax)."""
+    from mgnns_amd.model import Attention
+    p = H.params_for({"a.w_q.weight": (300, 300), "a.w_q.bias": (300,), "a.w_k.weight": (300, 365), "a.w_k.bias": (300,),
+                      "a.w_v.weight": (300, 365), "a.w_v.bias": (300,), "a.fc.weight": (300, 300), "a.fc.bias": (300,)})
+    att = Attention(300, 365, 5, 0.5).eval()
+    att.load_state_dict({k[2:]: v for k, v in p.items()})
+    att = att.to(DEV)
+    rs = np.random.RandomState(5)
+    B, NLQ = 9, 3
+    q = torch.from_numpy(rs.standard_normal((NLQ, 300)).astype(np.float32))
+    key = torch.from_numpy(rs.standard_normal((B, 365)).astype(np.float32))
+    full = torch.from_numpy((rs.uniform(size=(B, NLQ, 5, 60)) > 0.3).astype(np.int64))
+    full[2] = 0                                                    # a sample with every position masked
+    masks = [full, full[:, :1, :1, :].contiguous(), full[:1, :1, :1, :].contiguous(), (full[:, :, :, :1] * 0 + 1).float(),
+             full.bool()]
+    qd, kd = dev(q), dev(key)
+    with torch.no_grad():
+        plain = att(qd, kd, kd)
+        for m in masks:
+            want = R.label_attention(p, "a", q, key, n_heads=5, mask=m)
+            got = att(qd, kd, kd, mask=dev(m))
+            assert H.relerr(got.cpu(), want) < 1e-5
+        assert torch.equal(att(qd, kd, kd, mask=dev(masks[3])), plain)      # an all-ones mask changes nothing
+        assert H.relerr(plain.cpu(), R.label_attention(p, "a", q, key, n_heads=5)) < 1e-5
+
+
 def test_image_gcn_chain_against_goldens():
     g = H.load_golden("image_gcn.npz")
     adjg = H.load_golden("adjacency.npz")
