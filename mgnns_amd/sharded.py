@@ -40,6 +40,12 @@ class ShardedForward:
         shape = (self.world * logits.shape[0],) + tuple(logits.shape[1:])
         if self._out is None or self._out.shape != shape or self._out.device != logits.device:
             self._out = torch.empty(shape, dtype=logits.dtype, device=logits.device)
+        if logits.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo stages device tensors through the host anyway; joining the device FIRST keeps its copy streams from waiting on
+            # a hipGraph replay still in flight.  Without it, two processes sharing one GPU (the one-GPU test hooks) degrade to
+            # 20-230 ms per step -- reproduced with twelve trivial kernels and nothing of this library
+            # (tools/dev/two_proc_gloo.py, NOTES_r05 section 6); with RCCL (one process per GPU) this branch is never taken
+            torch.cuda.current_stream(logits.device).synchronize()
         dist.all_gather_into_tensor(self._out, logits.contiguous(), group=self.group)
         return self._out
 
