@@ -4,6 +4,11 @@
         RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment; every rank on cuda:0 (one-GPU box); gloo rendezvous.
         Builds the product model (seeded weights), runs it EAGERLY on its contiguous slice of the seeded batch through
         mgnns_amd.sharded.ShardedForward (the product's sharding + the logits all-gather) and saves the gathered logits.
+    python tests/sharded_worker.py forward_graph <out.pt> <config> <B> <seed> <precision>
+        The same slice captured as hipGraphs (mgnns_amd.graph.GraphedForward) and replayed four times, the DEVICE logits of every
+        replay gathered over gloo right behind it (no host synchronisation in the loop: the shape of bench.py's timed region, the
+        pattern that degraded to 20-230 ms per step before ShardedForward joined the device in front of a gloo collective);
+        saves the last gathered logits and the slowest step.
     python tests/sharded_worker.py stress <out.pt> <n> <batch>
         configs[4]: this rank's blocks of mgnns_amd.stress.StressWorkload(rank, world) (no data-path collective: plan_shards).
 """
@@ -42,11 +47,26 @@ def main():
     mine = {k: (v[lo:hi] if k != "label_query" else v) for k, v in inp.items()}
     # RCCL refuses two ranks on one device, so on this one-GPU box the collective is gloo's, on the host copy of the local logits
     # (ShardedForward gathers on whatever device the logits live); with one GPU per rank the same class gathers over RCCL
-    fwd = ShardedForward(lambda *a: model(*a).cpu())
-    with torch.no_grad():
-        gathered = fwd(*harness.call_args(mine, dev))
+    extra = {}
+    if mode == "forward_graph":
+        import time
+        from mgnns_amd.graph import GraphedForward
+        with torch.no_grad():
+            gf = GraphedForward(model, harness.call_args(mine, dev))
+            fwd = ShardedForward(lambda *a: gf.replay())
+            dist.barrier()
+            worst = 0.0
+            for _ in range(4):
+                t0 = time.perf_counter()
+                gathered = fwd()
+                worst = max(worst, time.perf_counter() - t0)
+        extra = {"worst_step_ms": worst * 1e3, "graph_mode": gf.mode}
+    else:
+        fwd = ShardedForward(lambda *a: model(*a).cpu())
+        with torch.no_grad():
+            gathered = fwd(*harness.call_args(mine, dev))
     torch.cuda.synchronize()
-    torch.save({"rank": rank, "lo": lo, "hi": hi, "logits": gathered.cpu()}, out_path)
+    torch.save(dict({"rank": rank, "lo": lo, "hi": hi, "logits": gathered.cpu()}, **extra), out_path)
     dist.barrier()
     dist.destroy_process_group()
     return 0

@@ -93,6 +93,33 @@ def test_child_ranks_gathered_logits_equal_the_single_process_logits(precision, 
     assert spread < (1e-6 if precision == "fp32" else 2e-3)
 
 
+def test_child_ranks_replaying_graphs_gather_device_logits(tmp_path):
+    """Two child ranks capture their slice as hipGraphs and gather the DEVICE logits of each replay over gloo, four steps back to
+    back without a host synchronisation (bench.py's timed loop).  The gathered logits equal this process's shard-by-shard
+    logits bit for bit, and no step takes long: this pattern read 20-230 ms per step until ShardedForward joined the device
+    in front of a gloo collective on device tensors (tools/dev/two_proc_gloo.py reproduces it without this library)."""
+    cfg_name, seed, B, world, precision = "tumemo_b64", 977, 16, 2, "bf16"
+    outs = _run_ranks(world, ["forward_graph", cfg_name, B, seed, precision], tmp_path)
+    cfg = synth.CONFIGS[cfg_name]
+    pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
+    A_obj, A_place = harness.synthetic_adjacencies(cfg)
+    inp = synth.make_inputs(cfg, B=B, seed=seed, pmi=pmi)
+    model = harness.build_model(cfg, pmi, count, A_obj, A_place, inp["label_query"], DEV)
+    model.set_precision(precision)
+    parts = []
+    with torch.no_grad():
+        for r in range(world):
+            lo, hi = shard_bounds(B, world, r)
+            sub = {k: (v[lo:hi] if k != "label_query" else v) for k, v in inp.items()}
+            parts.append(model(*harness.call_args(sub, DEV)).cpu())
+    by_shard = torch.cat(parts, 0)
+    got = [torch.load(o) for o in outs]
+    for g in got:
+        assert torch.equal(g["logits"], by_shard), float((g["logits"] - by_shard).abs().max())
+        print("rank %d: %s graph, slowest of four replay + gather steps %.2f ms" % (g["rank"], g["graph_mode"], g["worst_step_ms"]))
+        assert g["worst_step_ms"] < 15.0
+
+
 def test_stress_shard_plan_in_three_child_processes(tmp_path):
     """BASELINE configs[4] at n = 1 500, batch 48: three processes take plan_shards' blocks (whole channels, no collective); put
     together they are the one-rank result bit for bit."""
