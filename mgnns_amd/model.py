@@ -580,8 +580,9 @@ class Multi_GCN_Multihead_Att(nn.Module):
         key = str(device)      # probed against the stream that is current at FIRST use (never inside a graph capture)
         if self._streams is None or self._streams[0] != key:
             from .streams import independent_streams
-            chosen, distinct = independent_streams(device, 3)
-            self._streams = (key, {"s1": chosen[0], "s2": chosen[1], "s3": chosen[2]}, distinct)
+            n = max(int(k[1:]) for sch in self.SCHEDULES.values() for _, k in sch if k != "main")
+            chosen, distinct = independent_streams(device, n)
+            self._streams = (key, {"s%d" % (i + 1): c for i, c in enumerate(chosen)}, distinct)
         return self._streams[1]
 
     # data dependencies between the forward's segments (MODEL:444-567)
@@ -641,6 +642,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
         # chip-filling kernels in two chains, every small launch on a stream of its own:
         #   main: BiLSTM -> head;  s1: both image banks, then the two masked stacks;  s2: the two text->image stacks;
         #   s3: text GCN, label GCNs, label-attention tails
+        # (round 5: a six-stream schedule -- BiLSTM, text GCN, two label GCNs and two memory banks each at the head of a stream of
+        #  its own -- lost at every batch: 0.536 against 0.388 ms at B = 32 on the runtime's four hardware queues, where the extra
+        #  streams share a queue, and GPU_MAX_HW_QUEUES=8 slows EVERY schedule down, 0.54-0.72 ms at B = 32 and 0.93 at B = 256:
+        #  NOTES_r05 section 5)
         "bigsmall": [("text_gcn", "s3"), ("bank_obj", "s1"), ("text_bank", "main"), ("lgcn_obj", "s3"), ("bank_place", "s1"),
                      ("lgcn_place", "s3"), ("tio", "s2"), ("tail_obj", "s3"), ("tail_place", "s3"), ("tip", "s2"),
                      ("iot", "s1"), ("ipt", "s1"), ("head", "main")],

@@ -5,10 +5,10 @@
         Builds the product model (seeded weights), runs it EAGERLY on its contiguous slice of the seeded batch through
         mgnns_amd.sharded.ShardedForward (the product's sharding + the logits all-gather) and saves the gathered logits.
     python tests/sharded_worker.py forward_graph <out.pt> <config> <B> <seed> <precision>
-        The same slice captured as hipGraphs (mgnns_amd.graph.GraphedForward) and replayed four times, the DEVICE logits of every
+        The same slice captured as hipGraphs (mgnns_amd.graph.GraphedForward) and replayed eight times, the DEVICE logits of every
         replay gathered over gloo right behind it (no host synchronisation in the loop: the shape of bench.py's timed region, the
         pattern that degraded to 20-230 ms per step before ShardedForward joined the device in front of a gloo collective);
-        saves the last gathered logits and the slowest step.
+        saves the last gathered logits, the mean and the slowest step.
     python tests/sharded_worker.py stress <out.pt> <n> <batch>
         configs[4]: this rank's blocks of mgnns_amd.stress.StressWorkload(rank, world) (no data-path collective: plan_shards).
 """
@@ -54,13 +54,17 @@ def main():
         with torch.no_grad():
             gf = GraphedForward(model, harness.call_args(mine, dev))
             fwd = ShardedForward(lambda *a: gf.replay())
+            for _ in range(2):
+                fwd()                                              # (gloo's staging buffers, first-use costs: untimed)
             dist.barrier()
-            worst = 0.0
-            for _ in range(4):
+            worst, steps = 0.0, 8
+            t_all = time.perf_counter()
+            for _ in range(steps):
                 t0 = time.perf_counter()
                 gathered = fwd()
                 worst = max(worst, time.perf_counter() - t0)
-        extra = {"worst_step_ms": worst * 1e3, "graph_mode": gf.mode}
+            mean = (time.perf_counter() - t_all) / steps
+        extra = {"worst_step_ms": worst * 1e3, "mean_step_ms": mean * 1e3, "graph_mode": gf.mode}
     else:
         fwd = ShardedForward(lambda *a: model(*a).cpu())
         with torch.no_grad():

@@ -94,9 +94,9 @@ def test_child_ranks_gathered_logits_equal_the_single_process_logits(precision, 
 
 
 def test_child_ranks_replaying_graphs_gather_device_logits(tmp_path):
-    """Two child ranks capture their slice as hipGraphs and gather the DEVICE logits of each replay over gloo, four steps back to
+    """Two child ranks capture their slice as hipGraphs and gather the DEVICE logits of each replay over gloo, eight steps back to
     back without a host synchronisation (bench.py's timed loop).  The gathered logits equal this process's shard-by-shard
-    logits bit for bit, and no step takes long: this pattern read 20-230 ms per step until ShardedForward joined the device
+    logits bit for bit, and the steps stay short: this pattern read 20-230 ms per step until ShardedForward joined the device
     in front of a gloo collective on device tensors (tools/dev/two_proc_gloo.py reproduces it without this library)."""
     cfg_name, seed, B, world, precision = "tumemo_b64", 977, 16, 2, "bf16"
     outs = _run_ranks(world, ["forward_graph", cfg_name, B, seed, precision], tmp_path)
@@ -115,9 +115,10 @@ def test_child_ranks_replaying_graphs_gather_device_logits(tmp_path):
     by_shard = torch.cat(parts, 0)
     got = [torch.load(o) for o in outs]
     for g in got:
+        print("rank %d: %s graph, eight replay + gather steps: mean %.2f ms, slowest %.2f ms"
+              % (g["rank"], g["graph_mode"], g["mean_step_ms"], g["worst_step_ms"]))
         assert torch.equal(g["logits"], by_shard), float((g["logits"] - by_shard).abs().max())
-        print("rank %d: %s graph, slowest of four replay + gather steps %.2f ms" % (g["rank"], g["graph_mode"], g["worst_step_ms"]))
-        assert g["worst_step_ms"] < 15.0
+        assert g["mean_step_ms"] < 10.0          # (degraded: 20-230 ms in EVERY step; a single slow gloo step reads 5-20 ms)
 
 
 def test_stress_shard_plan_in_three_child_processes(tmp_path):
