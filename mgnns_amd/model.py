@@ -646,6 +646,15 @@ class Multi_GCN_Multihead_Att(nn.Module):
         #  its own -- lost at every batch: 0.536 against 0.388 ms at B = 32 on the runtime's four hardware queues, where the extra
         #  streams share a queue, and GPU_MAX_HW_QUEUES=8 slows EVERY schedule down, 0.54-0.72 ms at B = 32 and 0.93 at B = 256:
         #  NOTES_r05 section 5)
+        # small batches (round 5; default below 64 samples): the memory banks in FRONT of the two shorter heads -- object label
+        # GCN, text GCN -- instead of behind the label GCNs ('channels2': label GCN 75 / 105 us, THEN the bank 59 / 54 us, then the
+        # tail); the place label GCN (the longest head, C = 365) and the BiLSTM start at t = 0 on streams of their own; the
+        # text->object stack behind the BiLSTM, the object->text stack behind the object tail.  B = 32: 0.305-0.325 ms two in
+        # flight / 0.369-0.370 one at a time against 0.348-0.352 / 0.387-0.390 ('channels2', same box); B = 16: 0.310 / 0.361
+        # against 0.340 / 0.378; B = 48: 0.330 / 0.396 against 0.357 / 0.396; at B = 64 it loses (0.42 against 0.37)
+        "small": [("text_bank", "main"), ("lgcn_place", "s2"), ("bank_obj", "s1"), ("bank_place", "s3"), ("lgcn_obj", "s1"),
+                  ("text_gcn", "s3"), ("tail_place", "s2"), ("tail_obj", "s1"), ("tip", "s3"), ("tio", "main"), ("ipt", "s2"),
+                  ("iot", "s1"), ("head", "main")],
         "bigsmall": [("text_gcn", "s3"), ("bank_obj", "s1"), ("text_bank", "main"), ("lgcn_obj", "s3"), ("bank_place", "s1"),
                      ("lgcn_place", "s3"), ("tio", "s2"), ("tail_obj", "s3"), ("tail_place", "s3"), ("tip", "s2"),
                      ("iot", "s1"), ("ipt", "s1"), ("head", "main")],
@@ -658,10 +667,10 @@ class Multi_GCN_Multihead_Att(nn.Module):
         one box, B = 256): 0.647-0.654 against 0.665-0.673 ms with two forwards in flight, 0.690-0.703 against 0.717-0.721 one at a
         time; equal at B = 128 (0.502 / 0.503).  Below 128 the BiLSTM chain on the caller's stream is the longest segment and
         'channels2' (no text->image stack queued behind it) wins: 0.381 vs 0.390 / 0.394 ms at B = 32, 0.412 vs 0.413 / 0.424 at
-        B = 64 ('channels' / 'place_bank_first')."""
+        B = 64 ('channels' / 'place_bank_first').  Below 64 (round 5): 'small' -- the memory banks in front of the shorter heads."""
         name = schedule or self.schedule
         if name == 'auto':
-            name = 'place_bank_first' if batch >= 128 else 'channels2'
+            name = 'place_bank_first' if batch >= 128 else ('channels2' if batch >= 64 else 'small')
         if name not in self.SCHEDULES:
             raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
         return name

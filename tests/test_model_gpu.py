@@ -327,7 +327,7 @@ def test_every_schedule_gives_the_same_logits_eager_and_graphed():
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
     model.set_precision("bf16")
     a = call_args(synth.make_inputs(cfg, B=24, seed=4, pmi=pmi), DEV)
-    assert model.resolve_schedule(24) == "channels2" and model.resolve_schedule(256) == "place_bank_first"
+    assert model.resolve_schedule(24) == "small" and model.resolve_schedule(64) == "channels2" and model.resolve_schedule(256) == "place_bank_first"
     model.use_streams = False
     ref = model(*a).clone()
     model.use_streams = True
