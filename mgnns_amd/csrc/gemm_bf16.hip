@@ -642,6 +642,196 @@ __global__ __launch_bounds__(512) void gemm_bf16_fixup_256_kernel(const float* _
 
 }  // namespace
 
+// ---- 160 x 256 tiles (round 5) -----------------------------------------------------------------------------------------------
+// What the two kernels above leave on the table at 10 000 x 1024 x 10 000: the 256 x 128 kernel streams at what the L2s deliver
+// (9.3 TB/s) but its 320 tiles are 1.25 rounds of 256 workgroups (a K split of the last quarter round + a fix-up launch: 254-265 us);
+// the 256 x 256 kernel has a third less traffic but 160 tiles on 256 CUs and no room for producer waves.  A 160 x 256 tile: 63 row
+// blocks x 4 column tiles = 252 tiles = ONE round on 252 of the 256 CUs, nothing to split or fix up; (160 + 256) operand rows per
+// 40 960 MACs = 13 % less L2 -> LDS traffic per MAC than 256 x 128 (2.10 GB instead of 2.46); and its 80 x 64 wave tile needs 80
+// accumulator registers, which still leaves room for the third wave per SIMD, i.e. for the four producer waves that make the
+// 256 x 128 kernel reach the L2 rate.  32-wide K slices (26 KB: 10 + 16 DMA pieces of 16 rows x 64 B) through a FIVE-stage ring:
+// four slices = 104 KB in flight per CU (256 x 128: two of 48 KB).  Operand rows in LDS as in the 256 x 256 kernel (64 B, chunk c at
+// slot c ^ g[(row >> 2) & 3]).  Whole tiles only, round robin over the XCD's workgroups in the XCD-aware order of the kernels above.
+namespace {
+#ifndef MG_GEMM160_NST
+#define MG_GEMM160_NST 5                                             // stages of the slice ring (measured: 4: same, 3: 239 us against 226)
+#endif
+constexpr int TM4 = 160, TN4 = 256, BK4 = 32, NST4 = MG_GEMM160_NST;
+constexpr int A4_BYTES = TM4 * BK4 * 2, B4_BYTES = TN4 * BK4 * 2, STG4 = A4_BYTES + B4_BYTES;          // 10 KB + 16 KB
+constexpr int A4_PIECES = A4_BYTES / 1024, B4_PIECES = B4_BYTES / 1024;                                  // 10 + 16
+constexpr int PPP4 = (A4_PIECES + B4_PIECES + NPROD - 1) / NPROD;                                       // 7 requests per producer and slice (two of the 28 are dummies)
+constexpr size_t SMEM4_BYTES = (size_t)NST4 * STG4 + 1024;                                              // + the dummies' landing strip
+constexpr int NTHR4 = 768;
+
+__global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+                                                                 int M, int N, int Kp, const float* __restrict__ bias,
+                                                                 float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nk = Kp / BK4;                                       // 32-wide slices of a tile
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    const int nitem = jj0 < T ? (T - jj0 + W - 1) / W : 0;         // tiles jj0, jj0 + W, ...
+    if (nitem == 0) return;
+    const int S = nitem * nk;
+
+    if (wave >= 8) {
+        // ---- producer q: requests q, q + 4, .. q + 24 of every slice: request p < 10 = A piece p, p < 26 = Bt piece p - 10, else a
+        //      dummy (16 B of zeros per lane onto the landing strip: every producer issues the SAME number of requests per slice, which
+        //      is what lets it wait with a constant vmcnt).  A piece = 16 rows x 64 B; lane (row_in = lane >> 2, slot = lane & 3)
+        //      fetches the chunk that belongs in its slot.
+        const int q = wave - 8;
+        const int row_in = lane >> 2, slot = lane & 3;
+        const int chunk = slot ^ ((0xD2 >> (2 * ((row_in >> 2) & 3))) & 3);
+        const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g_zero16);
+        unsigned char* strip = smem + (size_t)NST4 * STG4;
+        int ig = 0, ikt = 0, ii = 0, im0, in0;
+        auto open = [&](int i) {
+            const int j = jj0 + i * W;
+            im0 = (rb0 + j / nct) * TM4;
+            in0 = (j % nct) * TN4;
+        };
+        open(0);
+        auto issue = [&]() {                                       // slice ig of the stream -> stage ig % NST4; then advance
+            unsigned char* sb = smem + (size_t)(ig % NST4) * STG4;
+            const bool live = ig < S;                              // past the end: dummies keep the request count fixed
+            const size_t koff = (size_t)ikt * BK4 + chunk * 8;
+#pragma unroll
+            for (int i = 0; i < PPP4; ++i) {
+                const int p = q + NPROD * i;                       // (wave-uniform)
+                const unsigned short* src = zsrc;
+                unsigned char* dst = strip;
+                if (live && p < A4_PIECES) {
+                    int row = im0 + p * 16 + row_in;
+                    row = row < M ? row : M - 1;                   // rows beyond M: any valid row (never stored)
+                    src = A + (size_t)row * Kp + koff;
+                    dst = sb + (size_t)p * 1024;
+                } else if (live && p < A4_PIECES + B4_PIECES) {
+                    int row = in0 + (p - A4_PIECES) * 16 + row_in;
+                    row = row < N ? row : N - 1;
+                    src = Bt + (size_t)row * Kp + koff;
+                    dst = sb + A4_BYTES + (size_t)(p - A4_PIECES) * 1024;
+                }
+#ifndef MG_GEMM160_AUX
+#define MG_GEMM160_AUX 0                                           // cache policy bits of the operand requests (measured: nt 359 us against 226, sc0 / sc1 no change)
+#endif
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, MG_GEMM160_AUX);
+            }
+            ++ig;
+            if (++ikt == nk && ig < S) {
+                ikt = 0;
+                open(++ii);
+            }
+        };
+        // bare s_waitcnt + s_barrier: __syncthreads() carries vmcnt(0) and would wait for the slices just requested
+#pragma unroll
+        for (int g = 0; g < NST4 - 1; ++g) issue();
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST4 - 2) * PPP4) : "memory");     // slice 0 landed
+        issue();
+        for (int g = 0; g < S; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST4 - 2) * PPP4) : "memory"); // slice g + 1 landed; the stage of slice g is free
+            issue();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may land after the workgroup's LDS is gone
+        return;
+    }
+
+    // ---- compute wave: tile rows wr * 80 .., columns wc * 64 .. (5 x 4 MFMA tiles), one k-step per slice
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    const unsigned swz = (unsigned)((fg ^ ((0xD2 >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
+    const unsigned aoff = lds0 + (unsigned)((wr * 80 + fr) * 64) + swz, boff = lds0 + A4_BYTES + (unsigned)((wc * 64 + fr) * 64) + swz;
+    u32x4 a[2][5], b[2][4];
+    auto reads = [&](int stage, int buf) {
+        const unsigned so = (unsigned)stage * STG4;
+        a[buf][0] = mg_lds_read128<0>(aoff + so);
+        a[buf][1] = mg_lds_read128<1024>(aoff + so);
+        a[buf][2] = mg_lds_read128<2048>(aoff + so);
+        a[buf][3] = mg_lds_read128<3072>(aoff + so);
+        a[buf][4] = mg_lds_read128<4096>(aoff + so);
+        b[buf][0] = mg_lds_read128<0>(boff + so);
+        b[buf][1] = mg_lds_read128<1024>(boff + so);
+        b[buf][2] = mg_lds_read128<2048>(boff + so);
+        b[buf][3] = mg_lds_read128<3072>(boff + so);
+    };
+    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns
+    auto mmas = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
+                                                                    __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
+    };
+    int ci = 0, ckt = 0;
+    asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
+    reads(0, 0);
+    // per slice: its fragments are in registers -> barrier (everybody is done with the slice's stage; the next slice landed) -> the
+    // next slice's reads go out -> this slice's 20 MFMAs run over them.  Two slices per trip: the fragment buffers are named, not indexed.
+    auto slice = [&](int g, int buf) {
+        mg_lds_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        if (g + 1 < S) reads((g + 1) % NST4, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++ckt < nk) return;
+        ckt = 0;
+        // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*80 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
+        const int j = jj0 + ci * W;
+        const int cm0 = (rb0 + j / nct) * TM4, cn0 = (j % nct) * TN4;
+        ++ci;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = cn0 + wc * 64 + jj * 16 + fg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int m = cm0 + wr * 80 + i * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+                acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && m < cm0 + TM4 && n < N) {
+                    if (c_bf16) {                                  // C is a bf16 matrix (ldc in elements): the operand of the next product
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                    } else {
+                        // every workgroup of the one round stores its 164 KB at the same time: past the L2 (222 against 225-228 us)
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n));
+                    }
+                }
+            }
+        }
+    };
+    for (int g = 0; g < S; g += 2) {
+        slice(g, 0);
+        if (g + 1 < S) slice(g + 1, 1);
+    }
+}
+
+}  // namespace
+
+static int g_gemm_form = -1;            // -1: MGNNS_GEMM_160 (default 2); 0 never the 160 x 256 kernel, 1 whenever the shape fits, 2 by the estimate
+extern "C" int mgnns_gemm_bf16_set_form(int form) {
+    MG_REQUIRE(form >= -1 && form <= 2, "mgnns_gemm_bf16_set_form: form=%d (-1 environment, 0 never 160 x 256, 1 whenever it fits, 2 by estimate)", form);
+    g_gemm_form = form;
+    return 0;
+}
+
 // internal launcher (also used by the bf16-mode LSTM input projections): m_dev != nullptr -> the row count is read on the
 // device and M is only its upper bound
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
@@ -653,6 +843,43 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     MG_REQUIRE(mg_aligned16(A) && mg_aligned16(Bt) && mg_aligned16(C) && (!bias || mg_aligned16(bias)),
                "mgnns_gemm_bf16_nt_fwd: operands must be 16-byte aligned");
     if (M == 0) return 0;
+    // 160 x 256 tiles (round 5) where they fill the chip's rounds better than the other two kernels' tiles do: the estimate is
+    // rounds of the busiest XCD x operand rows per tile-slice (all three stream at what the L2s deliver); MGNNS_GEMM_160 /
+    // mgnns_gemm_bf16_set_form: 0 never, 1 whenever the shape fits, 2 (default) by the estimate
+    if (const int want160 = m_dev ? 0 : (g_gemm_form >= 0 ? g_gemm_form : mg_env_int("MGNNS_GEMM_160", 2, 9))) {
+        const int n_cu4 = mg_cu_count();
+        if (n_cu4 <= 0) return MGNNS_ERR_LAUNCH;
+        const int per4 = n_cu4 / 8 > 0 ? n_cu4 / 8 : 1;
+        const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4;
+        bool take = nrb4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4;
+        if (take && want160 == 2) {
+            // a last round that is at most a quarter full is cut along K by the other kernels (+ ~1/16 round for the fix-up launch)
+            auto rounds = [&](int t, bool ksplit) {
+                const int full = t / per4, rem = t % per4;
+                return full + (rem == 0 ? 0.0 : (ksplit && 4 * rem <= per4 ? 0.25 + 0.0625 : 1.0));
+            };
+            const int nrb1 = (M + TM - 1) / TM, nct1 = (N + TN - 1) / TN, nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
+            const bool ws_ok = workspace && mg_aligned16(workspace);
+            double other = rounds(((nrb1 + 7) / 8) * nct1, ws_ok) * (TM + TN);
+            const bool elig256 = ws_ok && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256 && nrb2 / 8 * nct2 >= per4 && N >= TN2 && Kp / BK >= 64 &&
+                                 workspace_bytes >= (size_t)8 * per4 * TM2 * TN2 * sizeof(float);
+            if (elig256) {
+                const double c256 = rounds(((nrb2 + 7) / 8) * nct2, true) * (TM2 + TN2);
+                other = c256 < other ? c256 : other;
+            }
+            // (measured, 10 000 rows, cache-cold: N = 1024, K = 10 000: 216-220 us against 236-261; K = 2048: 58 against 91; K = 320: 22.0
+            //  against 25.6; N = 2048, K = 1024: 68 either way; N = 2048, K = 10 000 stays with the 256 x 256 kernel, 380 against 430)
+            take = rounds(((nrb4 + 7) / 8) * nct4, false) * (TM4 + TN4) * 1.02 < other;
+        }
+        if (take) {
+            MG_DYN_LDS(gemm_bf16_nt_160_kernel, SMEM4_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_160_kernel, dim3(8 * per4), dim3(NTHR4), SMEM4_BYTES, stream,
+                               reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
+                               ldc, act, nrb4, nct4, c_bf16);
+            MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(160)");
+            return 0;
+        }
+    }
     // at least 128 tiles of 256 x 256 (half a chip of workgroups) and the workspace for its pieces: the form with a third less
     // L2 -> LDS traffic (MGNNS_GEMM_TILE=128: the 256 x 128 kernel)
     if (!m_dev && workspace && mg_aligned16(workspace) && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256) {     // (=128: the 256 x 128 kernel only)

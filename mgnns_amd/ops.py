@@ -1441,6 +1441,12 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=Non
     return c
 
 
+def gemm_bf16_set_form(form):
+    """Tile shape of gemm_bf16_nt (tests / timings): -1 environment (MGNNS_GEMM_160, default by estimate), 0 never the 160 x 256
+    kernel, 1 whenever the shape fits it, 2 by the launcher's estimate."""
+    _lib.check(_lib.lib().mgnns_gemm_bf16_set_form(int(form)), "mgnns_gemm_bf16_set_form")
+
+
 def dense_adj_matmul_bf16(adj_bf16, support, act=ACT_NONE):
     """act(adj @ support) with the DENSE adjacency kept in bf16 ([C, Kp], from cast_pad_bf16(adj, ld=Kp)) and the fp32
     support [C, F] transposed + cast on the fly: the dense counterpart of spmm_csr for graphs that are not sparse."""

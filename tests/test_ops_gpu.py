@@ -1654,6 +1654,39 @@ def test_gemm_bf16_nt_last_round_k_split_equals_whole_tiles(M, N, K):
         ops.GEMM_BF16_KSPLIT = old
 
 
+@pytest.mark.parametrize("M,N,K", [(10000, 1024, 2048), (1280, 256, 320), (2600, 1000, 704), (5000, 516, 1100), (1281, 260, 4200)])
+def test_gemm_bf16_nt_160_tiles(M, N, K):
+    """csrc/gemm_bf16.hip::gemm_bf16_nt_160_kernel (round 5: 160 x 256 tiles, five-stage ring of 32-wide slices, whole tiles only)
+    forced on, against the other kernels with it off (fp32 sums in another order only) and against fp64 on sampled entries: one and
+    several tiles per workgroup, ragged M / N / K (clamped rows, a last row block of 1 row, N % 256 != 0, K padded to 64), bias +
+    activation + bf16 output, repeatable bits; and the launcher's estimate picks it for the adjacency product's shape."""
+    rs = np.random.RandomState(M + N + K)
+    kp = (K + 63) // 64 * 64
+    a32 = rs.standard_normal((M, K)).astype(np.float32) * 0.1
+    b32 = rs.standard_normal((N, K)).astype(np.float32) * 0.1
+    a = ops.cast_pad_bf16(dev(a32), ld=kp)
+    bt = ops.cast_pad_bf16(dev(b32), ld=kp)
+    bias = dev(rs.standard_normal(N).astype(np.float32))
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            ops.gemm_bf16_set_form(0)
+            ref = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            ops.gemm_bf16_set_form(1)
+            got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            got2 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            assert torch.equal(got, got2)
+            scale = float(ref.float().abs().max())
+            tol = 2e-6 if dt == torch.float32 else 8e-3          # (bf16 output: one ulp where a sum sits on a rounding boundary)
+            assert float((got.float() - ref.float()).abs().max()) <= tol * scale, (dt, M, N, K)
+        plain = ops.gemm_bf16_nt(a, bt)                           # no bias, no activation: fp64 on sampled rows
+        rows = rs.choice(M, size=min(M, 64), replace=False)
+        rows[0], rows[1] = M - 1, 0
+        want = _bf16_round(a32[rows]).double() @ _bf16_round(b32).double().t()
+        assert float((plain[torch.from_numpy(rows).to(DEV)].cpu().double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    finally:
+        ops.gemm_bf16_set_form(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 4096), (10000, 2048, 4200), (8300, 2312, 4100)])
 def test_gemm_bf16_nt_256_tiles(M, N, K):
     """Products with at least a full round of 256 x 256 tiles on every XCD and K >= 4096 run
