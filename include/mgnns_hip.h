@@ -539,7 +539,8 @@ size_t mgnns_gemm_bf16_workspace_bytes(void);
 int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
                            int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
 /* Which tile shape mgnns_gemm_bf16_nt_fwd runs (tests and A/B timings; production leaves it alone): -1 the environment
- * (MGNNS_GEMM_160, default 2), 0 never the 160 x 256 kernel, 1 whenever the shape fits it, 2 by the launcher's estimate. */
+ * (MGNNS_GEMM_160, default 2), 0 round 4's kernels only (256 x 128, 256 x 256), 1 the 160 x 256 kernel whenever the shape fits it,
+ * 2 by the launcher's estimate, 3 the 320 x 256 kernel whenever the shape fits it. */
 int mgnns_gemm_bf16_set_form(int form);
 
 /* ---- f4 (metrics half): the evaluation tail after the logits (ENGINE:828-838) -------------------------------------

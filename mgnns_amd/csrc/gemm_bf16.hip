@@ -825,9 +825,162 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
 
 }  // namespace
 
-static int g_gemm_form = -1;            // -1: MGNNS_GEMM_160 (default 2); 0 never the 160 x 256 kernel, 1 whenever the shape fits, 2 by the estimate
+// ---- 320 x 256 tiles, sixteen waves (round 5) -------------------------------------------------------------------------------
+// The F = 2048 adjacency product (10 000 x 2048 x 10 000) on 256 x 256 tiles is 320 tiles = 1.25 rounds (left-over tiles cut along K,
+// a fix-up launch) and 3.28 GB of L2 -> LDS traffic.  320 x 256 tiles: 32 row blocks x 8 column tiles = 256 tiles = ONE round, 2.95 GB.
+// 80 x 64 wave tiles (80 accumulators) x SIXTEEN waves = four per SIMD at <= 128 registers: no producer waves, but a wave issues
+// only 3 requests per 32-wide slice (waves 0..11; 36 pieces of 16 rows x 64 B) between its 20 MFMAs and three other waves of its
+// SIMD cover its waits -- the eight-wave 256 x 256 kernel loses ~850 of 1850 cycles per slice to the issue of its own requests.
+// Fragments are single buffered (read, wait, multiply: the other waves of the SIMD fill the pipe meanwhile).  Four-stage ring of
+// 36-KB slices; whole tiles round robin over the XCD's workgroups; operand rows in LDS as in the kernels above.
+namespace {
+constexpr int TM5 = 320, TN5 = 256, BK5 = 32, NST5 = 4;
+constexpr int A5_BYTES = TM5 * BK5 * 2, B5_BYTES = TN5 * BK5 * 2, STG5 = A5_BYTES + B5_BYTES;          // 20 KB + 16 KB
+constexpr int A5_PIECES = A5_BYTES / 1024, B5_PIECES = B5_BYTES / 1024;                                  // 20 + 16 = 36 = 12 waves x 3
+constexpr int REQW5 = 12, RPW5 = (A5_PIECES + B5_PIECES) / REQW5;
+static_assert(REQW5 * RPW5 == A5_PIECES + B5_PIECES, "every requesting wave issues the same number of pieces");
+constexpr size_t SMEM5_BYTES = (size_t)NST5 * STG5;
+constexpr int NTHR5 = 1024;
+
+__global__ __launch_bounds__(NTHR5) void gemm_bf16_nt_320_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+                                                                 int M, int N, int Kp, const float* __restrict__ bias,
+                                                                 float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nk = Kp / BK5;
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    const int nitem = jj0 < T ? (T - jj0 + W - 1) / W : 0;
+    if (nitem == 0) return;
+    const int S = nitem * nk;
+    // ---- requests (waves 0..11): piece p = wave + 12 i of a slice: p < 20 = A piece p, else Bt piece p - 20; lane (row_in = lane >> 2,
+    //      slot = lane & 3) fetches the chunk that belongs in its slot; rows beyond M / N read zeros (buffer bounds)
+    const bool requester = wave < REQW5;
+    const int row_in = lane >> 2, slot = lane & 3;
+    const int chunk = slot ^ ((0xD2 >> (2 * ((row_in >> 2) & 3))) & 3);
+    const unsigned voff = (unsigned)((row_in * Kp + chunk * 8) * 2);
+    int ii = 0, ik = 0;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    auto open_tile = [&](int i) {
+        const int j = jj0 + i * W;
+        const int m0 = (rb0 + j / nct) * TM5, n0 = (j % nct) * TN5;
+        const int mr = M - m0 < TM5 ? M - m0 : TM5, nr = N - n0 < TN5 ? N - n0 : TN5;
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A + (size_t)m0 * Kp), 0, mr * Kp * 2, 0x00027000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bt + (size_t)n0 * Kp), 0, nr * Kp * 2, 0x00027000);
+    };
+    open_tile(0);
+    auto issue_one = [&](int g, int i) {                           // request i (0..2) of slice g, k slice ik of the open tile
+        unsigned char* sb = smem + (size_t)(g & (NST5 - 1)) * STG5;
+        const int p = wave + REQW5 * i;                            // (wave-uniform)
+        if (p < A5_PIECES) {
+            const unsigned soff = (unsigned)((p * 16 * Kp + ik * BK5) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, voff, soff, 0, 0);
+        } else {
+            const unsigned soff = (unsigned)(((p - A5_PIECES) * 16 * Kp + ik * BK5) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + A5_BYTES + (size_t)(p - A5_PIECES) * 1024), 16, voff, soff, 0, 0);
+        }
+    };
+    auto issue_done = [&]() {
+        if (++ik == nk && ++ii < nitem) {
+            ik = 0;
+            open_tile(ii);
+        }
+    };
+    // ---- compute: wave tile rows wr * 80 .., columns wc * 64 .. (5 x 4 MFMA tiles)
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    const unsigned swz = (unsigned)((fg ^ ((0xD2 >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
+    const unsigned aoff = lds0 + (unsigned)((wr * 80 + fr) * 64) + swz, boff = lds0 + A5_BYTES + (unsigned)((wc * 64 + fr) * 64) + swz;
+    u32x4 a[5], b[4];
+    if (requester) {
+        for (int g = 0; g < NST5 - 1; ++g) {                       // (S >= 10: the launcher asks for it)
+#pragma unroll
+            for (int i = 0; i < RPW5; ++i) issue_one(g, i);
+            issue_done();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST5 - 2) * RPW5) : "memory");      // this wave's pieces of slice 0 landed
+    }
+    asm volatile("s_barrier" ::: "memory");                        // everybody's
+    int ci = 0, ck = 0;
+    for (int g = 0; g < S; ++g) {
+        const bool req = requester && g + NST5 - 1 < S;            // slice g + 3 -> the stage of slice g - 1: read by everybody before the last barrier
+        const unsigned so = (unsigned)(g & (NST5 - 1)) * STG5;
+        b[0] = mg_lds_read128<0>(boff + so);
+        b[1] = mg_lds_read128<1024>(boff + so);
+        b[2] = mg_lds_read128<2048>(boff + so);
+        b[3] = mg_lds_read128<3072>(boff + so);
+        a[0] = mg_lds_read128<0>(aoff + so);
+        a[1] = mg_lds_read128<1024>(aoff + so);
+        a[2] = mg_lds_read128<2048>(aoff + so);
+        a[3] = mg_lds_read128<3072>(aoff + so);
+        a[4] = mg_lds_read128<4096>(aoff + so);
+        mg_lds_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns; the wave's three
+        // requests of slice g + 3 ride behind the MFMAs of rows 0, 2 and 4
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[jj]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                    acc[i][jj], 0, 0, 0);
+            if (req && (i & 1) == 0) issue_one(g + NST5 - 1, i >> 1);
+        }
+        if (req) issue_done();
+        __builtin_amdgcn_sched_barrier(0);
+        // slice g + 1 landed (this wave's pieces: at most those of slices g + 2, g + 3 are younger); everybody is done with slice g
+        if (requester) {
+            if (req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RPW5) : "memory");
+            else if (g + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW5) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (++ck < nk) continue;
+        ck = 0;
+        // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*80 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
+        const int j = jj0 + ci * W;
+        const int cm0 = (rb0 + j / nct) * TM5, cn0 = (j % nct) * TN5;
+        ++ci;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = cn0 + wc * 64 + jj * 16 + fg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int m = cm0 + wr * 80 + i * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+                acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && n < N) {
+                    if (c_bf16) {                                  // C is a bf16 matrix (ldc in elements): the operand of the next product
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                    } else {
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n));
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+static int g_gemm_form = -1;            // -1: MGNNS_GEMM_160 (default 2); 0 round 4's kernels only, 1 / 3 the 160 x 256 / 320 x 256 kernel whenever the shape fits, 2 by the estimate
 extern "C" int mgnns_gemm_bf16_set_form(int form) {
-    MG_REQUIRE(form >= -1 && form <= 2, "mgnns_gemm_bf16_set_form: form=%d (-1 environment, 0 never 160 x 256, 1 whenever it fits, 2 by estimate)", form);
+    MG_REQUIRE(form >= -1 && form <= 3, "mgnns_gemm_bf16_set_form: form=%d (-1 environment, 0 round 4's kernels only, 1 160 x 256 whenever it fits, 2 by estimate, 3 320 x 256 whenever it fits)", form);
     g_gemm_form = form;
     return 0;
 }
@@ -843,40 +996,71 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     MG_REQUIRE(mg_aligned16(A) && mg_aligned16(Bt) && mg_aligned16(C) && (!bias || mg_aligned16(bias)),
                "mgnns_gemm_bf16_nt_fwd: operands must be 16-byte aligned");
     if (M == 0) return 0;
-    // 160 x 256 tiles (round 5) where they fill the chip's rounds better than the other two kernels' tiles do: the estimate is
-    // rounds of the busiest XCD x operand rows per tile-slice (all three stream at what the L2s deliver); MGNNS_GEMM_160 /
-    // mgnns_gemm_bf16_set_form: 0 never, 1 whenever the shape fits, 2 (default) by the estimate
-    if (const int want160 = m_dev ? 0 : (g_gemm_form >= 0 ? g_gemm_form : mg_env_int("MGNNS_GEMM_160", 2, 9))) {
+    // Round 5's tile shapes -- 160 x 256 with producer waves, 320 x 256 with sixteen waves -- where they fill the chip's rounds
+    // better than the other kernels' tiles do: the estimate is rounds of the busiest XCD x operand rows per tile-slice (all of them
+    // stream at about what the L2s deliver).  MGNNS_GEMM_160 / mgnns_gemm_bf16_set_form: 0 neither, 1 160 x 256 whenever the shape
+    // fits, 2 (default) by the estimate, 3 320 x 256 whenever the shape fits
+    if (const int want = m_dev ? 0 : (g_gemm_form >= 0 ? g_gemm_form : mg_env_int("MGNNS_GEMM_160", 2, 9))) {
         const int n_cu4 = mg_cu_count();
         if (n_cu4 <= 0) return MGNNS_ERR_LAUNCH;
         const int per4 = n_cu4 / 8 > 0 ? n_cu4 / 8 : 1;
-        const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4;
-        bool take = nrb4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4;
-        if (take && want160 == 2) {
-            // a last round that is at most a quarter full is cut along K by the other kernels (+ ~1/16 round for the fix-up launch)
+        const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4, nrb5 = (M + TM5 - 1) / TM5, nct5 = (N + TN5 - 1) / TN5;
+        const bool fits4 = nrb4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4, fits5 = nrb5 >= 8 && N >= TN5 && Kp / BK5 >= 10;
+        int pick = want == 1 && fits4 ? 4 : (want == 3 && fits5 ? 5 : 0);
+        if (want == 2 && (fits4 || fits5)) {
+            // cost of a form = rounds of the busiest XCD x (32-wide slices x operand rows per tile-slice + the tile's fixed cost in
+            // the same unit); ~1.7 ns per row-slice for every kernel (they stream at what the L2s deliver), fixed costs fitted at
+            // K = 320 (3.6 / 8.8 / 15 us per tile: pipeline fill + an epilogue that nothing overlaps).  A last round that is at most a
+            // quarter full is cut along K by round 4's kernels (+ ~1/16 round for the fix-up launch) if a part keeps >= 8 slices.
+            const int nk64 = Kp / BK;
             auto rounds = [&](int t, bool ksplit) {
                 const int full = t / per4, rem = t % per4;
-                return full + (rem == 0 ? 0.0 : (ksplit && 4 * rem <= per4 ? 0.25 + 0.0625 : 1.0));
+                if (rem == 0) return (double)full;
+                int f = per4 / rem > 8 ? 8 : per4 / rem;
+                return full + (ksplit && 4 * rem <= per4 && f * 8 <= nk64 ? 1.0 / f + 0.0625 : 1.0);
             };
+            auto cost = [&](double r, int rows, int fixed) { return r * ((double)(Kp / BK5) * rows + fixed); };
             const int nrb1 = (M + TM - 1) / TM, nct1 = (N + TN - 1) / TN, nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
             const bool ws_ok = workspace && mg_aligned16(workspace);
-            double other = rounds(((nrb1 + 7) / 8) * nct1, ws_ok) * (TM + TN);
+            double best = cost(rounds(((nrb1 + 7) / 8) * nct1, ws_ok), TM + TN, 2100);
             const bool elig256 = ws_ok && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256 && nrb2 / 8 * nct2 >= per4 && N >= TN2 && Kp / BK >= 64 &&
                                  workspace_bytes >= (size_t)8 * per4 * TM2 * TN2 * sizeof(float);
             if (elig256) {
-                const double c256 = rounds(((nrb2 + 7) / 8) * nct2, true) * (TM2 + TN2);
-                other = c256 < other ? c256 : other;
+                const double c256 = cost(rounds(((nrb2 + 7) / 8) * nct2, true), TM2 + TN2, 8000);
+                best = c256 < best ? c256 : best;
             }
-            // (measured, 10 000 rows, cache-cold: N = 1024, K = 10 000: 216-220 us against 236-261; K = 2048: 58 against 91; K = 320: 22.0
-            //  against 25.6; N = 2048, K = 1024: 68 either way; N = 2048, K = 10 000 stays with the 256 x 256 kernel, 380 against 430)
-            take = rounds(((nrb4 + 7) / 8) * nct4, false) * (TM4 + TN4) * 1.02 < other;
+            // measured, cache-cold, us (round 4's kernels / 160 x 256 / 320 x 256): 10 000 x 1024 x 10 000: 229-264 / 215-226 / 277;
+            // 10 000 x 2048 x 10 000: 380-412 / 426-430 / 320; 10 000 x 1024 x 2048: 89-92 / 56-57 / 66; 10 000 x 2048 x 1024: 65-70 /
+            // 62-64 / 53; 10 000 x 1024 x 320: 25.6 / 22.0 / -; 20 154 x 1200 x 320 (the LSTM's folded table): 40 / 47 / 51
+            if (fits4) {
+                const double c4 = cost(rounds(((nrb4 + 7) / 8) * nct4, false), TM4 + TN4, 5200) * 1.02;
+                if (c4 < best) {
+                    best = c4;
+                    pick = 4;
+                }
+            }
+            if (fits5) {
+                const double c5 = cost(rounds(((nrb5 + 7) / 8) * nct5, false), TM5 + TN5, 8800) * 1.02;
+                if (c5 < best) {
+                    best = c5;
+                    pick = 5;
+                }
+            }
         }
-        if (take) {
+        if (pick == 4) {
             MG_DYN_LDS(gemm_bf16_nt_160_kernel, SMEM4_BYTES);
             hipLaunchKernelGGL(gemm_bf16_nt_160_kernel, dim3(8 * per4), dim3(NTHR4), SMEM4_BYTES, stream,
                                reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
                                ldc, act, nrb4, nct4, c_bf16);
             MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(160)");
+            return 0;
+        }
+        if (pick == 5) {
+            MG_DYN_LDS(gemm_bf16_nt_320_kernel, SMEM5_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_320_kernel, dim3(8 * per4), dim3(NTHR5), SMEM5_BYTES, stream,
+                               reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
+                               ldc, act, nrb5, nct5, c_bf16);
+            MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(320)");
             return 0;
         }
     }

@@ -1442,8 +1442,8 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=Non
 
 
 def gemm_bf16_set_form(form):
-    """Tile shape of gemm_bf16_nt (tests / timings): -1 environment (MGNNS_GEMM_160, default by estimate), 0 never the 160 x 256
-    kernel, 1 whenever the shape fits it, 2 by the launcher's estimate."""
+    """Tile shape of gemm_bf16_nt (tests / timings): -1 environment (MGNNS_GEMM_160, default by estimate), 0 round 4's kernels only,
+    1 the 160 x 256 kernel whenever the shape fits it, 2 by the launcher's estimate, 3 the 320 x 256 kernel whenever it fits."""
     _lib.check(_lib.lib().mgnns_gemm_bf16_set_form(int(form)), "mgnns_gemm_bf16_set_form")
 
 

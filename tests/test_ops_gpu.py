@@ -1654,12 +1654,14 @@ def test_gemm_bf16_nt_last_round_k_split_equals_whole_tiles(M, N, K):
         ops.GEMM_BF16_KSPLIT = old
 
 
-@pytest.mark.parametrize("M,N,K", [(10000, 1024, 2048), (1280, 256, 320), (2600, 1000, 704), (5000, 516, 1100), (1281, 260, 4200)])
-def test_gemm_bf16_nt_160_tiles(M, N, K):
-    """csrc/gemm_bf16.hip::gemm_bf16_nt_160_kernel (round 5: 160 x 256 tiles, five-stage ring of 32-wide slices, whole tiles only)
-    forced on, against the other kernels with it off (fp32 sums in another order only) and against fp64 on sampled entries: one and
-    several tiles per workgroup, ragged M / N / K (clamped rows, a last row block of 1 row, N % 256 != 0, K padded to 64), bias +
-    activation + bf16 output, repeatable bits; and the launcher's estimate picks it for the adjacency product's shape."""
+@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("M,N,K", [(10000, 1024, 2048), (2560, 256, 320), (2600, 1000, 704), (5000, 516, 1100), (2561, 260, 4200)])
+def test_gemm_bf16_nt_160_and_320_tiles(M, N, K, form):
+    """csrc/gemm_bf16.hip::gemm_bf16_nt_160_kernel (round 5: 160 x 256 tiles, producer waves, five-stage ring of 32-wide slices) and
+    gemm_bf16_nt_320_kernel (320 x 256 tiles, sixteen waves, four-stage ring), whole tiles only, forced on (form 1 / 3), against round
+    4's kernels (fp32 sums in another order only) and against fp64 on sampled entries: one and several tiles per workgroup, ragged
+    M / N / K (rows beyond M clamped or read as zeros, a last row block of 1 row, N % 256 != 0, K padded to 64), bias + activation +
+    bf16 output, repeatable bits."""
     rs = np.random.RandomState(M + N + K)
     kp = (K + 63) // 64 * 64
     a32 = rs.standard_normal((M, K)).astype(np.float32) * 0.1
@@ -1671,7 +1673,7 @@ def test_gemm_bf16_nt_160_tiles(M, N, K):
         for dt in (torch.float32, torch.bfloat16):
             ops.gemm_bf16_set_form(0)
             ref = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
-            ops.gemm_bf16_set_form(1)
+            ops.gemm_bf16_set_form(form)
             got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
             got2 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
             assert torch.equal(got, got2)

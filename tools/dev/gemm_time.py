@@ -24,7 +24,7 @@ for n, F, kk in shapes:
         t[:, :kk] = torch.randn(t.shape[0], kk, device=dev, generator=g).bfloat16()
     out = torch.empty(n, F, device=dev)
     outs = {}
-    for form in (0, 1, 2, 0, 1):
+    for form in (0, 1, 3, 2, 0, 1, 3):
         ops.gemm_bf16_set_form(form)
         for i in range(3):
             ops.gemm_bf16_nt(adjs[i % sets], xts[i % sets], out=out)
@@ -42,11 +42,12 @@ for n, F, kk in shapes:
             torch.cuda.synchronize()
             ds.append(a.elapsed_time(b) / reps * 1e3)
         us = statistics.median(ds)
-        print("%d x %d x %d, 160 x 256 kernel %s: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (n, F, kk, ("off", "forced", "by estimate")[form], us, min(ds),
+        print("%d x %d x %d, %s: %.1f us (min %.1f)  %.1f %% of 2.5 PF" % (n, F, kk, ("round-4 kernels", "160 x 256", "by estimate", "320 x 256")[form], us, min(ds),
                                                                                            2.0 * n * kk * F / (us * 1e-6) / 2.5e15 * 100), flush=True)
     ops.gemm_bf16_set_form(-1)
-    d = float((outs[0] - outs[1]).abs().max())
-    print("   max |160 x 256 - other kernels| = %.3e of max |C| = %.3e" % (d, float(outs[0].abs().max())))
+    for f_ in (1, 3):
+        print("   max |%s - round-4 kernels| = %.3e of max |C| = %.3e" % (("", "160 x 256", "", "320 x 256")[f_], float((outs[0] - outs[f_]).abs().max()),
+                                                                       float(outs[0].abs().max())))
     if os.environ.get("MGNNS_GEMM_TRACE") == "1":
         import ctypes
         from mgnns_amd import _lib
