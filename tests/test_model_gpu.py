@@ -328,6 +328,9 @@ def test_every_schedule_gives_the_same_logits_eager_and_graphed():
     model.set_precision("bf16")
     a = call_args(synth.make_inputs(cfg, B=24, seed=4, pmi=pmi), DEV)
     assert model.resolve_schedule(24) == "small" and model.resolve_schedule(64) == "channels2" and model.resolve_schedule(256) == "place_bank_first"
+    model.set_precision("bf16x3")
+    assert model.resolve_schedule(256) == "channels2" and model.resolve_schedule(24) == "small"       # (bf16x3: 'channels2' from 64 samples)
+    model.set_precision("bf16")
     model.use_streams = False
     ref = model(*a).clone()
     model.use_streams = True
