@@ -629,6 +629,8 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "place_bank_first": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("bank_place", "s2"),
                              ("lgcn_place", "s2"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
                              ("iot", "s1"), ("ipt", "s2"), ("head", "main")],
+        # ('place_bank_first' with the object bank WAITING for the place bank -- the two HBM-bound kernels one after the other,
+        #  place first -- loses: 0.644-0.647 / 0.715-0.721 ms against 0.613-0.621 / 0.678-0.682, three alternating runs, round 5)
         # the same with the place label GCN on the text-GCN stream (idle until the place bank is done)
         "place_bank_first_lgcn_s3": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("bank_place", "s2"),
                                      ("lgcn_place", "s3"), ("tail_obj", "s1"), ("tail_place", "s2"), ("tio", "main"), ("tip", "s3"),
