@@ -672,10 +672,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
         B = 64 ('channels' / 'place_bank_first').  Below 64 (round 5): 'small' -- the memory banks in front of the shorter heads."""
         name = schedule or self.schedule
         if name == 'auto':
-            # 'bf16x3' (three times the matrix work in the chip-filling kernels, the fp32 recurrence): 'channels2' at every batch from
-            # 64 -- 1.499-1.505 ms against 1.534-1.537 two in flight, three alternating runs (NOTES_r05 section 1)
-            big = batch >= 128 and getattr(self, 'precision', 'fp32') != 'bf16x3'
-            name = 'place_bank_first' if big else ('channels2' if batch >= 64 else 'small')
+            # 'bf16x3' (three times the matrix work in the chip-filling kernels, the fp32 recurrence): 'channels2' at every batch --
+            # B = 256: 1.499-1.505 ms against 1.534-1.537 two in flight, three alternating runs; B = 128: 0.86 against 0.99; B = 32:
+            # 0.571 against 0.582-0.592 for 'small' (NOTES_r05 section 1)
+            if getattr(self, 'precision', 'fp32') == 'bf16x3':
+                name = 'channels2'
+            else:
+                name = 'place_bank_first' if batch >= 128 else ('channels2' if batch >= 64 else 'small')
         if name not in self.SCHEDULES:
             raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
         return name

@@ -329,7 +329,7 @@ def test_every_schedule_gives_the_same_logits_eager_and_graphed():
     a = call_args(synth.make_inputs(cfg, B=24, seed=4, pmi=pmi), DEV)
     assert model.resolve_schedule(24) == "small" and model.resolve_schedule(64) == "channels2" and model.resolve_schedule(256) == "place_bank_first"
     model.set_precision("bf16x3")
-    assert model.resolve_schedule(256) == "channels2" and model.resolve_schedule(24) == "small"       # (bf16x3: 'channels2' from 64 samples)
+    assert model.resolve_schedule(256) == "channels2" and model.resolve_schedule(24) == "channels2"   # (bf16x3: 'channels2' at every batch)
     model.set_precision("bf16")
     model.use_streams = False
     ref = model(*a).clone()
