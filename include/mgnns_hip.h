@@ -542,6 +542,10 @@ int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, 
  * (MGNNS_GEMM_160, default 2), 0 round 4's kernels only (256 x 128, 256 x 256), 1 the 160 x 256 kernel whenever the shape fits it,
  * 2 by the launcher's estimate, 3 the 320 x 256 kernel whenever the shape fits it. */
 int mgnns_gemm_bf16_set_form(int form);
+/* The launcher's choice for a product, by its estimate (host arithmetic, no device call; n_cu = compute units of the device, 256 on
+ * MI355X; with_workspace: the workspace of mgnns_gemm_bf16_workspace_bytes() is passed): 4 = 160 x 256 tiles, 5 = 320 x 256 tiles,
+ * 0 = round 4's kernels (256 x 128, or 256 x 256 for K >= 4096 with at least a full round of tiles per XCD); < 0 = bad arguments. */
+int mgnns_gemm_bf16_pick_form(int M, int N, int Kp, int with_workspace, int n_cu);
 
 /* ---- f4 (metrics half): the evaluation tail after the logits (ENGINE:828-838) -------------------------------------
  * probs = softmax(logits, dim=1) (max-subtracted), pred = first arg-max of probs; when target (int64 [B]) and

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c = ctypes
 _P = _c.c_void_p
@@ -75,6 +75,7 @@ SIGNATURES = {
     "mgnns_transpose_cast_bf16": [_P, _I, _I, _I, _P, _P],
     "mgnns_gemm_bf16_nt_fwd": [_P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _SZ, _P],
     "mgnns_gemm_bf16_set_form": [_I],
+    "mgnns_gemm_bf16_pick_form": [_I, _I, _I, _I, _I],
     "mgnns_softmax_argmax_fwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "mgnns_conv_fold_bn_bf16": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P],
     "mgnns_stem_conv7_fwd": [_P, _I, _I, _I, _P, _P, _P, _P],

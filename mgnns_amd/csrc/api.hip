@@ -102,7 +102,7 @@ int mg_env_int(const char* name, int fallback, int slot) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 16; }
+extern "C" int mgnns_abi_version(void) { return 17; }
 
 namespace {
 // which XCD (hardware XCC_ID) a workgroup runs on, per block index

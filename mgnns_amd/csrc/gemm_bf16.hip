@@ -978,6 +978,61 @@ __global__ __launch_bounds__(NTHR5) void gemm_bf16_nt_320_kernel(const unsigned 
 
 }  // namespace
 
+// Which round-5 tile shape a product takes: 4 = 160 x 256, 5 = 320 x 256, 0 = neither (round 4's kernels decide between themselves
+// below).  Pure host arithmetic (no device call): mgnns_gemm_bf16_pick_form exposes it to tests.
+//   want: 1 / 3 = the 160 x 256 / 320 x 256 kernel whenever the shape fits it, 2 = by the estimate, 0 = neither.
+static int mg_gemm_pick(int M, int N, int Kp, bool ws_ok, size_t workspace_bytes, int n_cu, int want, bool allow256) {
+    if (want == 0 || n_cu <= 0) return 0;
+    const int per4 = n_cu / 8 > 0 ? n_cu / 8 : 1;
+    const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4, nrb5 = (M + TM5 - 1) / TM5, nct5 = (N + TN5 - 1) / TN5;
+    const bool fits4 = nrb4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4, fits5 = nrb5 >= 8 && N >= TN5 && Kp / BK5 >= 10;
+    int pick = want == 1 && fits4 ? 4 : (want == 3 && fits5 ? 5 : 0);
+    if (want != 2 || !(fits4 || fits5)) return pick;
+    // cost of a form = rounds of the busiest XCD x (32-wide slices x operand rows per tile-slice + the tile's fixed cost in the same
+    // unit); ~1.7 ns per row-slice for every kernel (they stream at what the L2s deliver), fixed costs fitted at K = 320 (3.6 / 8.8 /
+    // 15 us per tile: pipeline fill + an epilogue that nothing overlaps).  A last round that is at most a quarter full is cut along K
+    // by round 4's kernels (+ ~1/16 round for the fix-up launch) if a part keeps >= 8 slices.
+    const int nk64 = Kp / BK;
+    auto rounds = [&](int t, bool ksplit) {
+        const int full = t / per4, rem = t % per4;
+        if (rem == 0) return (double)full;
+        const int f = per4 / rem > 8 ? 8 : per4 / rem;
+        return full + (ksplit && 4 * rem <= per4 && f * 8 <= nk64 ? 1.0 / f + 0.0625 : 1.0);
+    };
+    auto cost = [&](double r, int rows, int fixed) { return r * ((double)(Kp / BK5) * rows + fixed); };
+    const int nrb1 = (M + TM - 1) / TM, nct1 = (N + TN - 1) / TN, nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
+    double best = cost(rounds(((nrb1 + 7) / 8) * nct1, ws_ok), TM + TN, 2100);
+    const bool elig256 = ws_ok && allow256 && nrb2 / 8 * nct2 >= per4 && N >= TN2 && Kp / BK >= 64 &&
+                         workspace_bytes >= (size_t)8 * per4 * TM2 * TN2 * sizeof(float);
+    if (elig256) {
+        const double c256 = cost(rounds(((nrb2 + 7) / 8) * nct2, true), TM2 + TN2, 8000);
+        best = c256 < best ? c256 : best;
+    }
+    // measured, cache-cold, us (round 4's kernels / 160 x 256 / 320 x 256): 10 000 x 1024 x 10 000: 229-264 / 215-226 / 277;
+    // 10 000 x 2048 x 10 000: 380-412 / 426-430 / 320; 10 000 x 1024 x 2048: 89-92 / 56-57 / 66; 10 000 x 2048 x 1024: 65-70 /
+    // 62-64 / 53; 10 000 x 1024 x 320: 25.6 / 22.0 / -; 20 154 x 1200 x 320 (the LSTM's folded table): 40 / 47 / 51
+    if (fits4) {
+        const double c4 = cost(rounds(((nrb4 + 7) / 8) * nct4, false), TM4 + TN4, 5200) * 1.02;
+        if (c4 < best) {
+            best = c4;
+            pick = 4;
+        }
+    }
+    if (fits5) {
+        const double c5 = cost(rounds(((nrb5 + 7) / 8) * nct5, false), TM5 + TN5, 8800) * 1.02;
+        if (c5 < best) {
+            best = c5;
+            pick = 5;
+        }
+    }
+    return pick;
+}
+
+extern "C" int mgnns_gemm_bf16_pick_form(int M, int N, int Kp, int with_workspace, int n_cu) {
+    MG_REQUIRE(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && n_cu > 0, "mgnns_gemm_bf16_pick_form: M=%d N=%d Kp=%d n_cu=%d", M, N, Kp, n_cu);
+    return mg_gemm_pick(M, N, Kp, with_workspace != 0, with_workspace ? (size_t)256 * TM2 * TN2 * sizeof(float) : 0, n_cu, 2, true);
+}
+
 static int g_gemm_form = -1;            // -1: MGNNS_GEMM_160 (default 2); 0 round 4's kernels only, 1 / 3 the 160 x 256 / 320 x 256 kernel whenever the shape fits, 2 by the estimate
 extern "C" int mgnns_gemm_bf16_set_form(int form) {
     MG_REQUIRE(form >= -1 && form <= 3, "mgnns_gemm_bf16_set_form: form=%d (-1 environment, 0 round 4's kernels only, 1 160 x 256 whenever it fits, 2 by estimate, 3 320 x 256 whenever it fits)", form);
@@ -1005,48 +1060,8 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
         if (n_cu4 <= 0) return MGNNS_ERR_LAUNCH;
         const int per4 = n_cu4 / 8 > 0 ? n_cu4 / 8 : 1;
         const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4, nrb5 = (M + TM5 - 1) / TM5, nct5 = (N + TN5 - 1) / TN5;
-        const bool fits4 = nrb4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4, fits5 = nrb5 >= 8 && N >= TN5 && Kp / BK5 >= 10;
-        int pick = want == 1 && fits4 ? 4 : (want == 3 && fits5 ? 5 : 0);
-        if (want == 2 && (fits4 || fits5)) {
-            // cost of a form = rounds of the busiest XCD x (32-wide slices x operand rows per tile-slice + the tile's fixed cost in
-            // the same unit); ~1.7 ns per row-slice for every kernel (they stream at what the L2s deliver), fixed costs fitted at
-            // K = 320 (3.6 / 8.8 / 15 us per tile: pipeline fill + an epilogue that nothing overlaps).  A last round that is at most a
-            // quarter full is cut along K by round 4's kernels (+ ~1/16 round for the fix-up launch) if a part keeps >= 8 slices.
-            const int nk64 = Kp / BK;
-            auto rounds = [&](int t, bool ksplit) {
-                const int full = t / per4, rem = t % per4;
-                if (rem == 0) return (double)full;
-                int f = per4 / rem > 8 ? 8 : per4 / rem;
-                return full + (ksplit && 4 * rem <= per4 && f * 8 <= nk64 ? 1.0 / f + 0.0625 : 1.0);
-            };
-            auto cost = [&](double r, int rows, int fixed) { return r * ((double)(Kp / BK5) * rows + fixed); };
-            const int nrb1 = (M + TM - 1) / TM, nct1 = (N + TN - 1) / TN, nrb2 = (M + TM2 - 1) / TM2, nct2 = (N + TN2 - 1) / TN2;
-            const bool ws_ok = workspace && mg_aligned16(workspace);
-            double best = cost(rounds(((nrb1 + 7) / 8) * nct1, ws_ok), TM + TN, 2100);
-            const bool elig256 = ws_ok && mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256 && nrb2 / 8 * nct2 >= per4 && N >= TN2 && Kp / BK >= 64 &&
-                                 workspace_bytes >= (size_t)8 * per4 * TM2 * TN2 * sizeof(float);
-            if (elig256) {
-                const double c256 = cost(rounds(((nrb2 + 7) / 8) * nct2, true), TM2 + TN2, 8000);
-                best = c256 < best ? c256 : best;
-            }
-            // measured, cache-cold, us (round 4's kernels / 160 x 256 / 320 x 256): 10 000 x 1024 x 10 000: 229-264 / 215-226 / 277;
-            // 10 000 x 2048 x 10 000: 380-412 / 426-430 / 320; 10 000 x 1024 x 2048: 89-92 / 56-57 / 66; 10 000 x 2048 x 1024: 65-70 /
-            // 62-64 / 53; 10 000 x 1024 x 320: 25.6 / 22.0 / -; 20 154 x 1200 x 320 (the LSTM's folded table): 40 / 47 / 51
-            if (fits4) {
-                const double c4 = cost(rounds(((nrb4 + 7) / 8) * nct4, false), TM4 + TN4, 5200) * 1.02;
-                if (c4 < best) {
-                    best = c4;
-                    pick = 4;
-                }
-            }
-            if (fits5) {
-                const double c5 = cost(rounds(((nrb5 + 7) / 8) * nct5, false), TM5 + TN5, 8800) * 1.02;
-                if (c5 < best) {
-                    best = c5;
-                    pick = 5;
-                }
-            }
-        }
+        const int pick = mg_gemm_pick(M, N, Kp, workspace && mg_aligned16(workspace), workspace_bytes, n_cu4, want,
+                                      mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256);
         if (pick == 4) {
             MG_DYN_LDS(gemm_bf16_nt_160_kernel, SMEM4_BYTES);
             hipLaunchKernelGGL(gemm_bf16_nt_160_kernel, dim3(8 * per4), dim3(NTHR4), SMEM4_BYTES, stream,

@@ -125,3 +125,20 @@ def test_every_schedule_is_a_valid_plan_without_a_gpu():
         assert plan[-1][0] == "head" and plan[-1][1] == "main", name
     with pytest.raises(ValueError):
         m.forward_plan(*args, schedule="no-such-schedule")
+
+
+def test_dense_gemm_tile_shape_is_chosen_by_host_arithmetic():
+    """csrc/gemm_bf16.hip::mg_gemm_pick through mgnns_gemm_bf16_pick_form (no device call): the tile shape of the configs[4] products
+    on a 256-CU device.  4 = 160 x 256 tiles (one round of 252 tiles for 10 000 x 1024), 5 = 320 x 256 (one round of 256 tiles for
+    10 000 x 2048), 0 = round 4's kernels; the choices are the ones tools/dev/gemm_time.py measured as fastest (NOTES_r05 section 9)."""
+    L = _lib.lib()
+    pick = lambda M, N, Kp, ws=1, cu=256: L.mgnns_gemm_bf16_pick_form(M, N, Kp, ws, cu)
+    assert pick(10000, 1024, 10048) == 4 and pick(10000, 1024, 10048, ws=0) == 4      # adjacency product, F = 1024
+    assert pick(10000, 2048, 10048) == 5                                              # adjacency product, F = 2048
+    assert pick(10000, 1024, 2048) == 4 and pick(10000, 2048, 1024) == 5              # X . W products
+    assert pick(10000, 1024, 320) == 4
+    assert pick(20154, 1200, 320) == 0            # the BiLSTM's folded table: short K, the 256 x 128 kernel's small fixed cost wins
+    assert pick(512, 10000, 2048) == 0            # the read-out: fewer row blocks than XCDs (the column-split map of the 256 x 128 kernel)
+    assert pick(8192, 2048, 4096) == 0 and pick(8192, 2048, 4096, ws=0) == 5          # exactly one round of 256 x 256 tiles, if its workspace is there
+    assert pick(64, 256, 64) == 0
+    assert pick(0, 256, 64) < 0 and pick(256, 256, 100) < 0                           # bad arguments are refused
