@@ -107,6 +107,9 @@ def test_every_schedule_is_a_valid_plan_without_a_gpu():
     t = {k: torch.from_numpy(v) for k, v in inp.items()}
     args = (t["text"], t["text_lens"], t["text_mask"], t["object_feature"], t["place_feature"], t["object_inp"], t["place_inp"])
     assert m.schedule == "auto" and m.resolve_schedule(2) == "small" and m.resolve_schedule(64) == "channels2" and m.resolve_schedule(128) == "place_bank_first"
+    m.precision = "bf16x3"                                            # (the mode's own default: 'channels2' at every batch, NOTES_r05 section 1)
+    assert m.resolve_schedule(2) == m.resolve_schedule(64) == m.resolve_schedule(256) == "channels2"
+    m.precision = "fp32"
     for name, sched in m.SCHEDULES.items():
         plan, ctx = m.forward_plan(*args, schedule=name)
         assert ctx == {}                                              # nothing ran
