@@ -657,6 +657,13 @@ class Multi_GCN_Multihead_Att(nn.Module):
         "small": [("text_bank", "main"), ("lgcn_place", "s2"), ("bank_obj", "s1"), ("bank_place", "s3"), ("lgcn_obj", "s1"),
                   ("text_gcn", "s3"), ("tail_place", "s2"), ("tail_obj", "s1"), ("tip", "s3"), ("tio", "main"), ("ipt", "s2"),
                   ("iot", "s1"), ("head", "main")],
+        # mid-size batches (found by tools/dev/sched_search.py from 'channels2' at B = 64; NOT the default): both memory banks behind
+        # the object label GCN on ONE stream, the place label GCN (the longest head) alone on its own.  Throughput for latency: B = 64:
+        # 0.348-0.352 ms two in flight / 0.456-0.457 one at a time against 0.369-0.370 / 0.418-0.419 ('channels2'); B = 96: 0.402-0.404 /
+        # 0.486-0.492 against 0.425-0.439 / 0.470; B = 48: 0.310-0.317 / 0.453-0.455 against 0.326 / 0.397-0.405 ('small'); B = 128: loses
+        "mid": [("text_bank", "main"), ("text_gcn", "s3"), ("lgcn_obj", "s1"), ("bank_obj", "s1"), ("lgcn_place", "s2"),
+                ("bank_place", "s1"), ("tio", "s1"), ("tail_place", "s2"), ("tail_obj", "s3"), ("iot", "main"), ("tip", "s3"),
+                ("ipt", "s2"), ("head", "main")],
         "bigsmall": [("text_gcn", "s3"), ("bank_obj", "s1"), ("text_bank", "main"), ("lgcn_obj", "s3"), ("bank_place", "s1"),
                      ("lgcn_place", "s3"), ("tio", "s2"), ("tail_obj", "s3"), ("tail_place", "s3"), ("tip", "s2"),
                      ("iot", "s1"), ("ipt", "s1"), ("head", "main")],
