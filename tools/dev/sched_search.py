@@ -2,7 +2,9 @@
 """Local search over segment -> stream schedules of the forward (model.SCHEDULES), scored by the headline measurement: two captures
 replayed round robin without a join (GraphedPipeline), ms per forward, median of three regions.
 
-    python tools/dev/sched_search.py [evaluations] [batch] [start schedule] [seed] [precision] [attention]
+    python tools/dev/sched_search.py [evaluations] [batch] [start schedule] [seed] [precision] [attention] [pipe|serial]
+
+(serial: one forward at a time -- one capture, every replay joins the four streams before the next starts -- instead of two in flight)
 
 Moves: a segment to another stream, or one position earlier / later in the enqueue order (per-stream order follows the list).
 A candidate that forward_plan rejects (a segment in front of what it depends on) is skipped.  The incumbent is re-measured every
@@ -27,6 +29,7 @@ start = sys.argv[3] if len(sys.argv) > 3 else "place_bank_first"
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"
 attention = sys.argv[6] if len(sys.argv) > 6 else "faithful"
+objective = sys.argv[7] if len(sys.argv) > 7 else "pipe"
 
 dev = torch.device("cuda:0")
 cfg = synth.CONFIGS["mvsa_multiple_b256"]
@@ -53,20 +56,24 @@ def measure(sched, steps=20, regions=3):
     model.SCHEDULES["_cand"] = sched
     model.schedule = "_cand"
     with torch.no_grad():
-        pipe = GraphedPipeline.of([GraphedForward(model, call, mode="segments") for _ in range(2)])
+        if objective == "serial":
+            gf = GraphedForward(model, call, mode="segments")
+            run, end = gf.replay, (lambda: None)
+        else:
+            pipe = GraphedPipeline.of([GraphedForward(model, call, mode="segments") for _ in range(2)])
+            run, end = pipe.replay, pipe.wait
         for _ in range(6):
-            pipe.replay()
-        pipe.wait()
+            run()
+        end()
         torch.cuda.synchronize()
         ds = []
         for _ in range(regions):
             t0 = time.perf_counter()
             for _ in range(steps):
-                pipe.replay()
-            pipe.wait()
+                run()
+            end()
             torch.cuda.synchronize()
             ds.append((time.perf_counter() - t0) / steps * 1e3)
-    del pipe
     return statistics.median(ds)
 
 
