@@ -14,7 +14,7 @@
 #include "mha_tail_body.hpp"      // (defines bf16x8)
 
 #ifndef MG_MHA_ABLATE
-#define MG_MHA_ABLATE 0      // measurement builds only (tools/dev/build_variant.py): 1 = no weight-fragment reloads, 2 = no bank-fragment reloads
+#define MG_MHA_ABLATE 0      // measurement builds only (tools/dev/build_variant.py): 1 = no weight-fragment reloads, 2 = no bank-fragment reloads, 4 = the bank is not staged at all, 8 = a 12-tile class (L <= 192)
 #endif
 #ifdef MG_MHA_TRACE
 // profiling aid (off by default): s_memtime stamps of wave 0 / wave 4 of two workgroups at every phase boundary
@@ -482,13 +482,18 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
     const int n_mt = (lvalid + 15) >> 4;
     // tile-count class the branch-free GEMM body is instantiated for (dead rows inside the class are computed on
     // zero / masked data and get probability 0)
+#if MG_MHA_ABLATE & 8
+    const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : n_mt <= 12 ? 12 : MT;      // (measurement: what the 13th row tile costs)
+#else
     const int n_sel = n_mt <= 1 ? 1 : n_mt <= 2 ? 2 : n_mt <= 4 ? 4 : n_mt <= 7 ? 7 : MT;
+#endif
     const int rows_live = n_sel * 16;
 
     // ---- stage X (bf16) once by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, every piece in flight at
     //      once).  A DMA instruction fills 1 KiB of CONTIGUOUS LDS (M0 base + lane*16) from per-lane addresses, so
     //      the padded [row][42-chunk] image is walked linearly: lanes that fall on the 2 pad chunks of a row are
     //      switched off, rows >= L read a zero chunk (the zero padding at the end of bank row 0).
+#if !(MG_MHA_ABLATE & 4)
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int total = rows_live * LSTR;
@@ -503,6 +508,7 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
             }
         }
     }
+#endif
     {                                   // this sample's query row -> LDS (visible after the staging barrier in mha_body)
         float* s_q = reinterpret_cast<float*>(smem + OFF_Q);
         for (int i = tid * 4; i < H * DK; i += NTHR * 4)
@@ -514,6 +520,9 @@ __device__ __forceinline__ void mha_core_part(unsigned char* smem, const float* 
         case 2: mha_body<2, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
         case 4: mha_body<4, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
         case 7: mha_body<7, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+#if MG_MHA_ABLATE & 8
+        case 12: mha_body<12, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
+#endif
         default: mha_body<MT, COH>(smem, B, L, H, Wp, bv, temp, o, attn, lvalid); break;
     }
 }

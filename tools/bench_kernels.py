@@ -47,6 +47,7 @@ def timeit(fn, n=20, warm=5):
 
 
 def mha(kind, B=256, L=196, H=8, masked=False):
+    L = int(os.environ.get("MGNNS_BENCH_L", L)) if not masked else L          # (L = 192 with the 12-tile ablation build: the 13th tile's cost)
     g = torch.Generator(device=DEV).manual_seed(0)
     bank = torch.randn(B, L, 300, device=DEV, generator=g)
     qh = torch.randn(B, H * 128, device=DEV, generator=g)
