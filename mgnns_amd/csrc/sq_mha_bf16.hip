@@ -37,7 +37,10 @@ constexpr int KSTEPS = KP / 32;
 constexpr int CH = KP / 8;              // 40 16-byte chunks per row
 constexpr int LSTR = 42;                // LDS row stride in chunks (672 B)
 constexpr int DK = 128;
-constexpr int NTHR = 512;
+#ifndef MG_MHA_NTHR
+#define MG_MHA_NTHR 512          // (measurement: 768 = three waves per SIMD at <= 168 registers)
+#endif
+constexpr int NTHR = MG_MHA_NTHR;
 constexpr int QMAX = 2048;              // floats of the projected query kept in LDS (H * 128 <= QMAX)
 
 __device__ __forceinline__ unsigned short f2bf(float x) {      // round-to-nearest-even
