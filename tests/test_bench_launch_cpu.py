@@ -118,3 +118,55 @@ def test_stress_config_shards_channels_then_batch(n):
     assert len(seen) == 3 * 512
     assert line["value"] == pytest.approx(3 * 512 / (line["ms_per_step"] * 1e-3), rel=1e-3)
     assert line["ms_per_step"] == pytest.approx(max(line["dt_ranks"]) / 3 * 1e3, abs=1e-3)
+
+
+# ---- the result line stays small enough for the driver to parse (round 5's 21.7 KB line was not) ----
+def _full_line():
+    """A synthetic full result object: round 5's committed line (every detail leg present, 21.7 KB)."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_bf16.json")) as f:
+        return json.load(f)
+
+
+def test_compact_line_is_small_strict_json_and_keeps_the_contract():
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _full_line()
+    assert len(json.dumps(full)) > 20000
+    compact, detail = bench.compact_line(full)
+    text = json.dumps(compact, allow_nan=False)                 # strict: no NaN / Infinity tokens
+    assert len(text) <= bench.LINE_TARGET_BYTES < bench.LINE_LIMIT_BYTES <= 8000
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "max_abs_logit_diff_vs_cpu_oracle"):
+        assert k in back, k
+    assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert back["roofline"][k] == full["roofline"][k]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"]
+    assert back["config"]["workload"] and "model" not in back["config"]
+    for k in ("roofline_all", "variants", "small_batch", "stress", "text_pipeline", "trunks", "timing"):
+        assert k not in back and k in detail                    # moved, not lost
+    assert all(len(v) <= bench.STR_LIMIT for v in back["config"].values() if isinstance(v, str))
+    assert back["value_bf16x3_faithful"] == full["value_bf16x3_faithful"]
+    digest = json.dumps(bench.summary_of(full), allow_nan=False)
+    assert len(digest) + len(text) < bench.LINE_LIMIT_BYTES
+
+
+def test_emit_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "DETAIL_FILE", str(tmp_path / "bench_detail.json"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(_full_line())
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert [ln.startswith("{") for ln in lines] == [False] * (len(lines) - 1) + [True]
+    assert lines[0].startswith("bench_detail ") and lines[-2].startswith("bench_summary ")
+    last = json.loads(lines[-1])
+    assert len(lines[-1]) < 8000 and last["roofline"] and last["cpu_baseline"]
+    with open(tmp_path / "bench_detail.json") as f:
+        assert json.load(f)["roofline_all"] == json.loads(lines[0][len("bench_detail "):])["roofline_all"]
+    huge = dict(_full_line())
+    huge["config"] = dict(huge["config"], **{"workload": "x" * 100000})
+    bench.emit(huge)                                            # over-long strings are cut, not fatal
+    assert len(capsys.readouterr().out.splitlines()[-1]) < 8000
