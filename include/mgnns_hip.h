@@ -45,6 +45,7 @@ typedef struct mgnns_comm_s* mgnns_comm_t;      /* an RCCL communicator (one per
  * NULL unregisters.  Without a registered word the waits are still bounded, only the report is lost. */
 #define MGNNS_STATUS_LABEL_GCN_TIMEOUT 1
 #define MGNNS_STATUS_CLUSTER_TIMEOUT   2
+#define MGNNS_STATUS_BAD_PLAN          3      /* a masked attention launch was handed a plan of another kind / batch: it did nothing */
 int mgnns_set_status_word(int32_t* host_pinned);
 int mgnns_take_status(void);
 

@@ -189,7 +189,8 @@ def take_status():
     synchronise; the next persistent launch reports a raised word on its own."""
     code = lib().mgnns_take_status()
     if code:
-        raise RuntimeError("a persistent launch gave up a bounded wait (status %d): results since then are invalid" % code)
+        raise RuntimeError("a launch raised the library status word (status %d: 1 / 2 = a persistent launch gave up a bounded wait, "
+                           "3 = a masked attention launch refused its plan): results since then are invalid" % code)
 
 
 def check(rc, name):

@@ -50,7 +50,9 @@ int mg_check_status(const char* who) {
                     "from them since are invalid; the device is fine, re-run the forward",
                     who, (int)code,
                     code == MGNNS_STATUS_LABEL_GCN_TIMEOUT ? "label GCN item queue"
-                    : code == MGNNS_STATUS_CLUSTER_TIMEOUT ? "workgroup-cluster exchange" : "unknown");
+                    : code == MGNNS_STATUS_CLUSTER_TIMEOUT ? "workgroup-cluster exchange"
+                    : code == MGNNS_STATUS_BAD_PLAN      ? "a masked attention launch refused a plan of another kind or batch (it wrote nothing)"
+                                                         : "unknown");
     return MGNNS_ERR_LAUNCH;
 }
 

@@ -723,7 +723,13 @@ __global__ __launch_bounds__(NTHR) void sq_mha32_packed_kernel(const float* __re
                                                                const float* __restrict__ mask, const int* __restrict__ plan,
                                                                int B, int L, int H, const unsigned short* __restrict__ Wp,
                                                                const float* __restrict__ bv, float temp, float* __restrict__ o,
-                                                               float* __restrict__ attn) {
+                                                               float* __restrict__ attn, int* __restrict__ status) {
+    // a plan of the other kind (the grouped split-bf16 core's has the same size) or of another batch: nothing is trusted, nothing
+    // is written, the library's status word says so (uniform over the launch: every workgroup leaves here)
+    if (plan[2] != mg_plan::kind_word(8, PR, PS) || plan[1] != B) {
+        if (threadIdx.x == 0 && status) __hip_atomic_store(status, MGNNS_STATUS_BAD_PLAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_mb = reinterpret_cast<float*>(smem + P_OFF_MB);
     int* s_src = reinterpret_cast<int*>(smem + P_OFF_SRC);
@@ -736,7 +742,10 @@ __global__ __launch_bounds__(NTHR) void sq_mha32_packed_kernel(const float* __re
     const int hl = H - h0 < PHL ? H - h0 : PHL;
     const uint4* xb = reinterpret_cast<const uint4*>(bank);
     for (int g = blockIdx.x; g < ng; g += gridDim.x) {
-        const int first = plan[PLAN_HDR + 4 * g], cnt = plan[PLAN_HDR + 4 * g + 1], rows = plan[PLAN_HDR + 4 * g + 2];
+        const int first = plan[PLAN_HDR + 4 * g];
+        int cnt = plan[PLAN_HDR + 4 * g + 1], rows = plan[PLAN_HDR + 4 * g + 2];
+        cnt = cnt > PS ? PS : cnt;                       // (what the LDS maps hold, whatever the plan says)
+        rows = rows > PR ? PR : rows;
         __syncthreads();                                 // the previous group's LDS is free
         if (tid < 8) s_int[tid] = 0;                     // tickets, arrival counts
         if (tid < PS) {
@@ -840,7 +849,7 @@ extern "C" int mgnns_sq_mha32_core_bf16_fwd(const float* qh, const void* bank_bf
         if (gx > n_cu) gx = n_cu;
         hipLaunchKernelGGL(sq_mha32_packed_kernel, dim3(gx, pairs), dim3(NTHR), P_SMEM_BYTES, (hipStream_t)stream, qh,
                            reinterpret_cast<const unsigned short*>(bank_bf16), mask, plan, B, L, H,
-                           reinterpret_cast<const unsigned short*>(Wp), bv, temp, o, attn);
+                           reinterpret_cast<const unsigned short*>(Wp), bv, temp, o, attn, mg_status_word());
         MG_CHECK_LAUNCH("mgnns_sq_mha32_core_bf16_fwd (packed)");
         return 0;
     }

@@ -12,8 +12,12 @@ constexpr int PS = 16;                  // samples a group holds
 constexpr int PLAN_HDR = 4;
 constexpr int MAX_B = 4096;             // one workgroup scans the batch
 __host__ __device__ constexpr size_t lds_bytes(int B) { return ((size_t)8 * B + 4) * sizeof(int); }
+// plan[2]: the KIND of the plan (its ALIGN / ROWS / SAMP).  The two forms have the same size for a batch, so the size cannot tell
+// them apart: every consumer compares this word (and plan[1] with its B) before it trusts a group's extents, and raises
+// MGNNS_STATUS_BAD_PLAN instead of running on a plan of the other kind.
+__host__ __device__ constexpr int kind_word(int align, int rows, int samp) { return align | (rows << 8) | (samp << 20); }
 
-// plan = int32 [PLAN_HDR + 4 B + 2 B]: [0] number of groups, [1] B; group g at PLAN_HDR + 4 g: first sample, samples, rows;
+// plan = int32 [PLAN_HDR + 4 B + 2 B]: [0] number of groups, [1] B, [2] kind_word(ALIGN, ROWS, SAMP), [3] 0; group g at PLAN_HDR + 4 g: first sample, samples, rows;
 // sample b at PLAN_HDR + 4 B + 2 b: first row inside its group, live rows (last unmasked position + 1).
 // Greedy first fit in batch order (a group closes at 16 samples or when the next sample's 8-aligned rows would pass 128),
 // computed without a serial pass over the samples: every sample finds where a group STARTING at it would end (<= 16 steps,
@@ -91,7 +95,8 @@ __device__ __forceinline__ void build(const float* __restrict__ mask, int B, int
         *s_ng = g;
         plan[0] = g;
         plan[1] = B;
-        plan[2] = plan[3] = 0;
+        plan[2] = kind_word(ALIGN, ROWS, SAMP);
+        plan[3] = 0;
     }
     __syncthreads();
     const int ng = *s_ng;

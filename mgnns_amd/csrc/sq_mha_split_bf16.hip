@@ -640,7 +640,9 @@ __device__ __forceinline__ void group_body(const GCtx& c) {
             for (int i = 0; i < (NMT + 3) / 4 * 4; ++i) {
                 float a = 0.f, cc = 0.f;
                 if (i < NMT) {
-                    const float* qv = s_q + (ts[i] * GHL + n) * DK + dbase;
+                    // (a tile of the class behind the group's rows has no sample, ts = -1: it reads sample 0's query -- its rows
+                    //  are zero chunks and its mask bias -inf, so any FINITE query gives e = 0; -1 would index in front of s_q)
+                    const float* qv = s_q + ((ts[i] < 0 ? 0 : ts[i]) * GHL + n) * DK + dbase;
                     const f32x4 qd0 = *reinterpret_cast<const f32x4*>(qv), qd1 = *reinterpret_cast<const f32x4*>(qv + 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -753,7 +755,13 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const f
                                                                          const float* __restrict__ mask, int B, int L, int H,
                                                                          const unsigned short* __restrict__ Wp, int lo_off,
                                                                          const float* __restrict__ bv, float temp, float* __restrict__ o,
-                                                                         const int* __restrict__ plan) {
+                                                                         const int* __restrict__ plan, int* __restrict__ status) {
+    // a plan of the other kind (the packed bf16 kernel's: same size, up to 16 samples / 128 rows per group) or of another batch would
+    // index past the 48-int maps below: nothing is trusted, nothing is written, the library's status word says so
+    if (plan[2] != mg_plan::kind_word(16, LH, GS) || plan[1] != B) {
+        if (threadIdx.x == 0 && status) __hip_atomic_store(status, MGNNS_STATUS_BAD_PLAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_int = reinterpret_cast<int*>(smem + G_OFF_INT);
     float* s_mb = reinterpret_cast<float*>(smem + G_OFF_MB);
@@ -762,7 +770,10 @@ __global__ __launch_bounds__(NTHR) void sq_mha_core_split_grouped_kernel(const f
     const int ng = plan[0];
     const int h0 = (int)blockIdx.y * GHL, nheads = H - h0 < GHL ? H - h0 : GHL;
     for (int g = blockIdx.x; g < ng; g += gridDim.x) {
-        const int b0 = plan[mg_plan::PLAN_HDR + 4 * g], ns = plan[mg_plan::PLAN_HDR + 4 * g + 1], rows = plan[mg_plan::PLAN_HDR + 4 * g + 2];
+        const int b0 = plan[mg_plan::PLAN_HDR + 4 * g];
+        int ns = plan[mg_plan::PLAN_HDR + 4 * g + 1], rows = plan[mg_plan::PLAN_HDR + 4 * g + 2];
+        ns = ns > GS ? GS : ns;                          // (what the maps below hold, whatever the plan says)
+        rows = rows > LH ? LH : rows;
         const int nt = rows >> 4;
         // ---- the group's tile maps, counters (s_int: [0..3] tickets, [4..5] kdone, [6..7] smdone, [8] flush mask, [16..23] sample of
         //      a tile, [24..31] first tile of that sample, [32..38] first row of a sample, [40..46] its live rows)
@@ -905,7 +916,7 @@ extern "C" int mgnns_sq_mha_core_split_fwd(const float* qh, const void* bank_hi,
         const int lo_g = (int)(mgnns_sq_mha_split_packed_weight_bytes(H) / 2);
         hipLaunchKernelGGL(sq_mha_core_split_grouped_kernel, dim3(gx, (H + GHL - 1) / GHL), dim3(NTHR), G_SMEM_BYTES, (hipStream_t)stream, qh,
                            reinterpret_cast<const unsigned short*>(bank_hi), reinterpret_cast<const unsigned short*>(bank_lo), mask, B, L,
-                           H, reinterpret_cast<const unsigned short*>(Wp), lo_g, bv, temp_g, o, plan);
+                           H, reinterpret_cast<const unsigned short*>(Wp), lo_g, bv, temp_g, o, plan, mg_status_word());
         MG_CHECK_LAUNCH("mgnns_sq_mha_core_split_fwd(grouped)");
         return 0;
     }

@@ -376,7 +376,8 @@ extern "C" int mgnns_textgcn_fwd(const int64_t* tok, int B, int T, const float* 
     // its launch sat in front of the long documents' in the stream.  MGNNS_TEXTGCN_LEAN=0 or a shape it does not take (D % 4,
     // alignment, a band beyond 12 KB): the two-launch form
     const size_t lds_lean = ((size_t)Cs * Dp + (size_t)Tm * W) * sizeof(float) + (3 * (size_t)Tm + 4) * sizeof(int);
-    const bool lean_ok = Cs >= 1 && vec && D % 4 == 0 && lds_lean <= 12 * 1024;
+    // (the lean kernel addresses node rows with 32-bit buffer offsets: tables of 2 GiB and more take the 64-bit forms)
+    const bool lean_ok = Cs >= 1 && vec && D % 4 == 0 && lds_lean <= 12 * 1024 && (size_t)V * D * 4 < ((size_t)1 << 31);
     const bool lean = form == 3 ? lean_ok : (form == 0 && B >= 64 && lean_ok && mg_env_int("MGNNS_TEXTGCN_LEAN", 1, 8) != 0);
 #define TG_ARGS(Tn_, C_, mode_, lds_) tok, B, T, Tm, node_hidden, V, D, edge_w, n_edge_w, pmi_row_ptr, pmi_col, pmi_eid, ngram, out, vec, C_, Tn_, mode_, TG_SHORT_CAP, lds_, st
 #define TG_LAUNCH(GT_)                                                                                     \

@@ -727,6 +727,12 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # the packing plan of the mask for both image->text stacks (MODEL:509-527) rides on the BiLSTM's prep launch: one more
             # workgroup there instead of a launch per channel (round 4) on the stacks' critical paths
             ctx['text_bank'] = self._text_bank(text, text_lens, ctx['text_mask'] if (PLAN_IN_PREP and plan_kind == 'packed') else None)
+            # bf16x3 + faithful: BOTH masked stacks read the bank's split-bf16 (hi + lo) images and run on different streams --
+            # the images are made HERE, in the segment both wait for (made lazily inside the first stack, the other stack's
+            # core had no event ordering it behind the conversion launch: a stale read under graph replay)
+            if any(m.slf_attn._split_core() for st in (self.img_object_text_multi_head_att, self.img_place_text_multi_head_att)
+                   for m in st):
+                ctx['text_bank'].split
             prep_plan = getattr(ctx['text_bank'], 'mask_plan', None)
             if prep_plan is not None:
                 ctx['mha_plan'] = prep_plan

@@ -1050,6 +1050,9 @@ def sq_mha_core_bf16(qh, bank_bf16, mask, n_head, d_kv, wp, bk, bv, want_attn=Tr
             if mask is None or L_ > PLAN_MAX_L or plan.numel() != L.mgnns_sq_mha32_plan_ints(B):
                 raise ValueError("a packing plan needs a mask, L <= %d and exactly %d ints (a plan built for this batch size)"
                                  % (PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
+            if getattr(plan, "_mg_plan_kind", 'packed') != 'packed':       # (the grouped split-bf16 core's plan has the same size)
+                raise ValueError("sq_mha_core_bf16 takes the plan sq_mha_plan(mask) / bilstm(plan_mask=...) returned (got kind %r)"
+                                 % plan._mg_plan_kind)
         _launch("mgnns_sq_mha_core_bf16_fwd", ("mgnns_sq_mha_core_bf16_fwd", L_, mask is not None),
                 L.mgnns_sq_mha32_core_bf16_fwd, _p(qh), _p(bank_bf16), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk),
                 _p(bv), _p(o), _p(attn), _p(plan), _stream())
@@ -1127,6 +1130,12 @@ def sq_mha_core_split(qh, bank_split, mask, n_head, d_kv, wp, bk, bv, want_attn=
         if mask is None or L_ > SPLIT_PLAN_MAX_L or want_attn or plan.numel() != L.mgnns_sq_mha32_plan_ints(B):
             raise ValueError("a group plan needs a mask, L <= %d, want_attn=False and exactly %d ints (a plan built for this batch)"
                              % (SPLIT_PLAN_MAX_L, L.mgnns_sq_mha32_plan_ints(B)))
+        # the packed bf16 kernel's plan has the SAME size (up to 16 samples / 128 rows per group: past this kernel's LDS maps); only
+        # the tensor sq_mha_split_plan returned is taken (a view / clone loses the tag -- the kernel checks the plan's own header word
+        # too and raises the library's status word instead of running)
+        if getattr(plan, "_mg_plan_kind", None) != 'grouped':
+            raise ValueError("sq_mha_core_split takes the plan sq_mha_split_plan(mask) returned (got kind %r)"
+                             % getattr(plan, "_mg_plan_kind", None))
     _launch("mgnns_sq_mha_core_split_fwd", ("mgnns_sq_mha_core_split_fwd", L_, mask is not None), L.mgnns_sq_mha_core_split_fwd,
             _p(qh), _p(bank_split[0]), _p(bank_split[1]), _p(mask), B, L_, ld, n_head, d_kv, _p(wp), _p(bk), _p(bv), _p(o),
             _p(attn), _p(plan), _stream())

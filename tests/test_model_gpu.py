@@ -224,7 +224,9 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
     a1 = call_args(synth.make_inputs(cfg, B=16, seed=1, pmi=pmi), DEV)
     a2 = call_args(synth.make_inputs(cfg, B=16, seed=2, pmi=pmi), DEV)
-    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded")):
+    # (bf16x3 + faithful: both masked stacks read the text bank's hi + lo images on different streams -- made in the segment
+    #  both wait for; alternating batches through one capture is what a stale read would fail)
+    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded"), ("bf16x3", "faithful")):
         model.set_precision(prec).set_attention(att)
         model.use_streams = False
         ref1, ref2 = model(*a1).clone(), model(*a2).clone()
@@ -234,6 +236,8 @@ def test_graph_replay_and_streams_equal_eager_single_stream():
         assert torch.equal(gf.replay(), ref1)
         assert torch.equal(gf(*a2), ref2)          # copy-in + replay on new inputs
         assert torch.equal(gf(*a1), ref1)
+        for _ in range(3):                         # alternating batches: a stage reading the previous batch's buffers shows here
+            assert torch.equal(gf(*a2), ref2) and torch.equal(gf(*a1), ref1)
 
 
 def test_load_state_dict_under_a_live_graph_with_the_lstm_table_fold():
@@ -294,7 +298,7 @@ def test_pipelined_replays_two_forwards_in_flight_equal_serial_ones():
     pmi, count = synth.synth_pmi(cfg.V, seed=91)
     model = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], lq, DEV)
     sets = [call_args(synth.make_inputs(cfg, B=16, seed=s, pmi=pmi), DEV) for s in (1, 2, 3, 4, 5)]
-    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded")):
+    for prec, att in (("fp32", "faithful"), ("bf16", "faithful"), ("bf16", "folded"), ("bf16x3", "faithful")):
         # (folded: the layer tails' partial sums are added in rank order by whichever workgroup arrives last -- the same bits)
         model.set_precision(prec).set_attention(att)
         refs = [model(*a).clone() for a in sets]

@@ -893,6 +893,55 @@ def test_sq_mha_core_split_grouped_plan_equals_one_workgroup_per_sample(Hn, B, L
         assert torch.isnan(o3[2]).all() and H.maxabs(o3[keep].cpu(), o1[keep].cpu()) < 5e-6
 
 
+def test_a_plan_of_the_other_kind_is_refused_by_the_wrapper_and_by_the_kernel():
+    """The packed bf16 kernel's plan (8-row alignment, up to 16 samples / 128 rows per group) and the grouped split-bf16 core's
+    (16 / 7 / 112) have the SAME size for a batch: the wrappers take only the tensor their own plan builder returned, and a plan
+    that reaches a kernel anyway (tag forged here) is recognised by its header word -- the launch writes nothing and raises the
+    library's status word instead of indexing past its LDS maps."""
+    from mgnns_amd import _lib
+    rs = np.random.RandomState(5)
+    Hn, B, L = 8, 64, 100
+    wk, wv = (dev((0.06 * rs.standard_normal((Hn * 128, 300))).astype(np.float32)) for _ in range(2))
+    bk, bv = (dev((0.05 * rs.standard_normal(Hn * 128)).astype(np.float32)) for _ in range(2))
+    qh = dev(rs.standard_normal((B, Hn * 128)).astype(np.float32))
+    bank32 = dev(rs.standard_normal((B, L, 300)).astype(np.float32))
+    m = np.zeros((B, L), np.float32)
+    for b in range(B):
+        m[b, :1 + (b * 7) % 9] = 1                     # short samples: the packed plan puts 16 of them into a group
+    mask = dev(m)
+    packed, grouped = ops.sq_mha_plan(mask), ops.sq_mha_split_plan(mask)
+    assert packed.numel() == grouped.numel() and int(packed[2]) != int(grouped[2]) and int(packed[1]) == int(grouped[1]) == B
+    assert max(g[1] for g in _decode_plan(packed, B)[0]) > 7
+    sp, wps = ops.split_pad_bf16(bank32), ops.pack_kv_weights_split(wk, wv, Hn, 128)
+    bb, wp32 = ops.cast_pad_bf16(bank32), ops.pack_kv_weights_bf16(wk, wv, Hn, 128, form=32)
+    with pytest.raises(ValueError, match="sq_mha_split_plan"):
+        ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wps, bk, bv, want_attn=False, plan=packed)
+    with pytest.raises(ValueError, match="sq_mha_split_plan"):
+        ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wps, bk, bv, want_attn=False, plan=grouped.clone())     # (the tag does not survive)
+    with pytest.raises(ValueError, match="sq_mha_plan"):
+        ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp32, bk, bv, want_attn=False, plan=grouped)
+    torch.cuda.synchronize()
+    _lib.take_status()
+    forged = packed.clone()
+    forged._mg_plan_kind = 'grouped'
+    ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wps, bk, bv, want_attn=False, plan=forged)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="status 3"):
+        _lib.take_status()
+    forged = grouped.clone()
+    forged._mg_plan_kind = 'packed'
+    ops.sq_mha_core_bf16(qh, bb, mask, Hn, 128, wp32, bk, bv, want_attn=False, plan=forged)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="status 3"):
+        _lib.take_status()
+    # and the real plans still run
+    o, _ = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wps, bk, bv, want_attn=False, plan=grouped)
+    o1, _ = ops.sq_mha_core_split(qh, sp, mask, Hn, 128, wps, bk, bv, want_attn=False)
+    torch.cuda.synchronize()
+    _lib.take_status()
+    assert H.maxabs(o.cpu(), o1.cpu()) < 5e-6
+
+
 def _decode_plan(plan, B):
     pl = plan.cpu().numpy()
     ng = int(pl[0])
