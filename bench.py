@@ -271,6 +271,8 @@ def summary_of(line):
             elif "ms_per_3_channel_forward" in r:
                 d[k] = [r["ms_per_3_channel_forward"], r.get("ms_gcn_of_one_channel"),
                         r.get("ms_per_3_channel_forward_graphs_on_3_streams")]
+                if "max_abs_diff_vs_reference_order_over_output_scale" in r:
+                    d[k].append(r["max_abs_diff_vs_reference_order_over_output_scale"])
         out["stress"] = d if d else st
     tp = line.get("text_pipeline")
     if isinstance(tp, dict):

@@ -121,6 +121,15 @@ class _PlanCtx(dict):
         pass
 
 
+def default_schedule(batch, precision='fp32'):
+    """What schedule 'auto' resolves to (Multi_GCN_Multihead_Att.resolve_schedule): chosen from alternating-run A/Bs (NOTES_r04 / r05),
+    pinned by tests/test_surface_cpu.py so that a default cannot change silently.  'bf16x3': 'channels2' at every batch; otherwise
+    'place_bank_first' from 128 samples, 'channels2' from 64, 'small' below."""
+    if precision == 'bf16x3':
+        return 'channels2'
+    return 'place_bank_first' if batch >= 128 else ('channels2' if batch >= 64 else 'small')
+
+
 class Multi_GCN_Multihead_Att(nn.Module):
     def __init__(self, opt, num_labels, text_model, object_model, place_model,
                  object_num_classes, place_num_classes, object_t=0, place_t=0, in_channel=300,
@@ -682,10 +691,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # 'bf16x3' (three times the matrix work in the chip-filling kernels, the fp32 recurrence): 'channels2' at every batch --
             # B = 256: 1.499-1.505 ms against 1.534-1.537 two in flight, three alternating runs; B = 128: 0.86 against 0.99; B = 32:
             # 0.571 against 0.582-0.592 for 'small' (NOTES_r05 section 1)
-            if getattr(self, 'precision', 'fp32') == 'bf16x3':
-                name = 'channels2'
-            else:
-                name = 'place_bank_first' if batch >= 128 else ('channels2' if batch >= 64 else 'small')
+            name = default_schedule(batch, getattr(self, 'precision', 'fp32'))
         if name not in self.SCHEDULES:
             raise ValueError("unknown schedule %r (one of %s, or 'auto')" % (name, sorted(self.SCHEDULES)))
         return name

@@ -100,6 +100,34 @@ def _sets_for(bytes_per_set):
 
 N_CHANNELS = 3
 
+_marks = None                      # launch_times(): [(label, event)] recorded behind every launch of a channel forward
+
+
+def _mark(label):
+    if _marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _marks.append((label, ev))
+
+
+class launch_times:
+    """with launch_times() as t: wl.forward()  ->  t.ms = [(label, ms)]: every launch of the eager forward between HIP events on the
+    current stream (the time from the previous launch's end to this one's end: its duration back to back)."""
+
+    def __enter__(self):
+        global _marks
+        _marks = []
+        _mark("start")
+        self.ms = []
+        return self
+
+    def __exit__(self, *exc):
+        global _marks
+        marks, _marks = _marks, None
+        torch.cuda.synchronize()
+        self.ms = [(marks[i][0], round(marks[i - 1][1].elapsed_time(marks[i][1]), 4)) for i in range(1, len(marks))]
+        return False
+
 
 class StressChannel:
     """One label-graph channel at stress size.  forward(pooled) -> read-out [B, N] like MODEL:461-474.
@@ -108,11 +136,21 @@ class StressChannel:
     the K-contiguous bf16 operand of the next one (no cast / transpose pass in between):
       sparse   S1 = X.W1 -> X1 = lrelu(adj @ S1) -> S2 = X1.W2 -> G = adj @ S2 -> pooled.G^T       (GEMM, SpMM, GEMM, SpMM, GEMM)
       dense    S1^T = W1^T.X^T -> X1 = lrelu(adj . S1) -> S2^T = W2^T.X1^T -> G = adj . S2 -> pooled.G^T   (five GEMMs)
-    dtype "f32": fp32 features on the exact-f32 MFMA + the fp32 CSR SpMM (the arithmetic of the model's own label GCN)."""
+    dtype "f32": fp32 features on the exact-f32 MFMA + the fp32 CSR SpMM (the arithmetic of the model's own label GCN).
 
-    def __init__(self, n=N_NODES, density=DENSITIES[0], dense=False, seed=0, dev="cuda:0", dtype="bf16"):
+    order "reference" (default): every layer as the reference's GraphConvolution does, support = X.W first, then adj . support
+    (MODEL:52-58) -- the products above.  order "reassociated" (bf16 only; a reported VARIANT, never the default): the same layer as
+    (adj . X) . W -- the adjacency product runs on the layer's INPUT width (300 -> 320, 1024) instead of its output width (1024,
+    2048): 3.2 x / 2 x fewer adjacency FLOPs (dense) or gathered bytes (sparse) per layer; algebraically equal, rounded differently
+    (the intermediate that is stored as bf16 is adj.X instead of X.W):
+      dense    AX = adj . X -> X1^T = lrelu(W1^T . AX^T) -> AX1 = adj . X1 -> G = AX1 . W2 -> pooled.G^T          (five GEMMs)
+      sparse   AX = adj @ X -> X1 = lrelu(AX . W1) -> AX1 = adj @ X1 -> G = AX1 . W2 -> pooled.G^T               (SpMM, GEMM, SpMM, GEMM, GEMM)"""
+
+    def __init__(self, n=N_NODES, density=DENSITIES[0], dense=False, seed=0, dev="cuda:0", dtype="bf16", order="reference"):
+        if order not in ("reference", "reassociated") or (order == "reassociated" and dtype != "bf16"):
+            raise ValueError("order must be 'reference' or (bf16 only) 'reassociated'")
         g = torch.Generator(device=dev).manual_seed(seed)
-        self.n, self.dense, self.dtype = n, dense, dtype
+        self.n, self.dense, self.dtype, self.order = n, dense, dtype, order
         self.X = torch.randn(n, 300, device=dev, generator=g) * 0.45
         self.W1 = torch.randn(300, 1024, device=dev, generator=g) * 0.05
         self.W2 = torch.randn(1024, 2048, device=dev, generator=g) * 0.05
@@ -130,22 +168,54 @@ class StressChannel:
             self.W2t = ops.transpose_cast_bf16(self.W2)                   # [2048, 1024]
             if dense:
                 self.S1t = torch.zeros(1024, self.kp, device=dev, dtype=torch.bfloat16)    # K padding stays zero
-                self.S2t = torch.zeros(2048, self.kp, device=dev, dtype=torch.bfloat16)
+                if order == "reassociated":
+                    self.Xt = torch.zeros(320, self.kp, device=dev, dtype=torch.bfloat16)  # X^T, K-contiguous (rows 300.. and the K padding zero)
+                    self.Xt[:300, :n] = self.Xb[:, :300].t()
+                else:
+                    self.S2t = torch.zeros(2048, self.kp, device=dev, dtype=torch.bfloat16)
             else:
                 self.sadj = ops.SparseAdjBf16(self.csr)
 
     def gcn(self):
         bf = torch.bfloat16
+        if self.dtype == "bf16" and self.order == "reassociated":
+            if self.dense:
+                ax = ops.gemm_bf16_nt(self.adj_bf16, self.Xt, out_dtype=bf)                      # adj . X            [n, 320]
+                _mark("adj.X")
+                ops.gemm_bf16_nt(self.W1t, ax, None, ops.ACT_LRELU2, out=self.S1t[:, :self.n])   # X1^T = lrelu(W1^T . AX^T)
+                _mark("(adj.X).W1")
+                ax1 = ops.gemm_bf16_nt(self.adj_bf16, self.S1t, out_dtype=bf)                    # adj . X1           [n, 1024]
+                _mark("adj.X1")
+            else:
+                ax = ops.spmm_bf16(self.sadj, self.Xb)
+                _mark("adj@X")
+                x1 = ops.gemm_bf16_nt(ax, self.W1t, None, ops.ACT_LRELU2, out_dtype=bf)
+                _mark("(adj@X).W1")
+                ax1 = ops.spmm_bf16(self.sadj, x1)
+                _mark("adj@X1")
+            G = ops.gemm_bf16_nt(ax1, self.W2t, out_dtype=bf)                                    # G [n, 2048] bf16
+            _mark("(adj.X1).W2")
+            return G
         if self.dtype == "bf16" and self.dense:
             ops.gemm_bf16_nt(self.W1t, self.Xb, out=self.S1t[:, :self.n])
+            _mark("X.W1")
             x1 = ops.gemm_bf16_nt(self.adj_bf16, self.S1t, None, ops.ACT_LRELU2, out_dtype=bf)
+            _mark("adj.S1")
             ops.gemm_bf16_nt(self.W2t, x1, out=self.S2t[:, :self.n])
-            return ops.gemm_bf16_nt(self.adj_bf16, self.S2t, out_dtype=bf)                       # G [n, 2048] bf16
+            _mark("X1.W2")
+            G = ops.gemm_bf16_nt(self.adj_bf16, self.S2t, out_dtype=bf)                          # G [n, 2048] bf16
+            _mark("adj.S2")
+            return G
         if self.dtype == "bf16":
             s1 = ops.gemm_bf16_nt(self.Xb, self.W1t, out_dtype=bf)
+            _mark("X.W1")
             x1 = ops.spmm_bf16(self.sadj, s1, act=ops.ACT_LRELU2)
+            _mark("adj@S1")
             s2 = ops.gemm_bf16_nt(x1, self.W2t, out_dtype=bf)
-            return ops.spmm_bf16(self.sadj, s2)
+            _mark("X1.W2")
+            G = ops.spmm_bf16(self.sadj, s2)
+            _mark("adj@S2")
+            return G
         prop = (lambda sup, act: ops.dense_adj_matmul_bf16(self.adj_bf16, sup, act=act)) if self.dense else \
                (lambda sup, act: ops.spmm_csr(self.csr, sup, act=act))
         x = prop(ops.matmul(self.X, self.W1), ops.ACT_LRELU2)
@@ -156,7 +226,9 @@ class StressChannel:
         G = self.gcn()
         if self.dtype == "bf16":
             pb = pooled if pooled.dtype == torch.bfloat16 else ops.cast_pad_bf16(pooled, ld=2048)
-            return ops.gemm_bf16_nt(pb, G)
+            out = ops.gemm_bf16_nt(pb, G)
+            _mark("read-out")
+            return out
         return ops.linear(pooled, G)
 
 
@@ -185,13 +257,13 @@ class StressWorkload:
     """The whole of configs[4] as one rank sees it: its share of the 3 channels x batch 512 (plan_shards)."""
 
     def __init__(self, rank=0, world=1, n=N_NODES, batch=BATCH, density=DENSITIES[0], dense=False, dev="cuda:0", dtype="bf16",
-                 n_channels=N_CHANNELS):
+                 n_channels=N_CHANNELS, order="reference"):
         self.shards = plan_shards(world, n_channels, batch)[rank]
         g = torch.Generator(device=dev).manual_seed(1234)
         self.channels, self.pooled = {}, {}
         for c, b0, b1 in self.shards:
             if c not in self.channels:
-                self.channels[c] = StressChannel(n=n, density=density, dense=dense, seed=10 * c, dev=dev, dtype=dtype)
+                self.channels[c] = StressChannel(n=n, density=density, dense=dense, seed=10 * c, dev=dev, dtype=dtype, order=order)
                 full = torch.relu(torch.randn(batch, 2048, device=dev, generator=torch.Generator(device=dev).manual_seed(77 + c)))
                 self.pooled[c] = ops.cast_pad_bf16(full, ld=2048) if dtype == "bf16" else full
         del g
@@ -202,7 +274,7 @@ class StressWorkload:
         block-diagonal union of their adjacencies (ops.SparseAdjBf16.block_diagonal); same bits as channel by channel."""
         chans = sorted(self.channels)
         ch0 = self.channels[chans[0]]
-        can = (len(chans) > 1 and ch0.dtype == "bf16" and not ch0.dense
+        can = (len(chans) > 1 and ch0.dtype == "bf16" and not ch0.dense and ch0.order == "reference"
                and ch0.sadj.avg_nnz < ops.SparseAdjBf16.TILED_MIN_AVG_NNZ)
         if union is None:
             union = can         # measured: 0.520 ms against 0.540 channel by channel (eager, density 4e-4)
@@ -332,7 +404,10 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
                                          "operand_GBps": round(by / ms / 1e6, 1)}
         del As, Sts, Cs
     # ---- the whole workload on this GPU: 3 channels x (gc1 + LeakyReLU + gc2 + read-out of 512 samples), bf16 ----
-    for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("csr_d0.01", dict(density=DENSITIES[1])), ("dense", dict(dense=True))):
+    ref_out = {}
+    for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("csr_d0.01", dict(density=DENSITIES[1])), ("dense", dict(dense=True)),
+                     ("csr_d0.0004_reassociated", dict(density=DENSITIES[0], order="reassociated")),
+                     ("dense_reassociated", dict(dense=True, order="reassociated"))):
         wl = StressWorkload(n=n, batch=batch, dev=dev, **kw)
         ms = time_warm(wl.forward, (), reps=5)
         ms_sep = time_warm(lambda: wl.forward(union=False), (), reps=5)
@@ -350,7 +425,23 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
                                                  "samples_per_s_graphs_on_3_streams": round(batch / msg * 1e3, 1)})
         except Exception as e:                                # capture refused: the eager figure stands
             out["workload_bf16_" + name]["graphs_on_3_streams_error"] = "%s: %s" % (type(e).__name__, e)
-        del wl, ch
+        # every launch of one eager 3-channel forward between HIP events (channel by channel), ms
+        wl.forward(union=False)
+        with launch_times() as lt:
+            res = wl.forward(union=False)
+        out["workload_bf16_" + name]["launches_ms"] = [[k, v] for k, v in lt.ms]
+        out["workload_bf16_" + name]["launches_ms_sum"] = round(sum(v for _, v in lt.ms), 4)
+        first = res[next(iter(res))]
+        if name.endswith("_reassociated"):
+            base = ref_out[name[:-len("_reassociated")]]
+            out["workload_bf16_" + name].update({
+                "what": "VARIANT, not the reference's order: every layer as (adj . X) . W instead of adj . (X . W) (MODEL:52-58) -- the adjacency "
+                        "product on the layer's input width; same five launches per channel",
+                "max_abs_diff_vs_reference_order_over_output_scale": round(float((first - base).abs().max() / base.abs().max()), 6),
+                "parity": "tests/test_stress_gpu.py: every output against fp64 at full size, <= 2e-2 of the output scale (the reference order's gate)"})
+        else:
+            ref_out[name] = first.clone()
+        del wl, ch, res, first
     pooled = torch.relu(torch.randn(batch, 2048, device=dev, generator=g))
     ch = StressChannel(n=n, dev=dev, density=DENSITIES[0], dtype="f32")
     out["channel_f32_csr_d0.0004"] = {"ms": round(time_warm(ch.forward, (pooled,), reps=3), 4),

@@ -195,6 +195,36 @@ def test_stress_channel_end_to_end_small_vs_fp64():
     assert np.abs(chd.forward(pooled).cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-2
 
 
+def test_stress_channel_reassociated_order_small_vs_fp64():
+    """order='reassociated' -- every layer as (adj . X) . W instead of the reference's adj . (X . W) (MODEL:52-58): algebraically the
+    same channel, the adjacency product on the layer's input width; against the same fp64 reference under the same bf16 gate (2e-2 of
+    the output scale: four bf16 roundings of intermediates either way), and within that gate of the reference order's own result."""
+    import scipy.sparse as sp
+    n, B = 1500, 32
+    pooled = torch.relu(torch.randn(B, 2048, device=DEV))
+    for dens in (4e-3, 5e-2):
+        a = stress.StressChannel(n=n, density=dens, seed=5, dev=DEV)
+        b = stress.StressChannel(n=n, density=dens, seed=5, dev=DEV, order="reassociated")
+        rp, col, val = (t.cpu().numpy() for t in b.csr)
+        A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(n, n))
+        ref = _channel_fp64(b, pooled, A)
+        oa, ob = a.forward(pooled).cpu().numpy(), b.forward(pooled).cpu().numpy()
+        ea, eb = np.abs(oa - ref).max() / np.abs(ref).max(), np.abs(ob - ref).max() / np.abs(ref).max()
+        print("sparse d=%g: reference order %.2e, reassociated %.2e of the output scale" % (dens, ea, eb))
+        assert eb < 2e-2 and np.abs(oa - ob).max() / np.abs(ref).max() < 2e-2
+    a = stress.StressChannel(n=n, dense=True, seed=6, dev=DEV)
+    b = stress.StressChannel(n=n, dense=True, seed=6, dev=DEV, order="reassociated")
+    assert torch.equal(a.adj_bf16, b.adj_bf16)
+    ref = _channel_fp64(b, pooled, b.adj.cpu().numpy().astype(np.float64))
+    oa, ob = a.forward(pooled).cpu().numpy(), b.forward(pooled).cpu().numpy()
+    eb = np.abs(ob - ref).max() / np.abs(ref).max()
+    print("dense: reference order %.2e, reassociated %.2e of the output scale" % (np.abs(oa - ref).max() / np.abs(ref).max(), eb))
+    assert eb < 2e-2
+    assert torch.equal(b.forward(pooled), b.forward(pooled))                     # repeatable
+    with pytest.raises(ValueError):
+        stress.StressChannel(n=64, dev=DEV, dtype="f32", order="reassociated")
+
+
 def test_stress_workload_shards_equal_the_single_rank_result():
     """configs[4] sharded (plan_shards): every rank's blocks, put together, are the one-rank result bit for bit."""
     n, B = 1200, 48
@@ -259,12 +289,13 @@ def _channel_ref_fp64_device(ch, pooled_bf16):
     return exact, chain
 
 
-@pytest.mark.parametrize("kind", ["csr_d4e-4", "csr_d1e-2", "dense"])
+@pytest.mark.parametrize("kind", ["csr_d4e-4", "csr_d1e-2", "dense", "dense_reassociated"])
 def test_stress_workload_full_size(kind):
     """BASELINE.json configs[4] AS A WORKLOAD at its stated size -- N = 10 000 nodes, 3 channels, batch 512, bf16 -- the forward
     bench.py's `stress` leg times (MODEL:52-58, 460-474 at stress size): every one of the 3 x 512 x 10 000 outputs against fp64
     (not a sample), and -- for the PMI-like density -- the 3- and 8-rank shard plans against the one-rank result at that size."""
-    kw = {"csr_d4e-4": dict(density=stress.DENSITIES[0]), "csr_d1e-2": dict(density=stress.DENSITIES[1]), "dense": dict(dense=True)}[kind]
+    kw = {"csr_d4e-4": dict(density=stress.DENSITIES[0]), "csr_d1e-2": dict(density=stress.DENSITIES[1]), "dense": dict(dense=True),
+          "dense_reassociated": dict(dense=True, order="reassociated")}[kind]      # (the (adj . X) . W variant: same gates vs fp64)
     wl = stress.StressWorkload(0, 1, dev=DEV, **kw)
     assert [s for s in wl.shards] == [(0, 0, stress.BATCH), (1, 0, stress.BATCH), (2, 0, stress.BATCH)]
     out = wl.forward()
@@ -279,13 +310,14 @@ def test_stress_workload_full_size(kind):
         e_exact = float((v.double() - exact).abs().max()) / scale
         # same roundings as the kernels' chain: what is left is fp32 accumulation order and the odd 1-ulp bf16 flip of an
         # intermediate it causes; against unrounded fp64: four bf16 roundings of intermediates
-        assert e_chain < 4e-3, (kind, c, e_chain)
+        if kind != "dense_reassociated":                 # (`chain` rounds the reference order's intermediates)
+            assert e_chain < 4e-3, (kind, c, e_chain)
         assert e_exact < 2e-2, (kind, c, e_exact)
         # >= 64 sampled (sample, node) entries per channel, relative to each entry's own magnitude where it is not tiny
         g = torch.Generator(device="cpu").manual_seed(100 + c)
         bi = torch.randint(0, stress.BATCH, (256,), generator=g).to(v.device)
         ni = torch.randint(0, N, (256,), generator=g).to(v.device)
-        got, want = v[bi, ni].double(), chain[bi, ni]
+        got, want = v[bi, ni].double(), (exact if kind == "dense_reassociated" else chain)[bi, ni]
         big = want.abs() > 0.05 * scale
         assert int(big.sum()) >= 64, (kind, c, int(big.sum()))
         assert float(((got - want).abs() / want.abs())[big].max()) < 3e-2, (kind, c)

@@ -130,6 +130,30 @@ def test_every_schedule_is_a_valid_plan_without_a_gpu():
         m.forward_plan(*args, schedule="no-such-schedule")
 
 
+def test_default_schedules_are_pinned():
+    """resolve_schedule('auto') for B in {16, 32, 64, 128, 256} x the precision modes: the defaults were chosen from alternating-run
+    A/Bs on one box (NOTES_r04 / r05, +-1.5 % noise) -- changing one is a measured decision that edits this table, not a side effect."""
+    from mgnns_amd.model import default_schedule
+    table = {
+        "fp32":   {16: "small", 32: "small", 64: "channels2", 128: "place_bank_first", 256: "place_bank_first"},
+        "bf16":   {16: "small", 32: "small", 64: "channels2", 128: "place_bank_first", 256: "place_bank_first"},
+        "bf16x3": {16: "channels2", 32: "channels2", 64: "channels2", 128: "channels2", 256: "channels2"},
+    }
+    for prec, row in table.items():
+        for B, want in row.items():
+            assert default_schedule(B, prec) == want, (prec, B)
+    cfg = synth.CONFIGS["mvsa_single_b8"]
+    pmi, count = synth.synth_pmi(cfg.V, seed=3)
+    adj = H.load_golden("adjacency.npz")
+    m = build_model(cfg, pmi, count, adj["object_t04_A"], adj["place_t03_A"], np.zeros((7, 300), np.float32))
+    for att in ("faithful", "folded"):
+        m.set_attention(att)
+        for prec, row in table.items():
+            m.set_precision(prec)
+            assert {B: m.resolve_schedule(B) for B in row} == row, (prec, att)
+            assert all(m.resolve_schedule(B) in m.SCHEDULES for B in row)
+
+
 def test_dense_gemm_tile_shape_is_chosen_by_host_arithmetic():
     """csrc/gemm_bf16.hip::mg_gemm_pick through mgnns_gemm_bf16_pick_form (no device call): the tile shape of the configs[4] products
     on a 256-CU device.  4 = 160 x 256 tiles (one round of 252 tiles for 10 000 x 1024), 5 = 320 x 256 (one round of 256 tiles for
