@@ -8,7 +8,8 @@
 //
 // Two 512-thread workgroups per sample, one per half of the 196 regions (112 | 84 rows = 7 | 6 row tiles of 16).  A BK = 64
 // slice of the half's feature rows is loaded k-major as it lies in memory (wave w streams feature rows 8w..8w+7 of the slice,
-// lane = one region quad: 8 x 16 B in flight per lane, requested a slice ahead), split and transposed in registers, and
+// a 32-lane half of the wave four of them, lane & 31 = one region quad: 4 x 16 B in flight per lane, requested a slice ahead), split and
+// transposed in registers (the halves exchange their half chunks through v_permlane32_swap), and
 // written to LDS as 16-B chunks of 8 consecutive k per region row (chunk index XOR row tile: conflict-free for the transposing
 // ds_write_b128 and for the MFMA A-fragment ds_read_b128); wave w owns column tiles w, w + 8, w + 16 (3,3,3,2,2,2,2,2 of the
 // 19) for all row tiles; the W fragments (hi, lo; mgnns_pack_weight_bf16_split layout, L2 resident) of the next k-step are
@@ -82,38 +83,55 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < IS_TPW; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- producer side (all waves): wave = chunk (8 feature rows of the slice), lane = region quad ----
-    const int pq = lane < nq ? lane : nq - 1;                   // idle lanes repeat the last quad (unconditional loads), never store
-    const bool st_on = lane < nq;
-    f32x4 sl[8];
+    // ---- producer side (all waves): wave = chunk (8 feature rows of the slice = one 16-B chunk of 8 consecutive k per region row);
+    //      the two 32-lane HALVES of the wave take four of its rows each, lane & 31 = region quad.  (Rounds 3-5: lane = region quad and
+    //      all eight rows in the lane -- 28 of 64 lanes converting 32 elements each; now 56 lanes convert 16 each and the halves swap
+    //      their packed half chunks (v_permlane32_swap) so that every lane still writes whole 16-B chunks: the lower half the region
+    //      rows 4q, 4q + 1 of its quad, the upper half 4q + 2, 4q + 3.)
+    const int hw = lane >> 5, ql = lane & 31;
+    const int pq = ql < nq ? ql : nq - 1;                       // idle lanes repeat the last quad (unconditional loads), never store
+    const bool st_on = ql < nq;
+    f32x4 sl[4];
     auto gload = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sl[i] = *reinterpret_cast<const f32x4*>(fb + (size_t)(c * IS_BK + wave * 8 + i) * P + 4 * pq);
+        for (int i = 0; i < 4; ++i) sl[i] = *reinterpret_cast<const f32x4*>(fb + (size_t)(c * IS_BK + wave * 8 + hw * 4 + i) * P + 4 * pq);
     };
     auto emit = [&](int buf) {
         float* pmb = pm + buf * 64 * IS_PMS;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (st_on) pmb[(wave * 8 + i) * IS_PMS + lane] = fmaxf(fmaxf(sl[i][0], sl[i][1]), fmaxf(sl[i][2], sl[i][3]));
+        for (int i = 0; i < 4; ++i)
+            if (st_on) pmb[(wave * 8 + hw * 4 + i) * IS_PMS + ql] = fmaxf(fmaxf(sl[i][0], sl[i][1]), fmaxf(sl[i][2], sl[i][3]));
+        // this lane's four k (its half of the chunk) of the quad's four region rows: hi / lo images, two packed dwords each
+        unsigned ch[4][2], cl[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = sl[i][j];
+                h[i] = __builtin_bit_cast(float, (is_pack2(x, 0.f) << 16));              // bf16(x) as fp32
+                l[i] = x - h[i];
+            }
+            ch[j][0] = is_pack2(h[0], h[1]); ch[j][1] = is_pack2(h[2], h[3]);
+            cl[j][0] = is_pack2(l[0], l[1]); cl[j][1] = is_pack2(l[2], l[3]);
+        }
+        // v_permlane32_swap a, b: a = [a.lo, b.lo], b = [a.hi, b.hi].  With a = region row j, b = region row j + 2: the lower half
+        // ends with (its own k 0-3, the upper half's k 4-7) of row j, the upper half with (the lower half's k 0-3, its own k 4-7) of
+        // row j + 2 -- a whole chunk per lane and row pair.  (All 64 lanes take part; s_nop: the VALU write -> swap read and swap
+        // write -> VALU read hazards the compiler does not see through an asm block.)
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                     "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\t"
+                     "s_nop 1"
+                     : "+v"(ch[0][0]), "+v"(ch[0][1]), "+v"(ch[1][0]), "+v"(ch[1][1]), "+v"(ch[2][0]), "+v"(ch[2][1]), "+v"(ch[3][0]), "+v"(ch[3][1]),
+                       "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[1][0]), "+v"(cl[1][1]), "+v"(cl[2][0]), "+v"(cl[2][1]), "+v"(cl[3][0]), "+v"(cl[3][1]));
         if (st_on) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float h[8], l[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float x = sl[i][j];
-                    h[i] = __builtin_bit_cast(float, (is_pack2(x, 0.f) << 16));          // bf16(x) as fp32
-                    l[i] = x - h[i];
-                }
-                // (converting PAIRS -- the packed hi word is the image's word, its halves shifted / masked back give both residuals:
-                //  six instructions per pair instead of eight -- measured 3 % SLOWER on the same box: 246 against 239 us)
-                uint4 ch, cl;
-                ch.x = is_pack2(h[0], h[1]); ch.y = is_pack2(h[2], h[3]); ch.z = is_pack2(h[4], h[5]); ch.w = is_pack2(h[6], h[7]);
-                cl.x = is_pack2(l[0], l[1]); cl.y = is_pack2(l[2], l[3]); cl.z = is_pack2(l[4], l[5]); cl.w = is_pack2(l[6], l[7]);
-                const int row = 4 * lane + j;
+            for (int r = 0; r < 2; ++r) {
+                const int row = 4 * ql + 2 * hw + r;
                 const int at = (buf * IS_ROWS + row) * IS_STR + (wave ^ ((row >> 4) & 7));
-                Ahi[at] = ch;
-                Alo[at] = cl;
+                Ahi[at] = uint4{ch[r][0], ch[r][1], ch[r + 2][0], ch[r + 2][1]};
+                Alo[at] = uint4{cl[r][0], cl[r][1], cl[r + 2][0], cl[r + 2][1]};
             }
         }
     };
