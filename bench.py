@@ -197,7 +197,7 @@ STR_LIMIT = 150                          # strings of the compact line (the full
 HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
              "vs_baseline", "dtype", "data")
 CONFIG_KEYS = ("workload", "global_batch", "parallelism", "launch", "attention", "forwards_in_flight", "schedule",
-               "collective")
+               "collective", "sources")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed",
                  "avg_launch_ms_rocprof", "frac_rocprof", "avg_launch_ms_back_to_back", "flops_per_launch",
                  "bytes_per_launch")
@@ -1293,6 +1293,8 @@ def run_rank(args):
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_logit_diff_vs_cpu_oracle": parity,
     }
     line["config"]["forwards_in_flight"] = head.get("in_flight", 1)
+    built, tree, same = _lib.source_state()          # which sources the library that ran was built from (mgnns_amd/build.py)
+    line["config"]["sources"] = built if same else "%s (the tree next to it: %s)" % (built, tree)
     if hasattr(model, "resolve_schedule"):      # segment -> stream schedule of the timed forward (mgnns_amd/model.py::SCHEDULES)
         line["config"]["schedule"] = model.resolve_schedule(B)
     if args.dtype == "bf16":

@@ -53,6 +53,10 @@ int mgnns_take_status(void);
 const char* mgnns_last_error(void);
 /* ABI version (bumped on any signature change). */
 int mgnns_abi_version(void);
+/* 16 hex digits: sha256 over the sources this library was built from (every .hip and .hpp file of csrc and every header of
+ * include; mgnns_amd/build.py generates the unit).  A measurement records it; the host side refuses to file a profile under
+ * sources that differ. */
+const char* mgnns_source_fingerprint(void);
 /* Measurement, not an operator: does `blockIdx.x & 7` select the XCD on this device / runtime?  Several kernels place work that
  * way (SpMM feature slabs, the dense GEMM's row-block ranges) -- only their SPEED depends on it.  out9[0] = 1 / 0, out9[1 + k] =
  * the hardware XCC_ID observed for block indices with b & 7 == k (-1: more than one).  Synchronises the device. */

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGNNS_LIB") or os.path.join(_HERE, "libmgnns_hip.so")   # MGNNS_LIB: an instrumented build (tools/)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c = ctypes
 _P = _c.c_void_p
@@ -142,6 +142,8 @@ def lib():
     L.mgnns_last_error.argtypes = []
     L.mgnns_abi_version.restype = _I
     L.mgnns_abi_version.argtypes = []
+    L.mgnns_source_fingerprint.restype = ctypes.c_char_p
+    L.mgnns_source_fingerprint.argtypes = []
     if L.mgnns_abi_version() != ABI_VERSION:
         raise MgnnsLibraryError("libmgnns_hip.so ABI %d != binding ABI %d; rebuild" % (L.mgnns_abi_version(), ABI_VERSION))
     for name, args in SIZE_GETTERS.items():
@@ -155,6 +157,23 @@ def lib():
     _lib = L
     _register_status_word(L)
     return L
+
+
+def source_state():
+    """(fingerprint compiled into the loaded library, fingerprint of the sources next to it, equal?) -- mgnns_amd/build.py."""
+    from . import build
+    built, tree = lib().mgnns_source_fingerprint().decode(), build.source_fingerprint()
+    return built, tree, built == tree
+
+
+def check_sources(who="this measurement"):
+    """Raise unless the loaded library was built from exactly the sources in the tree (an instrumented MGNNS_LIB build is named
+    as such by the caller): a profile must not be filed under sources newer than the kernels that ran."""
+    built, tree, same = source_state()
+    if not same:
+        raise MgnnsLibraryError("%s: %s was built from sources %s, the tree holds %s -- rebuild (python -m mgnns_amd.build) first"
+                                % (who, LIB_PATH, built, tree))
+    return built
 
 
 _status_word = None

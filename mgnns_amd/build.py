@@ -27,6 +27,20 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_fingerprint():
+    """sha256 (16 hex digits) over every source the library is built from (csrc/*.hip, csrc/*.hpp, include/*.h; names + bytes).
+    Compiled into the library as mgnns_source_fingerprint(): a profile or a bench line can say which sources produced it, and
+    _lib.check_sources() refuses a library older than the tree it sits in."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -57,6 +71,17 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
+    # the fingerprint of the sources, as one more (generated) translation unit
+    fp, fp_src, fp_obj = source_fingerprint(), os.path.join(objdir, "fingerprint.cpp"), os.path.join(objdir, "fingerprint_gen.o")
+    text = 'extern "C" const char* mgnns_source_fingerprint(void) { return "%s"; }\n' % fp
+    if not os.path.exists(fp_src) or open(fp_src).read() != text or not os.path.exists(fp_obj):
+        with open(fp_src, "w") as f:
+            f.write(text)
+        r = subprocess.run([hipcc, "-O1", "-fPIC", "-x", "c++", "-c", fp_src, "-o", fp_obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on the fingerprint unit:\n" + r.stdout)
+        procs.append((fp_src, None))
+    objs.append(fp_obj)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -66,4 +91,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--fingerprint" in sys.argv:
+        print(source_fingerprint())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -104,7 +104,7 @@ int mg_env_int(const char* name, int fallback, int slot) {
 }
 
 extern "C" const char* mgnns_last_error(void) { return g_err; }
-extern "C" int mgnns_abi_version(void) { return 17; }
+extern "C" int mgnns_abi_version(void) { return 18; }
 
 namespace {
 // which XCD (hardware XCC_ID) a workgroup runs on, per block index

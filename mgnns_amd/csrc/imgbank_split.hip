@@ -41,7 +41,6 @@ constexpr int IS_NT = 19;                // column tiles (N <= 304)
 constexpr int IS_TPW = 3;                // column tiles per wave (w, w + 8, w + 16)
 constexpr int IS_THR = 512;
 constexpr int IS_PSPLIT = 112;           // half 0: regions [0, 112), half 1: [112, P)
-constexpr int IS_PMS = 29;               // row stride of the partial-maxima tile [64][28 -> 29]
 
 __device__ __forceinline__ unsigned is_pack2(float a, float b) {
     unsigned r;
@@ -61,7 +60,6 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* Ahi = reinterpret_cast<uint4*>(smem);                                   // [2][IS_ROWS][IS_STR]
     uint4* Alo = Ahi + 2 * IS_ROWS * IS_STR;
-    float* pm = reinterpret_cast<float*>(Alo + 2 * IS_ROWS * IS_STR);              // [2][64][IS_PMS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x >> 1, mh = blockIdx.x & 1;
@@ -96,11 +94,40 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) sl[i] = *reinterpret_cast<const f32x4*>(fb + (size_t)(c * IS_BK + wave * 8 + hw * 4 + i) * P + 4 * pq);
     };
-    auto emit = [&](int buf) {
-        float* pmb = pm + buf * 64 * IS_PMS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (st_on) pmb[(wave * 8 + hw * 4 + i) * IS_PMS + ql] = fmaxf(fmaxf(sl[i][0], sl[i][1]), fmaxf(sl[i][2], sl[i][3]));
+    // cs: the slice in the registers (its pooled maxima are stored from here; < 0: none -- the extra conversion behind the last slice)
+    auto emit = [&](int buf, int cs) {
+        // pooled maxima of the slice's rows over this half's regions, without LDS: the lane's maximum over its four regions, then over
+        // the 16-lane rows by DPP (quad_perm x 2, row_half_mirror, row_mirror), then row_bcast:15 folds the first row of each 32-lane
+        // half into the second -- lanes 16-31 / 48-63 hold the half's maximum of feature row i; lanes 16-19 / 48-51 store the four rows.
+        // (Rounds 3-5: partial maxima through an LDS tile and a second pass of all 512 threads at the head of the next slice: 590
+        // cycles per slice and wave.)  One asm block, the four rows interleaved: a DPP read of a VGPR needs two wait states behind
+        // the VALU write (three other instructions in between here; s_nop 1 in front of the first).
+        if (pooled) {
+            float m0, m1, m2, m3;
+            {
+                const float ninf = -INFINITY;
+                m0 = st_on ? fmaxf(fmaxf(sl[0][0], sl[0][1]), fmaxf(sl[0][2], sl[0][3])) : ninf;
+                m1 = st_on ? fmaxf(fmaxf(sl[1][0], sl[1][1]), fmaxf(sl[1][2], sl[1][3])) : ninf;
+                m2 = st_on ? fmaxf(fmaxf(sl[2][0], sl[2][1]), fmaxf(sl[2][2], sl[2][3])) : ninf;
+                m3 = st_on ? fmaxf(fmaxf(sl[3][0], sl[3][1]), fmaxf(sl[3][2], sl[3][3])) : ninf;
+            }
+#define IS_MAX4(ctrl)                                                                   \
+    "v_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+    "v_max_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+    "v_max_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                  \
+    "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+            asm volatile("s_nop 1\n\t" IS_MAX4("quad_perm:[1,0,3,2]") IS_MAX4("quad_perm:[2,3,0,1]") IS_MAX4("row_half_mirror") IS_MAX4("row_mirror")
+                         "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                         "s_nop 1"
+                         : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+#undef IS_MAX4
+            const int r4 = lane & 3;
+            const float mv = r4 == 0 ? m0 : r4 == 1 ? m1 : r4 == 2 ? m2 : m3;
+            if (cs >= 0 && (lane & 0x1C) == 0x10) pooled[((size_t)b * 2 + mh) * K + cs * IS_BK + wave * 8 + hw * 4 + r4] = mv;
+        }
         // this lane's four k (its half of the chunk) of the quad's four region rows: hi / lo images, two packed dwords each
         unsigned ch[4][2], cl[4][2];
 #pragma unroll
@@ -159,7 +186,7 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
 #pragma unroll
     for (int d = 0; d < IS_WD - 1; ++d)
         if (d < KS) wload(d, d);
-    emit(0);
+    emit(0, 0);
     gload(nk > 1 ? 1 : 0);
     __syncthreads();
     // The two waves of a SIMD (w and w + 4) run a slice's two phases in OPPOSITE order: waves 0-3 first convert the next slice into
@@ -186,26 +213,12 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
         constexpr int PH = decltype(phc)::v;
         constexpr int buf = PH & 1;
         auto convert = [&]() {
-            emit(buf ^ 1);                                      // (behind the last slice: into the idle buffer, never read)
+            emit(buf ^ 1, c + 1 < nk ? c + 1 : -1);             // (behind the last slice: into the idle buffer, never read)
             gload(c + 2 < nk ? c + 2 : nk - 1);
         };
         if (convert_first) convert();
         IS_T(0)                                                 // conversion at the head of the slice (waves 0-3)
-        // the slice's partial maxima (written before the barrier that opened this iteration) -> pooled: eight threads per feature
-        // row take four region quads each, three DPP steps join them
-        if (pooled) {
-            const int row = tid >> 3, part = tid & 7;
-            const float* r = pm + buf * 64 * IS_PMS + row * IS_PMS;
-            float m = -INFINITY;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (part + 8 * q < nq) m = fmaxf(m, r[part + 8 * q]);
-            m = fmaxf(m, MG_DPP(m, 0xB1));                       // quad_perm [1,0,3,2]
-            m = fmaxf(m, MG_DPP(m, 0x4E));                       // quad_perm [2,3,0,1]
-            m = fmaxf(m, MG_DPP(m, 0x141));                      // row_half_mirror: lanes 0-3 <-> 7-4 of each eight
-            if (part == 0) pooled[((size_t)b * 2 + mh) * K + c * IS_BK + row] = m;
-        }
-        IS_T(1)                                                 // pooled maxima
+        IS_T(1)                                                 // (rounds 3-5: the pooled maxima pass; now inside the conversion)
         mg_mha::static_for<0, 2>([&](auto sc) {
             constexpr int s = decltype(sc)::v;
             constexpr int SL = (2 * PH + s) % IS_WD;
@@ -352,7 +365,7 @@ extern "C" int mgnns_imgbank_pool_split_fwd(const float* feat, int B, int K, int
     MG_REQUIRE(N > 0 && N <= IS_NT * 16, "mgnns_imgbank_pool_split_fwd: N=%d unsupported (<= %d)", N, IS_NT * 16);
     MG_REQUIRE(mg_aligned16(feat) && mg_aligned16(Wp_hi) && mg_aligned16(Wp_lo), "mgnns_imgbank_pool_split_fwd: feat / weights must be 16-byte aligned");
     if (B == 0) return 0;
-    const size_t lds = (size_t)4 * IS_ROWS * IS_STR * 16 + (size_t)2 * 64 * IS_PMS * sizeof(float);
+    const size_t lds = (size_t)4 * IS_ROWS * IS_STR * 16;
     MG_DYN_LDS(imgbank_split_kernel, lds);
     hipLaunchKernelGGL(imgbank_split_kernel, dim3(2 * B), dim3(IS_THR), lds, (hipStream_t)stream, feat, K, P,
                        reinterpret_cast<const uint4*>(Wp_hi), reinterpret_cast<const uint4*>(Wp_lo), bias, N, bank, pooled_halves,

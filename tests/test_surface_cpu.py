@@ -22,8 +22,12 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in sorted(declared):
         assert hasattr(L, name), "libmgnns_hip.so does not export %s" % name
-    assert set(_lib.SIGNATURES) | set(_lib.SIZE_GETTERS) | {"mgnns_last_error", "mgnns_abi_version"} == declared
+    assert set(_lib.SIGNATURES) | set(_lib.SIZE_GETTERS) | {"mgnns_last_error", "mgnns_abi_version", "mgnns_source_fingerprint"} == declared
     assert L.mgnns_abi_version() == _lib.ABI_VERSION
+    # the library says which sources it was built from; a build right before this test (the driver's build()) makes them the tree's
+    built, tree, same = _lib.source_state()
+    assert len(built) == 16 and same, "libmgnns_hip.so was built from sources %s, the tree holds %s: rebuild" % (built, tree)
+    assert _lib.check_sources("test") == tree
 
 
 def test_state_dict_surface_equals_reference():

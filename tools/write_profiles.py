@@ -59,6 +59,11 @@ def pmc(db, sub):
 
 def main():
     tag, pre = sys.argv[1], sys.argv[2]
+    # the library that ran must be the one these sources build: a profile is never filed under kernels newer than the ones measured
+    sys.path.insert(0, ROOT)
+    from mgnns_amd import _lib
+    fp = _lib.check_sources("tools/write_profiles.py")
+    stamp = "Library sources: fingerprint `%s` (`python -m mgnns_amd.build --fingerprint` on the commit that holds this file).\n\n" % fp
     cmds = {"bf16": "--steps 20 --warmup 5 --no-cpu-baseline --no-variants",
             "bf16_serial": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-graph --single-stream",
             "f32": "--steps 10 --warmup 3 --no-cpu-baseline --no-variants --dtype f32",
@@ -73,6 +78,7 @@ def main():
         line = [x for x in log if x.startswith('{"metric"')]
         with open(os.path.join(PR, "%s_%s_kernel_stats.md" % (pre, m)), "w") as f:
             f.write("# rocprofv3 --kernel-trace --stats, %s, mode %s\n\n" % (pre, m))
+            f.write(stamp)
             f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py %s` (hipGraph replays + the eager timing "
                     "forwards; in the graph replays kernels of the four streams overlap, so a kernel's duration there includes "
                     "what it shares the chip with -- the `bf16_serial` file has every kernel alone on one stream, which is the "
@@ -134,6 +140,7 @@ def main():
         with open(os.path.join(PR, "%s_pmc_summary.md" % pre), "w") as f:
             f.write("# rocprofv3 PMC passes, %s (bf16 mode, eager single forwards: `bench.py --steps 3 --warmup 1 --no-cpu-baseline "
                     "--no-variants --no-graph`)\n\n" % pre)
+            f.write(stamp)
             f.write("One counter per pass (`rocprofv3 --pmc <ctr> --kernel-trace`, tools/pmc.sh). FETCH_SIZE/WRITE_SIZE are in KiB; per "
                     "MI355X_MICROARCH.md the gfx950 FETCH_SIZE of a wide coalesced read is HALF the bytes (checked on `cast_pad_bf16`: "
                     "15.2 MB raw for a 30.7 MB read), so `hbm_read = 2 x FETCH_SIZE x 1024`; WRITE_SIZE is exact. Values are per launch "
