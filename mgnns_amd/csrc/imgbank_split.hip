@@ -50,6 +50,15 @@ __device__ __forceinline__ unsigned is_pack2(float a, float b) {
 
 constexpr int IS_WD = 3;                 // W-fragment ring: two k-steps in flight + the one being multiplied (four: 21 spilled registers)
 constexpr int IS_LD = 320;               // row length of the split-bf16 bank images
+#ifndef MG_IS_AD
+#define MG_IS_AD 2
+#endif
+#ifndef MG_IS_PF
+#define MG_IS_PF 1
+#endif
+constexpr int IS_PF = MG_IS_PF;          // slices of feature rows in flight ahead of their conversion (1 = rounds 3-5)
+static_assert(IS_PF == 1 || IS_PF == 2, "register sets per slice parity");
+constexpr int IS_AD = MG_IS_AD;          // A-fragment ring: row tiles in flight + the one being multiplied (3, 4: no faster, NOTES_r06 6)
 
 __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __restrict__ feat, int K, int P,
                                                               const uint4* __restrict__ Wh, const uint4* __restrict__ Wl,
@@ -89,13 +98,17 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
     const int hw = lane >> 5, ql = lane & 31;
     const int pq = ql < nq ? ql : nq - 1;                       // idle lanes repeat the last quad (unconditional loads), never store
     const bool st_on = ql < nq;
-    f32x4 sl[4];
-    auto gload = [&](int c) {
+    // feature rows in flight: IS_PF slices ahead of their conversion (IS_PF register sets of four rows; slice c lives in set c % IS_PF)
+    f32x4 slr[IS_PF][4];
+    auto gload = [&](int c, auto setc) {
+        constexpr int set = decltype(setc)::v;
+        const int cc = c < nk ? c : nk - 1;                      // (unconditional: behind the last slice the last one again)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sl[i] = *reinterpret_cast<const f32x4*>(fb + (size_t)(c * IS_BK + wave * 8 + hw * 4 + i) * P + 4 * pq);
+        for (int i = 0; i < 4; ++i) slr[set][i] = *reinterpret_cast<const f32x4*>(fb + (size_t)(cc * IS_BK + wave * 8 + hw * 4 + i) * P + 4 * pq);
     };
     // cs: the slice in the registers (its pooled maxima are stored from here; < 0: none -- the extra conversion behind the last slice)
-    auto emit = [&](int buf, int cs) {
+    auto emit = [&](int buf, int cs, auto setc) {
+        f32x4 (&sl)[4] = slr[decltype(setc)::v];
         // pooled maxima of the slice's rows over this half's regions, without LDS: the lane's maximum over its four regions, then over
         // the 16-lane rows by DPP (quad_perm x 2, row_half_mirror, row_mirror), then row_bcast:15 folds the first row of each 32-lane
         // half into the second -- lanes 16-31 / 48-63 hold the half's maximum of feature row i; lanes 16-19 / 48-51 store the four rows.
@@ -182,12 +195,14 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
     };
     const int fr = lane & 15, fg = lane >> 4;
 
-    gload(0);
+    gload(0, mg_mha::IC<0>{});
 #pragma unroll
     for (int d = 0; d < IS_WD - 1; ++d)
         if (d < KS) wload(d, d);
-    emit(0, 0);
-    gload(nk > 1 ? 1 : 0);
+    if constexpr (IS_PF == 2) gload(1, mg_mha::IC<1 % IS_PF>{});
+    emit(0, 0, mg_mha::IC<0>{});
+    if constexpr (IS_PF == 2) gload(2, mg_mha::IC<0>{});
+    else gload(1, mg_mha::IC<0>{});
     __syncthreads();
     // The two waves of a SIMD (w and w + 4) run a slice's two phases in OPPOSITE order: waves 0-3 first convert the next slice into
     // the other LDS buffer (VALU + LDS writes), then multiply; waves 4-7 multiply first.  While one wave of the SIMD holds the
@@ -213,8 +228,9 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
         constexpr int PH = decltype(phc)::v;
         constexpr int buf = PH & 1;
         auto convert = [&]() {
-            emit(buf ^ 1, c + 1 < nk ? c + 1 : -1);             // (behind the last slice: into the idle buffer, never read)
-            gload(c + 2 < nk ? c + 2 : nk - 1);
+            constexpr int set = (PH + 1) % IS_PF;               // slice c + 1's registers (PH = c % 6, IS_PF divides 6)
+            emit(buf ^ 1, c + 1 < nk ? c + 1 : -1, mg_mha::IC<set>{});      // (behind the last slice: into the idle buffer, never read)
+            gload(c + 1 + IS_PF, mg_mha::IC<set>{});
         };
         if (convert_first) convert();
         IS_T(0)                                                 // conversion at the head of the slice (waves 0-3)
@@ -231,18 +247,21 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
             // A fragments read a second time.
             // (A fragments one row tile ahead, by hand, with a scheduling fence per row tile: left alone the scheduler hoists all
             //  fourteen reads of a block in front of its MFMAs -- 127 spilled registers)
-            uint4 ah[2], al[2];
+            // (round 6, measured: a ring of three or four -- two / three row tiles ahead, MG_IS_AD -- changes nothing: 208.7-219.9 us whatever
+            //  the depth, three alternating rounds; the fragment reads are not what the MFMA blocks wait for)
+            uint4 ah[IS_AD], al[IS_AD];
             auto aread = [&](int i, int slot) {
                 const int at = (buf * IS_ROWS + i * 16 + fr) * IS_STR + ((4 * s + fg) ^ (i & 7));
                 ah[slot] = Ahi[at];
                 al[slot] = Alo[at];
             };
-            aread(0, 0);
+#pragma unroll
+            for (int d = 0; d < IS_AD - 1; ++d) aread(d, d);
             mg_mha::static_for<0, IS_MT>([&](auto ic) {
                 constexpr int i = decltype(ic)::v;
-                if constexpr (i + 1 < IS_MT) aread(i + 1, (i + 1) & 1);
+                if constexpr (i + IS_AD - 1 < IS_MT) aread(i + IS_AD - 1, (i + IS_AD - 1) % IS_AD);
                 __builtin_amdgcn_sched_barrier(0);              // (the reads stay IN FRONT of this tile's MFMAs: they were sunk behind four of them)
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i & 1]), xl = __builtin_bit_cast(bf16x8, al[i & 1]);
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i % IS_AD]), xl = __builtin_bit_cast(bf16x8, al[i % IS_AD]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[SL][t]), wl = __builtin_bit_cast(bf16x8, bl[SL][t]);
@@ -253,16 +272,38 @@ __global__ __launch_bounds__(IS_THR) void imgbank_split_kernel(const float* __re
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (has3) {
+                // the third column tile (waves 0-2), row tiles in PAIRS: three products on ONE accumulator in a row wait for each other
+                // (32 instead of 16 cycles per MFMA: rounds 3-5 ran this pass tile by tile); two row tiles give two independent chains.
+                // (Both passes as one -- two or three column tiles per row tile behind a wave-uniform branch -- is two instances of the
+                //  block: 395 spilled registers.)
                 const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[SL][2]), wl = __builtin_bit_cast(bf16x8, bl[SL][2]);
-                aread(0, 0);
-                mg_mha::static_for<0, IS_MT>([&](auto ic) {
-                    constexpr int i = decltype(ic)::v;
-                    if constexpr (i + 1 < IS_MT) aread(i + 1, (i + 1) & 1);
+                uint4 ph[4], pl[4];
+                auto pread = [&](int i, int slot) {
+                    const int at = (buf * IS_ROWS + i * 16 + fr) * IS_STR + ((4 * s + fg) ^ (i & 7));
+                    ph[slot] = Ahi[at];
+                    pl[slot] = Alo[at];
+                };
+                pread(0, 0);
+                pread(1, 1);
+                mg_mha::static_for<0, (IS_MT + 1) / 2>([&](auto pc) {
+                    constexpr int i0 = 2 * decltype(pc)::v, i1 = i0 + 1;
+                    if constexpr (i0 + 2 < IS_MT) pread(i0 + 2, (i0 + 2) & 3);
+                    if constexpr (i0 + 3 < IS_MT) pread(i0 + 3, (i0 + 3) & 3);
                     __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i & 1]), xl = __builtin_bit_cast(bf16x8, al[i & 1]);
-                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[i][2], 0, 0, 0);
-                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[i][2], 0, 0, 0);
-                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[i][2], 0, 0, 0);
+                    const bf16x8 xh0 = __builtin_bit_cast(bf16x8, ph[i0 & 3]), xl0 = __builtin_bit_cast(bf16x8, pl[i0 & 3]);
+                    if constexpr (i1 < IS_MT) {
+                        const bf16x8 xh1 = __builtin_bit_cast(bf16x8, ph[i1 & 3]), xl1 = __builtin_bit_cast(bf16x8, pl[i1 & 3]);
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh0, wl, acc[i0][2], 0, 0, 0);
+                        acc[i1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh1, wl, acc[i1][2], 0, 0, 0);
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl0, wh, acc[i0][2], 0, 0, 0);
+                        acc[i1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl1, wh, acc[i1][2], 0, 0, 0);
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh0, wh, acc[i0][2], 0, 0, 0);
+                        acc[i1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh1, wh, acc[i1][2], 0, 0, 0);
+                    } else {
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh0, wl, acc[i0][2], 0, 0, 0);
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl0, wh, acc[i0][2], 0, 0, 0);
+                        acc[i0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh0, wh, acc[i0][2], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
