@@ -218,7 +218,7 @@ def main():
         src = os.path.join(GO, "%s_%s.jsonl" % (tag, name))
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(PR, "%s_%s.jsonl" % (pre, name)))
-    for name in ("bench_bf16", "bench_f32", "bench_bf16x3", "stress_gcn"):
+    for name in ("bench_bf16", "bench_f32", "bench_bf16x3", "stress_gcn", "bench_bf16_detail", "bench_f32_detail", "bench_bf16x3_detail"):
         src = os.path.join(GO, "%s_%s.json" % (tag, name))
         if os.path.exists(src):
             shutil.copy(src, os.path.join(PR, "%s_%s.json" % (pre, name)))
