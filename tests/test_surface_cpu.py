@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol():
     assert _lib.check_sources("test") == tree
 
 
+def test_a_library_older_than_its_sources_is_refused(monkeypatch):
+    """tools/write_profiles.py files a profile only under the sources the measured library was built from: _lib.check_sources raises
+    when the tree's fingerprint differs from the one compiled into the library (here: the tree's is faked)."""
+    from mgnns_amd import build
+    assert _lib.check_sources("test") == build.source_fingerprint()
+    monkeypatch.setattr(build, "source_fingerprint", lambda: "0" * 16)
+    built, tree, same = _lib.source_state()
+    assert tree == "0" * 16 and not same
+    with pytest.raises(_lib.MgnnsLibraryError, match="rebuild"):
+        _lib.check_sources("tools/write_profiles.py")
+
+
 def test_state_dict_surface_equals_reference():
     cfg = synth.CONFIGS["tumemo_b64"]
     pmi, count = synth.synth_pmi(cfg.V, seed=cfg.seed + 17)
