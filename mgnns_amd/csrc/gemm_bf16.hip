@@ -748,19 +748,21 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
     const int fr = lane & 15, fg = lane >> 4;
     const unsigned lds0 = mg_lds_addr(smem);
     const unsigned swz = (unsigned)((fg ^ ((0xD2 >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
-    const unsigned aoff = lds0 + (unsigned)((wr * 80 + fr) * 64) + swz, boff = lds0 + A4_BYTES + (unsigned)((wc * 64 + fr) * 64) + swz;
+    const unsigned aoff = lds0 + (unsigned)((wr * 80 + fr) * 64) + swz;
+    const int bdelta = A4_BYTES + (wc * 64 - wr * 80) * 64;         // Bt fragment row of this lane - its A fragment row: wave-uniform (an SGPR, not a second address register)
     u32x4 a[2][5], b[2][4];
     auto reads = [&](int stage, int buf) {
         const unsigned so = (unsigned)stage * STG4;
-        a[buf][0] = mg_lds_read128<0>(aoff + so);
-        a[buf][1] = mg_lds_read128<1024>(aoff + so);
-        a[buf][2] = mg_lds_read128<2048>(aoff + so);
-        a[buf][3] = mg_lds_read128<3072>(aoff + so);
-        a[buf][4] = mg_lds_read128<4096>(aoff + so);
-        b[buf][0] = mg_lds_read128<0>(boff + so);
-        b[buf][1] = mg_lds_read128<1024>(boff + so);
-        b[buf][2] = mg_lds_read128<2048>(boff + so);
-        b[buf][3] = mg_lds_read128<3072>(boff + so);
+        const unsigned ao = aoff + so, bo = ao + (unsigned)bdelta;
+        a[buf][0] = mg_lds_read128<0>(ao);
+        a[buf][1] = mg_lds_read128<1024>(ao);
+        a[buf][2] = mg_lds_read128<2048>(ao);
+        a[buf][3] = mg_lds_read128<3072>(ao);
+        a[buf][4] = mg_lds_read128<4096>(ao);
+        b[buf][0] = mg_lds_read128<0>(bo);
+        b[buf][1] = mg_lds_read128<1024>(bo);
+        b[buf][2] = mg_lds_read128<2048>(bo);
+        b[buf][3] = mg_lds_read128<3072>(bo);
     };
     // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns
     auto mmas = [&](int buf) {
@@ -772,6 +774,30 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
                                                                     __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
     };
     int ci = 0, ckt = 0;
+    // ---- L2 prefetch by the COMPUTE waves (round 6; MG_GEMM160_PF slices ahead, 0 = off) -----------------------------------------
+    // The operand stream is bound by the round trip of a slice's FRESH lines (NOTES_r06 2a): the producers' requests complete in order,
+    // so a miss far ahead would hold back the nearer slices if a producer issued it -- the compute waves have no vector-memory
+    // traffic of their own, so their vmcnt is free: every second slice each of them touches one 128-B line per lane (8 waves x 64
+    // lanes >= the 160 + 256 operand rows of a slice pair) MG_GEMM160_PF slices ahead, as a 4-byte LDS-DMA onto the landing strip
+    // (no destination register, nobody waits for it).  The producers' requests then find their lines in the L2.
+#ifndef MG_GEMM160_PF
+#define MG_GEMM160_PF 0
+#endif
+    constexpr int PF = MG_GEMM160_PF;
+    // waves 0-2 touch the tile's 160 A rows (lane = row, 32 lanes idle), waves 3-6 its 256 Bt rows, wave 7 nothing: the base is wave-uniform
+    // (a buffer resource in SGPRs, rows beyond the matrix fall outside its bounds: no request), the lane keeps ONE register: its row offset
+    const bool pf_a = wave < 3, pf_on = wave < 7;
+    const int pf_local = pf_a ? wave * 64 + lane : (wave - 3) * 64 + lane;
+    const unsigned pf_voff = (unsigned)pf_local * (unsigned)Kp * 2u;
+    __amdgpu_buffer_rsrc_t pf_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0, 0x00027000);
+    auto pf_open = [&](int i) {
+        const int j = jj0 + i * W;
+        const int m0 = (rb0 + j / nct) * TM4, n0 = (j % nct) * TN4;
+        const int lim = pf_a ? (M - m0 < TM4 ? M - m0 : TM4) : (N - n0 < TN4 ? N - n0 : TN4);
+        const unsigned short* base = pf_a ? A + (size_t)m0 * Kp : Bt + (size_t)n0 * Kp;
+        pf_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0, pf_on && lim > 0 ? lim * Kp * 2 : 0, 0x00027000);
+    };
+    if (PF > 0) pf_open(0);
     asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
     reads(0, 0);
     // per slice: its fragments are in registers -> barrier (everybody is done with the slice's stage; the next slice landed) -> the
@@ -782,10 +808,14 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
         asm volatile("s_barrier" ::: "memory");
         if (g + 1 < S) reads((g + 1) % NST4, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (PF > 0 && (ckt & 1) == 0 && ckt + PF < nk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pf_rs, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)NST4 * STG4), 4, pf_voff,
+                                                     (ckt + PF) * BK4 * 2, 0, 0);
         mmas(buf);
         __builtin_amdgcn_sched_barrier(0);
         if (++ckt < nk) return;
         ckt = 0;
+        if (PF > 0 && ci + 1 < nitem) pf_open(ci + 1);
         // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*80 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
         const int j = jj0 + ci * W;
         const int cm0 = (rb0 + j / nct) * TM4, cn0 = (j % nct) * TN4;
