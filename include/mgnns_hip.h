@@ -545,7 +545,8 @@ int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, 
                            int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
 /* Which tile shape mgnns_gemm_bf16_nt_fwd runs (tests and A/B timings; production leaves it alone): -1 the environment
  * (MGNNS_GEMM_160, default 2), 0 round 4's kernels only (256 x 128, 256 x 256), 1 the 160 x 256 kernel whenever the shape fits it,
- * 2 by the launcher's estimate, 3 the 320 x 256 kernel whenever the shape fits it. */
+ * 2 by the launcher's estimate, 3 the 320 x 256 kernel whenever the shape fits it.  100 / 101 / 102: the K-slice width of the 160 x 256 tile --
+ * the environment (MGNNS_GEMM160_BK, default 64) / 32 (round 5's kernel: 64-B row segments) / 64 (round 6: whole 128-B lines, half the requests). */
 int mgnns_gemm_bf16_set_form(int form);
 /* The launcher's choice for a product, by its estimate (host arithmetic, no device call; n_cu = compute units of the device, 256 on
  * MI355X; with_workspace: the workspace of mgnns_gemm_bf16_workspace_bytes() is passed): 4 = 160 x 256 tiles, 5 = 320 x 256 tiles,

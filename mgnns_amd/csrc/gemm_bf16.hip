@@ -642,6 +642,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_fixup_256_kernel(const float* _
 
 }  // namespace
 
+namespace {
+template <int N_> struct mg_ic { static constexpr int v = N_; };
+template <typename F> __device__ __forceinline__ void mg_mha_static_for_2(F&& f) { f(mg_ic<0>{}); f(mg_ic<1>{}); }
+}  // namespace
+
 // ---- 160 x 256 tiles (round 5) -----------------------------------------------------------------------------------------------
 // What the two kernels above leave on the table at 10 000 x 1024 x 10 000: the 256 x 128 kernel streams at what the L2s deliver
 // (9.3 TB/s) but its 320 tiles are 1.25 rounds of 256 workgroups (a K split of the last quarter round + a fix-up launch: 254-265 us);
@@ -806,12 +811,19 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
         mg_lds_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_barrier" ::: "memory");
+#ifndef MG_GEMM160_ABLATE
+#define MG_GEMM160_ABLATE 0      // measurement builds only (results wrong on purpose): 1 = no MFMAs, 2 = no fragment reads either -- the operand stream alone
+#endif
+#if !(MG_GEMM160_ABLATE & 2)
         if (g + 1 < S) reads((g + 1) % NST4, buf ^ 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (PF > 0 && (ckt & 1) == 0 && ckt + PF < nk)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(pf_rs, (__attribute__((address_space(3))) void*)(uintptr_t)(smem + (size_t)NST4 * STG4), 4, pf_voff,
                                                      (ckt + PF) * BK4 * 2, 0, 0);
+#if !(MG_GEMM160_ABLATE & 1)
         mmas(buf);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (++ckt < nk) return;
         ckt = 0;
@@ -850,6 +862,173 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160_kernel(const unsigned 
     for (int g = 0; g < S; g += 2) {
         slice(g, 0);
         if (g + 1 < S) slice(g + 1, 1);
+    }
+}
+
+}  // namespace
+
+// ---- 160 x 256 tiles, 64-wide K slices (round 6) ---------------------------------------------------------------------------------
+// The L2 serves REQUESTS, not bytes (tools/dev/micro/l2_rowseg.hip: a 64-B row segment costs what a 128-B one costs; 33 G requests per
+// second and XCD), and the kernel above asks for its operands as 64-B row segments (32-wide slices): 33 M requests per 10 000 x 1024 x
+// 10 000 launch, 57 % of that capacity, and anything that adds requests costs time in proportion (the L2 prefetch: + 50 % requests,
+// + 22 % time).  The same tile with 64-wide slices asks for whole 128-B lines: half the requests for the same bytes.  Three stages of 52 KB
+// (two slices = 104 KB in flight, as before), pieces of 8 rows x 128 B, 13 requests per producer and slice (no dummies), operand rows in LDS
+// as in the 256 x 128 kernel (chunk c of a row at slot c ^ ((row >> 1) & 7)), two k-steps per slice software-pipelined across the slice
+// barrier.  MGNNS_GEMM160_BK=32 keeps the kernel above.
+namespace {
+constexpr int BK6 = 64, NST6 = 3;
+constexpr int A6_BYTES = TM4 * BK6 * 2, B6_BYTES = TN4 * BK6 * 2, STG6 = A6_BYTES + B6_BYTES;          // 20 KB + 32 KB
+constexpr int A6_PIECES = A6_BYTES / 1024, B6_PIECES = B6_BYTES / 1024;                                  // 20 + 32 = 52 = 4 producers x 13
+constexpr int PPP6 = (A6_PIECES + B6_PIECES) / NPROD;
+static_assert(PPP6 * NPROD == A6_PIECES + B6_PIECES, "every producer issues the same number of pieces");
+constexpr size_t SMEM6_BYTES = (size_t)NST6 * STG6;
+static_assert(SMEM6_BYTES <= 160 * 1024, "LDS");
+
+__global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160k_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+                                                                  int M, int N, int Kp, const float* __restrict__ bias,
+                                                                  float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];      // (the k-step XOR below relies on 128-B aligned rows)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nk = Kp / BK6;                                       // 64-wide slices of a tile (Kp % 64 == 0: the launcher checks)
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    const int nitem = jj0 < T ? (T - jj0 + W - 1) / W : 0;         // tiles jj0, jj0 + W, ...
+    if (nitem == 0) return;
+    const int S = nitem * nk;
+
+    if (wave >= 8) {
+        // ---- producer q: requests q, q + 4, .. q + 48 of every slice: request p < 20 = A piece p, else Bt piece p - 20.  A piece = 8 rows x
+        //      128 B; lane (row_in = lane >> 3, slot = lane & 7) fetches the chunk that belongs in its slot: slot = chunk ^ ((row >> 1) & 7),
+        //      a piece starts at a multiple of 8 rows, so (row >> 1) & 7 = 4 (piece & 1) + (row_in >> 1).
+        const int q = wave - 8;
+        const int row_in = lane >> 3, slot = lane & 7;
+        int ig = 0, ikt = 0, ii = 0, im0, in0;
+        auto open = [&](int i) {
+            const int j = jj0 + i * W;
+            im0 = (rb0 + j / nct) * TM4;
+            in0 = (j % nct) * TN4;
+        };
+        open(0);
+        auto issue = [&]() {                                       // slice ig of the stream -> stage ig % NST6; then advance
+            unsigned char* sb = smem + (size_t)(ig % NST6) * STG6;
+            const bool live = ig < S;                              // past the end: the last slice again (never read)
+#pragma unroll
+            for (int i = 0; i < PPP6; ++i) {
+                const int p = q + NPROD * i;                       // (wave-uniform)
+                const bool is_a = p < A6_PIECES;
+                const int pl = is_a ? p : p - A6_PIECES;           // piece of its operand
+                const int chunk = slot ^ (4 * (pl & 1) + (row_in >> 1));
+                int row = (is_a ? im0 : in0) + pl * 8 + row_in;
+                const int lim = is_a ? M : N;
+                row = row < lim ? row : lim - 1;                   // rows beyond the matrix: any valid row (never stored)
+                const unsigned short* src = (is_a ? A : Bt) + (size_t)row * Kp + (size_t)(live ? ikt : nk - 1) * BK6 + chunk * 8;
+                unsigned char* dst = sb + (is_a ? 0 : A6_BYTES) + (size_t)pl * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+            }
+            ++ig;
+            if (live && ++ikt == nk && ig < S) {
+                ikt = 0;
+                open(++ii);
+            }
+        };
+        // bare s_waitcnt + s_barrier: __syncthreads() carries vmcnt(0) and would wait for the slices just requested
+#pragma unroll
+        for (int g = 0; g < NST6 - 1; ++g) issue();
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST6 - 2) * PPP6) : "memory");     // slice 0 landed
+        issue();
+        for (int g = 0; g < S; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST6 - 2) * PPP6) : "memory"); // slice g + 1 landed; the stage of slice g is free
+            issue();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may land after the workgroup's LDS is gone
+        return;
+    }
+
+    // ---- compute wave: tile rows wr * 80 .., columns wc * 64 .. (5 x 4 MFMA tiles), two k-steps per slice
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: lane (r = lane & 15, g = lane >> 4) reads chunk (4 s + g) ^ ((r >> 1) & 7) of row (tile * 16 + r), 128-B rows;
+    // tile i of a wave lies i * 2 KiB further on (immediate offset); the two k-steps of a slice differ in bit 2 of the slot: an XOR of 64 B
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    const unsigned aoff0 = lds0 + (unsigned)(((wr * 80 + fr) * 8 + (fg ^ ((fr >> 1) & 7))) * 16);
+    const int bdelta = A6_BYTES + (wc * 64 - wr * 80) * 128;        // Bt fragment row of this lane - its A fragment row (wave-uniform)
+    u32x4 a[2][5], b[2][4];
+    auto reads = [&](int stage, int s2, int buf) {
+        const unsigned ao = (aoff0 ^ (unsigned)(s2 * 64)) + (unsigned)stage * STG6, bo = ao + (unsigned)bdelta;
+        a[buf][0] = mg_lds_read128<0>(ao);
+        a[buf][1] = mg_lds_read128<2048>(ao);
+        a[buf][2] = mg_lds_read128<4096>(ao);
+        a[buf][3] = mg_lds_read128<6144>(ao);
+        a[buf][4] = mg_lds_read128<8192>(ao);
+        b[buf][0] = mg_lds_read128<0>(bo);
+        b[buf][1] = mg_lds_read128<2048>(bo);
+        b[buf][2] = mg_lds_read128<4096>(bo);
+        b[buf][3] = mg_lds_read128<6144>(bo);
+    };
+    // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns
+    auto mmas = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[buf][jj]),
+                                                                    __builtin_bit_cast(bf16x8, a[buf][i]), acc[i][jj], 0, 0, 0);
+    };
+    int ci = 0, ckt = 0;
+    asm volatile("s_barrier" ::: "memory");                        // slice 0 landed (the producers waited for it)
+    reads(0, 0, 0);
+    // software pipeline (the 256 x 128 kernel's): the reads of k-step 1 go out before the MFMAs of k-step 0 and -- behind the slice barrier in
+    // the MIDDLE of the iteration -- the reads of the next slice's k-step 0 before the MFMAs of k-step 1
+    for (int g = 0; g < S; ++g) {
+        reads(g % NST6, 1, 1);
+        mg_lds_wait<9>();                                          // k-step 0 landed (the 9 reads of k-step 1 are behind it)
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done with the stage of slice g; slice g + 1 landed
+        if (g + 1 < S) reads((g + 1) % NST6, 0, 0);
+        if (g + 1 < S) mg_lds_wait<9>(); else mg_lds_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++ckt < nk) continue;
+        ckt = 0;
+        // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*80 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
+        const int j = jj0 + ci * W;
+        const int cm0 = (rb0 + j / nct) * TM4, cn0 = (j % nct) * TN4;
+        ++ci;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = cn0 + wc * 64 + jj * 16 + fg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int m = cm0 + wr * 80 + i * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+                acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && m < cm0 + TM4 && n < N) {
+                    if (c_bf16) {
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                    } else {
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n));
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1008,6 +1187,156 @@ __global__ __launch_bounds__(NTHR5) void gemm_bf16_nt_320_kernel(const unsigned 
 
 }  // namespace
 
+// ---- 320 x 256 tiles, 64-wide K slices (round 6) ---------------------------------------------------------------------------------
+// The same step as gemm_bf16_nt_160k_kernel for the sixteen-wave tile: whole 128-B operand lines (half the L2 requests per byte).  A slice
+// is 72 KB here, so the ring has TWO stages: the requests of slice g + 1 go out at the head of slice g (its stage was read for the last time
+// before the barrier that closed slice g - 1) and must have landed at its end -- one slice in flight instead of three; what that costs in
+// overlap the halved request count has to win back (measured: NOTES_r06 2a').  Pieces of 8 rows x 128 B, 72 per slice = 12 requesting
+// waves x 6; operand rows in LDS as in the 256 x 128 kernel; fragments single buffered, two k-steps per slice.
+namespace {
+constexpr int BK7 = 64, NST7 = 2;
+constexpr int A7_BYTES = TM5 * BK7 * 2, B7_BYTES = TN5 * BK7 * 2, STG7 = A7_BYTES + B7_BYTES;          // 40 KB + 32 KB
+constexpr int A7_PIECES = A7_BYTES / 1024, B7_PIECES = B7_BYTES / 1024;                                  // 40 + 32 = 72
+constexpr int RPW7 = (A7_PIECES + B7_PIECES) / REQW5;
+static_assert(REQW5 * RPW7 == A7_PIECES + B7_PIECES && REQW5 % 2 == 0, "every requesting wave issues the same number of pieces, all of its own parity");
+constexpr size_t SMEM7_BYTES = (size_t)NST7 * STG7;
+static_assert(SMEM7_BYTES <= 160 * 1024, "LDS");
+
+__global__ __launch_bounds__(NTHR5) void gemm_bf16_nt_320k_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+                                                                  int M, int N, int Kp, const float* __restrict__ bias,
+                                                                  float* __restrict__ C, int ldc, int act, int nrb, int nct, int c_bf16) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];      // (the k-step XOR below relies on 128-B aligned rows)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jj0 = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nk = Kp / BK7;
+    const int rb0 = xcd * nrb / 8, T = ((xcd + 1) * nrb / 8 - rb0) * nct;
+    const int nitem = jj0 < T ? (T - jj0 + W - 1) / W : 0;
+    if (nitem == 0) return;
+    const int S = nitem * nk;
+    // ---- requests (waves 0..11): piece p = wave + 12 i of a slice: p < 40 = A piece p, else Bt piece p - 40 (same parity as the wave);
+    //      lane (row_in = lane >> 3, slot = lane & 7) fetches the chunk that belongs in its slot: slot = chunk ^ ((row >> 1) & 7) with
+    //      (row >> 1) & 7 = 4 (piece & 1) + (row_in >> 1); rows beyond M / N read zeros (buffer bounds)
+    const bool requester = wave < REQW5;
+    const int row_in = lane >> 3, slot = lane & 7;
+    const int chunk = slot ^ (4 * (wave & 1) + (row_in >> 1));
+    const unsigned voff = (unsigned)((row_in * Kp + chunk * 8) * 2);
+    int ii = 0, ik = 0;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    auto open_tile = [&](int i) {
+        const int j = jj0 + i * W;
+        const int m0 = (rb0 + j / nct) * TM5, n0 = (j % nct) * TN5;
+        const int mr = M - m0 < TM5 ? M - m0 : TM5, nr = N - n0 < TN5 ? N - n0 : TN5;
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A + (size_t)m0 * Kp), 0, mr * Kp * 2, 0x00027000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bt + (size_t)n0 * Kp), 0, nr * Kp * 2, 0x00027000);
+    };
+    open_tile(0);
+    auto issue_one = [&](int g, int i) {                           // request i (0..5) of slice g, k slice ik of the open tile
+        unsigned char* sb = smem + (size_t)(g & 1) * STG7;
+        const int p = wave + REQW5 * i;                            // (wave-uniform)
+        if (p < A7_PIECES) {
+            const unsigned soff = (unsigned)((p * 8 * Kp + ik * BK7) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + (size_t)p * 1024), 16, voff, soff, 0, 0);
+        } else {
+            const unsigned soff = (unsigned)(((p - A7_PIECES) * 8 * Kp + ik * BK7) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)(sb + A7_BYTES + (size_t)(p - A7_PIECES) * 1024), 16, voff, soff, 0, 0);
+        }
+    };
+    auto issue_done = [&]() {
+        if (++ik == nk && ++ii < nitem) {
+            ik = 0;
+            open_tile(ii);
+        }
+    };
+    // ---- compute: wave tile rows wr * 80 .., columns wc * 64 .. (5 x 4 MFMA tiles)
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = mg_lds_addr(smem);
+    const unsigned aoff0 = lds0 + (unsigned)(((wr * 80 + fr) * 8 + (fg ^ ((fr >> 1) & 7))) * 16);
+    const int bdelta = A7_BYTES + (wc * 64 - wr * 80) * 128;        // Bt fragment row of this lane - its A fragment row (wave-uniform)
+    u32x4 a[5], b[4];
+    if (requester) {
+#pragma unroll
+        for (int i = 0; i < RPW7; ++i) issue_one(0, i);
+        issue_done();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of slice 0 landed
+    }
+    asm volatile("s_barrier" ::: "memory");                        // everybody's
+    int ci = 0, ck = 0;
+    for (int g = 0; g < S; ++g) {
+        const bool req = requester && g + 1 < S;                   // slice g + 1 -> the stage of slice g - 1: read by everybody before the last barrier
+        const unsigned so = (unsigned)(g & 1) * STG7;
+        mg_mha_static_for_2([&](auto sc) {
+            constexpr int s2 = decltype(sc)::v;
+            const unsigned ao = (aoff0 ^ (unsigned)(s2 * 64)) + so, bo = ao + (unsigned)bdelta;
+            b[0] = mg_lds_read128<0>(bo);
+            b[1] = mg_lds_read128<2048>(bo);
+            b[2] = mg_lds_read128<4096>(bo);
+            b[3] = mg_lds_read128<6144>(bo);
+            a[0] = mg_lds_read128<0>(ao);
+            a[1] = mg_lds_read128<2048>(ao);
+            a[2] = mg_lds_read128<4096>(ao);
+            a[3] = mg_lds_read128<6144>(ao);
+            a[4] = mg_lds_read128<8192>(ao);
+            mg_lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            // tiles are computed transposed (A operand = Bt fragment) so a lane ends up with four consecutive C columns; the wave's six
+            // requests of slice g + 1 ride behind the MFMAs of rows 0, 2 and 4 of both k-steps
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[jj]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                        acc[i][jj], 0, 0, 0);
+                if (req && (i & 1) == 0) issue_one(g + 1, 3 * s2 + (i >> 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (req) issue_done();
+        // slice g + 1 landed (this wave's pieces); everybody is done with slice g
+        if (requester) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (++ck < nk) continue;
+        ck = 0;
+        // ---- epilogue: acc[i][jj][r] = C[cm0 + wr*80 + 16 i + (lane & 15)][cn0 + wc*64 + 16 jj + 4 (lane >> 4) + r]
+        const int j = jj0 + ci * W;
+        const int cm0 = (rb0 + j / nct) * TM5, cn0 = (j % nct) * TN5;
+        ++ci;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int n = cn0 + wc * 64 + jj * 16 + fg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int m = cm0 + wr * 80 + i * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
+                acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && n < N) {
+                    if (c_bf16) {
+                        unsigned lo, hi;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(C) + (size_t)m * ldc + n) = u32x2_t{lo, hi};
+                    } else {
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n));
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
 // Which round-5 tile shape a product takes: 4 = 160 x 256, 5 = 320 x 256, 0 = neither (round 4's kernels decide between themselves
 // below).  Pure host arithmetic (no device call): mgnns_gemm_bf16_pick_form exposes it to tests.
 //   want: 1 / 3 = the 160 x 256 / 320 x 256 kernel whenever the shape fits it, 2 = by the estimate, 0 = neither.
@@ -1063,8 +1392,13 @@ extern "C" int mgnns_gemm_bf16_pick_form(int M, int N, int Kp, int with_workspac
     return mg_gemm_pick(M, N, Kp, with_workspace != 0, with_workspace ? (size_t)256 * TM2 * TN2 * sizeof(float) : 0, n_cu, 2, true);
 }
 
+static int g_gemm160_bk = 0;            // K-slice width of the 160 x 256 tile: 0 = MGNNS_GEMM160_BK (default 64), 32 / 64 forced (mgnns_gemm_bf16_set_form(101 / 102))
 static int g_gemm_form = -1;            // -1: MGNNS_GEMM_160 (default 2); 0 round 4's kernels only, 1 / 3 the 160 x 256 / 320 x 256 kernel whenever the shape fits, 2 by the estimate
 extern "C" int mgnns_gemm_bf16_set_form(int form) {
+    if (form >= 100 && form <= 102) {                   // K-slice width of the 160 x 256 tile: 100 environment (MGNNS_GEMM160_BK, default 64), 101 = 32, 102 = 64
+        g_gemm160_bk = form == 100 ? 0 : form == 101 ? 32 : 64;
+        return 0;
+    }
     MG_REQUIRE(form >= -1 && form <= 3, "mgnns_gemm_bf16_set_form: form=%d (-1 environment, 0 round 4's kernels only, 1 160 x 256 whenever it fits, 2 by estimate, 3 320 x 256 whenever it fits)", form);
     g_gemm_form = form;
     return 0;
@@ -1092,12 +1426,29 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
         const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4, nrb5 = (M + TM5 - 1) / TM5, nct5 = (N + TN5 - 1) / TN5;
         const int pick = mg_gemm_pick(M, N, Kp, workspace && mg_aligned16(workspace), workspace_bytes, n_cu4, want,
                                       mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256);
+        if (pick == 4 && Kp % BK6 == 0 && (g_gemm160_bk > 0 ? g_gemm160_bk : mg_env_int("MGNNS_GEMM160_BK", 64, 11)) == 64) {
+            MG_DYN_LDS(gemm_bf16_nt_160k_kernel, SMEM6_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_160k_kernel, dim3(8 * per4), dim3(NTHR4), SMEM6_BYTES, stream,
+                               reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
+                               ldc, act, nrb4, nct4, c_bf16);
+            MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(160, 64-wide slices)");
+            return 0;
+        }
         if (pick == 4) {
             MG_DYN_LDS(gemm_bf16_nt_160_kernel, SMEM4_BYTES);
             hipLaunchKernelGGL(gemm_bf16_nt_160_kernel, dim3(8 * per4), dim3(NTHR4), SMEM4_BYTES, stream,
                                reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
                                ldc, act, nrb4, nct4, c_bf16);
             MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(160)");
+            return 0;
+        }
+        if (pick == 5 && Kp % BK7 == 0 && (g_gemm160_bk > 0 ? g_gemm160_bk : mg_env_int("MGNNS_GEMM160_BK", 64, 11)) == 64 &&
+            mg_env_int("MGNNS_GEMM320_BK", 64, 12) == 64) {
+            MG_DYN_LDS(gemm_bf16_nt_320k_kernel, SMEM7_BYTES);
+            hipLaunchKernelGGL(gemm_bf16_nt_320k_kernel, dim3(8 * per4), dim3(NTHR5), SMEM7_BYTES, stream,
+                               reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
+                               ldc, act, nrb5, nct5, c_bf16);
+            MG_CHECK_LAUNCH("mgnns_gemm_bf16_nt_fwd(320, 64-wide slices)");
             return 0;
         }
         if (pick == 5) {

@@ -23,10 +23,12 @@ COLD_BYTES = 640 << 20            # rotate over more than 2x the 256 MiB Infinit
 GEMM_TILE = {"workgroup_tile": "256x128", "BK": 64, "lds_stages": 3, "lds_bytes_per_stage": 49152,
              "wave_tile": "64x64", "compute_waves": 8, "producer_waves": 4,
              "other_forms": {"160x256 (round 5; one round of 252 tiles for 10 000 x 1024: the F = 1024 adjacency product and the X.W products it "
-                             "balances better)": {"BK": 32, "lds_stages": 5, "lds_bytes_per_stage": 26624, "wave_tile": "80x64",
-                                                  "compute_waves": 8, "producer_waves": 4},
-                             "320x256 (round 5; one round of 256 tiles for 10 000 x 2048: the F = 2048 adjacency product, X1.W2)":
-                                 {"BK": 32, "lds_stages": 4, "lds_bytes_per_stage": 36864, "wave_tile": "80x64", "compute_waves": 16,
+                             "balances better; round 6: 64-wide K slices = whole 128-B operand lines, half the L2 requests)":
+                                 {"BK": 64, "lds_stages": 3, "lds_bytes_per_stage": 53248, "wave_tile": "80x64",
+                                  "compute_waves": 8, "producer_waves": 4},
+                             "320x256 (round 5; one round of 256 tiles for 10 000 x 2048: the F = 2048 adjacency product, X1.W2; round 6: 64-wide "
+                             "K slices, two stages)":
+                                 {"BK": 64, "lds_stages": 2, "lds_bytes_per_stage": 73728, "wave_tile": "80x64", "compute_waves": 16,
                                   "producer_waves": 0},
                              "256x256 (round 4; K >= 4096 where neither of the above balances better)":
                                  {"BK": 32, "lds_stages": 4, "lds_bytes_per_stage": 32768, "wave_tile": "64x128", "compute_waves": 8,

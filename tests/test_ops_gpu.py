@@ -1726,6 +1726,15 @@ def test_gemm_bf16_nt_160_and_320_tiles(M, N, K, form):
             got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
             got2 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
             assert torch.equal(got, got2)
+            if form in (1, 3):
+                # round 6: the 160 x 256 / 320 x 256 tile with 64-wide K slices (whole 128-B operand lines; three / two stages; the default)
+                # against the same tile with round 5's 32-wide slices: the same k-steps in the same order into the same accumulators -> the same bits
+                ops.gemm_bf16_set_form(101)
+                g32 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+                ops.gemm_bf16_set_form(102)
+                g64 = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+                ops.gemm_bf16_set_form(100)
+                assert torch.equal(g32, g64) and torch.equal(g64, got), (dt, M, N, K)
             scale = float(ref.float().abs().max())
             tol = 2e-6 if dt == torch.float32 else 8e-3          # (bf16 output: one ulp where a sum sits on a rounding boundary)
             assert float((got.float() - ref.float()).abs().max()) <= tol * scale, (dt, M, N, K)
@@ -1735,6 +1744,7 @@ def test_gemm_bf16_nt_160_and_320_tiles(M, N, K, form):
         want = _bf16_round(a32[rows]).double() @ _bf16_round(b32).double().t()
         assert float((plain[torch.from_numpy(rows).to(DEV)].cpu().double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
     finally:
+        ops.gemm_bf16_set_form(100)
         ops.gemm_bf16_set_form(-1)
 
 

@@ -6,7 +6,7 @@
 #include <stdio.h>
 
 template <int SEG>
-__global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ buf, int R, int RS, int passes, float* out) {
+__global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ buf, int R, int RS, int RW, int passes, float* out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int LPR = SEG / 16, RPP = 64 / LPR;                  // lanes per row segment, rows per 1-KiB piece
@@ -14,7 +14,7 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ buf, 
     const size_t region = (size_t)R * RS;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(buf) + xcd * region, 0, (int)region, 0x00027000);
     const unsigned lane_off = (unsigned)(lane / LPR) * RS + (lane % LPR) * 16;
-    const int npiece = R / RPP, nk = RS / SEG;
+    const int npiece = R / RPP, nk = RW / SEG;
     unsigned char* slot = smem + (size_t)wave * 8 * 1024;
     int p = (cu * 7 + wave) % npiece, kk = (cu * 3) % nk;
     const int total = passes * (npiece * nk / 8);
@@ -36,40 +36,48 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ buf, 
 }
 
 template <int SEG>
-void run(const unsigned char* buf, float* out, int R, int RS) {
+void run(const unsigned char* buf, float* out, int R, int RS, int RW = 0) {
+    if (RW == 0) RW = RS;
     const size_t lds = 8 * 8 * 1024;
     (void)hipFuncSetAttribute((const void*)k<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const size_t region = (size_t)R * RS;
-    int passes = (int)(((size_t)48 << 20) / region);
+    int passes = (int)(((size_t)48 << 20) / ((size_t)R * RW));
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    hipLaunchKernelGGL((k<SEG>), dim3(256), dim3(512), lds, 0, buf, R, RS, 2, out);
+    hipLaunchKernelGGL((k<SEG>), dim3(256), dim3(512), lds, 0, buf, R, RS, RW, 2, out);
     (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(a);
-        hipLaunchKernelGGL((k<SEG>), dim3(256), dim3(512), lds, 0, buf, R, RS, passes, out);
+        hipLaunchKernelGGL((k<SEG>), dim3(256), dim3(512), lds, 0, buf, R, RS, RW, passes, out);
         (void)hipEventRecord(b);
         (void)hipEventSynchronize(b);
         float ms;
         (void)hipEventElapsedTime(&ms, a, b);
         best = ms < best ? ms : best;
     }
-    const double bytes = 256.0 * 8 * (double)(passes * ((R / (64 / (SEG / 16))) * (RS / SEG) / 8) / 8 * 8) * 1024.0;
-    printf("row segments of %3d B (%2d rows per 1-KiB piece), [%d x %d B] per XCD: %7.1f us  %6.2f TB/s  %6.2f G requests of %d B per s and XCD (%s)\n", SEG,
+    const double bytes = 256.0 * 8 * (double)(passes * ((R / (64 / (SEG / 16))) * (RW / SEG) / 8) / 8 * 8) * 1024.0;
+    printf("row segments of %3d B (%2d rows per 1-KiB piece), [%d rows %d B apart] per XCD: %7.1f us  %6.2f TB/s  %6.2f G requests of %d B per s and XCD (%s)\n", SEG,
            64 / (SEG / 16), R, RS, best * 1e3, bytes / (best * 1e-3) / 1e12, bytes / SEG / (best * 1e-3) / 8 / 1e9, SEG, hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
     unsigned char* buf; float* out;
-    (void)hipMalloc(&buf, (size_t)64 << 20);
+    (void)hipMalloc(&buf, (size_t)160 << 20);
     (void)hipMalloc(&out, 65536 * 4);
-    (void)hipMemset(buf, 1, (size_t)64 << 20);
+    (void)hipMemset(buf, 1, (size_t)160 << 20);
     for (int RS : {2048, 8192, 20096}) {
         const int R = RS == 20096 ? 96 : (2 << 20) / RS;           // ~2 MB per XCD
         run<64>(buf, out, R / 16 * 16, RS);
         run<128>(buf, out, R / 16 * 16, RS);
         run<256>(buf, out, R / 16 * 16, RS);
+    }
+    // one row per 4-KiB page (row stride 4096 + 64 / 8192 + 64 B): does the number of PAGES a CU walks matter?  (the GEMM's tile is 416 rows
+    // 20 KB apart); only the first 512 B of every row are streamed so that the footprint stays L2 resident whatever the row count
+    printf("== rows one page apart, 512 B of each row streamed (L2 resident), 64-B and 128-B segments ==\n");
+    for (int R : {96, 416, 1024, 2048}) {
+        run<64>(buf, out, R / 16 * 16, 4160, 512);
+        run<128>(buf, out, R / 16 * 16, 4160, 512);
     }
     return 0;
 }
