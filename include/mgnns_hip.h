@@ -541,6 +541,8 @@ int mgnns_transpose_cast_bf16(const float* x, int rows, int cols, int ld, void* 
  * full round of 256 x 256 tiles per XCD run the 256 x 256-tile kernel (a third less L2 traffic per MAC), whose left-over tiles are
  * cut the same way.  NULL: every tile is computed whole by the 256 x 128 kernel. */
 size_t mgnns_gemm_bf16_workspace_bytes(void);
+/* c_bf16 (round 6: two bits): bit 0 = C is bf16 (else fp32); bit 1 = TRANSPOSED store: C is C^T [N, ldc >= M] (a product with a small M runs as
+ * its transpose and still leaves the K-contiguous operand the next product needs; the 160 x 256 kernel only: ceil(M / 160) >= 8, N >= 256, K >= 320). */
 int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
                            int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream);
 /* Which tile shape mgnns_gemm_bf16_nt_fwd runs (tests and A/B timings; production leaves it alone): -1 the environment

@@ -1016,8 +1016,23 @@ __global__ __launch_bounds__(NTHR4) void gemm_bf16_nt_160k_kernel(const unsigned
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = mg_act(acc[i][jj][r] + bv[r], act);
                 acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m < M && m < cm0 + TM4 && n < N) {
-                    if (c_bf16) {
+                if ((c_bf16 & 2) && m < M && m < cm0 + TM4) {
+                    // transposed store (round 6): C^T [N, ldc >= M] -- the 16 lanes of a row group hold 16 consecutive m of one n: 32 / 64 B
+                    // runs per column.  A product with a SMALL M (the workload's W^T . X^T products, its read-out) runs as its transpose
+                    // (M' = the long side: full rounds of tiles) and still leaves the K-contiguous operand the next product needs.
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (n + r >= N) continue;
+                        if (c_bf16 & 1) {
+                            unsigned pk;
+                            asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(o[r]));
+                            reinterpret_cast<unsigned short*>(C)[(size_t)(n + r) * ldc + m] = (unsigned short)(pk & 0xFFFFu);
+                        } else {
+                            C[(size_t)(n + r) * ldc + m] = o[r];
+                        }
+                    }
+                } else if (!(c_bf16 & 2) && m < M && m < cm0 + TM4 && n < N) {
+                    if (c_bf16 & 1) {
                         unsigned lo, hi;
                         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(o[0]), "v"(o[1]));
                         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(o[2]), "v"(o[3]));
@@ -1409,8 +1424,11 @@ extern "C" int mgnns_gemm_bf16_set_form(int form) {
 int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, float* C, int ldc, int act,
                         const int32_t* m_dev, hipStream_t stream, int c_bf16, void* workspace, size_t workspace_bytes) {
     MG_REQUIRE(A && Bt && C, "mgnns_gemm_bf16_nt_fwd: null pointer");
-    MG_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && Kp > 0 && Kp % BK == 0 && ldc >= N && ldc % 4 == 0,
+    const bool c_tr = (c_bf16 & 2) != 0;                           // C^T [N, ldc >= M] instead of C [M, ldc >= N]
+    MG_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && Kp > 0 && Kp % BK == 0 && ldc >= (c_tr ? M : N) && (c_tr || ldc % 4 == 0),
                "mgnns_gemm_bf16_nt_fwd: need N %% 4 == 0, Kp %% %d == 0, ldc %% 4 == 0 (M=%d N=%d Kp=%d ldc=%d)", BK, M, N, Kp, ldc);
+    MG_REQUIRE(!c_tr || (!m_dev && (M + TM4 - 1) / TM4 >= 8 && N >= TN4 && Kp / BK4 >= 2 * NST4),
+               "mgnns_gemm_bf16_nt_fwd: the transposed store is the 160 x 256 kernel's (M=%d >= 1121, N=%d >= 256, K=%d >= 320)", M, N, Kp);
     MG_REQUIRE(act >= 0 && act <= 2, "mgnns_gemm_bf16_nt_fwd: unknown activation %d", act);
     MG_REQUIRE(mg_aligned16(A) && mg_aligned16(Bt) && mg_aligned16(C) && (!bias || mg_aligned16(bias)),
                "mgnns_gemm_bf16_nt_fwd: operands must be 16-byte aligned");
@@ -1419,14 +1437,14 @@ int mg_launch_gemm_bf16(const void* A, const void* Bt, int M, int N, int Kp, con
     // better than the other kernels' tiles do: the estimate is rounds of the busiest XCD x operand rows per tile-slice (all of them
     // stream at about what the L2s deliver).  MGNNS_GEMM_160 / mgnns_gemm_bf16_set_form: 0 neither, 1 160 x 256 whenever the shape
     // fits, 2 (default) by the estimate, 3 320 x 256 whenever the shape fits
-    if (const int want = m_dev ? 0 : (g_gemm_form >= 0 ? g_gemm_form : mg_env_int("MGNNS_GEMM_160", 2, 9))) {
+    if (const int want = m_dev ? 0 : c_tr ? 1 : (g_gemm_form >= 0 ? g_gemm_form : mg_env_int("MGNNS_GEMM_160", 2, 9))) {
         const int n_cu4 = mg_cu_count();
         if (n_cu4 <= 0) return MGNNS_ERR_LAUNCH;
         const int per4 = n_cu4 / 8 > 0 ? n_cu4 / 8 : 1;
         const int nrb4 = (M + TM4 - 1) / TM4, nct4 = (N + TN4 - 1) / TN4, nrb5 = (M + TM5 - 1) / TM5, nct5 = (N + TN5 - 1) / TN5;
-        const int pick = mg_gemm_pick(M, N, Kp, workspace && mg_aligned16(workspace), workspace_bytes, n_cu4, want,
-                                      mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256);
-        if (pick == 4 && Kp % BK6 == 0 && (g_gemm160_bk > 0 ? g_gemm160_bk : mg_env_int("MGNNS_GEMM160_BK", 64, 11)) == 64) {
+        const int pick = c_tr ? 4 : mg_gemm_pick(M, N, Kp, workspace && mg_aligned16(workspace), workspace_bytes, n_cu4, want,
+                                                 mg_env_int("MGNNS_GEMM_TILE", 256, 2) == 256);
+        if (pick == 4 && Kp % BK6 == 0 && (c_tr || (g_gemm160_bk > 0 ? g_gemm160_bk : mg_env_int("MGNNS_GEMM160_BK", 64, 11)) == 64)) {
             MG_DYN_LDS(gemm_bf16_nt_160k_kernel, SMEM6_BYTES);
             hipLaunchKernelGGL(gemm_bf16_nt_160k_kernel, dim3(8 * per4), dim3(NTHR4), SMEM6_BYTES, stream,
                                reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(Bt), M, N, Kp, bias, C,
@@ -1542,6 +1560,7 @@ extern "C" size_t mgnns_gemm_bf16_workspace_bytes(void) { return (size_t)256 * T
 
 extern "C" int mgnns_gemm_bf16_nt_fwd(const void* A, const void* Bt, int M, int N, int Kp, const float* bias, void* C, int ldc,
                                       int c_bf16, int act, void* workspace, size_t workspace_bytes, mgnns_stream_t stream) {
-    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, static_cast<float*>(C), ldc, act, nullptr, (hipStream_t)stream, c_bf16 ? 1 : 0,
+    MG_REQUIRE(c_bf16 >= 0 && c_bf16 <= 3, "mgnns_gemm_bf16_nt_fwd: c_bf16=%d (bit 0: bf16 output, bit 1: transposed store)", c_bf16);
+    return mg_launch_gemm_bf16(A, Bt, M, N, Kp, bias, static_cast<float*>(C), ldc, act, nullptr, (hipStream_t)stream, c_bf16,
                                workspace, workspace_bytes);
 }

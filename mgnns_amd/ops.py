@@ -1424,10 +1424,13 @@ def _gemm_bf16_workspace(device):
     return ws
 
 
-def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None, out_dtype=torch.float32):
+def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=None, out_dtype=torch.float32, transposed_out=False):
     """act(A . Bt^T + bias): A bf16 [M, Kp], Bt bf16 [N, Kp] (Kp % 64 == 0) -> fp32 or bf16 [M, N].
     out: optional preallocated result; it may be a column slice [M, N] of a wider row-major matrix (row stride = its stride(0)),
-    e.g. the K-padded operand of the next product."""
+    e.g. the K-padded operand of the next product.
+    transposed_out (round 6): the result is stored as its transpose [N, M] (`out`, if given, is that [N, M] matrix or a column slice of a
+    wider one); bias stays per column n of the product.  For products whose natural orientation has a small M: run the transpose
+    (M = the long side) and keep the layout the consumer needs.  Needs ceil(M / 160) >= 8, N >= 256, K >= 320."""
     _chk(a_bf16, "A", torch.bfloat16, 2)
     _chk(bt_bf16, "Bt", torch.bfloat16, 2)
     M, Kp = a_bf16.shape
@@ -1436,16 +1439,20 @@ def gemm_bf16_nt(a_bf16, bt_bf16, bias=None, act=ACT_NONE, n_valid=None, out=Non
         raise ValueError("A %s / Bt %s: K rows must match and be a multiple of 64" % (tuple(a_bf16.shape), tuple(bt_bf16.shape)))
     if bias is not None:
         _chk(bias, "bias", ndim=1)
+    shape = (N, M) if transposed_out else (M, N)
     if out is None:
-        c = torch.empty(M, N, device=a_bf16.device, dtype=out_dtype)
+        c = torch.empty(*shape, device=a_bf16.device, dtype=out_dtype)
     else:
         c = out
-        if not (torch.is_tensor(c) and c.is_cuda and c.dim() == 2 and tuple(c.shape) == (M, N) and c.stride(1) == 1
+        if not (torch.is_tensor(c) and c.is_cuda and c.dim() == 2 and tuple(c.shape) == shape and c.stride(1) == 1
                 and c.dtype in (torch.float32, torch.bfloat16)):
-            raise ValueError("out must be a [%d, %d] fp32 / bf16 device matrix with unit column stride" % (M, N))
+            raise ValueError("out must be a [%d, %d] fp32 / bf16 device matrix with unit column stride" % shape)
+    if transposed_out and ((M + 159) // 160 < 8 or N < 256 or Kp < 320):
+        raise ValueError("transposed_out needs ceil(M / 160) >= 8, N >= 256, K >= 320 (M=%d N=%d K=%d)" % (M, N, Kp))
     ws = _gemm_bf16_workspace(a_bf16.device) if (GEMM_BF16_KSPLIT and M * N >= (1 << 20)) else None
     _lib.check(_lib.lib().mgnns_gemm_bf16_nt_fwd(_p(a_bf16), _p(bt_bf16), M, N, Kp, _p(bias), _p(c), c.stride(0),
-                                                 1 if c.dtype == torch.bfloat16 else 0, act, _p(ws), 0 if ws is None else ws.numel(),
+                                                 (1 if c.dtype == torch.bfloat16 else 0) | (2 if transposed_out else 0), act, _p(ws),
+                                                 0 if ws is None else ws.numel(),
                                                  _stream()), "mgnns_gemm_bf16_nt_fwd")
     return c
 

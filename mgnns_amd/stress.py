@@ -102,6 +102,12 @@ def _sets_for(bytes_per_set):
 
 N_CHANNELS = 3
 
+
+def _transposed_ok(n):
+    """ops.gemm_bf16_nt(transposed_out=True) takes a product whose M is at least eight 160-row blocks (MGNNS_STRESS_TRANSPOSED=0: never)."""
+    import os
+    return (n + 159) // 160 >= 8 and os.environ.get("MGNNS_STRESS_TRANSPOSED", "1") != "0"
+
 _marks = None                      # launch_times(): [(label, event)] recorded behind every launch of a channel forward
 
 
@@ -184,7 +190,10 @@ class StressChannel:
             if self.dense:
                 ax = ops.gemm_bf16_nt(self.adj_bf16, self.Xt, out_dtype=bf)                      # adj . X            [n, 320]
                 _mark("adj.X")
-                ops.gemm_bf16_nt(self.W1t, ax, None, ops.ACT_LRELU2, out=self.S1t[:, :self.n])   # X1^T = lrelu(W1^T . AX^T)
+                if _transposed_ok(self.n):                                                       # X1^T = lrelu(W1^T . AX^T), as AX . W1 stored transposed
+                    ops.gemm_bf16_nt(ax, self.W1t, None, ops.ACT_LRELU2, out=self.S1t[:, :self.n], transposed_out=True)
+                else:
+                    ops.gemm_bf16_nt(self.W1t, ax, None, ops.ACT_LRELU2, out=self.S1t[:, :self.n])
                 _mark("(adj.X).W1")
                 ax1 = ops.gemm_bf16_nt(self.adj_bf16, self.S1t, out_dtype=bf)                    # adj . X1           [n, 1024]
                 _mark("adj.X1")
@@ -199,11 +208,20 @@ class StressChannel:
             _mark("(adj.X1).W2")
             return G
         if self.dtype == "bf16" and self.dense:
-            ops.gemm_bf16_nt(self.W1t, self.Xb, out=self.S1t[:, :self.n])
+            # (round 6: S^T = W^T . X^T has the SHORT side as its M -- 1024 / 2048 rows of tiles that fill the chip's rounds badly -- so the
+            #  product runs as X . W with the long side as M and stores its result transposed: the same K-contiguous S^T)
+            tr = _transposed_ok(self.n)
+            if tr:
+                ops.gemm_bf16_nt(self.Xb, self.W1t, out=self.S1t[:, :self.n], transposed_out=True)
+            else:
+                ops.gemm_bf16_nt(self.W1t, self.Xb, out=self.S1t[:, :self.n])
             _mark("X.W1")
             x1 = ops.gemm_bf16_nt(self.adj_bf16, self.S1t, None, ops.ACT_LRELU2, out_dtype=bf)
             _mark("adj.S1")
-            ops.gemm_bf16_nt(self.W2t, x1, out=self.S2t[:, :self.n])
+            if tr:
+                ops.gemm_bf16_nt(x1, self.W2t, out=self.S2t[:, :self.n], transposed_out=True)
+            else:
+                ops.gemm_bf16_nt(self.W2t, x1, out=self.S2t[:, :self.n])
             _mark("X1.W2")
             G = ops.gemm_bf16_nt(self.adj_bf16, self.S2t, out_dtype=bf)                          # G [n, 2048] bf16
             _mark("adj.S2")
@@ -228,7 +246,7 @@ class StressChannel:
         G = self.gcn()
         if self.dtype == "bf16":
             pb = pooled if pooled.dtype == torch.bfloat16 else ops.cast_pad_bf16(pooled, ld=2048)
-            out = ops.gemm_bf16_nt(pb, G)
+            out = ops.gemm_bf16_nt(pb, G)      # (measured as (G . pooled^T)^T too: 45 us against 40 -- 126 tiles and 64-B fp32 column runs: kept straight)
             _mark("read-out")
             return out
         return ops.linear(pooled, G)

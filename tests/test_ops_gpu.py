@@ -1748,6 +1748,37 @@ def test_gemm_bf16_nt_160_and_320_tiles(M, N, K, form):
         ops.gemm_bf16_set_form(-1)
 
 
+@pytest.mark.parametrize("M,N,K", [(10000, 2048, 1024), (10000, 1024, 320), (10000, 512, 2048), (1300, 260, 448)])
+def test_gemm_bf16_nt_transposed_store(M, N, K):
+    """gemm_bf16_nt(transposed_out=True) (round 6): the 160 x 256 kernel stores C^T [N, M] -- a product whose natural orientation has a small
+    M runs as its transpose and still leaves the K-contiguous operand the next product needs.  Equal, bit for bit, to the transpose of
+    the ordinary result of the same kernel and to the product computed in the OTHER orientation (operands swapped: the same dot
+    products over k in the same order), fp32 and bf16, bias per column + activation, into a column slice of a wider matrix; shapes the
+    kernel does not take are refused."""
+    rs = np.random.RandomState(M + N + K)
+    kp = (K + 63) // 64 * 64
+    a = ops.cast_pad_bf16(dev(rs.standard_normal((M, K)).astype(np.float32) * 0.1), ld=kp)
+    bt = ops.cast_pad_bf16(dev(rs.standard_normal((N, K)).astype(np.float32) * 0.1), ld=kp)
+    bias = dev(rs.standard_normal(N).astype(np.float32))
+    try:
+        ops.gemm_bf16_set_form(1)
+        for dt in (torch.float32, torch.bfloat16):
+            ref = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt)
+            got = ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out_dtype=dt, transposed_out=True)
+            assert tuple(got.shape) == (N, M) and torch.equal(got, ref.t().contiguous()), (dt, M, N, K)
+            wide = torch.zeros(N, M + 64, device=DEV, dtype=dt)
+            assert ops.gemm_bf16_nt(a, bt, bias, ops.ACT_LRELU2, out=wide[:, :M], transposed_out=True).data_ptr() == wide.data_ptr()
+            assert torch.equal(wide[:, :M], got) and float(wide[:, M:].abs().max()) == 0.0
+        ops.gemm_bf16_set_form(-1)
+        plain_t = ops.gemm_bf16_nt(a, bt, transposed_out=True)                       # [N, M] = (A . Bt^T)^T
+        other = ops.gemm_bf16_nt(bt, a)                                              # [N, M] = Bt . A^T: the other orientation, any kernel
+        assert float((plain_t - other).abs().max()) <= 2e-6 * float(other.abs().max())
+    finally:
+        ops.gemm_bf16_set_form(-1)
+    with pytest.raises(ValueError):
+        ops.gemm_bf16_nt(a[:640], bt, transposed_out=True)                          # four row blocks: not the 160 x 256 kernel's
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 4096), (10000, 2048, 4200), (8300, 2312, 4100)])
 def test_gemm_bf16_nt_256_tiles(M, N, K):
     """Products with at least a full round of 256 x 256 tiles on every XCD and K >= 4096 run
