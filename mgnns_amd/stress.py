@@ -427,6 +427,7 @@ def measure(dev="cuda:0", n=N_NODES, batch=BATCH, quick=True):
     ref_out = {}
     for name, kw in (("csr_d0.0004", dict(density=DENSITIES[0])), ("csr_d0.01", dict(density=DENSITIES[1])), ("dense", dict(dense=True)),
                      ("csr_d0.0004_reassociated", dict(density=DENSITIES[0], order="reassociated")),
+                     ("csr_d0.01_reassociated", dict(density=DENSITIES[1], order="reassociated")),
                      ("dense_reassociated", dict(dense=True, order="reassociated"))):
         wl = StressWorkload(n=n, batch=batch, dev=dev, **kw)
         for _ in range(3):                                    # steady state: the caching allocator holds the forward's blocks, the clock is up
