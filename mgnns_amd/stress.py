@@ -183,6 +183,14 @@ class StressChannel:
                     self.S2t = torch.zeros(2048, self.kp, device=dev, dtype=torch.bfloat16)
             else:
                 self.sadj = ops.SparseAdjBf16(self.csr)
+                if order == "reassociated" and self.sadj.avg_nnz >= ops.SparseAdjBf16.TILED_MIN_AVG_NNZ:
+                    # adj @ X runs on the layer's INPUT width, 300 -> 320 columns, and the LDS-tiled SpMM takes widths that are multiples of
+                    # 256 (others fall to the gather kernel: 0.47-0.55 ms at density 1e-2 against 0.15 at F = 1024) -- pad the features and
+                    # W1's K to 512
+                    self.Xb = ops.cast_pad_bf16(self.X, ld=512)
+                    w1 = torch.zeros(1024, 512, device=dev, dtype=torch.bfloat16)
+                    w1[:, :320] = self.W1t
+                    self.W1t = w1
 
     def gcn(self):
         bf = torch.bfloat16
