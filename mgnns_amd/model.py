@@ -738,7 +738,7 @@ class Multi_GCN_Multihead_Att(nn.Module):
             # core had no event ordering it behind the conversion launch: a stale read under graph replay)
             if any(m.slf_attn._split_core() for st in (self.img_object_text_multi_head_att, self.img_place_text_multi_head_att)
                    for m in st):
-                ctx['text_bank'].split
+                ctx['text_bank_split'] = ctx['text_bank'].split      # (MemoryBank caches it: the stacks find the images made)
             prep_plan = getattr(ctx['text_bank'], 'mask_plan', None)
             if prep_plan is not None:
                 ctx['mha_plan'] = prep_plan
