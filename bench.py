@@ -436,9 +436,8 @@ def stress_run(args, rank, local_rank, world):
             "value": round(stress.N_CHANNELS * stress.BATCH / ms * 1e3, 1), "unit": "channel-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "none" if dry else "bf16", "data": "synthetic", "dry_launch": bool(dry),
-            "config": {"workload": "BASELINE configs[4]: %d-node graph, density %g CSR, 3 channels, batch %d, bf16 operands / fp32 "
-                                   "accumulation, channels (then the read-out batch) sharded over ranks, no data-path collective"
-                                   % (n_nodes, density, stress.BATCH)},
+            "config": {"workload": "configs[4]: %d-node graph, density %g CSR, 3 channels, batch %d, bf16 / fp32 accumulate; "
+                                   "sharded by channel, then read-out batch; no collective" % (n_nodes, density, stress.BATCH)},
             "dt_ranks": dts, "shards": [[list(b[:3]) for b in rb] for rb in every],
             "block_shapes": [[list(b[3:]) for b in rb] for rb in every]}
     emit(line)
